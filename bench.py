@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Throughput of the hot path: sampled showers/sec (Dataset-2, 400-step DDIM, batch 64 per GPU) on N MI355X.
+
+    python bench.py [--gpus N --steps K --warmup W]           # N = 1
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch: Diffusion.sample() = Philox start noise + 400 denoise steps + the
+final device->host copy of x, inputs (E, layers) already resident in HBM.  One process per GPU; the batch
+dimension is sharded with no data-path collective (weak scaling: 64 showers per GPU).  Rank 0 prints ONE JSON line.
+
+Extra legs, rank 0 at N = 1 only:
+  * roofline: one eager denoise step with HIP events around every launch (cd_profile_*), pricing the dominant kernel
+    (the 32->32 3x3x3 cylindrical conv at full resolution) in algorithmic TFLOP/s against the fp32 MFMA peak;
+  * cpu_baseline: the oracle (oracle/torch_oracle.py, stock PyTorch CPU kernels, the reference's own arithmetic
+    boundary) timed on this box's host cores on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32-in MFMA = vector fp32 peak
+PEAK_HBM_GBS = 8000.0
+
+
+def dist_info():
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+
+
+def max_over_ranks(value: float) -> float:
+    """Slowest rank's time (MAX all-reduce); identity in a single-process run."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(value)
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+
+
+def synthetic_inputs(cfg, batch, rank, device):
+    """E ~ U(0,1), layers ~ N(0,1) in normalised space; per-rank seeds so ranks hold different showers."""
+    g = torch.Generator().manual_seed(1234 + rank)
+    n_e = 3 if cfg.get("HGCAL", False) else 1
+    E = torch.rand((batch, n_e), generator=g).to(device)
+    layers = None
+    if "layer" in cfg.get("SHOWERMAP", ""):
+        layers = torch.randn((batch, 1 + cfg["SHAPE_FINAL"][2]), generator=g).to(device)
+    return E, layers
+
+
+def cpu_baseline(cfg, sample_steps, batch=16, timed=3):
+    """The oracle on the host cores: `timed` denoise steps at `batch` showers after one warm-up, extrapolated to
+    sample_steps steps per shower (every DDIM step costs the same U-Net forward)."""
+    from oracle import torch_oracle as O
+    from tests.helpers import seeded_unet  # same seeded weights as the GPU model
+    from calodiffusion_amd.unet import unet_kwargs_from_config  # noqa: F401
+    threads = torch.get_num_threads()
+    net = seeded_unet(cfg["_name"])
+    model = O.OracleModel(cfg, net.state_dict())
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn([batch] + list(cfg["SHAPE_PAD"][1:]), generator=g)
+    n_e = 3 if cfg.get("HGCAL", False) else 1
+    E = torch.rand((batch, n_e), generator=g)
+    layers = torch.randn((batch, 1 + cfg["SHAPE_FINAL"][2]), generator=g) if "layer" in cfg.get("SHOWERMAP", "") else None
+    sig = torch.full((batch,), 1.0)
+    with torch.no_grad():
+        model.denoise(x, E, sig, layers)
+        t0 = time.perf_counter()
+        for _ in range(timed):
+            model.denoise(x, E, sig, layers)
+        dt = (time.perf_counter() - t0) / timed
+    return {"value": batch / (dt * sample_steps), "unit": "showers/s", "cores": threads, "kind": "port",
+            "host_cpus": os.cpu_count(), "s_per_denoise_step": dt,
+            "sample": f"{timed} denoise steps (oracle/torch_oracle.py, PyTorch CPU fp32) at batch {batch} after 1 warm-up, "
+                      f"extrapolated x{sample_steps} steps"}
+
+
+def roofline_leg(model, cfg, batch, E, layers):
+    """One eager denoise step with HIP events around every kernel launch; returns the dominant kernel's roofline entry
+    and a per-category breakdown."""
+    from calodiffusion_amd import engine
+    shape = [batch] + list(cfg["SHAPE_PAD"][1:])
+    x = engine.randn(shape, "cuda", seed=99)
+    sig = torch.full((batch,), 1.0, device="cuda")
+    for _ in range(2):
+        model.denoise(x, E=E, sigma=sig, layers=layers)
+    torch.cuda.synchronize()
+    reps = 5
+    engine.profile_begin()
+    for _ in range(reps):
+        model.denoise(x, E=E, sigma=sig, layers=layers)
+    prof = engine.profile_end()
+    total_ms = sum(v["ms"] for v in prof.values()) / reps
+    # dominant kernel: the category with the largest total time
+    dom_name, dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
+    avg_ms = dom["ms"] / dom["launches"]
+    achieved = dom["flops"] / (avg_ms * 1e-3) / 1e12
+    breakdown = {k: {"ms_per_step": round(v["ms"] / reps, 4), "launches_per_step": v["launches"] // reps,
+                     "tflops": round(v["flops"] / (v["ms"] / v["launches"] * 1e-3) / 1e12, 2) if v["flops"] else None,
+                     "gbs": round(v["bytes"] / (v["ms"] / v["launches"] * 1e-3) / 1e9, 1) if v["bytes"] else None}
+                 for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+    roof = {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+            "avg_launch_us": round(avg_ms * 1e3, 2), "alg_flops_per_launch": dom["flops"],
+            "alg_bytes_per_launch": dom["bytes"],
+            "hbm_frac_of_same_kernel": round(dom["bytes"] / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+            "eager_step_ms_sum_of_kernels": round(total_ms, 3)}
+    return roof, breakdown
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="dataset2")
+    ap.add_argument("--batch", type=int, default=64, help="showers per GPU (weak scaling)")
+    ap.add_argument("--sample-steps", type=int, default=400)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the roofline and cpu_baseline legs")
+    ap.add_argument("--breakdown", action="store_true", help="print the per-kernel breakdown to stderr")
+    args = ap.parse_args()
+
+    rank, local_rank, world = dist_info()
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from calodiffusion_amd.calodiffusion import CaloDiffusion
+    from calodiffusion_amd.configs import load_config
+    cfg = dict(load_config(args.config))
+    cfg["_name"] = args.config
+    cfg["SAMPLER"] = "DDim"
+    cfg["SAMPLER_OPTIONS"] = {"HIP_GRAPH": not args.no_graph}
+    torch.manual_seed(1234)  # identical random-init weights on every rank
+    model = CaloDiffusion(cfg, n_steps=cfg["NSTEPS"], loss_type=cfg["LOSS_TYPE"])
+    B = args.batch
+    vox = int(np.prod(cfg["SHAPE_PAD"][1:]))
+    # disjoint slices of one Philox stream per rank: (start + per-step noise) * steps per sample() call
+    model.noise_offset = rank * (args.steps + args.warmup + 4) * (args.sample_steps + 2) * B * vox
+    E, layers = synthetic_inputs(cfg, B, rank, "cuda")
+
+    def one_pass():
+        out = model.sample(E, layers, num_steps=args.sample_steps)  # returns a host ndarray (final D2H included)
+        return out
+
+    for _ in range(args.warmup):
+        one_pass()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_pass()
+    torch.cuda.synchronize()
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0)
+    assert np.isfinite(out).all()
+
+    result = {
+        "metric": "sampled showers/sec (Dataset-2, 400-step DDIM)" if args.config == "dataset2" and args.sample_steps == 400
+        else f"sampled showers/sec ({args.config}, {args.sample_steps}-step DDIM)",
+        "value": world * args.steps * B / dt,
+        "unit": "showers/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"{args.config}: {'x'.join(str(v) for v in cfg['SHAPE_PAD'][2:])} voxels, "
+                               f"{args.sample_steps}-step DDIM, batch {B} per GPU, random-init weights (seed 1234)",
+                   "global_batch": B * world, "parallelism": f"batch-sharded x{world}, no collective",
+                   "hip_graph": not args.no_graph, "denoise_ms": 1e3 * dt / args.steps / args.sample_steps},
+    }
+    if rank == 0 and world == 1 and not args.no_extra:
+        roof, breakdown = roofline_leg(model, cfg, B, E, layers)
+        result["roofline"] = roof
+        if args.breakdown:
+            print(json.dumps(breakdown, indent=1), file=sys.stderr)
+        result["kernel_breakdown_ms_per_denoise"] = {k: v["ms_per_step"] for k, v in list(breakdown.items())[:8]}
+        result["cpu_baseline"] = cpu_baseline(cfg, args.sample_steps)
+        result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,191 @@
+// Shared declarations for the gfx950 CaloDiffusion hot-path library (internal; the public ABI is include/calodiff.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace cd {
+
+// ---- error plumbing ---------------------------------------------------------------------------------
+void set_error(const std::string& msg);
+struct Fail {
+  int code;
+  std::string msg;
+};
+#define CD_HIP(expr)                                                                                  \
+  do {                                                                                                \
+    hipError_t _e = (expr);                                                                           \
+    if (_e != hipSuccess)                                                                             \
+      throw cd::Fail{-2, std::string(#expr) + ": " + hipGetErrorString(_e)};                          \
+  } while (0)
+#define CD_REQUIRE(cond, msg)                                                                         \
+  do {                                                                                                \
+    if (!(cond)) throw cd::Fail{-1, std::string(msg)};                                                \
+  } while (0)
+
+// ---- optional per-launch profiling with HIP events (eager mode only; bench.py's roofline leg) -----------------
+namespace prof {
+bool enabled();
+void begin();
+// writes a JSON object {"<category>": {"launches": n, "ms": total, "flops": per_launch, "bytes": per_launch}, ...}
+int end(char* buf, int cap);
+struct Scope {
+  Scope(const char* category, hipStream_t s, double flops, double bytes);
+  ~Scope();
+  int idx;
+  hipStream_t stream;
+};
+}  // namespace prof
+
+// ---- channels-last tensor view ------------------------------------------------------------------------
+// Internal activation layout: (B, D, H, W, C) fp32, C a multiple of 32 => every voxel is a whole number of 128-B lines.
+struct Dims3 {
+  int d, h, w;
+  __host__ __device__ int64_t vox() const { return (int64_t)d * h * w; }
+};
+
+// Packed weight layout shared by every MFMA kernel (32x32x2 f32):
+//   wpk[chunk][tap][ct][q][lane][e]   chunk = ci/32, ct = co/32, lane = h*32 + j, m = 4q+e
+//   holds W[co = ct*32 + j][ci = chunk*32 + h*16 + m][tap]
+// so that one wave-wide 16-B load (fixed q) is 1 KiB contiguous and lane (j,h) receives the B-operand
+// values of MFMAs m = 4q..4q+3 for its output column j and k-half h.
+inline size_t packed_weight_floats(int cin, int cout, int taps) {
+  return (size_t)(cin / 32) * taps * ((cout + 31) / 32) * 2048;
+}
+
+// ---- kernel launchers (defined in the .hip files) ---------------------------------------------------------
+struct ConvGeom {
+  Dims3 in, out;
+  int kd, kh, kw;   // kernel extents
+  int sz, sh, sw;   // strides
+};
+
+// optional GroupNorm(+SiLU)(+embedding) applied to the conv's input while it is staged into LDS
+struct NormPrologue {
+  const double* partials = nullptr;  // [B][G][nsplit][2]
+  int nsplit = 0, groups = 0;
+  const float* gamma = nullptr;
+  const float* beta = nullptr;
+  const float* add_bc = nullptr;  // [B][ld] or null
+  int add_ld = 0;
+  int silu = 0;
+};
+
+void launch_pack_weights(const float* w_torch, float* wpk, int cout, int cin, int taps, bool transposed, hipStream_t s);
+void launch_pack_init_weights(const float* w_torch, float* wpk, int cout, int cin, hipStream_t s);
+
+void launch_conv_mfma(const float* in0, int c0, const float* in1, int c1, const float* wpk, const float* bias, float* out,
+                      int batch, int cout, const ConvGeom& g, hipStream_t s);
+void launch_conv_transpose_mfma(const float* in, int cin, const float* wpk, const float* bias, float* out, int batch,
+                                int cout, Dims3 din, Dims3 dout, int kz, int sz, hipStream_t s);
+
+enum A_Prologue { A_NONE = 0, A_GROUPNORM1 = 1, A_SOFTMAX32 = 2 };
+struct PointwiseArgs {
+  const float* in0 = nullptr;  // (B, vox, ld0) read at channel offset off0, c0 channels
+  int ld0 = 0, off0 = 0, c0 = 0;
+  const float* in1 = nullptr;  // optional concat source
+  int ld1 = 0, c1 = 0;
+  const float* wpk = nullptr;
+  int64_t w_batch_stride = 0;  // floats between per-sample weight sets (0 = shared)
+  const float* bias = nullptr;
+  const float* residual = nullptr;  // (B, vox, cout) added in the epilogue
+  float* out = nullptr;
+  int batch = 0, cout = 0;
+  int64_t vox = 0;
+  int prologue = A_NONE;
+  const double* gn_partials = nullptr;  // [B][1][nsplit][2]
+  int gn_nsplit = 0;
+  const float* gn_gamma = nullptr;
+  const float* gn_beta = nullptr;
+};
+void launch_pointwise(const PointwiseArgs& a, hipStream_t s);
+
+struct InitConvArgs {
+  const float* x = nullptr;       // (B, cx, D, H, W) planar
+  int cx = 0;                     // planar channels present in x
+  int cin = 0;                    // logical input channels of the conv (cx + synthesised coordinate channels)
+  const float* scale_b = nullptr; // per-sample multiplier of channel 0 (c_in) or null: scale_b[b * scale_stride]
+  int scale_stride = 1;
+  const float* r_w = nullptr;     // coordinate profiles, used when cin > cx
+  const float* z_d = nullptr;
+  const float* phi_h = nullptr;
+  int use_rz = 0, use_phi = 0;
+  const float* wpk = nullptr;     // [tap][ci][cout]
+  const float* bias = nullptr;
+  float* out = nullptr;           // channels-last
+  int batch = 0, cout = 0;
+  Dims3 dims{};
+};
+void launch_init_conv(const InitConvArgs& a, hipStream_t s);
+
+int gn_nsplit_for(int64_t vox, int batch);
+void launch_gn_stats(const float* x, double* partials, int batch, int channels, int64_t vox, int groups, int nsplit,
+                     hipStream_t s);
+void launch_gn_apply(const float* x, float* y, const double* partials, int nsplit, const float* gamma, const float* beta,
+                     int batch, int channels, int64_t vox, int groups, int silu, const float* add_bc, int add_ld,
+                     const float* residual, hipStream_t s);
+
+int attn_nsplit_for(int64_t vox, int batch);
+size_t attn_partial_floats(int batch, int nsplit);
+void launch_attn_context(const float* qkv, float* partials, int batch, int64_t vox, int nsplit, hipStream_t s);
+void launch_attn_combine(const float* partials, int nsplit, const float* w_out /*torch (C,32)*/, int cout, float* wpk_b,
+                         int batch, float scale, hipStream_t s);
+
+struct EmbedLayer {
+  const float* w;  // (cout, 128) torch layout
+  const float* b;
+  int cout;
+  int offset;  // column offset in the per-sample embedding row
+};
+struct EmbedArgs {
+  const float* cond = nullptr;  // (B, cond_size)
+  const float* time_or_sigma = nullptr;  // (B,)
+  int time_kind = 0;
+  float sigma_data = 1.f;
+  int cond_size = 0, cond_hidden = 0, half = 0;
+  const float *tw1, *tb1, *tw2, *tb2, *tw3, *tb3;
+  const float *cw1, *cb1, *cw2, *cb2, *cw3, *cb3;
+  const EmbedLayer* layers = nullptr;  // device array
+  int n_layers = 0;
+  float* emb = nullptr;  // (B, emb_ld)
+  int emb_ld = 0;
+  float* scal = nullptr;  // (B, 4): c_in, c_skip, c_out, sigma
+  int batch = 0;
+};
+void launch_embed(const EmbedArgs& a, hipStream_t s);
+void launch_silu_linear(const float* cond, const float* w, const float* bias, float* out, int batch, int nin, int nout,
+                        hipStream_t s);
+
+struct HeadArgs {
+  const float* h = nullptr;   // (B, vox, 32) channels-last
+  const float* w = nullptr;   // (32,) torch layout of the 1x1x1 head
+  const float* bias = nullptr;
+  const float* x = nullptr;   // (B, vox) network input before c_in scaling (null for raw unet_forward)
+  const float* scal = nullptr;  // (B,4) or null
+  int objective = 0;
+  float* out = nullptr;       // (B, vox): F (raw) or x0
+  int batch = 0;
+  int64_t vox = 0;
+};
+void launch_head(const HeadArgs& a, hipStream_t s);
+
+// x_next = x0 + sigma_prev*((x - x0)/sigma) + ddim_sigma*noise/denom, scalars read from stepvals[0..3]
+void launch_ddim_update(const float* x, const float* x0, const float* noise, const float* stepvals, float* x_next,
+                        float* xs_slot, float* x0s_slot, int64_t n, hipStream_t s);
+// stepvals <- table[*counter]; sigma_b[0..B) <- stepvals.sigma; (*counter)++
+void launch_load_step(const float* table, int* counter, float* stepvals, float* sigma_b, int batch, hipStream_t s);
+void launch_scale(const float* x, float* y, const float* stepvals_sigma, int64_t n, hipStream_t s);
+void launch_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, hipStream_t s);
+void launch_axpy_sigma(const float* data, const float* noise, const float* sigma_b, float* out, int batch, int64_t per,
+                       hipStream_t s);
+void launch_loss_partial(const float* x0, const float* data, const float* sigma_b, double* partial, int batch,
+                         int64_t per, hipStream_t s);
+void launch_loss_final(const double* partial, const float* sigma_b, double* loss, int batch, int64_t per, hipStream_t s);
+void launch_transpose_to_cl(const float* ncdhw, float* ndhwc, int batch, int channels, int64_t vox, hipStream_t s);
+void launch_transpose_to_planar(const float* ndhwc, float* ncdhw, int batch, int channels, int64_t vox, hipStream_t s);
+
+}  // namespace cd

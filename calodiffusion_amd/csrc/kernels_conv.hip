@@ -1,0 +1,684 @@
+// Convolution kernels for gfx950 (MI355X): phi-periodic 3D convolutions as implicit GEMMs on the fp32 matrix cores.
+//
+// All dense contractions use v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains, 64 FLOP/clk/SIMD = the chip's fp32 peak):
+//   M = 32 output voxels (A operand, one channels-last voxel per lane, staged through LDS with its halo),
+//   N = 32 output channels (B operand = pre-packed weights, 1-KiB coalesced wave loads, L2-resident),
+//   K = 2 input channels per instruction: lane half h = lane>>5 owns channels [16h, 16h+16) of a 32-channel chunk,
+//       so MFMA m of a tap contracts channels (m, 16+m).
+// Reference semantics: CylindricalConv / CylindricalConvTrans / Downsample / Upsample,
+// calodiffusion/models/models.py:25-96, 335-369: circular padding along phi (H), zero padding along z (D) and r (W).
+#include "cd_common.h"
+#include <cstdio>
+
+namespace cd {
+
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+static constexpr int LDS_VOX_PAD = 4;  // floats of padding per LDS voxel: stride 36/68/100 words => conflict-free ds_read_b128
+
+// ------------------------------------------------------------------------------------------------------------
+// weight packing (see cd_common.h for the layout)
+// ------------------------------------------------------------------------------------------------------------
+__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wpk, int cout, int cin, int taps,
+                                    int transposed, size_t total) {
+  size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int e = idx & 3, lane = (idx >> 2) & 63, q = (idx >> 8) & 3;
+  size_t rest = idx >> 10;
+  const int CT = (cout + 31) / 32;
+  const int ct = rest % CT;
+  rest /= CT;
+  const int tap = rest % taps;
+  const int chunk = rest / taps;
+  const int h = lane >> 5, j = lane & 31, m = q * 4 + e;
+  const int ci = chunk * 32 + h * 16 + m, co = ct * 32 + j;
+  float v = 0.f;
+  if (co < cout && ci < cin)
+    v = transposed ? w[((size_t)ci * cout + co) * taps + tap] : w[((size_t)co * cin + ci) * taps + tap];
+  wpk[idx] = v;
+}
+
+void launch_pack_weights(const float* w_torch, float* wpk, int cout, int cin, int taps, bool transposed, hipStream_t s) {
+  CD_REQUIRE(cin % 32 == 0, "MFMA convolutions need input channels in multiples of 32");
+  size_t total = packed_weight_floats(cin, cout, taps);
+  hipLaunchKernelGGL(pack_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, s, w_torch, wpk, cout, cin, taps,
+                     transposed ? 1 : 0, total);
+  CD_HIP(hipGetLastError());
+}
+
+// init conv weights: [tap][ci][cout] so that the 32 output-channel weights of one (tap, ci) are contiguous (scalar loads)
+__global__ void pack_init_weights_kernel(const float* __restrict__ w, float* __restrict__ wpk, int cout, int cin) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= cout * cin * 27) return;
+  const int co = idx % cout;
+  const int ci = (idx / cout) % cin;
+  const int tap = idx / (cout * cin);
+  wpk[idx] = w[((size_t)co * cin + ci) * 27 + tap];
+}
+void launch_pack_init_weights(const float* w_torch, float* wpk, int cout, int cin, hipStream_t s) {
+  int total = cout * cin * 27;
+  hipLaunchKernelGGL(pack_init_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, s, w_torch, wpk, cout, cin);
+  CD_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// forward conv (3x3x3 stride 1, and the strided (3,4,4) down-sampling conv)
+// ------------------------------------------------------------------------------------------------------------
+struct ConvKArgs {
+  const float* in0;
+  const float* in1;
+  int c0, c1;
+  const float* wpk;
+  const float* bias;
+  float* out;
+  int Din, Hin, Win, Do, Ho, Wo;
+  int KD, KH, KW, SZ, SH, SW;
+  int TZ, TH, nTZ, nTH;  // output tile (z, phi) extents and tile counts; tiles span the full r extent
+  int IZ, IH;            // staged input tile extents (with halo)
+  int cout, CTtot;
+};
+
+template <int VT, int CT>
+__global__ void __launch_bounds__(512) conv_mfma_kernel(ConvKArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
+  int bid = blockIdx.x;
+  const int thi = bid % a.nTH;
+  bid /= a.nTH;
+  const int tzi = bid % a.nTZ;
+  const int b = bid / a.nTZ;
+  const int ct0 = blockIdx.y * CT;
+  const int oz0 = tzi * a.TZ, oh0 = thi * a.TH;
+  const int tileVox = a.IZ * a.IH * a.Win;
+  const int ZERO = tileVox * 36;
+  const int half = lane >> 5, col = lane & 31;
+  if (tid < 36) lds[ZERO + tid] = 0.f;
+
+  int abase[VT], ooff[VT];
+  unsigned wmask[VT];
+  bool any_valid = false;
+#pragma unroll
+  for (int vt = 0; vt < VT; ++vt) {
+    const int v = (wave * VT + vt) * 32 + col;
+    const int ow = v % a.Wo;
+    const int t = v / a.Wo;
+    const int oh = t % a.TH, oz = t / a.TH;
+    const bool valid = (oz < a.TZ) && (oz0 + oz < a.Do) && (oh0 + oh < a.Ho);
+    abase[vt] = ((oz * a.SZ * a.IH + oh * a.SH) * a.Win + ow * a.SW - 1) * 36 + half * 16;
+    unsigned m = 0;
+    for (int kw = 0; kw < a.KW; ++kw) {
+      const int iw = ow * a.SW + kw - 1;
+      if (valid && iw >= 0 && iw < a.Win) m |= 1u << kw;
+    }
+    wmask[vt] = m;
+    ooff[vt] = valid ? (((oz0 + oz) * a.Ho + oh0 + oh) * a.Wo + ow) * a.cout : -1;
+    any_valid |= valid;
+  }
+  const bool wave_active = __any(any_valid);
+
+  f32x16 acc[VT][CT];
+#pragma unroll
+  for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[vt][ct][r] = 0.f;
+
+  const int nchunk = (a.c0 + a.c1) >> 5;
+  const int T = a.KD * a.KH * a.KW;
+  const int gz0 = oz0 * a.SZ - 1, gh0 = oh0 * a.SH - 1;
+  const int items = tileVox * 8;
+  const size_t in_vox = (size_t)a.Din * a.Hin * a.Win;
+
+  for (int chunk = 0; chunk < nchunk; ++chunk) {
+    const float* src;
+    int ldc, coff;
+    if (chunk * 32 < a.c0) {
+      src = a.in0; ldc = a.c0; coff = chunk * 32;
+    } else {
+      src = a.in1; ldc = a.c1; coff = chunk * 32 - a.c0;
+    }
+    src += (size_t)b * in_vox * ldc + coff;
+    __syncthreads();  // all reads of the previous chunk's tile are done
+    for (int idx = tid; idx < items; idx += nthreads) {
+      const int q = idx & 7, vox = idx >> 3;
+      const int iw = vox % a.Win;
+      const int r = vox / a.Win;
+      const int ih = r % a.IH, iz = r / a.IH;
+      const int gz = gz0 + iz;
+      int gh = (gh0 + ih) % a.Hin;
+      if (gh < 0) gh += a.Hin;
+      f32x4 val = {0.f, 0.f, 0.f, 0.f};
+      if (gz >= 0 && gz < a.Din) val = *(const f32x4*)(src + ((size_t)(gz * a.Hin + gh) * a.Win + iw) * ldc + q * 4);
+      *(f32x4*)(lds + vox * 36 + q * 4) = val;
+    }
+    __syncthreads();
+    if (!wave_active) continue;
+
+    const f32x4* wq = (const f32x4*)a.wpk + (size_t)chunk * T * a.CTtot * 256 + lane;
+    for (int kd = 0; kd < a.KD; ++kd) {
+      for (int kh = 0; kh < a.KH; ++kh) {
+        const int rowoff = (kd * a.IH + kh) * a.Win * 36;
+        for (int kw = 0; kw < a.KW; ++kw) {
+          const int tap = (kd * a.KH + kh) * a.KW + kw;
+          f32x4 bw[CT][4];
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bw[ct][q] = wq[((size_t)tap * a.CTtot + ct0 + ct) * 256 + q * 64];
+#pragma unroll
+          for (int vt = 0; vt < VT; ++vt) {
+            const int off = ((wmask[vt] >> kw) & 1u) ? abase[vt] + rowoff + kw * 36 : ZERO + half * 16;
+            f32x4 av[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) av[q] = *(const f32x4*)(lds + off + q * 4);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[vt][ct] = MFMA32(av[q][e], bw[ct][q][e], acc[vt][ct]);
+          }
+        }
+      }
+    }
+  }
+
+  // epilogue: C/D layout of the 32x32 tile: column (output channel) = lane&31, row (voxel) = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  float* outb = a.out + (size_t)b * a.Do * a.Ho * a.Wo * a.cout;
+#pragma unroll
+  for (int vt = 0; vt < VT; ++vt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int off = __shfl(ooff[vt], row, 64);
+      if (off >= 0) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          const int co = (ct0 + ct) * 32 + col;
+          const float bv = a.bias ? a.bias[co] : 0.f;
+          outb[off + co] = acc[vt][ct][r] + bv;
+        }
+      }
+    }
+  }
+}
+
+namespace {
+struct ConvTile {
+  int TZ, TH, NW, VT;
+  size_t lds;
+};
+
+// Pick the output tile and wave layout: minimise an estimate of whole-chip MFMA time (tile quantisation in
+// 32-voxel MFMA rows, SIMD balance, tail rounds over 256 CUs), subject to the 160 KiB LDS per CU.
+ConvTile choose_conv_tile(const ConvGeom& g, int batch, int CT) {
+  ConvTile best{0, 0, 0, 0, 0};
+  double best_cost = 1e300;
+  const int max_vt = 8 / CT;
+  for (int TZ = 1; TZ <= g.out.d && TZ <= 12; ++TZ) {
+    for (int nth = 1; nth <= g.out.h; ++nth) {
+      const int TH = (g.out.h + nth - 1) / nth;
+      if (nth > 1 && (g.out.h + nth - 2) / (nth - 1) == TH) continue;  // same TH as previous nth
+      const int IZ = (TZ - 1) * g.sz + g.kd, IH = (TH - 1) * g.sh + g.kh;
+      const size_t lds = ((size_t)IZ * IH * g.in.w * 36 + 36) * 4;
+      if (lds > 150 * 1024) continue;
+      const int tiles = (TZ * TH * g.out.w + 31) / 32;
+      for (int NW : {2, 4, 8}) {
+        const int VT = (tiles + NW - 1) / NW;
+        if (VT > max_vt || VT < 1) continue;
+        const int nTZ = (g.out.d + TZ - 1) / TZ;
+        const long nblocks = (long)batch * nTZ * nth;
+        int bpc = (int)(160 * 1024 / lds);
+        bpc = bpc < 1 ? 1 : bpc;
+        while (bpc > 1 && bpc * NW > 16) --bpc;
+        const long rounds = (nblocks + 256L * bpc - 1) / (256L * bpc);
+        double per_round = (double)bpc * NW * VT / 4.0;
+        if (per_round < VT) per_round = VT;
+        // staging cost: float4 items per block / threads, weighted against one 32x32xK tap pass (27*16 MFMAs of 64 clk)
+        const double stage = (double)IZ * IH * g.in.w * 8 / (64.0 * NW) * 40.0 / (g.kd * g.kh * g.kw * 16 * 64.0) * bpc;
+        const double cost = rounds * (per_round + stage) * (1.0 + 0.02 * (NW == 2));
+        if (cost < best_cost - 1e-9) {
+          best_cost = cost;
+          best = ConvTile{TZ, TH, NW, VT, lds};
+        }
+      }
+    }
+  }
+  CD_REQUIRE(best.NW > 0, "no convolution tiling fits in LDS (grid too wide in r?)");
+  return best;
+}
+
+template <int VT, int CT>
+void launch_conv_inst(const ConvKArgs& a, dim3 grid, int threads, size_t lds, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    CD_HIP(hipFuncSetAttribute((const void*)conv_mfma_kernel<VT, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_mfma_kernel<VT, CT>), grid, dim3(threads), lds, s, a);
+  CD_HIP(hipGetLastError());
+}
+}  // namespace
+
+void launch_conv_mfma(const float* in0, int c0, const float* in1, int c1, const float* wpk, const float* bias, float* out,
+                      int batch, int cout, const ConvGeom& g, hipStream_t s) {
+  CD_REQUIRE(c0 % 32 == 0 && c1 % 32 == 0 && c0 > 0, "conv: channel counts must be multiples of 32");
+  CD_REQUIRE(cout % 32 == 0, "conv: output channels must be a multiple of 32");
+  CD_REQUIRE(g.kw <= 4, "conv: r kernel extent > 4 unsupported");
+  const int CTtot = cout / 32;
+  int CT = CTtot <= 3 ? CTtot : 2;
+  CD_REQUIRE(CTtot % CT == 0, "conv: unsupported output channel count");
+  const ConvTile t = choose_conv_tile(g, batch, CT);
+  ConvKArgs a;
+  a.in0 = in0; a.in1 = in1; a.c0 = c0; a.c1 = c1; a.wpk = wpk; a.bias = bias; a.out = out;
+  a.Din = g.in.d; a.Hin = g.in.h; a.Win = g.in.w; a.Do = g.out.d; a.Ho = g.out.h; a.Wo = g.out.w;
+  a.KD = g.kd; a.KH = g.kh; a.KW = g.kw; a.SZ = g.sz; a.SH = g.sh; a.SW = g.sw;
+  a.TZ = t.TZ; a.TH = t.TH; a.nTZ = (g.out.d + t.TZ - 1) / t.TZ; a.nTH = (g.out.h + t.TH - 1) / t.TH;
+  a.IZ = (t.TZ - 1) * g.sz + g.kd; a.IH = (t.TH - 1) * g.sh + g.kh;
+  a.cout = cout; a.CTtot = CTtot;
+  dim3 grid((unsigned)(batch * a.nTZ * a.nTH), (unsigned)(CTtot / CT));
+  const int threads = t.NW * 64;
+  char cat[128];
+  std::snprintf(cat, sizeof cat, "conv%dx%dx%d_s%d C%d->%d @%dx%dx%d", g.kd, g.kh, g.kw, g.sh, c0 + c1, cout, g.in.d, g.in.h, g.in.w);
+  const double taps = (double)g.kd * g.kh * g.kw;
+  prof::Scope scope(cat, s, 2.0 * taps * (c0 + c1) * cout * (double)g.out.vox() * batch,
+                    4.0 * batch * ((double)g.in.vox() * (c0 + c1) + (double)g.out.vox() * cout));
+#define CD_CONV_CASE(V, C)                                        \
+  if (t.VT == V && CT == C) {                                     \
+    launch_conv_inst<V, C>(a, grid, threads, t.lds, s);           \
+    return;                                                       \
+  }
+  CD_CONV_CASE(1, 1) CD_CONV_CASE(2, 1) CD_CONV_CASE(3, 1) CD_CONV_CASE(4, 1)
+  CD_CONV_CASE(5, 1) CD_CONV_CASE(6, 1) CD_CONV_CASE(7, 1) CD_CONV_CASE(8, 1)
+  CD_CONV_CASE(1, 2) CD_CONV_CASE(2, 2) CD_CONV_CASE(3, 2) CD_CONV_CASE(4, 2)
+  CD_CONV_CASE(1, 3) CD_CONV_CASE(2, 3)
+#undef CD_CONV_CASE
+  CD_REQUIRE(false, "conv: no kernel instance for the chosen tiling");
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// transposed conv (Upsample): gather form, output voxels grouped by stride-parity class so that all 32 voxels of an
+// MFMA tile share one set of valid taps.
+//   out[o] = sum_k in[(o + pad - k)/s] * w[ci][co][k]   over k with (o + pad - k) % s == 0
+//   pad = (1, kH-1 after a circular halo of 1, 1)  (models.py:45,59-61)
+// ------------------------------------------------------------------------------------------------------------
+struct ConvTArgs {
+  const float* in;
+  int cin;
+  const float* wpk;
+  const float* bias;
+  float* out;
+  int Din, Hin, Win, Do, Ho, Wo;
+  int KZ, SZ;
+  int cout, CTtot;
+  int TZ, TH, nTZ, nTH;  // tile extents in class-index space: oz = SZ*a + pz, oh = 2*b + ph
+  int Cw;                // ceil(Wo/2)
+  int CS;                // LDS voxel stride in floats
+};
+
+template <int CT>
+__global__ void __launch_bounds__(256) conv_transpose_kernel(ConvTArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  int bid = blockIdx.x;
+  const int thi = bid % a.nTH;
+  bid /= a.nTH;
+  const int tzi = bid % a.nTZ;
+  const int b = bid / a.nTZ;
+  const int a0 = tzi * a.TZ, b0 = thi * a.TH;
+  const int PZ = a.TZ + 2, PH = a.TH + 2;
+  const int tileVox = PZ * PH * a.Win;
+  const int ZERO = tileVox * a.CS;
+  const int half = lane >> 5, col = lane & 31;
+  for (int i = tid; i < a.CS; i += blockDim.x) lds[ZERO + i] = 0.f;
+
+  // stage all input channels of the haloed tile
+  {
+    const int c4 = a.cin >> 2;
+    const int items = tileVox * c4;
+    const float* src = a.in + (size_t)b * a.Din * a.Hin * a.Win * a.cin;
+    for (int idx = tid; idx < items; idx += blockDim.x) {
+      const int q = idx % c4, vox = idx / c4;
+      const int iw = vox % a.Win;
+      const int r = vox / a.Win;
+      const int lh = r % PH, lz = r / PH;
+      const int gz = a0 - 1 + lz;
+      int gh = (b0 - 1 + lh) % a.Hin;
+      if (gh < 0) gh += a.Hin;
+      f32x4 val = {0.f, 0.f, 0.f, 0.f};
+      if (gz >= 0 && gz < a.Din) val = *(const f32x4*)(src + ((size_t)(gz * a.Hin + gh) * a.Win + iw) * a.cin + q * 4);
+      *(f32x4*)(lds + vox * a.CS + q * 4) = val;
+    }
+  }
+  __syncthreads();
+
+  const int ncls = a.SZ * 4;
+  const int njt = (a.TZ * a.TH * a.Cw + 31) / 32;
+  const int nchunk = a.cin >> 5;
+  const int T = a.KZ * 16;
+  float* outb = a.out + (size_t)b * a.Do * a.Ho * a.Wo * a.cout;
+
+  for (int job = wave; job < ncls * njt; job += nw) {
+    const int cls = job / njt, jt = job % njt;
+    const int pz = cls >> 2, ph = (cls >> 1) & 1, pw = cls & 1;
+    const int v = jt * 32 + col;
+    const int c = v % a.Cw;
+    const int t = v / a.Cw;
+    const int bb = t % a.TH, aa = t / a.TH;
+    const int oz = a.SZ * (a0 + aa) + pz, oh = 2 * (b0 + bb) + ph, ow = 2 * c + pw;
+    const bool valid = (aa < a.TZ) && (oz < a.Do) && (oh < a.Ho) && (ow < a.Wo);
+    if (!__any(valid)) continue;
+    const int ooff = valid ? ((oz * a.Ho + oh) * a.Wo + ow) * a.cout : -1;
+
+    f32x16 acc[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+
+    for (int kz = (pz + 1) % a.SZ; kz < a.KZ; kz += a.SZ) {
+      const int lz = aa + (pz + 1 - kz) / a.SZ + 1;
+      for (int kh = (ph + 3) & 1; kh < 4; kh += 2) {
+        const int lh = bb + (ph + 3 - kh) / 2;  // (.. )/2 - 1 (circular halo) + 1 (tile halo)
+        for (int kw = (pw + 1) & 1; kw < 4; kw += 2) {
+          const int iw = c + (pw + 1 - kw) / 2;
+          const bool ok = valid && iw >= 0 && iw < a.Win;
+          const int off = ok ? ((lz * PH + lh) * a.Win + iw) * a.CS + half * 16 : ZERO + half * 16;
+          const int tap = (kz * 4 + kh) * 4 + kw;
+          for (int chunk = 0; chunk < nchunk; ++chunk) {
+            f32x4 av[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) av[q] = *(const f32x4*)(lds + off + chunk * 32 + q * 4);
+            const f32x4* wq = (const f32x4*)a.wpk + ((size_t)(chunk * T + tap) * a.CTtot) * 256 + lane;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+              f32x4 bw[4];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) bw[q] = wq[ct * 256 + q * 64];
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[ct] = MFMA32(av[q][e], bw[q][e], acc[ct]);
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int off = __shfl(ooff, row, 64);
+      if (off >= 0) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          const int co = ct * 32 + col;
+          outb[off + co] = acc[ct][r] + (a.bias ? a.bias[co] : 0.f);
+        }
+      }
+    }
+  }
+}
+
+template <int CT>
+static void launch_convT_inst(const ConvTArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    CD_HIP(hipFuncSetAttribute((const void*)conv_transpose_kernel<CT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_transpose_kernel<CT>), grid, dim3(256), lds, s, a);
+  CD_HIP(hipGetLastError());
+}
+
+void launch_conv_transpose_mfma(const float* in, int cin, const float* wpk, const float* bias, float* out, int batch,
+                                int cout, Dims3 din, Dims3 dout, int kz, int sz, hipStream_t s) {
+  CD_REQUIRE(cin % 32 == 0 && cout % 32 == 0, "conv_transpose: channels must be multiples of 32");
+  CD_REQUIRE(sz == 1 || sz == 2, "conv_transpose: z stride must be 1 or 2");
+  ConvTArgs a;
+  a.in = in; a.cin = cin; a.wpk = wpk; a.bias = bias; a.out = out;
+  a.Din = din.d; a.Hin = din.h; a.Win = din.w; a.Do = dout.d; a.Ho = dout.h; a.Wo = dout.w;
+  a.KZ = kz; a.SZ = sz; a.cout = cout; a.CTtot = cout / 32;
+  a.Cw = (dout.w + 1) / 2;
+  a.CS = cin + LDS_VOX_PAD;
+  const int Az = (dout.d + sz - 1) / sz, Bh = (dout.h + 1) / 2;
+  // tile: largest (TZ, TH) whose haloed input tile stays under ~64 KiB (two blocks per CU); prefer full phi rings
+  int bestTZ = 1, bestTH = 1;
+  long bestv = -1;
+  for (int TZ = 1; TZ <= Az; ++TZ)
+    for (int TH = 1; TH <= Bh; ++TH) {
+      const size_t lds = ((size_t)(TZ + 2) * (TH + 2) * din.w + 1) * a.CS * 4;
+      if (lds > 64 * 1024) break;
+      const long v = (long)TZ * TH;
+      const long halo = (long)(TZ + 2) * (TH + 2);
+      // maximise useful/haloed ratio, then volume
+      const long score = v * 1000 / halo * 1000 + v;
+      if (score > bestv) { bestv = score; bestTZ = TZ; bestTH = TH; }
+    }
+  a.TZ = bestTZ; a.TH = bestTH;
+  a.nTZ = (Az + a.TZ - 1) / a.TZ; a.nTH = (Bh + a.TH - 1) / a.TH;
+  const size_t lds = ((size_t)(a.TZ + 2) * (a.TH + 2) * din.w + 1) * a.CS * 4;
+  CD_REQUIRE(lds <= 160 * 1024, "conv_transpose: tile does not fit in LDS");
+  dim3 grid((unsigned)(batch * a.nTZ * a.nTH));
+  char cat[128];
+  std::snprintf(cat, sizeof cat, "convT%dx4x4 C%d->%d @%dx%dx%d", kz, cin, cout, din.d, din.h, din.w);
+  prof::Scope scope(cat, s, 2.0 * kz * 16 * cin * cout * (double)din.vox() * batch,
+                    4.0 * batch * ((double)din.vox() * cin + (double)dout.vox() * cout));
+  switch (a.CTtot) {
+    case 1: launch_convT_inst<1>(a, grid, lds, s); break;
+    case 2: launch_convT_inst<2>(a, grid, lds, s); break;
+    case 3: launch_convT_inst<3>(a, grid, lds, s); break;
+    case 4: launch_convT_inst<4>(a, grid, lds, s); break;
+    default: CD_REQUIRE(false, "conv_transpose: more than 128 output channels unsupported");
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// pointwise (1x1x1) conv = per-voxel channel GEMM, A operand straight from global memory (HBM-bound).
+// Optional A prologues: GroupNorm(1) affine (PreNorm -> to_qkv) or a 32-way channel softmax (q of linear attention).
+// Optional per-sample weights (the folded  W_out * context^T  of linear attention) and residual add.
+// ------------------------------------------------------------------------------------------------------------
+template <int CT, int PRO>
+__global__ void __launch_bounds__(256) pointwise_kernel(PointwiseArgs a, int CTtot) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, col = lane & 31;
+  const int b = blockIdx.y;
+  const int ct0 = blockIdx.z * CT;
+  const int64_t n0 = (int64_t)blockIdx.x * 128 + wave * 32;
+  const int64_t n = n0 + col;
+  const bool valid = n < a.vox;
+
+  float mean = 0.f, rstd = 1.f;
+  if (PRO == A_GROUPNORM1) {
+    double s1 = 0.0, s2 = 0.0;
+    const double* p = a.gn_partials + (size_t)b * a.gn_nsplit * 2;
+    for (int i = 0; i < a.gn_nsplit; ++i) { s1 += p[2 * i]; s2 += p[2 * i + 1]; }
+    const double cnt = (double)a.vox * (a.c0 + a.c1);
+    const double mu = s1 / cnt;
+    double var = s2 / cnt - mu * mu;
+    var = var < 0.0 ? 0.0 : var;
+    mean = (float)mu;
+    rstd = (float)(1.0 / sqrt(var + 1e-5));
+  }
+
+  f32x16 acc[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+
+  const int nchunk = (a.c0 + a.c1) >> 5;
+  const float* wb = a.wpk + (size_t)b * a.w_batch_stride;
+  for (int chunk = 0; chunk < nchunk; ++chunk) {
+    const float* src;
+    if (chunk * 32 < a.c0) src = a.in0 + ((size_t)b * a.vox + (valid ? n : 0)) * a.ld0 + a.off0 + chunk * 32 + half * 16;
+    else src = a.in1 + ((size_t)b * a.vox + (valid ? n : 0)) * a.ld1 + (chunk * 32 - a.c0) + half * 16;
+    f32x4 av[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      av[q] = *(const f32x4*)(src + q * 4);
+      if (!valid) av[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (PRO == A_GROUPNORM1) {
+      const int cbase = chunk * 32 + half * 16;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 g = *(const f32x4*)(a.gn_gamma + cbase + q * 4);
+        const f32x4 bt = *(const f32x4*)(a.gn_beta + cbase + q * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) av[q][e] = (av[q][e] - mean) * rstd * g[e] + bt[e];
+      }
+    } else if (PRO == A_SOFTMAX32) {
+      float m = av[0][0];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m = fmaxf(m, av[q][e]);
+      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      float ssum = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          av[q][e] = expf(av[q][e] - m);
+          ssum += av[q][e];
+        }
+      ssum += __shfl_xor(ssum, 32, 64);
+      const float inv = 1.f / ssum;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) av[q][e] *= inv;
+    }
+    const f32x4* wq = (const f32x4*)wb + ((size_t)chunk * CTtot + ct0) * 256 + lane;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      f32x4 bw[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bw[q] = wq[ct * 256 + q * 64];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[ct] = MFMA32(av[q][e], bw[q][e], acc[ct]);
+    }
+  }
+
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+    const int64_t nr = n0 + row;
+    if (nr < a.vox) {
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        const int co = (ct0 + ct) * 32 + col;
+        if (co < a.cout) {
+          const size_t o = ((size_t)b * a.vox + nr) * a.cout + co;
+          float v = acc[ct][r] + (a.bias ? a.bias[co] : 0.f);
+          if (a.residual) v += a.residual[o];
+          a.out[o] = v;
+        }
+      }
+    }
+  }
+}
+
+void launch_pointwise(const PointwiseArgs& a, hipStream_t s) {
+  CD_REQUIRE(a.c0 % 32 == 0 && a.c1 % 32 == 0 && a.c0 > 0, "pointwise conv: channels must be multiples of 32");
+  CD_REQUIRE(a.prologue != A_SOFTMAX32 || (a.c0 == 32 && a.c1 == 0), "softmax prologue needs exactly 32 channels");
+  const int CTtot = (a.cout + 31) / 32;
+  const int CT = CTtot <= 3 ? CTtot : (CTtot % 2 == 0 ? 2 : 1);
+  dim3 grid((unsigned)((a.vox + 127) / 128), (unsigned)a.batch, (unsigned)(CTtot / CT));
+  char cat[128];
+  std::snprintf(cat, sizeof cat, "pointwise_p%d C%d->%d n%ld", a.prologue, a.c0 + a.c1, a.cout, (long)a.vox);
+  prof::Scope scope(cat, s, 2.0 * (a.c0 + a.c1) * a.cout * (double)a.vox * a.batch,
+                    4.0 * a.batch * (double)a.vox * (a.c0 + a.c1 + a.cout + (a.residual ? a.cout : 0)));
+#define CD_PW_CASE(C, P)                                                                   \
+  if (CT == C && a.prologue == P) {                                                        \
+    hipLaunchKernelGGL((pointwise_kernel<C, P>), grid, dim3(256), 0, s, a, CTtot);         \
+    CD_HIP(hipGetLastError());                                                             \
+    return;                                                                                \
+  }
+  CD_PW_CASE(1, A_NONE) CD_PW_CASE(2, A_NONE) CD_PW_CASE(3, A_NONE)
+  CD_PW_CASE(1, A_GROUPNORM1) CD_PW_CASE(2, A_GROUPNORM1) CD_PW_CASE(3, A_GROUPNORM1)
+  CD_PW_CASE(1, A_SOFTMAX32) CD_PW_CASE(2, A_SOFTMAX32) CD_PW_CASE(3, A_SOFTMAX32)
+#undef CD_PW_CASE
+  CD_REQUIRE(false, "pointwise conv: no kernel instance");
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// init conv: 3x3x3 cylindrical conv from a few planar channels (x, and the constant R / Z / phi coordinate images,
+// synthesised from their 1-D profiles instead of being materialised: calodiffusion.py:121-142) to 32*k channels-last.
+// One thread per output voxel; weights are wave-uniform => scalar loads.
+// ------------------------------------------------------------------------------------------------------------
+template <int CIN>
+__global__ void __launch_bounds__(256) init_conv_kernel(InitConvArgs a) {
+  const int64_t vox = a.dims.vox();
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  const int ct = blockIdx.z;
+  const bool valid = n < vox;
+  const int D = a.dims.d, H = a.dims.h, W = a.dims.w;
+  const int nn = valid ? (int)n : 0;
+  const int w = nn % W, h = (nn / W) % H, z = nn / (W * H);
+  const float sc = a.scale_b ? a.scale_b[(size_t)b * a.scale_stride] : 1.f;
+
+  float acc[32];
+  const float* __restrict__ bias = a.bias;
+#pragma unroll
+  for (int j = 0; j < 32; ++j) acc[j] = bias ? bias[ct * 32 + j] : 0.f;
+
+  const float* __restrict__ wpk = a.wpk;
+  for (int kd = 0; kd < 3; ++kd) {
+    const int zz = z + kd - 1;
+    for (int kh = 0; kh < 3; ++kh) {
+      int hh = h + kh - 1;
+      hh = hh < 0 ? hh + H : (hh >= H ? hh - H : hh);
+      hh = hh % H;  // H == 1 or 2
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int ww = w + kw - 1;
+        const bool inb = valid && zz >= 0 && zz < D && ww >= 0 && ww < W;
+        const int tap = (kd * 3 + kh) * 3 + kw;
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) {
+          float v = 0.f;
+          if (inb) {
+            if (ci < a.cx) {
+              v = a.x[(((size_t)b * a.cx + ci) * D + zz) * H * W + (size_t)hh * W + ww];
+              if (ci == 0) v *= sc;
+            } else {
+              const int k = ci - a.cx;
+              if (a.use_rz) v = (k == 0) ? a.r_w[ww] : (k == 1 ? a.z_d[zz] : a.phi_h[hh]);
+              else v = a.phi_h[hh];
+            }
+          }
+          const float* __restrict__ wr = wpk + ((size_t)(tap * CIN + ci) * a.cout + ct * 32);
+#pragma unroll
+          for (int j = 0; j < 32; ++j) acc[j] = fmaf(v, wr[j], acc[j]);
+        }
+      }
+    }
+  }
+  if (valid) {
+    f32x4* o = (f32x4*)(a.out + ((size_t)b * vox + n) * a.cout + ct * 32);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) o[q] = f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+  }
+}
+
+void launch_init_conv(const InitConvArgs& a, hipStream_t s) {
+  CD_REQUIRE(a.cout % 32 == 0, "init conv: output channels must be a multiple of 32");
+  CD_REQUIRE(a.cin >= 1 && a.cin <= 4 && a.cx <= a.cin, "init conv: 1..4 input channels supported");
+  dim3 grid((unsigned)((a.dims.vox() + 255) / 256), (unsigned)a.batch, (unsigned)(a.cout / 32));
+  prof::Scope scope("init_conv", s, 2.0 * 27 * a.cin * a.cout * (double)a.dims.vox() * a.batch,
+                    4.0 * a.batch * (double)a.dims.vox() * (a.cx + a.cout));
+  switch (a.cin) {
+    case 1: hipLaunchKernelGGL(init_conv_kernel<1>, grid, dim3(256), 0, s, a); break;
+    case 2: hipLaunchKernelGGL(init_conv_kernel<2>, grid, dim3(256), 0, s, a); break;
+    case 3: hipLaunchKernelGGL(init_conv_kernel<3>, grid, dim3(256), 0, s, a); break;
+    case 4: hipLaunchKernelGGL(init_conv_kernel<4>, grid, dim3(256), 0, s, a); break;
+  }
+  CD_HIP(hipGetLastError());
+}
+
+}  // namespace cd

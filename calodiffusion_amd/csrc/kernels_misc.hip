@@ -1,0 +1,339 @@
+// Small kernels around the U-Net: conditioning MLPs, EDM pre-conditioning head, sampler update, Philox noise,
+// loss reduction and layout transposes.
+#include "cd_common.h"
+
+namespace cd {
+
+// ------------------------------------------------------------------------------------------------------------
+// Conditioning: time MLP, cond MLP (exact-erf GELU), concat, and every ResnetBlock's SiLU->Linear(128, C) projection
+// in ONE launch (20 nn.Linear calls per forward in the reference: models.py:176-180, 575-608, 704-707).
+// Also derives the EDM scalings of Loss.get_scaling (loss.py:29-41) and the time embedding input
+// (calodiffusion.py:144-152) from sigma.  One 128-thread block per sample.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+
+__device__ void dense(const float* __restrict__ w, const float* __restrict__ bias, const float* in, float* out, int nin,
+                      int nout, bool gelu) {
+  for (int j = threadIdx.x; j < nout; j += blockDim.x) {
+    float acc = bias[j];
+    const float* wr = w + (size_t)j * nin;
+    for (int k = 0; k < nin; ++k) acc = fmaf(wr[k], in[k], acc);
+    out[j] = gelu ? gelu_erf(acc) : acc;
+  }
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(128) embed_kernel(EmbedArgs a) {
+  __shared__ float bufA[256], bufB[256], cat[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float tv = a.time_or_sigma[b];
+  float t_in = tv;
+  if (a.time_kind == 0) t_in = 0.5f * logf(tv);
+  else if (a.time_kind == 1) t_in = tv / sqrtf(1.f + tv * tv);
+  if (a.scal && tid == 0) {
+    const float sd = a.sigma_data;
+    const float s2 = tv * tv + sd * sd;
+    a.scal[b * 4 + 0] = 1.f / sqrtf(s2);           // c_in
+    a.scal[b * 4 + 1] = sd * sd / s2;              // c_skip
+    a.scal[b * 4 + 2] = tv * sd / sqrtf(s2);       // c_out
+    a.scal[b * 4 + 3] = tv;
+  }
+  const int half = a.half, q = half / 2;
+  // time branch: Linear(1, half/2) GELU Linear(half/2, half) GELU Linear(half, half)
+  if (tid == 0) bufA[0] = t_in;
+  __syncthreads();
+  dense(a.tw1, a.tb1, bufA, bufB, 1, q, true);
+  dense(a.tw2, a.tb2, bufB, bufA, q, half, true);
+  dense(a.tw3, a.tb3, bufA, cat, half, half, false);
+  // cond branch: Linear(cond_size, hidden) GELU Linear(hidden, half) GELU Linear(half, half)
+  for (int i = tid; i < a.cond_size; i += blockDim.x) bufA[i] = a.cond[(size_t)b * a.cond_size + i];
+  __syncthreads();
+  dense(a.cw1, a.cb1, bufA, bufB, a.cond_size, a.cond_hidden, true);
+  dense(a.cw2, a.cb2, bufB, bufA, a.cond_hidden, half, true);
+  dense(a.cw3, a.cb3, bufA, cat + half, half, half, false);
+  // SiLU of conditions = cat(t, c)  (models.py:707; ResnetBlock.mlp[0])
+  for (int i = tid; i < 2 * half; i += blockDim.x) {
+    const float v = cat[i];
+    bufA[i] = v / (1.f + expf(-v));
+  }
+  __syncthreads();
+  for (int l = 0; l < a.n_layers; ++l) {
+    const EmbedLayer L = a.layers[l];
+    for (int j = tid; j < L.cout; j += blockDim.x) {
+      float acc = L.b[j];
+      const float* wr = L.w + (size_t)j * 2 * half;
+      for (int k = 0; k < 2 * half; ++k) acc = fmaf(wr[k], bufA[k], acc);
+      a.emb[(size_t)b * a.emb_ld + L.offset + j] = acc;
+    }
+  }
+}
+
+void launch_embed(const EmbedArgs& a, hipStream_t s) {
+  CD_REQUIRE(a.half * 2 <= 256 && a.cond_hidden <= 256 && a.cond_size <= 256, "embedding widths above 256 unsupported");
+  prof::Scope scope("embed", s, 0, 0);
+  hipLaunchKernelGGL(embed_kernel, dim3(a.batch), dim3(128), 0, s, a);
+  CD_HIP(hipGetLastError());
+}
+
+// out[b][j] = bias[j] + sum_k w[j][k] * silu(cond[b][k])   (ResnetBlock.mlp, models.py:176-180; block-level tests only)
+__global__ void silu_linear_kernel(const float* __restrict__ cond, const float* __restrict__ w, const float* __restrict__ bias,
+                                   float* __restrict__ out, int nin, int nout) {
+  const int b = blockIdx.x;
+  for (int j = threadIdx.x; j < nout; j += blockDim.x) {
+    float acc = bias[j];
+    for (int k = 0; k < nin; ++k) {
+      const float v = cond[(size_t)b * nin + k];
+      acc = fmaf(w[(size_t)j * nin + k], v / (1.f + expf(-v)), acc);
+    }
+    out[(size_t)b * nout + j] = acc;
+  }
+}
+void launch_silu_linear(const float* cond, const float* w, const float* bias, float* out, int batch, int nin, int nout,
+                        hipStream_t s) {
+  hipLaunchKernelGGL(silu_linear_kernel, dim3(batch), dim3(128), 0, s, cond, w, bias, out, nin, nout);
+  CD_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Head: final 1x1x1 conv 32 -> 1 (models.py:696) fused with the EDM output scaling (calodiffusion.py:161-167).
+// 8 lanes per voxel, each a float4 of the 128-B channel vector.
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) head_kernel(HeadArgs a) {
+  const int64_t total = (int64_t)a.batch * a.vox;
+  const int sub = threadIdx.x & 7;
+  const f32x4 w = *(const f32x4*)(a.w + sub * 4);
+  const float bias = a.bias[0];
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3; i < total; i += ((int64_t)gridDim.x * 256) >> 3) {
+    const f32x4 h = *(const f32x4*)(a.h + (size_t)i * 32 + sub * 4);
+    float p = (h[0] * w[0] + h[1] * w[1]) + (h[2] * w[2] + h[3] * w[3]);
+    p += __shfl_xor(p, 1, 64);
+    p += __shfl_xor(p, 2, 64);
+    p += __shfl_xor(p, 4, 64);
+    if (sub == 0) {
+      float pred = p + bias;
+      if (a.scal) {
+        const int b = (int)(i / a.vox);
+        const float xv = a.x[i];
+        if (a.objective == 0) pred = a.scal[b * 4 + 1] * xv + a.scal[b * 4 + 2] * pred;
+        else if (a.objective == 1) pred = xv - a.scal[b * 4 + 3] * pred;
+      }
+      a.out[i] = pred;
+    }
+  }
+}
+
+void launch_head(const HeadArgs& a, hipStream_t s) {
+  const int64_t total = (int64_t)a.batch * a.vox;
+  int64_t blocks = (total * 8 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  prof::Scope scope("head", s, 64.0 * total, 4.0 * total * 34);
+  hipLaunchKernelGGL(head_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  CD_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Sampler loop helpers (DDim.__call__, models/sample.py:72-107).  Per-step scalars live in device memory so that one
+// captured step graph can be replayed for every iteration.
+//   stepvals = {sigma, sigma_prev*[t>0], ddim_sigma, denom}
+// ------------------------------------------------------------------------------------------------------------
+__global__ void load_step_kernel(const float* __restrict__ table, int* counter, float* stepvals, float* sigma_b, int batch) {
+  const int step = *counter;
+  const float* row = table + (size_t)step * 4;
+  const int tid = threadIdx.x;
+  if (tid < 4) stepvals[tid] = row[tid];
+  const float sg = row[0];
+  for (int i = tid; i < batch; i += blockDim.x) sigma_b[i] = sg;
+  __syncthreads();
+  if (tid == 0) *counter = step + 1;
+}
+void launch_load_step(const float* table, int* counter, float* stepvals, float* sigma_b, int batch, hipStream_t s) {
+  hipLaunchKernelGGL(load_step_kernel, dim3(1), dim3(256), 0, s, table, counter, stepvals, sigma_b, batch);
+  CD_HIP(hipGetLastError());
+}
+
+__global__ void __launch_bounds__(256) ddim_update_kernel(const float* x, const float* __restrict__ x0,
+                                                          const float* __restrict__ noise, const float* __restrict__ sv,
+                                                          float* x_next, float* __restrict__ xs,
+                                                          float* __restrict__ x0s, int64_t n) {
+  const float sigma = sv[0], sprev = sv[1], dsig = sv[2], denom = sv[3];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float xv = x[i], x0v = x0[i];
+    const float eps = (xv - x0v) / sigma;            // noise_pred (sample.py:90)
+    float r = x0v + sprev * eps;                     // mask * sigma_prev * noise_pred (sample.py:104)
+    if (noise) r += dsig * noise[i] / denom;
+    x_next[i] = r;
+    if (xs) xs[i] = r;
+    if (x0s) x0s[i] = x0v;
+  }
+}
+void launch_ddim_update(const float* x, const float* x0, const float* noise, const float* stepvals, float* x_next,
+                        float* xs_slot, float* x0s_slot, int64_t n, hipStream_t s) {
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  prof::Scope scope("ddim_update", s, 0, 12.0 * n);
+  hipLaunchKernelGGL(ddim_update_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, x0, noise, stepvals, x_next, xs_slot,
+                     x0s_slot, n);
+  CD_HIP(hipGetLastError());
+}
+
+// y = x * (*scale)   (x = start * sigma_start, sample.py:66)
+__global__ void scale_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ sc, int64_t n) {
+  const float f = sc[0];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = x[i] * f;
+}
+void launch_scale(const float* x, float* y, const float* sc, int64_t n, hipStream_t s) {
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(scale_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, y, sc, n);
+  CD_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Philox4x32-10 + Box-Muller unit normals.  Element i of a stream is a pure function of (seed, offset + i):
+// counter = (offset+i)/4, lane = (offset+i)%4, so batch shards on different GPUs draw disjoint slices of one stream.
+// (The reference's torch.randn CPU stream (mt19937) cannot be reproduced on device; parity tests pass noise in.)
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+
+__global__ void __launch_bounds__(256) randn_kernel(float* __restrict__ out, int64_t n, uint64_t seed, uint64_t offset) {
+  const uint64_t first = offset >> 2, last = (offset + (uint64_t)n + 3) >> 2;  // counter range [first, last)
+  for (uint64_t ctr = first + (uint64_t)blockIdx.x * 256 + threadIdx.x; ctr < last; ctr += (uint64_t)gridDim.x * 256) {
+    uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    float z[4];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const float u1 = ((float)(c[2 * p] >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0,1)
+      const float u2 = ((float)(c[2 * p + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+      const float rad = sqrtf(-2.f * logf(u1));
+      float sn, cs;
+      sincosf(6.283185307179586f * u2, &sn, &cs);
+      z[2 * p] = rad * cs;
+      z[2 * p + 1] = rad * sn;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint64_t g = ctr * 4 + e;
+      if (g >= offset && g < offset + (uint64_t)n) out[g - offset] = z[e];
+    }
+  }
+}
+void launch_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, hipStream_t s) {
+  if (n <= 0) return;
+  int64_t blocks = (n / 4 + 256) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(randn_kernel, dim3((unsigned)blocks), dim3(256), 0, s, out, n, seed, offset);
+  CD_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Training forward: x_noisy = data + sigma*noise (loss.py:169) and the weighted L2 reduction (loss.py:103-104,176)
+// ------------------------------------------------------------------------------------------------------------
+__global__ void axpy_sigma_kernel(const float* __restrict__ data, const float* __restrict__ noise,
+                                  const float* __restrict__ sigma_b, float* __restrict__ out, int64_t per) {
+  const int b = blockIdx.y;
+  const float sg = sigma_b[b];
+  const size_t base = (size_t)b * per;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per; i += (int64_t)gridDim.x * 256)
+    out[base + i] = data[base + i] + sg * noise[base + i];
+}
+void launch_axpy_sigma(const float* data, const float* noise, const float* sigma_b, float* out, int batch, int64_t per,
+                       hipStream_t s) {
+  int64_t bx = (per + 255) / 256;
+  if (bx > 64) bx = 64;
+  hipLaunchKernelGGL(axpy_sigma_kernel, dim3((unsigned)bx, batch), dim3(256), 0, s, data, noise, sigma_b, out, per);
+  CD_HIP(hipGetLastError());
+}
+
+// partial[b] = sum_i (x0 - data)^2 over sample b (fp64), one block per sample
+__global__ void __launch_bounds__(256) loss_partial_kernel(const float* __restrict__ x0, const float* __restrict__ data,
+                                                           double* __restrict__ partial, int64_t per) {
+  __shared__ double sh[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const size_t base = (size_t)b * per;
+  double acc = 0.0;
+  for (int64_t i = tid; i < per; i += 256) {
+    const float d = x0[base + i] - data[base + i];
+    acc += (double)(d * d);
+  }
+  sh[tid] = acc;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (tid < st) sh[tid] += sh[tid + st];
+    __syncthreads();
+  }
+  if (tid == 0) partial[b] = sh[0];
+}
+void launch_loss_partial(const float* x0, const float* data, const float* sigma_b, double* partial, int batch, int64_t per,
+                         hipStream_t s) {
+  (void)sigma_b;
+  hipLaunchKernelGGL(loss_partial_kernel, dim3(batch), dim3(256), 0, s, x0, data, partial, per);
+  CD_HIP(hipGetLastError());
+}
+// loss = sum_b w_b * partial[b] / (mean_b(w_b) * B * per),  w_b = 1 + 1/sigma_b^2
+__global__ void loss_final_kernel(const double* __restrict__ partial, const float* __restrict__ sigma_b, double* loss,
+                                  int batch, int64_t per) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double num = 0.0, wsum = 0.0;
+    for (int b = 0; b < batch; ++b) {
+      const float sg = sigma_b[b];
+      const float w = 1.0f + 1.0f / (sg * sg);
+      num += (double)w * partial[b];
+      wsum += (double)w;
+    }
+    loss[0] = num / ((wsum / batch) * (double)batch * (double)per);
+  }
+}
+void launch_loss_final(const double* partial, const float* sigma_b, double* loss, int batch, int64_t per, hipStream_t s) {
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, s, partial, sigma_b, loss, batch, per);
+  CD_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// layout transposes (tests / generic unet_forward input only; the denoise path never transposes: its I/O has C = 1)
+// ------------------------------------------------------------------------------------------------------------
+__global__ void to_cl_kernel(const float* __restrict__ src, float* __restrict__ dst, int channels, int64_t vox) {
+  const int b = blockIdx.y;
+  const int64_t total = vox * channels;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % channels);
+    const int64_t v = i / channels;
+    dst[(size_t)b * total + i] = src[(size_t)b * total + (size_t)c * vox + v];
+  }
+}
+__global__ void to_planar_kernel(const float* __restrict__ src, float* __restrict__ dst, int channels, int64_t vox) {
+  const int b = blockIdx.y;
+  const int64_t total = vox * channels;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t v = i % vox;
+    const int c = (int)(i / vox);
+    dst[(size_t)b * total + i] = src[(size_t)b * total + (size_t)v * channels + c];
+  }
+}
+void launch_transpose_to_cl(const float* ncdhw, float* ndhwc, int batch, int channels, int64_t vox, hipStream_t s) {
+  int64_t bx = (vox * channels + 255) / 256;
+  if (bx > 1024) bx = 1024;
+  hipLaunchKernelGGL(to_cl_kernel, dim3((unsigned)bx, batch), dim3(256), 0, s, ncdhw, ndhwc, channels, vox);
+  CD_HIP(hipGetLastError());
+}
+void launch_transpose_to_planar(const float* ndhwc, float* ncdhw, int batch, int channels, int64_t vox, hipStream_t s) {
+  int64_t bx = (vox * channels + 255) / 256;
+  if (bx > 1024) bx = 1024;
+  hipLaunchKernelGGL(to_planar_kernel, dim3((unsigned)bx, batch), dim3(256), 0, s, ndhwc, ncdhw, channels, vox);
+  CD_HIP(hipGetLastError());
+}
+
+}  // namespace cd

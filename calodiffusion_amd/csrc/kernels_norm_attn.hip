@@ -1,0 +1,273 @@
+// GroupNorm and linear-attention kernels (HBM-bound passes) for channels-last fp32 activations on gfx950.
+// Reference semantics: nn.GroupNorm(eps=1e-5, biased variance) as used by Block / PreNorm / LinearAttention.to_out
+// (calodiffusion/models/models.py:155,293,325) and LinearAttention.forward (models.py:301-318).
+#include "cd_common.h"
+
+namespace cd {
+
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+// ------------------------------------------------------------------------------------------------------------
+// GroupNorm statistics: per (sample, group) partial (sum, sum of squares) in fp64 over `nsplit` voxel ranges.
+// Consumers reduce the nsplit partials in a fixed order => bitwise deterministic statistics.
+// ------------------------------------------------------------------------------------------------------------
+int gn_nsplit_for(int64_t vox, int batch) {
+  // enough blocks to fill 256 CUs a few times over, but >= 256 voxels per block
+  int64_t want = (2048 + batch - 1) / batch;
+  int64_t cap = (vox + 255) / 256;
+  int64_t n = want < cap ? want : cap;
+  if (n < 1) n = 1;
+  if (n > 64) n = 64;
+  return (int)n;
+}
+
+__global__ void __launch_bounds__(256) gn_stats_kernel(const float* __restrict__ x, double* __restrict__ partials,
+                                                       int channels, int64_t vox, int groups, int nsplit) {
+  __shared__ double sP[256][2];
+  __shared__ double sC[64][2];
+  const int tid = threadIdx.x;
+  const int split = blockIdx.x, b = blockIdx.y;
+  const int cols = channels >> 2;           // float4 columns per voxel
+  const int rows = 256 / cols;              // voxels per pass
+  const int64_t per = (vox + nsplit - 1) / nsplit;
+  const int64_t v0 = split * per;
+  const int64_t v1 = (v0 + per < vox) ? v0 + per : vox;
+  const int colid = tid % cols, row = tid / cols;
+  float s1 = 0.f, s2 = 0.f;
+  if (row < rows) {
+    const float* base = x + (size_t)b * vox * channels + colid * 4;
+    for (int64_t v = v0 + row; v < v1; v += rows) {
+      const f32x4 t = *(const f32x4*)(base + (size_t)v * channels);
+      s1 += (t[0] + t[1]) + (t[2] + t[3]);
+      s2 += (t[0] * t[0] + t[1] * t[1]) + (t[2] * t[2] + t[3] * t[3]);
+    }
+  }
+  sP[tid][0] = (double)s1;
+  sP[tid][1] = (double)s2;
+  __syncthreads();
+  if (tid < cols) {
+    double a1 = 0.0, a2 = 0.0;
+    for (int r = 0; r < rows; ++r) {
+      a1 += sP[r * cols + tid][0];
+      a2 += sP[r * cols + tid][1];
+    }
+    sC[tid][0] = a1;
+    sC[tid][1] = a2;
+  }
+  __syncthreads();
+  if (tid < groups) {
+    const int cpg4 = cols / groups;  // float4 columns per group
+    double a1 = 0.0, a2 = 0.0;
+    for (int c = 0; c < cpg4; ++c) {
+      a1 += sC[tid * cpg4 + c][0];
+      a2 += sC[tid * cpg4 + c][1];
+    }
+    double* p = partials + (((size_t)b * groups + tid) * nsplit + split) * 2;
+    p[0] = a1;
+    p[1] = a2;
+  }
+}
+
+void launch_gn_stats(const float* x, double* partials, int batch, int channels, int64_t vox, int groups, int nsplit,
+                     hipStream_t s) {
+  CD_REQUIRE(channels % 4 == 0 && channels <= 256, "group norm: channels must be a multiple of 4 and <= 256");
+  CD_REQUIRE(channels % groups == 0 && (channels / groups) % 4 == 0, "group norm: channels per group must be a multiple of 4");
+  prof::Scope scope("gn_stats", s, 0, 4.0 * batch * (double)vox * channels);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(nsplit, batch), dim3(256), 0, s, x, partials, channels, vox, groups, nsplit);
+  CD_HIP(hipGetLastError());
+}
+
+// y = act((x - mean) * rstd * gamma + beta) [+ add_bc[b][c]] [+ residual]
+__global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                       const double* __restrict__ partials, int nsplit,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       int channels, int64_t vox, int groups, int silu,
+                                                       const float* __restrict__ add_bc, int add_ld,
+                                                       const float* __restrict__ residual, int blocks_per_sample) {
+  __shared__ float sMean[64], sRstd[64];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x / blocks_per_sample, blk = blockIdx.x % blocks_per_sample;
+  if (tid < groups) {
+    const double* p = partials + ((size_t)b * groups + tid) * nsplit * 2;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = 0; i < nsplit; ++i) { s1 += p[2 * i]; s2 += p[2 * i + 1]; }
+    const double cnt = (double)vox * (channels / groups);
+    const double mu = s1 / cnt;
+    double var = s2 / cnt - mu * mu;
+    var = var < 0.0 ? 0.0 : var;
+    sMean[tid] = (float)mu;
+    sRstd[tid] = (float)(1.0 / sqrt(var + 1e-5));
+  }
+  __syncthreads();
+  const int cols = channels >> 2;
+  const int64_t total = vox * cols;  // float4 items of this sample
+  const int64_t per = (total + blocks_per_sample - 1) / blocks_per_sample;
+  const int64_t i0 = blk * per;
+  const int64_t i1 = (i0 + per < total) ? i0 + per : total;
+  const size_t sbase = (size_t)b * vox * channels;
+  const int cpg = channels / groups;
+  for (int64_t i = i0 + tid; i < i1; i += 256) {
+    const int c = (int)(i % cols) * 4;
+    const int g = c / cpg;
+    const float mu = sMean[g], rs = sRstd[g];
+    f32x4 t = *(const f32x4*)(x + sbase + i * 4);
+    const f32x4 gm = *(const f32x4*)(gamma + c);
+    const f32x4 bt = *(const f32x4*)(beta + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = (t[e] - mu) * rs * gm[e] + bt[e];
+      if (silu) v = v / (1.f + expf(-v));
+      t[e] = v;
+    }
+    if (add_bc) {
+      const f32x4 ad = *(const f32x4*)(add_bc + (size_t)b * add_ld + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[e] += ad[e];
+    }
+    if (residual) {
+      const f32x4 rr = *(const f32x4*)(residual + sbase + i * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[e] += rr[e];
+    }
+    *(f32x4*)(y + sbase + i * 4) = t;
+  }
+}
+
+void launch_gn_apply(const float* x, float* y, const double* partials, int nsplit, const float* gamma, const float* beta,
+                     int batch, int channels, int64_t vox, int groups, int silu, const float* add_bc, int add_ld,
+                     const float* residual, hipStream_t s) {
+  CD_REQUIRE(groups <= 64, "group norm: at most 64 groups");
+  const int64_t items = vox * (channels / 4);
+  int bps = (int)((items + 2047) / 2048);  // >= 8 float4 per thread
+  const int want = (4096 + batch - 1) / batch;
+  if (bps > want) bps = want;
+  if (bps < 1) bps = 1;
+  prof::Scope scope("gn_apply", s, 0, 4.0 * batch * (double)vox * channels * (2 + (residual ? 1 : 0)));
+  hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)(batch * bps)), dim3(256), 0, s, x, y, partials, nsplit, gamma, beta,
+                     channels, vox, groups, silu, add_bc, add_ld, residual, bps);
+  CD_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Linear attention (heads = 1, dim_head = 32).  qkv is channels-last (B, n, 96): q = [0,32), k = [32,64), v = [64,96).
+//   k <- softmax over the n voxels (per channel d);  context[d][e] = sum_n k[d,n] v[e,n]      (models.py:309,312)
+//   q <- softmax over the 32 channels (per voxel) * 32^-1/2;  out[e,n] = sum_d context[d][e] q[d,n]   (:308,311,314)
+// Pass 1 (this kernel): per (sample, voxel range) a local max m[d], local sum s[d] = sum exp(k - m) and the
+// un-normalised context partial ctx[d][e] = sum exp(k[n][d] - m[d]) v[n][e] on the matrix cores (K = voxels).
+// Pass 2 (attn_combine_kernel): merge the partials log-sum-exp style and fold the result into the to_out 1x1 conv:
+//   W'[c][d] = scale * sum_e W_out[c][e] context[d][e], written in packed MFMA layout as per-sample weights.
+// Pass 3 is the pointwise kernel with the softmax-32 A prologue and per-sample weights.
+// ------------------------------------------------------------------------------------------------------------
+int attn_nsplit_for(int64_t vox, int batch) {
+  int64_t want = (1024 + batch - 1) / batch;
+  int64_t cap = (vox + 511) / 512;  // >= 128 voxels per wave
+  int64_t n = want < cap ? want : cap;
+  if (n < 1) n = 1;
+  if (n > 128) n = 128;
+  return (int)n;
+}
+size_t attn_partial_floats(int batch, int nsplit) { return (size_t)batch * nsplit * (64 + 1024); }
+
+__global__ void __launch_bounds__(256) attn_context_kernel(const float* __restrict__ qkv, float* __restrict__ partials,
+                                                           int64_t vox, int nsplit) {
+  __shared__ float sMax[4][32];
+  __shared__ float sSum[8][32];
+  __shared__ float sCtx[4][1024];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, col = lane & 31;
+  const int split = blockIdx.x, b = blockIdx.y;
+  const int64_t per = (((vox + nsplit - 1) / nsplit) + 1) & ~(int64_t)1;  // even
+  const int64_t v0 = split * per;
+  const int64_t v1 = (v0 + per < vox) ? v0 + per : vox;
+  const float* base = qkv + (size_t)b * vox * 96;
+
+  // local max of k over this block's voxels, per channel
+  float m = -3.0e38f;
+  for (int64_t n = v0 + 2 * wave + half; n < v1; n += 8) m = fmaxf(m, base[(size_t)n * 96 + 32 + col]);
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  if (half == 0) sMax[wave][col] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(sMax[0][col], sMax[1][col]), fmaxf(sMax[2][col], sMax[3][col]));
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float ssum = 0.f;
+  // A[i = d][k = voxel half] = exp(k[n][d] - m[d]),  B[k][j = e] = v[n][e]
+  for (int64_t n = v0 + 2 * wave + half; n < v0 + per; n += 8) {
+    float av = 0.f, bv = 0.f;
+    if (n < v1) {
+      av = expf(base[(size_t)n * 96 + 32 + col] - m);
+      bv = base[(size_t)n * 96 + 64 + col];
+    }
+    ssum += av;
+    acc = MFMA32(av, bv, acc);
+  }
+  sSum[wave * 2 + half][col] = ssum;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int d = (r & 3) + 8 * (r >> 2) + 4 * half;  // row = A index = channel d; column = e
+    sCtx[wave][d * 32 + col] = acc[r];
+  }
+  __syncthreads();
+  float* out = partials + ((size_t)b * nsplit + split) * (64 + 1024);
+  if (tid < 32) {
+    out[tid] = m;
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += sSum[i][tid];
+    out[32 + tid] = t;
+  }
+  for (int i = tid; i < 1024; i += 256) out[64 + i] = (sCtx[0][i] + sCtx[1][i]) + (sCtx[2][i] + sCtx[3][i]);
+}
+
+void launch_attn_context(const float* qkv, float* partials, int batch, int64_t vox, int nsplit, hipStream_t s) {
+  prof::Scope scope("attn_context", s, 2.0 * 32 * 32 * (double)vox * batch, 4.0 * batch * (double)vox * 96);
+  hipLaunchKernelGGL(attn_context_kernel, dim3(nsplit, batch), dim3(256), 0, s, qkv, partials, vox, nsplit);
+  CD_HIP(hipGetLastError());
+}
+
+__global__ void __launch_bounds__(256) attn_combine_kernel(const float* __restrict__ partials, int nsplit,
+                                                           const float* __restrict__ w_out, int cout,
+                                                           float* __restrict__ wpk_b, float scale) {
+  __shared__ float sM[32], sInv[32];
+  __shared__ float sCtx[1024];
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const float* p = partials + (size_t)b * nsplit * (64 + 1024);
+  if (tid < 32) {
+    float M = -3.0e38f;
+    for (int i = 0; i < nsplit; ++i) M = fmaxf(M, p[(size_t)i * 1088 + tid]);
+    float S = 0.f;
+    for (int i = 0; i < nsplit; ++i) S += p[(size_t)i * 1088 + 32 + tid] * expf(p[(size_t)i * 1088 + tid] - M);
+    sM[tid] = M;
+    sInv[tid] = scale / S;
+  }
+  __syncthreads();
+  for (int i = tid; i < 1024; i += 256) {
+    const int d = i >> 5;
+    float c = 0.f;
+    for (int k = 0; k < nsplit; ++k) c += p[(size_t)k * 1088 + 64 + i] * expf(p[(size_t)k * 1088 + d] - sM[d]);
+    sCtx[i] = c * sInv[d];
+  }
+  __syncthreads();
+  // W'[c][d] = sum_e W_out[c][e] * ctx[d][e]; packed: ((ct*4+q)*64 + h*32+j)*4+e4 with c = ct*32+j, d = h*16 + 4q + e4
+  const int CT = (cout + 31) / 32;
+  float* wo = wpk_b + (size_t)b * CT * 1024;
+  for (int i = tid; i < CT * 1024; i += 256) {
+    const int e4 = i & 3, lane = (i >> 2) & 63, q = (i >> 8) & 3, ct = i >> 10;
+    const int c = ct * 32 + (lane & 31), d = (lane >> 5) * 16 + q * 4 + e4;
+    float acc = 0.f;
+    if (c < cout)
+      for (int e = 0; e < 32; ++e) acc = fmaf(w_out[c * 32 + e], sCtx[d * 32 + e], acc);
+    wo[i] = acc;
+  }
+}
+
+void launch_attn_combine(const float* partials, int nsplit, const float* w_out, int cout, float* wpk_b, int batch,
+                         float scale, hipStream_t s) {
+  prof::Scope scope("attn_combine", s, 0, 0);
+  hipLaunchKernelGGL(attn_combine_kernel, dim3(batch), dim3(256), 0, s, partials, nsplit, w_out, cout, wpk_b, scale);
+  CD_HIP(hipGetLastError());
+}
+
+}  // namespace cd

@@ -1,0 +1,999 @@
+// Host side of the C ABI (include/calodiff.h): plan construction, weight arena, and the launch sequences of
+// CondUnet.forward / CaloDiffusion.denoise / DDim.__call__ / hybrid_weight loss on one HIP stream.
+// Nothing here allocates or synchronises inside a compute call, so a sampler step is hipGraph-capturable.
+#include "../../include/calodiff.h"
+#include "cd_common.h"
+
+#include <array>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace cd {
+
+static thread_local std::string g_last_error;
+void set_error(const std::string& msg) { g_last_error = msg; }
+
+// ------------------------------------------------------------------------------------------------------------
+// weight registry
+// ------------------------------------------------------------------------------------------------------------
+enum PackKind { PK_NONE = 0, PK_CONV = 1, PK_CONVT = 2, PK_INIT = 3 };
+struct WeightEntry {
+  std::string name;
+  int64_t numel = 0;
+  size_t raw_off = 0;   // floats into the arena
+  PackKind pack = PK_NONE;
+  int cin = 0, cout = 0, taps = 0;
+  size_t pk_off = 0;
+  bool set = false;
+};
+
+struct ResW {
+  int cin = 0, cout = 0;
+  bool has_mlp = false, has_res = false;
+  int c1w = -1, c1b = -1, n1g = -1, n1b = -1, c2w = -1, c2b = -1, n2g = -1, n2b = -1, mw = -1, mb = -1, rw = -1, rb = -1;
+  int emb_off = 0;
+};
+struct AttnW {
+  int c = 0;
+  int ng = -1, nb = -1, qkv = -1, ow = -1, ob = -1, gg = -1, gb = -1;
+};
+struct LevelW {
+  ResW r1, r2;
+  AttnW attn;
+  int sw = -1, sb = -1;  // down / up sampling conv
+};
+
+// ------------------------------------------------------------------------------------------------------------
+// workspace allocator: deterministic first-fit over the caller's workspace, replayed identically by a dry run
+// (to size the workspace) and by every real call (so captured graphs see stable addresses).
+// ------------------------------------------------------------------------------------------------------------
+class Arena {
+ public:
+  void reset(char* base, size_t cap, bool dry) {
+    base_ = base; cap_ = cap; dry_ = dry; high_ = 0;
+    blocks_.clear();
+    blocks_.push_back({0, (size_t)1 << 60, true});
+  }
+  void* alloc(size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (bytes == 0) bytes = 256;
+    for (size_t i = 0; i < blocks_.size(); ++i) {
+      if (blocks_[i].free && blocks_[i].size >= bytes) {
+        const size_t off = blocks_[i].off;
+        if (blocks_[i].size > bytes) {
+          Block rest{off + bytes, blocks_[i].size - bytes, true};
+          blocks_[i].size = bytes;
+          blocks_.insert(blocks_.begin() + i + 1, rest);
+        }
+        blocks_[i].free = false;
+        if (off + bytes > high_) high_ = off + bytes;
+        if (!dry_ && off + bytes > cap_) throw Fail{CD_EWORKSPACE, "workspace too small: call cd_plan_workspace_bytes for this batch size"};
+        return dry_ ? (void*)(uintptr_t)(0x1000 + off) : (void*)(base_ + off);
+      }
+    }
+    throw Fail{CD_EWORKSPACE, "workspace allocator exhausted"};
+  }
+  template <typename T>
+  T* get(size_t count) { return (T*)alloc(count * sizeof(T)); }
+  void release(const void* p) {
+    if (!p) return;
+    const size_t off = dry_ ? (size_t)((uintptr_t)p - 0x1000) : (size_t)((const char*)p - base_);
+    for (size_t i = 0; i < blocks_.size(); ++i) {
+      if (blocks_[i].off == off && !blocks_[i].free) {
+        blocks_[i].free = true;
+        if (i + 1 < blocks_.size() && blocks_[i + 1].free) {
+          blocks_[i].size += blocks_[i + 1].size;
+          blocks_.erase(blocks_.begin() + i + 1);
+        }
+        if (i > 0 && blocks_[i - 1].free) {
+          blocks_[i - 1].size += blocks_[i].size;
+          blocks_.erase(blocks_.begin() + i);
+        }
+        return;
+      }
+    }
+    throw Fail{CD_EINVAL, "internal: release of unknown workspace block"};
+  }
+  size_t high() const { return high_; }
+  bool dry() const { return dry_; }
+
+ private:
+  struct Block { size_t off, size; bool free; };
+  std::vector<Block> blocks_;
+  char* base_ = nullptr;
+  size_t cap_ = 0, high_ = 0;
+  bool dry_ = false;
+};
+
+}  // namespace cd
+
+using namespace cd;
+
+struct CdPlan {
+  CdUnetDesc desc{};
+  int nres = 0;
+  std::vector<Dims3> shapes;           // per level
+  std::vector<int> up_kz;              // per up step (i = 0 .. nres-2)
+  std::vector<Dims3> up_out;           // expected output dims of each up step
+  std::vector<WeightEntry> weights;
+  std::map<std::string, int> index;
+  float* arena = nullptr;
+  size_t arena_floats = 0;
+
+  int init_w = -1, init_b = -1, head_w = -1, head_b = -1;
+  int tw[3] = {-1, -1, -1}, tb[3] = {-1, -1, -1}, cw[3] = {-1, -1, -1}, cb[3] = {-1, -1, -1};
+  std::vector<LevelW> downs, ups;
+  ResW mid1, mid2, fin;
+  AttnW mid_attn;
+  int emb_ld = 0;
+  EmbedLayer* d_embed_layers = nullptr;
+  int n_embed_layers = 0;
+  std::vector<std::pair<int, int>> embed_list;  // (weight idx of mlp w, emb offset) in ResW order
+
+  float* d_coords = nullptr;  // r[W], z[D], phi[H]
+  bool coords_set = false;
+
+  // sampler state (device): step table, counter, stepvals
+  static constexpr int kMaxSteps = 4096;
+  float* d_table = nullptr;
+  int* d_counter = nullptr;
+  float* d_stepvals = nullptr;
+
+  // cached step graph
+  hipGraphExec_t graph_exec = nullptr;
+  struct GraphKey {
+    int batch = 0; const void* ws = nullptr; const void* cond = nullptr; const void* x = nullptr; int noisy = 0; uint64_t seed = 0, offset = 0;
+    bool operator==(const GraphKey& o) const {
+      return batch == o.batch && ws == o.ws && cond == o.cond && x == o.x && noisy == o.noisy && seed == o.seed && offset == o.offset;
+    }
+  } graph_key;
+
+  Arena ws;
+
+  const float* raw(int i) const { return arena + weights[i].raw_off; }
+  const float* packed(int i) const { return arena + weights[i].pk_off; }
+};
+
+namespace {
+
+int add_weight(CdPlan* p, const std::string& name, int64_t numel, PackKind pk = PK_NONE, int cin = 0, int cout = 0, int taps = 0) {
+  WeightEntry e;
+  e.name = name; e.numel = numel; e.pack = pk; e.cin = cin; e.cout = cout; e.taps = taps;
+  p->weights.push_back(e);
+  p->index[name] = (int)p->weights.size() - 1;
+  return (int)p->weights.size() - 1;
+}
+
+ResW add_res(CdPlan* p, const std::string& pre, int cin, int cout, bool mlp) {
+  ResW r;
+  r.cin = cin; r.cout = cout; r.has_mlp = mlp; r.has_res = cin != cout;
+  if (mlp) {
+    r.mw = add_weight(p, pre + ".mlp.1.weight", (int64_t)cout * p->desc.cond_dim);
+    r.mb = add_weight(p, pre + ".mlp.1.bias", cout);
+    r.emb_off = p->emb_ld;
+    p->emb_ld += cout;
+    p->embed_list.push_back({r.mw, r.emb_off});
+  }
+  r.c1w = add_weight(p, pre + ".block1.proj.conv.weight", (int64_t)cout * cin * 27, PK_CONV, cin, cout, 27);
+  r.c1b = add_weight(p, pre + ".block1.proj.conv.bias", cout);
+  r.n1g = add_weight(p, pre + ".block1.norm.weight", cout);
+  r.n1b = add_weight(p, pre + ".block1.norm.bias", cout);
+  r.c2w = add_weight(p, pre + ".block2.proj.conv.weight", (int64_t)cout * cout * 27, PK_CONV, cout, cout, 27);
+  r.c2b = add_weight(p, pre + ".block2.proj.conv.bias", cout);
+  r.n2g = add_weight(p, pre + ".block2.norm.weight", cout);
+  r.n2b = add_weight(p, pre + ".block2.norm.bias", cout);
+  if (r.has_res) {
+    r.rw = add_weight(p, pre + ".res_conv.conv.weight", (int64_t)cout * cin, PK_CONV, cin, cout, 1);
+    r.rb = add_weight(p, pre + ".res_conv.conv.bias", cout);
+  }
+  return r;
+}
+
+AttnW add_attn(CdPlan* p, const std::string& pre, int c) {
+  AttnW a;
+  a.c = c;
+  a.qkv = add_weight(p, pre + ".fn.fn.to_qkv.conv.weight", (int64_t)96 * c, PK_CONV, c, 96, 1);
+  a.ow = add_weight(p, pre + ".fn.fn.to_out.0.conv.weight", (int64_t)c * 32);
+  a.ob = add_weight(p, pre + ".fn.fn.to_out.0.conv.bias", c);
+  a.gg = add_weight(p, pre + ".fn.fn.to_out.1.weight", c);
+  a.gb = add_weight(p, pre + ".fn.fn.to_out.1.bias", c);
+  a.ng = add_weight(p, pre + ".fn.norm.weight", c);
+  a.nb = add_weight(p, pre + ".fn.norm.bias", c);
+  return a;
+}
+
+void check_channels(int c, const char* what) {
+  if (c % 32 != 0 || c <= 0 || c > 256)
+    throw Fail{CD_EINVAL, std::string(what) + ": channel widths must be multiples of 32 (<= 256) for the MFMA kernels"};
+}
+
+void build_plan(CdPlan* p) {
+  const CdUnetDesc& d = p->desc;
+  CD_REQUIRE(d.n_sizes >= 2 && d.n_sizes <= CD_MAX_SIZES, "LAYER_SIZE_UNET must have 2..8 entries");
+  CD_REQUIRE(d.in_channels >= 1 && d.in_channels <= 4, "in_channels must be 1..4");
+  CD_REQUIRE(d.cond_dim == 128 || (d.cond_dim % 4 == 0 && d.cond_dim <= 256), "COND_SIZE_UNET must be <= 256");
+  CD_REQUIRE(d.cond_size >= 1 && d.cond_size <= 256, "cond_size must be 1..256");
+  CD_REQUIRE(d.groups >= 1 && d.groups <= 64, "BLOCK_GROUPS must be 1..64");
+  for (int i = 0; i < d.n_sizes; ++i) check_channels(d.layer_sizes[i], "LAYER_SIZE_UNET");
+  CD_REQUIRE(d.layer_sizes[0] == 32, "the fused output head needs LAYER_SIZE_UNET[0] == 32");
+  CD_REQUIRE(d.layer_sizes[0] == d.layer_sizes[1], "final_conv expects LAYER_SIZE_UNET[1] input channels (models.py:698): sizes 0 and 1 must agree");
+  for (int i = 0; i < d.n_sizes; ++i)
+    CD_REQUIRE(d.layer_sizes[i] % d.groups == 0 && (d.layer_sizes[i] / d.groups) % 4 == 0,
+               "channels per GroupNorm group must be a multiple of 4");
+  p->nres = d.n_sizes - 1;
+  const int nres = p->nres;
+  const int zs = d.compress_z ? 2 : 1;
+
+  // level shapes and up-sampling geometry (CondUnet.__init__, models.py:619-635; Upsample, :335-348)
+  Dims3 s{d.grid[0], d.grid[1], d.grid[2]};
+  CD_REQUIRE(s.d > 0 && s.h > 0 && s.w > 0, "grid extents must be positive");
+  p->shapes.push_back(s);
+  std::vector<std::array<int, 3>> extras;
+  for (int lv = 0; lv + 1 < nres; ++lv) {
+    extras.push_back({(s.d + 1) % 2, s.h % 2, s.w % 2});
+    const Dims3 n{d.compress_z ? (s.d + 1) / 2 : s.d, s.h / 2, s.w / 2};
+    CD_REQUIRE(n.h >= 1 && n.w >= 1, "grid too small for the number of resolution levels");
+    // the strided conv must actually produce that shape
+    const int od = (s.d + 2 - 3) / zs + 1, oh = (s.h + 2 - 4) / 2 + 1, ow = (s.w + 2 - 4) / 2 + 1;
+    CD_REQUIRE(od == n.d && oh == n.h && ow == n.w, "down-sampling output shape mismatch");
+    s = n;
+    p->shapes.push_back(s);
+  }
+  for (int i = 0; i + 1 < nres; ++i) {
+    const auto e = extras[nres - 2 - i];
+    const int kz = e[0] > 0 ? 4 : 3;
+    const Dims3 in = p->shapes[nres - 1 - i];
+    const Dims3 out{(in.d - 1) * zs - 2 + kz, 2 * in.h + e[1], 2 * in.w + e[2]};
+    const Dims3 want = p->shapes[nres - 2 - i];
+    CD_REQUIRE(out.d == want.d && out.h == want.h && out.w == want.w,
+               "up-sampling output shape does not match the skip connection (the reference would fail in torch.cat)");
+    p->up_kz.push_back(kz);
+    p->up_out.push_back(out);
+  }
+
+  // weights, in CondUnet.state_dict() order
+  const int half = d.cond_dim / 2, hidden = d.cond_size > half / 2 ? d.cond_size : half / 2;
+  p->init_w = add_weight(p, "init_conv.conv.weight", (int64_t)d.layer_sizes[0] * d.in_channels * 27, PK_INIT, d.in_channels, d.layer_sizes[0], 27);
+  p->init_b = add_weight(p, "init_conv.conv.bias", d.layer_sizes[0]);
+  const int tin[3] = {1, half / 2, half}, tout[3] = {half / 2, half, half};
+  for (int i = 0; i < 3; ++i) {
+    p->tw[i] = add_weight(p, "time_mlp." + std::to_string(2 * i + 1) + ".weight", (int64_t)tin[i] * tout[i]);
+    p->tb[i] = add_weight(p, "time_mlp." + std::to_string(2 * i + 1) + ".bias", tout[i]);
+  }
+  const int cin3[3] = {d.cond_size, hidden, half}, cout3[3] = {hidden, half, half};
+  for (int i = 0; i < 3; ++i) {
+    p->cw[i] = add_weight(p, "cond_mlp." + std::to_string(2 * i) + ".weight", (int64_t)cin3[i] * cout3[i]);
+    p->cb[i] = add_weight(p, "cond_mlp." + std::to_string(2 * i) + ".bias", cout3[i]);
+  }
+  p->downs.resize(nres);
+  p->ups.resize(nres);
+  for (int i = 0; i < nres; ++i) {
+    const int ci = d.layer_sizes[i], co = d.layer_sizes[i + 1];
+    const std::string pre = "downs." + std::to_string(i);
+    p->downs[i].r1 = add_res(p, pre + ".0", ci, co, true);
+    p->downs[i].r2 = add_res(p, pre + ".1", co, co, true);
+    if (i + 1 < nres) {
+      p->downs[i].sw = add_weight(p, pre + ".2.conv.weight", (int64_t)co * co * 48, PK_CONV, co, co, 48);
+      p->downs[i].sb = add_weight(p, pre + ".2.conv.bias", co);
+    }
+  }
+  for (int i = 0; i < nres; ++i) {
+    const int lv = nres - 1 - i;
+    const int ci = d.layer_sizes[lv], co = d.layer_sizes[lv + 1];
+    const std::string pre = "ups." + std::to_string(i);
+    p->ups[i].r1 = add_res(p, pre + ".0", co * 2, ci, true);
+    p->ups[i].r2 = add_res(p, pre + ".1", ci, ci, true);
+    if (i + 1 < nres) {
+      const int kz = p->up_kz[i];
+      p->ups[i].sw = add_weight(p, pre + ".2.convTrans.weight", (int64_t)ci * ci * kz * 16, PK_CONVT, ci, ci, kz * 16);
+      p->ups[i].sb = add_weight(p, pre + ".2.convTrans.bias", ci);
+    }
+    check_channels(co * 2, "skip concat");
+  }
+  if (d.block_attn) {
+    for (int i = 0; i < nres; ++i) p->downs[i].attn = add_attn(p, "downs_attn." + std::to_string(i), d.layer_sizes[i + 1]);
+    for (int i = 0; i < nres; ++i) p->ups[i].attn = add_attn(p, "ups_attn." + std::to_string(i), d.layer_sizes[nres - 1 - i]);
+  }
+  const int mid = d.layer_sizes[nres];
+  p->mid1 = add_res(p, "mid_block1", mid, mid, true);
+  if (d.mid_attn) p->mid_attn = add_attn(p, "mid_attn", mid);
+  p->mid2 = add_res(p, "mid_block2", mid, mid, true);
+  p->fin = add_res(p, "final_conv.0", d.layer_sizes[1], d.layer_sizes[0], false);
+  p->head_w = add_weight(p, "final_conv.1.conv.weight", d.layer_sizes[0]);
+  p->head_b = add_weight(p, "final_conv.1.conv.bias", 1);
+
+  // arena layout
+  size_t off = 0;
+  auto bump = [&](size_t n) { size_t o = off; off += (n + 63) & ~(size_t)63; return o; };
+  for (auto& w : p->weights) {
+    w.raw_off = bump((size_t)w.numel);
+    if (w.pack == PK_CONV || w.pack == PK_CONVT) w.pk_off = bump(packed_weight_floats(w.cin, w.cout, w.taps));
+    else if (w.pack == PK_INIT) w.pk_off = bump((size_t)w.numel);
+  }
+  p->arena_floats = off;
+  CD_HIP(hipMalloc((void**)&p->arena, off * sizeof(float)));
+  CD_HIP(hipMemset(p->arena, 0, off * sizeof(float)));
+
+  // embedding projection descriptors
+  std::vector<EmbedLayer> layers;
+  for (auto& e : p->embed_list) {
+    const WeightEntry& w = p->weights[e.first];
+    EmbedLayer L;
+    L.w = p->arena + w.raw_off;
+    L.b = p->arena + p->weights[e.first + 1].raw_off;
+    L.cout = (int)(w.numel / d.cond_dim);
+    L.offset = e.second;
+    layers.push_back(L);
+  }
+  p->n_embed_layers = (int)layers.size();
+  CD_HIP(hipMalloc((void**)&p->d_embed_layers, sizeof(EmbedLayer) * (layers.size() + 1)));
+  CD_HIP(hipMemcpy(p->d_embed_layers, layers.data(), sizeof(EmbedLayer) * layers.size(), hipMemcpyHostToDevice));
+  if (p->emb_ld == 0) p->emb_ld = 4;
+
+  CD_HIP(hipMalloc((void**)&p->d_coords, sizeof(float) * (size_t)(d.grid[0] + d.grid[1] + d.grid[2] + 4)));
+  CD_HIP(hipMalloc((void**)&p->d_table, sizeof(float) * 4 * CdPlan::kMaxSteps));
+  CD_HIP(hipMalloc((void**)&p->d_counter, sizeof(int) * 4));
+  CD_HIP(hipMalloc((void**)&p->d_stepvals, sizeof(float) * 8));
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// launch sequences
+// ------------------------------------------------------------------------------------------------------------
+struct Run {
+  Arena* ws;
+  hipStream_t s;
+  int B;
+  int groups;
+  bool dry() const { return ws->dry(); }
+};
+
+// weights of one block resolved to device pointers (conv weights in packed MFMA layout)
+struct ResP {
+  int cin = 0, cout = 0;
+  bool has_res = false;
+  const float *c1w = nullptr, *c1b = nullptr, *n1g = nullptr, *n1b = nullptr;
+  const float *c2w = nullptr, *c2b = nullptr, *n2g = nullptr, *n2b = nullptr;
+  const float *rw = nullptr, *rb = nullptr;
+  const float* emb = nullptr;  // (B, emb_ld) slice for this block, or null
+  int emb_ld = 0;
+};
+struct AttnP {
+  int c = 0;
+  const float *ng = nullptr, *nb = nullptr, *qkv = nullptr, *ow = nullptr, *ob = nullptr, *gg = nullptr, *gb = nullptr;
+};
+
+ResP resolve(const CdPlan* p, const ResW& w, const float* emb) {
+  ResP r;
+  r.cin = w.cin; r.cout = w.cout; r.has_res = w.has_res;
+  r.c1w = p->packed(w.c1w); r.c1b = p->raw(w.c1b); r.n1g = p->raw(w.n1g); r.n1b = p->raw(w.n1b);
+  r.c2w = p->packed(w.c2w); r.c2b = p->raw(w.c2b); r.n2g = p->raw(w.n2g); r.n2b = p->raw(w.n2b);
+  if (w.has_res) { r.rw = p->packed(w.rw); r.rb = p->raw(w.rb); }
+  if (w.has_mlp && emb) { r.emb = emb + w.emb_off; r.emb_ld = p->emb_ld; }
+  return r;
+}
+AttnP resolve(const CdPlan* p, const AttnW& w) {
+  AttnP a;
+  a.c = w.c;
+  a.ng = p->raw(w.ng); a.nb = p->raw(w.nb); a.qkv = p->packed(w.qkv); a.ow = p->raw(w.ow); a.ob = p->raw(w.ob);
+  a.gg = p->raw(w.gg); a.gb = p->raw(w.gb);
+  return a;
+}
+
+double* gn_stats(Run& r, const float* x, int C, int64_t vox, int G, int* nsplit_out) {
+  const int ns = gn_nsplit_for(vox, r.B);
+  double* part = r.ws->get<double>((size_t)r.B * G * ns * 2);
+  if (!r.dry()) launch_gn_stats(x, part, r.B, C, vox, G, ns, r.s);
+  *nsplit_out = ns;
+  return part;
+}
+
+// ResnetBlock.forward (models.py:191-200): block1 -> (+ mlp(cond)) -> block2 -> + res_conv(x)
+float* res_block(Run& r, const ResP& w, const float* x0, int c0, const float* x1, int c1, Dims3 dims) {
+  Arena* ws = r.ws;
+  CD_REQUIRE(c0 + c1 == w.cin, "internal: resnet block input width mismatch");
+  const int64_t vox = dims.vox();
+  const int G = r.groups;
+  ConvGeom g{dims, dims, 3, 3, 3, 1, 1, 1};
+  float* h1 = ws->get<float>((size_t)r.B * vox * w.cout);
+  if (!r.dry()) launch_conv_mfma(x0, c0, x1, c1, w.c1w, w.c1b, h1, r.B, w.cout, g, r.s);
+  int ns;
+  double* st = gn_stats(r, h1, w.cout, vox, G, &ns);
+  if (!r.dry()) launch_gn_apply(h1, h1, st, ns, w.n1g, w.n1b, r.B, w.cout, vox, G, 1, w.emb, w.emb_ld, nullptr, r.s);
+  ws->release(st);
+  float* h2 = ws->get<float>((size_t)r.B * vox * w.cout);
+  if (!r.dry()) launch_conv_mfma(h1, w.cout, nullptr, 0, w.c2w, w.c2b, h2, r.B, w.cout, g, r.s);
+  ws->release(h1);
+  st = gn_stats(r, h2, w.cout, vox, G, &ns);
+  if (w.has_res) {
+    float* res = ws->get<float>((size_t)r.B * vox * w.cout);
+    if (!r.dry()) {
+      PointwiseArgs a;
+      a.in0 = x0; a.ld0 = c0; a.off0 = 0; a.c0 = c0; a.in1 = x1; a.ld1 = c1; a.c1 = c1;
+      a.wpk = w.rw; a.bias = w.rb; a.out = res; a.batch = r.B; a.cout = w.cout; a.vox = vox;
+      launch_pointwise(a, r.s);
+      launch_gn_apply(h2, h2, st, ns, w.n2g, w.n2b, r.B, w.cout, vox, G, 1, nullptr, 0, res, r.s);
+    }
+    ws->release(res);
+  } else {
+    CD_REQUIRE(c1 == 0, "internal: identity residual on a concatenated input");
+    if (!r.dry()) launch_gn_apply(h2, h2, st, ns, w.n2g, w.n2b, r.B, w.cout, vox, G, 1, nullptr, 0, x0, r.s);
+  }
+  ws->release(st);
+  return h2;
+}
+
+// Residual(PreNorm(LinearAttention)) (models.py:111-117, 281-329)
+float* attn_block(Run& r, const AttnP& w, const float* x, Dims3 dims) {
+  Arena* ws = r.ws;
+  const int64_t vox = dims.vox();
+  const int C = w.c;
+  int ns;
+  double* st = gn_stats(r, x, C, vox, 1, &ns);
+  float* qkv = ws->get<float>((size_t)r.B * vox * 96);
+  if (!r.dry()) {
+    PointwiseArgs a;
+    a.in0 = x; a.ld0 = C; a.c0 = C; a.wpk = w.qkv; a.out = qkv; a.batch = r.B; a.cout = 96; a.vox = vox;
+    a.prologue = A_GROUPNORM1; a.gn_partials = st; a.gn_nsplit = ns; a.gn_gamma = w.ng; a.gn_beta = w.nb;
+    launch_pointwise(a, r.s);
+  }
+  ws->release(st);
+  const int nsp = attn_nsplit_for(vox, r.B);
+  float* part = ws->get<float>(attn_partial_floats(r.B, nsp));
+  const int CT = (C + 31) / 32;
+  float* wpb = ws->get<float>((size_t)r.B * CT * 1024);
+  if (!r.dry()) {
+    launch_attn_context(qkv, part, r.B, vox, nsp, r.s);
+    launch_attn_combine(part, nsp, w.ow, C, wpb, r.B, 0.17677669529663689f /* 32^-1/2 */, r.s);
+  }
+  float* y = ws->get<float>((size_t)r.B * vox * C);
+  if (!r.dry()) {
+    PointwiseArgs a;
+    a.in0 = qkv; a.ld0 = 96; a.off0 = 0; a.c0 = 32; a.wpk = wpb; a.w_batch_stride = (int64_t)CT * 1024; a.bias = w.ob;
+    a.out = y; a.batch = r.B; a.cout = C; a.vox = vox; a.prologue = A_SOFTMAX32;
+    launch_pointwise(a, r.s);
+  }
+  ws->release(part);
+  ws->release(wpb);
+  ws->release(qkv);
+  st = gn_stats(r, y, C, vox, 1, &ns);
+  if (!r.dry()) launch_gn_apply(y, y, st, ns, w.gg, w.gb, r.B, C, vox, 1, 0, nullptr, 0, x, r.s);
+  ws->release(st);
+  return y;
+}
+
+// CondUnet.forward after init_conv / embeddings (models.py:713-748). Takes ownership of h (a workspace block).
+float* unet_body(CdPlan* p, Run& r, const float* emb, float* h) {
+  const CdUnetDesc& d = p->desc;
+  const int nres = p->nres;
+  const int zs = d.compress_z ? 2 : 1;
+  std::vector<float*> skips(nres, nullptr);
+  float* x = h;
+  int cx = d.layer_sizes[0];
+  for (int i = 0; i < nres; ++i) {
+    const Dims3 dims = p->shapes[i];
+    float* t = res_block(r, resolve(p, p->downs[i].r1, emb), x, cx, nullptr, 0, dims);
+    r.ws->release(x);
+    x = t; cx = p->downs[i].r1.cout;
+    t = res_block(r, resolve(p, p->downs[i].r2, emb), x, cx, nullptr, 0, dims);
+    r.ws->release(x);
+    x = t;
+    if (d.block_attn) {
+      t = attn_block(r, resolve(p, p->downs[i].attn), x, dims);
+      r.ws->release(x);
+      x = t;
+    }
+    skips[i] = x;
+    if (i + 1 < nres) {
+      const Dims3 nd = p->shapes[i + 1];
+      float* y = r.ws->get<float>((size_t)r.B * nd.vox() * cx);
+      if (!r.dry()) {
+        ConvGeom g{dims, nd, 3, 4, 4, zs, 2, 2};
+        launch_conv_mfma(x, cx, nullptr, 0, p->packed(p->downs[i].sw), p->raw(p->downs[i].sb), y, r.B, cx, g, r.s);
+      }
+      x = y;
+    } else {
+      // Identity: the last level's skip and the running tensor are the same tensor (models.py:719-720)
+      x = skips[i];
+    }
+  }
+  const Dims3 md = p->shapes[nres - 1];
+  float* t = res_block(r, resolve(p, p->mid1, emb), x, cx, nullptr, 0, md);
+  // x aliases skips[nres-1]: keep it alive for the concat
+  x = t;
+  if (d.mid_attn) {
+    t = attn_block(r, resolve(p, p->mid_attn), x, md);
+    r.ws->release(x);
+    x = t;
+  }
+  t = res_block(r, resolve(p, p->mid2, emb), x, cx, nullptr, 0, md);
+  r.ws->release(x);
+  x = t;
+
+  for (int i = 0; i < nres; ++i) {
+    const int lv = nres - 1 - i;
+    const Dims3 dims = p->shapes[lv];
+    const int cs = d.layer_sizes[lv + 1];  // width of the skip (and of x after the previous stage)
+    CD_REQUIRE(cx == cs, "internal: up path width mismatch");
+    t = res_block(r, resolve(p, p->ups[i].r1, emb), x, cx, skips[lv], cs, dims);
+    r.ws->release(x);
+    r.ws->release(skips[lv]);
+    x = t; cx = p->ups[i].r1.cout;
+    t = res_block(r, resolve(p, p->ups[i].r2, emb), x, cx, nullptr, 0, dims);
+    r.ws->release(x);
+    x = t;
+    if (d.block_attn) {
+      t = attn_block(r, resolve(p, p->ups[i].attn), x, dims);
+      r.ws->release(x);
+      x = t;
+    }
+    if (i + 1 < nres) {
+      const Dims3 od = p->up_out[i];
+      float* y = r.ws->get<float>((size_t)r.B * od.vox() * cx);
+      if (!r.dry())
+        launch_conv_transpose_mfma(x, cx, p->packed(p->ups[i].sw), p->raw(p->ups[i].sb), y, r.B, cx, dims, od, p->up_kz[i], zs, r.s);
+      r.ws->release(x);
+      x = y;
+    }
+  }
+  t = res_block(r, resolve(p, p->fin, nullptr), x, cx, nullptr, 0, p->shapes[0]);
+  r.ws->release(x);
+  return t;
+}
+
+void check_ready(CdPlan* p, bool need_coords) {
+  for (auto& w : p->weights)
+    if (!w.set) throw Fail{CD_EWEIGHTS, "weight '" + w.name + "' was never set (cd_plan_set_weight)"};
+  if (need_coords && (p->desc.rz_input || p->desc.phi_input) && !p->coords_set)
+    throw Fail{CD_EWEIGHTS, "coordinate profiles were never set (cd_plan_set_coords)"};
+}
+
+EmbedArgs embed_args(CdPlan* p, int B, const float* cond, const float* t, int kind, float* emb, float* scal) {
+  const CdUnetDesc& d = p->desc;
+  EmbedArgs e;
+  e.cond = cond; e.time_or_sigma = t; e.time_kind = kind; e.sigma_data = d.sigma_data;
+  e.cond_size = d.cond_size; e.half = d.cond_dim / 2;
+  e.cond_hidden = d.cond_size > e.half / 2 ? d.cond_size : e.half / 2;
+  e.tw1 = p->raw(p->tw[0]); e.tb1 = p->raw(p->tb[0]); e.tw2 = p->raw(p->tw[1]); e.tb2 = p->raw(p->tb[1]);
+  e.tw3 = p->raw(p->tw[2]); e.tb3 = p->raw(p->tb[2]);
+  e.cw1 = p->raw(p->cw[0]); e.cb1 = p->raw(p->cb[0]); e.cw2 = p->raw(p->cw[1]); e.cb2 = p->raw(p->cb[1]);
+  e.cw3 = p->raw(p->cw[2]); e.cb3 = p->raw(p->cb[2]);
+  e.layers = p->d_embed_layers; e.n_layers = p->n_embed_layers; e.emb = emb; e.emb_ld = p->emb_ld; e.scal = scal; e.batch = B;
+  return e;
+}
+
+// shared by cd_unet_forward (raw = true) and cd_denoise; workspace must have been reset by the caller
+void forward_impl(CdPlan* p, int B, const float* x, const float* cond, const float* t, float* out, bool raw, hipStream_t s) {
+  const CdUnetDesc& d = p->desc;
+  const Dims3 dims = p->shapes[0];
+  Run r{&p->ws, s, B, d.groups};
+  float* emb = p->ws.get<float>((size_t)B * p->emb_ld);
+  float* scal = p->ws.get<float>((size_t)B * 4);
+  float* h = p->ws.get<float>((size_t)B * dims.vox() * d.layer_sizes[0]);
+  if (!r.dry()) {
+    launch_embed(embed_args(p, B, cond, t, raw ? CD_TIME_RAW : d.time_embed_kind, emb, raw ? nullptr : scal), s);
+    InitConvArgs a;
+    a.x = x; a.cin = d.in_channels; a.wpk = p->packed(p->init_w); a.bias = p->raw(p->init_b); a.out = h; a.batch = B;
+    a.cout = d.layer_sizes[0]; a.dims = dims;
+    if (raw) {
+      a.cx = d.in_channels;
+    } else {
+      a.cx = 1; a.scale_b = scal; a.scale_stride = 4; a.use_rz = d.rz_input; a.use_phi = d.phi_input;
+      a.r_w = p->d_coords; a.z_d = p->d_coords + d.grid[2]; a.phi_h = p->d_coords + d.grid[2] + d.grid[0];
+    }
+    launch_init_conv(a, s);
+  }
+  float* hf = unet_body(p, r, emb, h);
+  if (!r.dry()) {
+    HeadArgs ha;
+    ha.h = hf; ha.w = p->raw(p->head_w); ha.bias = p->raw(p->head_b); ha.out = out; ha.batch = B; ha.vox = dims.vox();
+    if (!raw) { ha.x = x; ha.scal = scal; ha.objective = d.objective; }
+    launch_head(ha, s);
+  }
+  r.ws->release(hf);
+  r.ws->release(scal);
+  r.ws->release(emb);
+}
+
+template <typename F>
+int guarded(F&& f) {
+  try {
+    f();
+    return CD_OK;
+  } catch (const Fail& e) {
+    set_error(e.msg);
+    return e.code;
+  } catch (const std::exception& e) {
+    set_error(std::string("internal error: ") + e.what());
+    return CD_EINVAL;
+  }
+}
+
+void destroy_graph(CdPlan* p) {
+  if (p->graph_exec) {
+    hipGraphExecDestroy(p->graph_exec);
+    p->graph_exec = nullptr;
+  }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* cd_last_error(void) { return g_last_error.c_str(); }
+
+int cd_device_check(char* name, int cap) {
+  return guarded([&] {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) throw Fail{CD_ENOGPU, "no HIP device visible"};
+    int dev = 0;
+    CD_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    CD_HIP(hipGetDeviceProperties(&prop, dev));
+    if (name && cap > 0) {
+      std::snprintf(name, cap, "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+      throw Fail{CD_ENOGPU, std::string("this library is built for gfx950 only; found ") + prop.gcnArchName};
+  });
+}
+
+int cd_plan_create(const CdUnetDesc* desc, CdPlan** plan) {
+  return guarded([&] {
+    CD_REQUIRE(desc && plan, "null argument");
+    std::unique_ptr<CdPlan> p(new CdPlan());
+    p->desc = *desc;
+    build_plan(p.get());
+    *plan = p.release();
+  });
+}
+
+int cd_plan_destroy(CdPlan* plan) {
+  return guarded([&] {
+    if (!plan) return;
+    destroy_graph(plan);
+    if (plan->arena) hipFree(plan->arena);
+    if (plan->d_embed_layers) hipFree(plan->d_embed_layers);
+    if (plan->d_coords) hipFree(plan->d_coords);
+    if (plan->d_table) hipFree(plan->d_table);
+    if (plan->d_counter) hipFree(plan->d_counter);
+    if (plan->d_stepvals) hipFree(plan->d_stepvals);
+    delete plan;
+  });
+}
+
+int cd_plan_num_weights(const CdPlan* plan, int* n) {
+  return guarded([&] {
+    CD_REQUIRE(plan && n, "null argument");
+    *n = (int)plan->weights.size();
+  });
+}
+
+int cd_plan_weight_name(const CdPlan* plan, int idx, char* name, int cap, int64_t* numel) {
+  return guarded([&] {
+    CD_REQUIRE(plan && idx >= 0 && idx < (int)plan->weights.size(), "weight index out of range");
+    if (name && cap > 0) std::snprintf(name, cap, "%s", plan->weights[idx].name.c_str());
+    if (numel) *numel = plan->weights[idx].numel;
+  });
+}
+
+int cd_plan_set_weight(CdPlan* plan, const char* name, const float* dev_ptr, int64_t numel, void* stream) {
+  return guarded([&] {
+    CD_REQUIRE(plan && name && dev_ptr, "null argument");
+    auto it = plan->index.find(name);
+    if (it == plan->index.end()) throw Fail{CD_EWEIGHTS, std::string("unknown weight name '") + name + "'"};
+    WeightEntry& w = plan->weights[it->second];
+    if (w.numel != numel)
+      throw Fail{CD_EWEIGHTS, std::string("weight '") + name + "' has " + std::to_string(numel) + " elements, expected " + std::to_string(w.numel)};
+    hipStream_t s = (hipStream_t)stream;
+    CD_HIP(hipMemcpyAsync(plan->arena + w.raw_off, dev_ptr, sizeof(float) * (size_t)numel, hipMemcpyDeviceToDevice, s));
+    if (w.pack == PK_CONV) launch_pack_weights(plan->arena + w.raw_off, plan->arena + w.pk_off, w.cout, w.cin, w.taps, false, s);
+    else if (w.pack == PK_CONVT) launch_pack_weights(plan->arena + w.raw_off, plan->arena + w.pk_off, w.cout, w.cin, w.taps, true, s);
+    else if (w.pack == PK_INIT) launch_pack_init_weights(plan->arena + w.raw_off, plan->arena + w.pk_off, w.cout, w.cin, s);
+    w.set = true;
+  });
+}
+
+int cd_plan_set_coords(CdPlan* plan, const float* r_w, const float* z_d, const float* phi_h, void* stream) {
+  return guarded([&] {
+    CD_REQUIRE(plan && r_w && z_d && phi_h, "null argument");
+    const CdUnetDesc& d = plan->desc;
+    hipStream_t s = (hipStream_t)stream;
+    CD_HIP(hipMemcpyAsync(plan->d_coords, r_w, sizeof(float) * d.grid[2], hipMemcpyHostToDevice, s));
+    CD_HIP(hipMemcpyAsync(plan->d_coords + d.grid[2], z_d, sizeof(float) * d.grid[0], hipMemcpyHostToDevice, s));
+    CD_HIP(hipMemcpyAsync(plan->d_coords + d.grid[2] + d.grid[0], phi_h, sizeof(float) * d.grid[1], hipMemcpyHostToDevice, s));
+    CD_HIP(hipStreamSynchronize(s));  // the host arrays may be temporaries
+    plan->coords_set = true;
+  });
+}
+
+int cd_plan_workspace_bytes(CdPlan* plan, int batch, size_t* bytes) {
+  return guarded([&] {
+    CD_REQUIRE(plan && bytes && batch > 0, "bad argument");
+    const int64_t n = (int64_t)batch * plan->shapes[0].vox();
+    plan->ws.reset(nullptr, 0, true);
+    // superset of what any entry point allocates around forward_impl: x0 / noise / x_noisy, sigma, partials
+    float* a = plan->ws.get<float>((size_t)n);
+    float* b = plan->ws.get<float>((size_t)n);
+    float* c = plan->ws.get<float>((size_t)batch + 64);
+    double* dd = plan->ws.get<double>((size_t)batch + 8);
+    forward_impl(plan, batch, nullptr, nullptr, nullptr, nullptr, false, nullptr);
+    (void)a; (void)b; (void)c; (void)dd;
+    *bytes = plan->ws.high() + 4096;
+  });
+}
+
+int cd_unet_forward(CdPlan* plan, int batch, const float* x, const float* cond, const float* time, float* out,
+                    void* workspace, size_t workspace_bytes, void* stream) {
+  return guarded([&] {
+    CD_REQUIRE(plan && x && cond && time && out && workspace && batch > 0, "bad argument");
+    check_ready(plan, false);
+    plan->ws.reset((char*)workspace, workspace_bytes, false);
+    forward_impl(plan, batch, x, cond, time, out, true, (hipStream_t)stream);
+  });
+}
+
+int cd_denoise(CdPlan* plan, int batch, const float* x, const float* sigma, const float* cond, float* out,
+               void* workspace, size_t workspace_bytes, void* stream) {
+  return guarded([&] {
+    CD_REQUIRE(plan && x && sigma && cond && out && workspace && batch > 0, "bad argument");
+    check_ready(plan, true);
+    plan->ws.reset((char*)workspace, workspace_bytes, false);
+    forward_impl(plan, batch, x, cond, sigma, out, false, (hipStream_t)stream);
+  });
+}
+
+int cd_profile_begin(void) {
+  return guarded([&] { prof::begin(); });
+}
+int cd_profile_end(char* json, int cap) {
+  return guarded([&] {
+    CD_REQUIRE(json && cap > 2, "bad argument");
+    if (prof::end(json, cap) < 0) throw Fail{CD_EINVAL, "profile buffer too small"};
+  });
+}
+
+int cd_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream) {
+  return guarded([&] {
+    CD_REQUIRE(out && n >= 0, "bad argument");
+    launch_randn(out, n, seed, offset, (hipStream_t)stream);
+  });
+}
+
+int cd_ddim_sample(CdPlan* plan, int batch, const float* start, const float* cond, const CdStep* steps, int n_steps,
+                   const float* step_noise, uint64_t seed, uint64_t offset, float* x_out, float* xs, float* x0s,
+                   int use_graph, void* workspace, size_t workspace_bytes, void* stream) {
+  return guarded([&] {
+    CD_REQUIRE(plan && start && cond && steps && x_out && workspace && batch > 0, "bad argument");
+    CD_REQUIRE(n_steps >= 1 && n_steps <= CdPlan::kMaxSteps, "n_steps out of range (1..4096)");
+    check_ready(plan, true);
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n = (int64_t)batch * plan->shapes[0].vox();
+    bool noisy = false;
+    for (int i = 0; i < n_steps; ++i) noisy |= steps[i].ddim_sigma != 0.f;
+
+    static_assert(sizeof(CdStep) == 16, "CdStep must be 4 floats");
+    CD_HIP(hipMemcpyAsync(plan->d_table, steps, sizeof(CdStep) * n_steps, hipMemcpyHostToDevice, s));
+    CD_HIP(hipMemsetAsync(plan->d_counter, 0, sizeof(int), s));
+    // x = start * sigma_start (sample.py:62-66); x_out doubles as the running x
+    launch_scale(start, x_out, plan->d_table, n, s);
+
+    plan->ws.reset((char*)workspace, workspace_bytes, false);
+    float* x0 = plan->ws.get<float>((size_t)n);
+    float* noise_buf = plan->ws.get<float>((size_t)n);
+    float* sigma_b = plan->ws.get<float>((size_t)batch + 64);
+    // remaining workspace for the network: a nested arena view
+    const size_t used = plan->ws.high();
+    char* sub = (char*)workspace + used;
+    const size_t sub_bytes = workspace_bytes > used ? workspace_bytes - used : 0;
+
+    auto one_step = [&](int i, const float* noise_i, float* xs_i, float* x0s_i, bool philox_from_counter) {
+      launch_load_step(plan->d_table, plan->d_counter, plan->d_stepvals, sigma_b, batch, s);
+      plan->ws.reset(sub, sub_bytes, false);
+      forward_impl(plan, batch, x_out, cond, sigma_b, x0, false, s);
+      const float* nz = noise_i;
+      if (!nz && noisy) {
+        (void)philox_from_counter;
+        launch_randn(noise_buf, n, seed, offset + (uint64_t)i * (uint64_t)n, s);
+        nz = noise_buf;
+      }
+      launch_ddim_update(x_out, x0, nz, plan->d_stepvals, x_out, xs_i, x0s_i, n, s);
+    };
+
+    // A hipGraph of one step can be replayed only if nothing in it depends on the host-side step index:
+    // deterministic DDIM (eta = 0) without trajectories.
+    const bool graphable = use_graph && !noisy && !step_noise && !xs && !x0s && !prof::enabled();
+    if (graphable) {
+      CdPlan::GraphKey key;
+      key.batch = batch; key.ws = workspace; key.cond = cond; key.x = x_out; key.noisy = 0;
+      if (!(plan->graph_exec && plan->graph_key == key)) {
+        destroy_graph(plan);
+        hipGraph_t graph = nullptr;
+        CD_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        try {
+          one_step(0, nullptr, nullptr, nullptr, false);
+        } catch (...) {
+          hipStreamEndCapture(s, &graph);
+          if (graph) hipGraphDestroy(graph);
+          throw;
+        }
+        CD_HIP(hipStreamEndCapture(s, &graph));
+        hipError_t e = hipGraphInstantiate(&plan->graph_exec, graph, nullptr, nullptr, 0);
+        hipGraphDestroy(graph);
+        if (e != hipSuccess) {
+          plan->graph_exec = nullptr;
+          throw Fail{CD_EHIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)};
+        }
+        plan->graph_key = key;
+      }
+      for (int i = 0; i < n_steps; ++i) CD_HIP(hipGraphLaunch(plan->graph_exec, s));
+    } else {
+      for (int i = 0; i < n_steps; ++i)
+        one_step(i, step_noise ? step_noise + (size_t)i * n : nullptr, xs ? xs + (size_t)i * n : nullptr,
+                 x0s ? x0s + (size_t)i * n : nullptr, false);
+    }
+  });
+}
+
+int cd_loss_hybrid_l2(CdPlan* plan, int batch, const float* data, const float* noise, const float* sigma,
+                      const float* cond, double* loss_out, void* workspace, size_t workspace_bytes, void* stream) {
+  return guarded([&] {
+    CD_REQUIRE(plan && data && noise && sigma && cond && loss_out && workspace && batch > 0, "bad argument");
+    CD_REQUIRE(plan->desc.objective == CD_OBJ_HYBRID, "cd_loss_hybrid_l2 needs a hybrid_weight plan");
+    check_ready(plan, true);
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t per = plan->shapes[0].vox();
+    const int64_t n = (int64_t)batch * per;
+    plan->ws.reset((char*)workspace, workspace_bytes, false);
+    float* xn = plan->ws.get<float>((size_t)n);
+    float* x0 = plan->ws.get<float>((size_t)n);
+    double* part = plan->ws.get<double>((size_t)batch + 8);
+    const size_t used = plan->ws.high();
+    launch_axpy_sigma(data, noise, sigma, xn, batch, per, s);
+    plan->ws.reset((char*)workspace + used, workspace_bytes > used ? workspace_bytes - used : 0, false);
+    forward_impl(plan, batch, xn, cond, sigma, x0, false, s);
+    launch_loss_partial(x0, data, sigma, part, batch, per, s);
+    launch_loss_final(part, sigma, loss_out, batch, per, s);
+  });
+}
+
+// ---- primitives -----------------------------------------------------------------------------------------------
+size_t cd_op_scratch_bytes(int batch, int max_channels, int64_t max_voxels) {
+  // packed weights of the largest supported conv (256 x 256 x 64 taps) + norm partials + one activation
+  return (size_t)256 * 256 * 64 * 4 + (size_t)batch * 64 * 64 * 16 + (size_t)batch * max_channels * max_voxels * 4 + (1 << 20);
+}
+
+int cd_op_to_channels_last(const float* ncdhw, float* ndhwc, int batch, int channels, int64_t voxels, void* stream) {
+  return guarded([&] { launch_transpose_to_cl(ncdhw, ndhwc, batch, channels, voxels, (hipStream_t)stream); });
+}
+int cd_op_to_ncdhw(const float* ndhwc, float* ncdhw, int batch, int channels, int64_t voxels, void* stream) {
+  return guarded([&] { launch_transpose_to_planar(ndhwc, ncdhw, batch, channels, voxels, (hipStream_t)stream); });
+}
+
+int cd_op_cyl_conv(const float* x0, int c0, const float* x1, int c1, const float* w, const float* bias, float* y,
+                   int batch, int cout, const int32_t dims_in[3], const int32_t kernel[3], const int32_t stride[3],
+                   void* scratch, void* stream) {
+  return guarded([&] {
+    CD_REQUIRE(x0 && w && y && scratch, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int taps = kernel[0] * kernel[1] * kernel[2];
+    float* wpk = (float*)scratch;
+    launch_pack_weights(w, wpk, cout, c0 + c1, taps, false, s);
+    const Dims3 din{dims_in[0], dims_in[1], dims_in[2]};
+    if (taps == 1) {
+      PointwiseArgs a;
+      a.in0 = x0; a.ld0 = c0; a.c0 = c0; a.in1 = x1; a.ld1 = c1; a.c1 = c1; a.wpk = wpk; a.bias = bias; a.out = y;
+      a.batch = batch; a.cout = cout; a.vox = din.vox();
+      launch_pointwise(a, s);
+    } else {
+      CD_REQUIRE(cout % 32 == 0, "cout must be a multiple of 32");
+      ConvGeom g;
+      g.in = din;
+      g.kd = kernel[0]; g.kh = kernel[1]; g.kw = kernel[2]; g.sz = stride[0]; g.sh = stride[1]; g.sw = stride[2];
+      g.out = Dims3{(din.d + 2 - g.kd) / g.sz + 1, (din.h + 2 - g.kh) / g.sh + 1, (din.w + 2 - g.kw) / g.sw + 1};
+      launch_conv_mfma(x0, c0, x1, c1, wpk, bias, y, batch, cout, g, s);
+    }
+  });
+}
+
+int cd_op_cyl_conv_transpose(const float* x, const float* w, const float* bias, float* y, int batch, int channels,
+                             const int32_t dims_in[3], int kernel_z, int stride_z, const int32_t out_pad[3],
+                             void* scratch, void* stream) {
+  return guarded([&] {
+    CD_REQUIRE(x && w && y && scratch, "null argument");
+    CD_REQUIRE(out_pad[0] == 0, "z output padding is always 0 (models.py:339)");
+    hipStream_t s = (hipStream_t)stream;
+    float* wpk = (float*)scratch;
+    launch_pack_weights(w, wpk, channels, channels, kernel_z * 16, true, s);
+    const Dims3 din{dims_in[0], dims_in[1], dims_in[2]};
+    const Dims3 dout{(din.d - 1) * stride_z - 2 + kernel_z, 2 * din.h + out_pad[1], 2 * din.w + out_pad[2]};
+    launch_conv_transpose_mfma(x, channels, wpk, bias, y, batch, channels, din, dout, kernel_z, stride_z, s);
+  });
+}
+
+int cd_op_init_conv(const float* x_ncdhw, const float* w, const float* bias, float* y, int batch, int cin, int cout,
+                    const int32_t dims[3], void* scratch, void* stream) {
+  return guarded([&] {
+    CD_REQUIRE(x_ncdhw && w && y && scratch, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    float* wpk = (float*)scratch;
+    launch_pack_init_weights(w, wpk, cout, cin, s);
+    InitConvArgs a;
+    a.x = x_ncdhw; a.cx = cin; a.cin = cin; a.wpk = wpk; a.bias = bias; a.out = y; a.batch = batch; a.cout = cout;
+    a.dims = Dims3{dims[0], dims[1], dims[2]};
+    launch_init_conv(a, s);
+  });
+}
+
+int cd_op_group_norm(const float* x, float* y, const float* gamma, const float* beta, int batch, int channels,
+                     int64_t voxels, int groups, int silu, const float* add_bc, const float* residual,
+                     void* scratch, void* stream) {
+  return guarded([&] {
+    CD_REQUIRE(x && y && gamma && beta && scratch, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int ns = gn_nsplit_for(voxels, batch);
+    double* part = (double*)scratch;
+    launch_gn_stats(x, part, batch, channels, voxels, groups, ns, s);
+    launch_gn_apply(x, y, part, ns, gamma, beta, batch, channels, voxels, groups, silu, add_bc, channels, residual, s);
+  });
+}
+
+int cd_op_resnet_block(const float* x0, int c0, const float* x1, int c1, const float* const* w, const float* cond, float* y,
+                       int batch, int cout, const int32_t dims[3], int groups, void* workspace, size_t workspace_bytes,
+                       void* stream) {
+  return guarded([&] {
+    CD_REQUIRE(x0 && w && y && workspace, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int cin = c0 + c1;
+    Arena ws;
+    ws.reset((char*)workspace, workspace_bytes, false);
+    float* p1 = ws.get<float>(packed_weight_floats(cin, cout, 27));
+    float* p2 = ws.get<float>(packed_weight_floats(cout, cout, 27));
+    launch_pack_weights(w[0], p1, cout, cin, 27, false, s);
+    launch_pack_weights(w[4], p2, cout, cout, 27, false, s);
+    ResP r;
+    r.cin = cin; r.cout = cout; r.has_res = w[10] != nullptr;
+    r.c1w = p1; r.c1b = w[1]; r.n1g = w[2]; r.n1b = w[3]; r.c2w = p2; r.c2b = w[5]; r.n2g = w[6]; r.n2b = w[7];
+    if (r.has_res) {
+      float* p3 = ws.get<float>(packed_weight_floats(cin, cout, 1));
+      launch_pack_weights(w[10], p3, cout, cin, 1, false, s);
+      r.rw = p3; r.rb = w[11];
+    }
+    if (w[8] && cond) {
+      float* emb = ws.get<float>((size_t)batch * cout);
+      launch_silu_linear(cond, w[8], w[9], emb, batch, 128, cout, s);
+      r.emb = emb; r.emb_ld = cout;
+    }
+    Run run{&ws, s, batch, groups};
+    const Dims3 d{dims[0], dims[1], dims[2]};
+    float* out = res_block(run, r, x0, c0, x1, c1, d);
+    CD_HIP(hipMemcpyAsync(y, out, sizeof(float) * (size_t)batch * d.vox() * cout, hipMemcpyDeviceToDevice, s));
+  });
+}
+
+int cd_op_linear_attention(const float* x, const float* const* w, float* y, int batch, int channels, const int32_t dims[3],
+                           void* workspace, size_t workspace_bytes, void* stream) {
+  return guarded([&] {
+    CD_REQUIRE(x && w && y && workspace, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    Arena ws;
+    ws.reset((char*)workspace, workspace_bytes, false);
+    float* pq = ws.get<float>(packed_weight_floats(channels, 96, 1));
+    launch_pack_weights(w[2], pq, 96, channels, 1, false, s);
+    AttnP a;
+    a.c = channels; a.ng = w[0]; a.nb = w[1]; a.qkv = pq; a.ow = w[3]; a.ob = w[4]; a.gg = w[5]; a.gb = w[6];
+    Run run{&ws, s, batch, 8};
+    const Dims3 d{dims[0], dims[1], dims[2]};
+    float* out = attn_block(run, a, x, d);
+    CD_HIP(hipMemcpyAsync(y, out, sizeof(float) * (size_t)batch * d.vox() * channels, hipMemcpyDeviceToDevice, s));
+  });
+}
+
+}  // extern "C"

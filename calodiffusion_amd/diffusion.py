@@ -1,0 +1,100 @@
+"""Generic diffusion wrapper: sampling, generation loop, loss (mirror of reference calodiffusion/models/diffusion.py)."""
+from __future__ import annotations
+
+import copy
+from abc import ABC, abstractmethod
+from typing import Callable, Optional, Union
+
+import numpy as np
+import torch
+
+from . import utils
+from .configs import load_config
+
+
+class Diffusion(torch.nn.Module, ABC):
+    """Same constructor and public methods as the reference class (models/diffusion.py:18-197)."""
+
+    def __init__(self, config: Union[str, dict], n_steps: int = 400, loss_type: str = "l2"):
+        super().__init__()
+        self.config = load_config(config)
+        self.device = utils.get_device()
+        self.nsteps = n_steps
+        self.loss_type = loss_type
+        self.hgcal = self.pre_embed = False
+        loss_algo = self.config.get("TRAINING_OBJ", "noise_pred")
+        self.loss_function = utils.load_attr("loss", loss_algo)(self.config, self.nsteps, self.loss_type)
+        sampler_algo = self.config.get("SAMPLER", "DDim")
+        self.sampler_algorithm = utils.load_attr("sampler", sampler_algo)(self.config)
+        self.NN_embed = None
+        if "orig" not in self.config.get("SHOWER_EMBED", ""):
+            self._data_shape = self.config["SHAPE_PAD"][1:]
+        else:
+            self._data_shape = self.config["SHAPE_ORIG"][1:]
+        # device Philox stream for noise_generation: (seed, running offset); ranks of a sharded job set disjoint offsets
+        self.noise_seed = int(self.config.get("SEED", 1234))
+        self.noise_offset = 0
+
+    @abstractmethod
+    def init_model(self):
+        raise NotImplementedError
+
+    def init_embedding_model(self):
+        return None
+
+    @abstractmethod
+    def noise_generation(self, shape):
+        """Unit normal start tensor (diffusion.py:58-61); drawn from the device Philox stream."""
+        from .engine import randn
+        out = randn(shape, self.device, self.noise_seed, self.noise_offset)
+        self.noise_offset += out.numel()
+        return out
+
+    @abstractmethod
+    def forward(self):
+        raise NotImplementedError
+
+    @abstractmethod
+    def __call__(self, x_noisy, E, sigma, model, layers):
+        raise NotImplementedError
+
+    def sample(self, energy: torch.Tensor, layers, num_steps: int = 400, debug: bool = False,
+               sample_offset: Optional[int] = 0, start: Optional[torch.Tensor] = None):
+        """diffusion.py:77-104.  ``start`` (optional, parity hook) replaces the internally drawn noise."""
+        shape = [energy.shape[0]] + list(copy.copy(self._data_shape))
+        if start is None:
+            start = self.noise_generation(shape)
+        x, xs, x0s = self.sampler_algorithm(self, start, energy, layers, num_steps, sample_offset, debug)
+        # every step of a stochastic sampler consumed start.numel() normals after the start tensor's own
+        self.noise_offset += start.numel() * num_steps
+        if debug:
+            return x.detach().cpu().numpy(), xs, x0s
+        return x.detach().cpu().numpy()
+
+    def compute_loss(self, data, energy, noise, layers, time=None, rnd_normal=None):
+        """diffusion.py:106-110 (like the reference, `time` is not forwarded)."""
+        return self.loss_function(self, data, energy, noise=noise, layers=layers, rnd_normal=rnd_normal)
+
+    def generate(self, data_loader, sample_steps: int, debug: bool = False, sample_offset: Optional[int] = 0,
+                 sparse_decoding: Optional[bool] = False, sparse_per_batch: Optional[bool] = False,
+                 reverse_norm: Optional[Callable] = None):
+        """Sampling loop over a loader of (E, layers, data) batches (diffusion.py:118-197).
+
+        The inverse pre-processing (``utils.ReverseNorm``, host numpy) is outside the hot path:
+        pass the reference's function as ``reverse_norm`` to get physical energies, otherwise the normalised-space
+        showers are returned.
+        """
+        generated, energies, layers = [], [], []
+        for E, layers_, d_batch in data_loader:
+            E = E.to(device=self.device)
+            layers_ = layers_.to(device=self.device)
+            out = self.sample(E, layers=layers_, num_steps=sample_steps, debug=debug, sample_offset=sample_offset)
+            generated.append(out[0] if debug else out)
+            energies.append(E.detach().cpu().numpy())
+            if "layer" in self.config["SHOWERMAP"]:
+                layers.append(layers_.detach().cpu().numpy())
+        generated, energies = np.concatenate(generated), np.concatenate(energies)
+        layers = np.concatenate(layers) if layers else None
+        if reverse_norm is not None:
+            generated, energies = reverse_norm(generated, energies, layers, self.config)
+        return generated, np.reshape(energies, (energies.shape[0], -1))

@@ -1,0 +1,426 @@
+"""ctypes binding of ``lib/libcalodiff_hip.so`` (C ABI: ``include/calodiff.h``).
+
+PyTorch is used here for device memory, streams and parameter storage only.  There is no fallback of
+any kind: if the library is missing, or no gfx950 GPU is visible, every compute entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcalodiff_hip.so")
+
+CD_MAX_SIZES = 8
+TIME_KINDS = {"log": 0, "sigma": 1, "raw": 2}
+OBJECTIVES = {"hybrid": 0, "noise_pred": 1, "mean_pred": 2}
+
+
+class CdUnetDesc(C.Structure):
+    _fields_ = [
+        ("grid", C.c_int32 * 3),
+        ("in_channels", C.c_int32),
+        ("n_sizes", C.c_int32),
+        ("layer_sizes", C.c_int32 * CD_MAX_SIZES),
+        ("groups", C.c_int32),
+        ("block_attn", C.c_int32),
+        ("mid_attn", C.c_int32),
+        ("compress_z", C.c_int32),
+        ("cond_size", C.c_int32),
+        ("cond_dim", C.c_int32),
+        ("rz_input", C.c_int32),
+        ("phi_input", C.c_int32),
+        ("time_embed_kind", C.c_int32),
+        ("objective", C.c_int32),
+        ("sigma_data", C.c_float),
+    ]
+
+
+class CdStep(C.Structure):
+    _fields_ = [("sigma", C.c_float), ("sigma_prev_masked", C.c_float), ("ddim_sigma", C.c_float), ("denom", C.c_float)]
+
+
+# every symbol include/calodiff.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+_SIGNATURES = {
+    "cd_last_error": (C.c_char_p, []),
+    "cd_device_check": (C.c_int, [C.c_char_p, C.c_int]),
+    "cd_plan_create": (C.c_int, [C.POINTER(CdUnetDesc), C.POINTER(_P)]),
+    "cd_plan_destroy": (C.c_int, [_P]),
+    "cd_plan_num_weights": (C.c_int, [_P, C.POINTER(C.c_int)]),
+    "cd_plan_weight_name": (C.c_int, [_P, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int64)]),
+    "cd_plan_set_weight": (C.c_int, [_P, C.c_char_p, _P, C.c_int64, _P]),
+    "cd_plan_set_coords": (C.c_int, [_P, _P, _P, _P, _P]),
+    "cd_plan_workspace_bytes": (C.c_int, [_P, C.c_int, C.POINTER(C.c_size_t)]),
+    "cd_unet_forward": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "cd_denoise": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "cd_ddim_sample": (C.c_int, [_P, C.c_int, _P, _P, C.POINTER(CdStep), C.c_int, _P, C.c_uint64, C.c_uint64, _P, _P, _P,
+                                 C.c_int, _P, C.c_size_t, _P]),
+    "cd_randn": (C.c_int, [_P, C.c_int64, C.c_uint64, C.c_uint64, _P]),
+    "cd_profile_begin": (C.c_int, []),
+    "cd_profile_end": (C.c_int, [C.c_char_p, C.c_int]),
+    "cd_loss_hybrid_l2": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "cd_op_to_channels_last": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int64, _P]),
+    "cd_op_to_ncdhw": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int64, _P]),
+    "cd_op_cyl_conv": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.POINTER(C.c_int32),
+                                 C.POINTER(C.c_int32), C.POINTER(C.c_int32), _P, _P]),
+    "cd_op_cyl_conv_transpose": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_int,
+                                           C.POINTER(C.c_int32), _P, _P]),
+    "cd_op_init_conv": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), _P, _P]),
+    "cd_op_group_norm": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, _P, _P, _P, _P]),
+    "cd_op_resnet_block": (C.c_int, [_P, C.c_int, _P, C.c_int, C.POINTER(_P), _P, _P, C.c_int, C.c_int,
+                                     C.POINTER(C.c_int32), C.c_int, _P, C.c_size_t, _P]),
+    "cd_op_linear_attention": (C.c_int, [_P, C.POINTER(_P), _P, C.c_int, C.c_int, C.POINTER(C.c_int32), _P, C.c_size_t, _P]),
+    "cd_op_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int64]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """dlopen the HIP library and bind every declared symbol; fails loudly if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m calodiffusion_amd.build` (hipcc, --offload-arch=gfx950). "
+            "calodiffusion_amd has no CPU or PyTorch fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def _check(code: int):
+    if code != 0:
+        msg = load_library().cd_last_error().decode(errors="replace")
+        exc = ValueError if code == -1 else RuntimeError
+        raise exc(f"calodiff[{code}]: {msg}")
+
+
+def require_gpu() -> str:
+    lib = load_library()
+    if not torch.cuda.is_available():
+        raise RuntimeError("calodiffusion_amd needs an MI355X (gfx950) GPU: torch.cuda.is_available() is False and "
+                           "there is no CPU fallback")
+    buf = C.create_string_buffer(256)
+    _check(lib.cd_device_check(buf, 256))
+    return buf.value.decode()
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev32(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA(ROCm) tensor: calodiffusion_amd computes on the GPU only")
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        t = t.to(torch.float32).contiguous()
+    return t
+
+
+def _i32x3(v: Sequence[int]):
+    return (C.c_int32 * 3)(*[int(a) for a in v])
+
+
+class UnetEngine:
+    """One HIP plan bound to one CondUnet parameter set on one device."""
+
+    def __init__(self, unet, rz_input=False, phi_input=False, time_kind="raw", objective="hybrid", sigma_data=1.0,
+                 coords=None):
+        self.lib = load_library()
+        self.device_name = require_gpu()
+        self.unet = unet
+        d = CdUnetDesc()
+        d.grid = _i32x3(unet.grid)
+        d.in_channels = unet.channels
+        d.n_sizes = len(unet.layer_sizes)
+        for i, v in enumerate(unet.layer_sizes):
+            d.layer_sizes[i] = int(v)
+        d.groups = unet.groups
+        d.block_attn = int(bool(unet.block_attn))
+        d.mid_attn = int(unet.mid_attn is not False)
+        d.compress_z = int(bool(unet.compress_Z))
+        d.cond_size, d.cond_dim = unet.cond_size, unet.cond_dim
+        d.rz_input, d.phi_input = int(bool(rz_input)), int(bool(phi_input))
+        d.time_embed_kind = TIME_KINDS[time_kind]
+        d.objective = OBJECTIVES[objective]
+        d.sigma_data = float(sigma_data)
+        self.desc = d
+        self.grid = tuple(unet.grid)
+        self.voxels = int(np.prod(self.grid))
+        handle = _P()
+        _check(self.lib.cd_plan_create(C.byref(d), C.byref(handle)))
+        self.plan = handle
+        self._weights_version = None
+        self._ws: Dict[int, torch.Tensor] = {}
+        self.device = next(unet.parameters()).device
+        if self.device.type != "cuda":
+            raise RuntimeError("move the model to the GPU first (model.to('cuda')): calodiffusion_amd has no CPU path")
+        if coords is not None:
+            r, z, phi = (np.ascontiguousarray(a, dtype=np.float32) for a in coords)
+            assert len(r) == self.grid[2] and len(z) == self.grid[0] and len(phi) == self.grid[1]
+            _check(self.lib.cd_plan_set_coords(self.plan, r.ctypes.data, z.ctypes.data, phi.ctypes.data, _stream()))
+        self.sync_weights(force=True)
+
+    @classmethod
+    def for_unet(cls, unet):
+        opts = getattr(unet, "_engine_opts", {})
+        return cls(unet, **opts)
+
+    def __del__(self):
+        try:
+            if getattr(self, "plan", None):
+                self.lib.cd_plan_destroy(self.plan)
+                self.plan = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ weights
+    def _version(self):
+        return tuple(p._version for p in self.unet.parameters()) + tuple(p.data_ptr() for p in self.unet.parameters())
+
+    def sync_weights(self, force=False):
+        """(Re-)pack the parameters into the plan's arena; cheap no-op when nothing changed."""
+        ver = self._version()
+        if not force and ver == self._weights_version:
+            return
+        sd = self.unet.state_dict()
+        n = C.c_int()
+        _check(self.lib.cd_plan_num_weights(self.plan, C.byref(n)))
+        buf = C.create_string_buffer(256)
+        numel = C.c_int64()
+        seen = set()
+        for i in range(n.value):
+            _check(self.lib.cd_plan_weight_name(self.plan, i, buf, 256, C.byref(numel)))
+            name = buf.value.decode()
+            if name not in sd:
+                raise RuntimeError(f"state_dict has no tensor named {name!r}")
+            t = _dev32(sd[name].detach(), name)
+            if t.numel() != numel.value:
+                raise RuntimeError(f"{name}: {t.numel()} elements, HIP plan expects {numel.value}")
+            _check(self.lib.cd_plan_set_weight(self.plan, name.encode(), t.data_ptr(), t.numel(), _stream()))
+            seen.add(name)
+        missing = set(sd) - seen
+        if missing:
+            raise RuntimeError(f"HIP plan does not consume these state_dict tensors: {sorted(missing)[:5]} ...")
+        self._weights_version = ver
+
+    def workspace(self, batch: int) -> torch.Tensor:
+        ws = self._ws.get(batch)
+        if ws is None:
+            nbytes = C.c_size_t()
+            _check(self.lib.cd_plan_workspace_bytes(self.plan, batch, C.byref(nbytes)))
+            ws = torch.empty(nbytes.value, dtype=torch.uint8, device=self.device)
+            self._ws = {batch: ws}  # keep one: workspaces are large
+        return ws
+
+    # ------------------------------------------------------------------ compute
+    def unet_forward(self, x, cond, time):
+        x, cond, time = _dev32(x, "x"), _dev32(cond, "cond"), _dev32(time, "time")
+        B = x.shape[0]
+        if tuple(x.shape[1:]) != (self.unet.channels,) + self.grid:
+            raise ValueError(f"x has shape {tuple(x.shape)}, expected (B, {self.unet.channels}, {self.grid})")
+        if cond.shape != (B, self.unet.cond_size) or time.numel() != B:
+            raise ValueError("cond must be (B, cond_size) and time (B,)")
+        self.sync_weights()
+        ws = self.workspace(B)
+        out = torch.empty((B, 1) + self.grid, dtype=torch.float32, device=x.device)
+        _check(self.lib.cd_unet_forward(self.plan, B, x.data_ptr(), cond.data_ptr(), time.data_ptr(), out.data_ptr(),
+                                        ws.data_ptr(), ws.numel(), _stream()))
+        return out
+
+    def denoise(self, x, sigma, cond):
+        x, cond = _dev32(x, "x"), _dev32(cond, "cond")
+        B = x.shape[0]
+        sigma = _dev32(sigma, "sigma").reshape(-1)
+        if sigma.numel() == 1 and B > 1:
+            sigma = sigma.expand(B).contiguous()
+        if tuple(x.shape[1:]) != (1,) + self.grid or sigma.numel() != B or cond.shape != (B, self.unet.cond_size):
+            raise ValueError(f"denoise shapes: x {tuple(x.shape)}, sigma {tuple(sigma.shape)}, cond {tuple(cond.shape)}")
+        self.sync_weights()
+        ws = self.workspace(B)
+        out = torch.empty_like(x)
+        _check(self.lib.cd_denoise(self.plan, B, x.data_ptr(), sigma.data_ptr(), cond.data_ptr(), out.data_ptr(),
+                                   ws.data_ptr(), ws.numel(), _stream()))
+        return out
+
+    def ddim_sample(self, start, cond, steps: np.ndarray, step_noise=None, seed=0, offset=0, debug=False, use_graph=True,
+                    out=None):
+        """steps: float32 array (n_steps, 4) = (sigma, sigma_prev*[t>0], ddim_sigma, denom)."""
+        start, cond = _dev32(start, "start"), _dev32(cond, "cond")
+        B = start.shape[0]
+        steps = np.ascontiguousarray(steps, dtype=np.float32)
+        n_steps = steps.shape[0]
+        assert steps.shape == (n_steps, 4)
+        self.sync_weights()
+        ws = self.workspace(B)
+        x_out = torch.empty_like(start) if out is None else out
+        xs = x0s = None
+        if debug:
+            xs = torch.empty((n_steps,) + tuple(start.shape), dtype=torch.float32, device=start.device)
+            x0s = torch.empty_like(xs)
+        if step_noise is not None:
+            step_noise = _dev32(step_noise, "step_noise")
+            assert step_noise.shape[0] == n_steps and step_noise[0].numel() == start.numel()
+        _check(self.lib.cd_ddim_sample(self.plan, B, start.data_ptr(), cond.data_ptr(),
+                                       steps.ctypes.data_as(C.POINTER(CdStep)), n_steps, _ptr(step_noise), int(seed),
+                                       int(offset), x_out.data_ptr(), _ptr(xs), _ptr(x0s), int(bool(use_graph)),
+                                       ws.data_ptr(), ws.numel(), _stream()))
+        return x_out, xs, x0s
+
+    def loss_hybrid_l2(self, data, noise, sigma, cond):
+        data, noise, cond = _dev32(data, "data"), _dev32(noise, "noise"), _dev32(cond, "cond")
+        sigma = _dev32(sigma, "sigma").reshape(-1)
+        B = data.shape[0]
+        self.sync_weights()
+        ws = self.workspace(B)
+        out = torch.empty((), dtype=torch.float64, device=data.device)
+        _check(self.lib.cd_loss_hybrid_l2(self.plan, B, data.data_ptr(), noise.data_ptr(), sigma.data_ptr(), cond.data_ptr(),
+                                          out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+        return out
+
+
+def profile_begin():
+    _check(load_library().cd_profile_begin())
+
+
+def profile_end() -> dict:
+    import json
+    buf = C.create_string_buffer(1 << 16)
+    _check(load_library().cd_profile_end(buf, 1 << 16))
+    return json.loads(buf.value.decode())
+
+
+def randn(shape, device, seed: int, offset: int = 0) -> torch.Tensor:
+    """Unit normals from the device Philox stream (element i is a function of (seed, offset + i) only)."""
+    lib = load_library()
+    require_gpu()
+    out = torch.empty(tuple(shape), dtype=torch.float32, device=device)
+    _check(lib.cd_randn(out.data_ptr(), out.numel(), int(seed), int(offset), _stream()))
+    return out
+
+
+# ---------------------------------------------------------------------- primitive ops (parity tests)
+class Ops:
+    """Thin wrappers over the cd_op_* entry points.  Activations are channels-last (B, D, H, W, C)."""
+
+    def __init__(self):
+        self.lib = load_library()
+        require_gpu()
+        self._scratch = None
+
+    def scratch(self, batch, channels, voxels):
+        need = self.lib.cd_op_scratch_bytes(batch, channels, voxels)
+        if self._scratch is None or self._scratch.numel() < need:
+            self._scratch = torch.empty(need, dtype=torch.uint8, device="cuda")
+        return self._scratch
+
+    def to_channels_last(self, x):
+        x = _dev32(x, "x")
+        B, Cc = x.shape[:2]
+        vox = int(np.prod(x.shape[2:]))
+        y = torch.empty((B,) + tuple(x.shape[2:]) + (Cc,), dtype=torch.float32, device=x.device)
+        _check(self.lib.cd_op_to_channels_last(x.data_ptr(), y.data_ptr(), B, Cc, vox, _stream()))
+        return y
+
+    def to_ncdhw(self, y):
+        y = _dev32(y, "y")
+        B, Cc = y.shape[0], y.shape[-1]
+        vox = int(np.prod(y.shape[1:-1]))
+        x = torch.empty((B, Cc) + tuple(y.shape[1:-1]), dtype=torch.float32, device=y.device)
+        _check(self.lib.cd_op_to_ncdhw(y.data_ptr(), x.data_ptr(), B, Cc, vox, _stream()))
+        return x
+
+    def cyl_conv(self, x_cl, w, bias, stride=(1, 1, 1), x1_cl=None):
+        x_cl, w = _dev32(x_cl, "x"), _dev32(w, "w")
+        B, D, H, W, c0 = x_cl.shape
+        c1 = 0 if x1_cl is None else x1_cl.shape[-1]
+        cout = w.shape[0]
+        k = tuple(w.shape[2:])
+        if k == (1, 1, 1):
+            od = (D, H, W)
+        else:
+            od = ((D + 2 - k[0]) // stride[0] + 1, (H + 2 - k[1]) // stride[1] + 1, (W + 2 - k[2]) // stride[2] + 1)
+        y = torch.empty((B,) + od + (cout,), dtype=torch.float32, device=x_cl.device)
+        sc = self.scratch(B, max(c0 + c1, cout), D * H * W)
+        _check(self.lib.cd_op_cyl_conv(x_cl.data_ptr(), c0, _ptr(x1_cl), c1, w.data_ptr(), _ptr(bias), y.data_ptr(), B, cout,
+                                       _i32x3((D, H, W)), _i32x3(k), _i32x3(stride), sc.data_ptr(), _stream()))
+        return y
+
+    def cyl_conv_transpose(self, x_cl, w, bias, kernel_z, stride_z, out_pad):
+        x_cl, w = _dev32(x_cl, "x"), _dev32(w, "w")
+        B, D, H, W, c = x_cl.shape
+        od = ((D - 1) * stride_z - 2 + kernel_z, 2 * H + out_pad[1], 2 * W + out_pad[2])
+        y = torch.empty((B,) + od + (c,), dtype=torch.float32, device=x_cl.device)
+        sc = self.scratch(B, c, int(np.prod(od)))
+        _check(self.lib.cd_op_cyl_conv_transpose(x_cl.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), B, c,
+                                                 _i32x3((D, H, W)), kernel_z, stride_z, _i32x3(out_pad), sc.data_ptr(),
+                                                 _stream()))
+        return y
+
+    def init_conv(self, x_ncdhw, w, bias):
+        x, w = _dev32(x_ncdhw, "x"), _dev32(w, "w")
+        B, cin, D, H, W = x.shape
+        cout = w.shape[0]
+        y = torch.empty((B, D, H, W, cout), dtype=torch.float32, device=x.device)
+        sc = self.scratch(B, cout, D * H * W)
+        _check(self.lib.cd_op_init_conv(x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), B, cin, cout, _i32x3((D, H, W)),
+                                        sc.data_ptr(), _stream()))
+        return y
+
+    def group_norm(self, x_cl, gamma, beta, groups, silu=False, add_bc=None, residual=None):
+        x = _dev32(x_cl, "x")
+        B, Cc = x.shape[0], x.shape[-1]
+        vox = int(np.prod(x.shape[1:-1]))
+        y = torch.empty_like(x)
+        sc = self.scratch(B, Cc, vox)
+        _check(self.lib.cd_op_group_norm(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), B, Cc, vox, groups,
+                                         int(silu), _ptr(add_bc), _ptr(residual), sc.data_ptr(), _stream()))
+        return y
+
+    _RES_KEYS = ("block1.proj.conv.weight", "block1.proj.conv.bias", "block1.norm.weight", "block1.norm.bias",
+                 "block2.proj.conv.weight", "block2.proj.conv.bias", "block2.norm.weight", "block2.norm.bias",
+                 "mlp.1.weight", "mlp.1.bias", "res_conv.conv.weight", "res_conv.conv.bias")
+
+    def resnet_block(self, x_cl, sd: Dict[str, torch.Tensor], cond=None, groups=8, x1_cl=None):
+        """ResnetBlock on channels-last input; ``sd`` uses the reference's key names (models.py:172-200)."""
+        x = _dev32(x_cl, "x")
+        B, D, H, W, c0 = x.shape
+        c1 = 0 if x1_cl is None else x1_cl.shape[-1]
+        cout = sd["block1.proj.conv.weight"].shape[0]
+        ptrs = (_P * 12)(*[(sd[k].data_ptr() if k in sd else None) for k in self._RES_KEYS])
+        y = torch.empty((B, D, H, W, cout), dtype=torch.float32, device=x.device)
+        nbytes = self.lib.cd_op_scratch_bytes(B, max(c0 + c1, cout), D * H * W) + 4 * B * D * H * W * cout * 4 * 4
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        _check(self.lib.cd_op_resnet_block(x.data_ptr(), c0, _ptr(x1_cl), c1, ptrs, _ptr(cond), y.data_ptr(), B, cout,
+                                           _i32x3((D, H, W)), groups, ws.data_ptr(), ws.numel(), _stream()))
+        return y
+
+    _ATTN_KEYS = ("fn.norm.weight", "fn.norm.bias", "fn.fn.to_qkv.conv.weight", "fn.fn.to_out.0.conv.weight",
+                  "fn.fn.to_out.0.conv.bias", "fn.fn.to_out.1.weight", "fn.fn.to_out.1.bias")
+
+    def linear_attention(self, x_cl, sd: Dict[str, torch.Tensor]):
+        """Residual(PreNorm(LinearAttention)) on channels-last input (models.py:281-329)."""
+        x = _dev32(x_cl, "x")
+        B, D, H, W, c = x.shape
+        ptrs = (_P * 7)(*[sd[k].data_ptr() for k in self._ATTN_KEYS])
+        y = torch.empty_like(x)
+        nbytes = self.lib.cd_op_scratch_bytes(B, 96, D * H * W) + 4 * B * D * H * W * 96 * 4
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        _check(self.lib.cd_op_linear_attention(x.data_ptr(), ptrs, y.data_ptr(), B, c, _i32x3((D, H, W)), ws.data_ptr(),
+                                               ws.numel(), _stream()))
+        return y

@@ -1,0 +1,66 @@
+"""Training objectives of the hot path (mirror of reference calodiffusion/models/loss.py for `hybrid_weight`)."""
+from __future__ import annotations
+
+import torch
+
+from . import schedule
+from .utils import subsample_alphas
+
+
+class Loss:
+    """EDM scalings + noise-level draw (models/loss.py:9-142).  Only the `l2` reduction runs on the HIP path."""
+
+    def __init__(self, config, n_steps, loss_type="l1") -> None:
+        self.config = config
+        self.update_step(n_steps)
+        self.discrete_time = True
+        self.P_mean, self.P_std, self.sigma_data = -1, 1, 0.5
+        if "log" in config.get("NOISE_SCHED", "linear"):
+            self.discrete_time = False
+            self.P_mean, self.P_std, self.sigma_data = -1.2, 1.2, 1.0
+        self.loss_type = loss_type
+
+    def get_scaling(self, sigma):
+        s2 = sigma ** 2 + self.sigma_data ** 2
+        return {"c_skip": self.sigma_data ** 2 / s2, "c_out": sigma * self.sigma_data / s2 ** 0.5, "c_in": 1 / s2 ** 0.5}
+
+    def update_step(self, steps: int):
+        self.n_steps = steps
+        tb = schedule.tables(steps)
+        self.sqrt_alphas_cumprod = tb["sqrt_alphas_cumprod"]
+        self.sqrt_one_minus_alphas_cumprod = tb["sqrt_one_minus_alphas_cumprod"]
+        self.posterior_variance = tb["betas"] * (1.0 - tb["alphas_cumprod_prev"]) / (1.0 - tb["alphas_cumprod"])
+
+    def draw_sigma(self, data, time=None, rnd_normal=None):
+        """Noise level per sample, as Loss.__call__ draws it (models/loss.py:124-140)."""
+        B = data.shape[0]
+        if self.discrete_time:
+            if time is None:
+                time = torch.randint(0, self.n_steps, (B,), device=data.device).long()
+            a = subsample_alphas(self.sqrt_alphas_cumprod, time, data.shape)
+            b = subsample_alphas(self.sqrt_one_minus_alphas_cumprod, time, data.shape)
+            return (b / a).reshape(B)
+        if rnd_normal is None:
+            rnd_normal = torch.randn((B,), device=data.device)
+        return (rnd_normal * self.P_std + self.P_mean).exp().reshape(B)
+
+    def __call__(self, model, data, E, noise=None, time=None, layers=None, rnd_normal=None):
+        if noise is None:
+            noise = torch.randn_like(data)
+        sigma = self.draw_sigma(data, time=time, rnd_normal=rnd_normal)
+        return self.loss_function(model, data, E, sigma=sigma, noise=noise, layers=layers)
+
+    def loss_function(self, model, data, E, sigma=None, noise=None, layers=None):
+        raise NotImplementedError
+
+
+class hybrid_weight(Loss):
+    """x0-prediction with weight 1 + sigma^-2 (models/loss.py:163-179); value computed by cd_loss_hybrid_l2."""
+
+    def __init__(self, config, n_steps, loss_type="l1") -> None:
+        super().__init__(config, n_steps, loss_type)
+
+    def loss_function(self, model, data, E, sigma=None, noise=None, layers=None):
+        if self.loss_type != "l2":
+            raise NotImplementedError("the HIP path implements LOSS_TYPE 'l2' (the only one the shipped configs use)")
+        return model.engine().loss_hybrid_l2(data, noise, sigma, model.cond_tensor(E, layers))

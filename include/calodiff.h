@@ -1,0 +1,170 @@
+/*
+ * calodiff.h -- C ABI of the MI355X (gfx950) CaloDiffusion denoising hot path.
+ *
+ * The reference (OzAmram/CaloDiffusion) has no FFI of its own: its seam for this path is a Python
+ * class protocol.  Each entry point below states the reference interface it
+ * stands behind (file:line into the reference tree).  INTEGRATION.md shows the ctypes binding a
+ * maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative CD_E* code; cd_last_error() gives the message
+ *     (thread-local, valid until the next failing call on that thread).  Nothing throws across the ABI.
+ *   - all tensor pointers are DEVICE pointers to contiguous fp32 unless marked "host".
+ *     User-facing activations are NCDHW (D = layer/z, H = phi, periodic, W = r), as in the reference
+ *     (calodiffusion/models/models.py:26,66).  Channels-last (NDHWC) is the library's internal layout
+ *     and appears only in the cd_op_* primitive entry points, which say so.
+ *   - memory is owned by the caller (PyTorch's caching allocator in the shipped host code).  The
+ *     library allocates only plan-private metadata and the packed-weight arena at plan creation /
+ *     cd_plan_set_weight time, never inside a compute call (compute calls are hipGraph-capturable).
+ *   - `stream` is a hipStream_t passed as void*; all work of a call is enqueued on it and the call
+ *     returns without synchronising.
+ *   - a plan is not thread-safe; use one plan per device per process.
+ */
+#ifndef CALODIFF_H
+#define CALODIFF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CD_OK 0
+#define CD_EINVAL -1       /* bad argument / unsupported configuration */
+#define CD_EHIP -2         /* HIP runtime error */
+#define CD_ENOGPU -3       /* no gfx950 device visible */
+#define CD_EWEIGHTS -4     /* a weight tensor is missing or has the wrong size */
+#define CD_EWORKSPACE -5   /* workspace too small */
+
+#define CD_MAX_SIZES 8
+
+#define CD_TIME_LOG 0      /* t_emb = 0.5*ln(sigma)         (calodiffusion.py:150) */
+#define CD_TIME_SIGMA 1    /* t_emb = sigma/sqrt(1+sigma^2) (calodiffusion.py:149) */
+#define CD_TIME_RAW 2      /* t_emb = the value passed (CondUnet.forward's `time` argument) */
+
+#define CD_OBJ_HYBRID 0     /* c_skip*x + c_out*F  (calodiffusion.py:166-167) */
+#define CD_OBJ_NOISE_PRED 1 /* x - sigma*F         (calodiffusion.py:161-162) */
+#define CD_OBJ_MEAN_PRED 2  /* F                   (calodiffusion.py:164-165) */
+
+typedef struct CdPlan CdPlan;
+
+/* Mirrors the arguments of CondUnet.__init__ (models/models.py:525-543) as CaloDiffusion.init_model
+ * derives them from the config (models/calodiffusion.py:39-81). */
+typedef struct CdUnetDesc {
+  int32_t grid[3];                 /* D, H, W of SHAPE_FINAL */
+  int32_t in_channels;             /* `channels`: 1 (+2 if R_Z_INPUT) (+1 if PHI_INPUT) */
+  int32_t n_sizes;                 /* len(LAYER_SIZE_UNET) */
+  int32_t layer_sizes[CD_MAX_SIZES];
+  int32_t groups;                  /* BLOCK_GROUPS (8) */
+  int32_t block_attn, mid_attn, compress_z;
+  int32_t cond_size;               /* width of cat(E, layers) */
+  int32_t cond_dim;                /* COND_SIZE_UNET */
+  int32_t rz_input, phi_input;     /* which coordinate channels cd_denoise synthesises */
+  int32_t time_embed_kind;         /* CD_TIME_* used by cd_denoise */
+  int32_t objective;               /* CD_OBJ_*  used by cd_denoise */
+  float sigma_data;                /* Loss.sigma_data (models/loss.py:18-25) */
+} CdUnetDesc;
+
+/* One row per sampler loop iteration; computed on the host exactly as DDim.__call__ does in fp32
+ * (models/sample.py:45-101): sigma = sqrt(1-abar_t)/sqrt(abar_t); sigma_prev = sqrt(1-abar_prev-ddim_sigma^2)/denom
+ * (already multiplied by the t>0 mask); ddim_sigma = eta*sqrt(...); denom = sqrt(abar_{max(t-1,0)}). */
+typedef struct CdStep {
+  float sigma;
+  float sigma_prev_masked;
+  float ddim_sigma;
+  float denom;
+} CdStep;
+
+const char* cd_last_error(void);
+/* 0 if a gfx950 device is usable by this process, CD_ENOGPU otherwise. Fills name (may be NULL). */
+int cd_device_check(char* name, int cap);
+
+/* ---- plan ------------------------------------------------------------------------------------------- */
+/* Replaces CondUnet.__init__ + CaloDiffusion.init_model (models.py:525-699, calodiffusion.py:39-81). */
+int cd_plan_create(const CdUnetDesc* desc, CdPlan** plan);
+int cd_plan_destroy(CdPlan* plan);
+/* Names follow CondUnet.state_dict() (e.g. "downs.0.0.block1.proj.conv.weight"); iteration helpers so the host
+ * can check it feeds every tensor.  *numel is the element count the plan expects. */
+int cd_plan_num_weights(const CdPlan* plan, int* n);
+int cd_plan_weight_name(const CdPlan* plan, int idx, char* name, int cap, int64_t* numel);
+/* Copies/re-packs one state_dict tensor (device pointer, torch layout) into the plan's arena on `stream`.
+ * Replaces nn.Module.load_state_dict for this path (calodiffusion.py:31-37). Call again after an optimizer step. */
+int cd_plan_set_weight(CdPlan* plan, const char* name, const float* dev_ptr, int64_t numel, void* stream);
+/* Host arrays: the 1-D profiles of the constant R (len W), Z (len D) and phi (len H) input images
+ * (utils/utils.py:33-150, calodiffusion.py:17-20). */
+int cd_plan_set_coords(CdPlan* plan, const float* r_w, const float* z_d, const float* phi_h, void* stream);
+int cd_plan_workspace_bytes(CdPlan* plan, int batch, size_t* bytes);
+
+/* ---- hot path ------------------------------------------------------------------------------------------ */
+/* CondUnet.forward(x, cond, time) (models.py:701-748).  x: (B, in_channels, D, H, W); cond: (B, cond_size);
+ * time: (B,); out: (B, 1, D, H, W). */
+int cd_unet_forward(CdPlan* plan, int batch, const float* x, const float* cond, const float* time, float* out,
+                    void* workspace, size_t workspace_bytes, void* stream);
+/* CaloDiffusion.denoise / __call__ (calodiffusion.py:154-173) incl. Loss.get_scaling (loss.py:29-41),
+ * do_time_embed (calodiffusion.py:144-152), forward + add_RZPhi (calodiffusion.py:86-98,121-142).
+ * x: (B,1,D,H,W); sigma: (B,); cond: (B, cond_size) = cat(E, layers); out: (B,1,D,H,W). */
+int cd_denoise(CdPlan* plan, int batch, const float* x, const float* sigma, const float* cond, float* out,
+               void* workspace, size_t workspace_bytes, void* stream);
+/* DDim.__call__ / DDPM (models/sample.py:41-121) with Diffusion.sample's start tensor (diffusion.py:77-104).
+ * start: (B,1,D,H,W) unit normal; steps: host array of n_steps rows; x_out: (B,1,D,H,W).
+ * step_noise: NULL (DDIM, eta = 0: the reference draws and discards it) or device (n_steps, B,1,D,H,W);
+ * if NULL and any ddim_sigma != 0 the noise comes from the device Philox stream (seed, offset).
+ * xs / x0s: NULL or device (n_steps, B,1,D,H,W) trajectories (`debug`). use_graph: capture one step as a
+ * hipGraph and replay it. */
+int cd_ddim_sample(CdPlan* plan, int batch, const float* start, const float* cond, const CdStep* steps, int n_steps,
+                   const float* step_noise, uint64_t seed, uint64_t offset, float* x_out, float* xs, float* x0s,
+                   int use_graph, void* workspace, size_t workspace_bytes, void* stream);
+/* Diffusion.noise_generation (diffusion.py:58-61): n unit normals from Philox4x32-10 + Box-Muller;
+ * element i depends only on (seed, offset + i), so shards of one global stream can be drawn per rank. */
+int cd_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
+/* Loss.__call__ + hybrid_weight.loss_function + l2_loss forward value (models/loss.py:103-104,118-142,163-179):
+ * x_noisy = data + sigma*noise; x0 = denoise(x_noisy); loss = sum(w (x0-data)^2) / (mean(w) numel), w = 1 + sigma^-2.
+ * sigma: (B,) device. loss_out: 1 double on device. */
+int cd_loss_hybrid_l2(CdPlan* plan, int batch, const float* data, const float* noise, const float* sigma,
+                      const float* cond, double* loss_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- measurement ---------------------------------------------------------------------------------------------- */
+/* Per-launch timing with HIP events on the launch stream (eager mode; graphs are bypassed while active).
+ * cd_profile_end synchronises the device and writes a JSON object
+ *   {"<kernel category>": {"launches": n, "ms": total_ms, "flops": algorithmic_per_launch, "bytes": algorithmic_per_launch}} */
+int cd_profile_begin(void);
+int cd_profile_end(char* json, int cap);
+
+/* ---- primitives (parity tests of the individual kernels; activations CHANNELS-LAST (B, D, H, W, C)) ---- */
+int cd_op_to_channels_last(const float* ncdhw, float* ndhwc, int batch, int channels, int64_t voxels, void* stream);
+int cd_op_to_ncdhw(const float* ndhwc, float* ncdhw, int batch, int channels, int64_t voxels, void* stream);
+/* phi-periodic Conv3d (CylindricalConv, models.py:65-96; Downsample, :360-365). w: torch layout (Cout,Cin,kD,kH,kW).
+ * kernel (kD,kH,kW) in {(3,3,3),(3,4,4),(1,1,1)}; padding 1 (z,r zero; phi circular) unless 1x1x1.
+ * x0/x1: two channel-concatenated sources (c1 may be 0).  scratch: >= cd_op_scratch_bytes(). */
+int cd_op_cyl_conv(const float* x0, int c0, const float* x1, int c1, const float* w, const float* bias, float* y,
+                   int batch, int cout, const int32_t dims_in[3], const int32_t kernel[3], const int32_t stride[3],
+                   void* scratch, void* stream);
+/* CylindricalConvTrans as built by Upsample (models.py:25-62, 335-348). w: (Cin,Cout,kD,4,4); padding (1, circ, 1). */
+int cd_op_cyl_conv_transpose(const float* x, const float* w, const float* bias, float* y, int batch, int channels,
+                             const int32_t dims_in[3], int kernel_z, int stride_z, const int32_t out_pad[3],
+                             void* scratch, void* stream);
+/* small-Cin planar 3x3x3 conv (init_conv, models.py:562-564): x NCDHW (B,cin,D,H,W) -> y channels-last (B,D,H,W,cout). */
+int cd_op_init_conv(const float* x_ncdhw, const float* w, const float* bias, float* y, int batch, int cin, int cout,
+                    const int32_t dims[3], void* scratch, void* stream);
+/* GroupNorm (+SiLU) (+ per-(b,c) additive embedding) (+ residual), Block.forward / PreNorm (models.py:160-169,321-329). */
+int cd_op_group_norm(const float* x, float* y, const float* gamma, const float* beta, int batch, int channels,
+                     int64_t voxels, int groups, int silu, const float* add_bc, const float* residual,
+                     void* scratch, void* stream);
+/* ResnetBlock.forward (models.py:172-200) on channels-last input(s) x0 (+ x1 concatenated).  w: 12 device pointers in
+ * torch layout: block1.proj.conv.{weight,bias}, block1.norm.{weight,bias}, block2.proj.conv.{weight,bias},
+ * block2.norm.{weight,bias}, mlp.1.{weight,bias} (NULL without conditioning), res_conv.conv.{weight,bias} (NULL if
+ * cin == cout).  cond: (B, 128) or NULL. */
+int cd_op_resnet_block(const float* x0, int c0, const float* x1, int c1, const float* const* w, const float* cond, float* y,
+                       int batch, int cout, const int32_t dims[3], int groups, void* workspace, size_t workspace_bytes,
+                       void* stream);
+/* Residual(PreNorm(LinearAttention)) (models.py:111-117, 281-329).  w: 7 device pointers: fn.norm.{weight,bias},
+ * fn.fn.to_qkv.conv.weight, fn.fn.to_out.0.conv.{weight,bias}, fn.fn.to_out.1.{weight,bias}. */
+int cd_op_linear_attention(const float* x, const float* const* w, float* y, int batch, int channels, const int32_t dims[3],
+                           void* workspace, size_t workspace_bytes, void* stream);
+size_t cd_op_scratch_bytes(int batch, int max_channels, int64_t max_voxels);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CALODIFF_H */

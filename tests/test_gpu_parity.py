@@ -1,0 +1,279 @@
+"""GPU (MI355X): the HIP path, through the C ABI, against the golden vectors of the reference and the CPU oracle.
+
+Tolerances: north_star asks for <= 1e-4 relative L2 of the reference CPU path.  Single kernels / single denoise calls are
+held to 1e-5 (the fp32 reorder floor of the reference itself is 5.5e-7 per denoise call); multi-step
+trajectories to 1e-4.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import gold, rel_l2
+from helpers import d1grid_kwargs, seeded_unet, t, verify_checksums
+
+pytestmark = pytest.mark.gpu
+
+TOL_OP = 1e-5
+TOL_TRAJ = 1e-4
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from calodiffusion_amd.engine import Ops
+    return Ops()
+
+
+def cl(ops, a):
+    return ops.to_channels_last(t(a).cuda())
+
+
+def back(ops, y_cl):
+    return ops.to_ncdhw(y_cl).cpu().numpy()
+
+
+def test_library_is_the_hip_one_and_device_is_gfx950():
+    from calodiffusion_amd import engine
+    name = engine.require_gpu()
+    assert "gfx950" in name
+
+
+def test_layout_roundtrip(ops):
+    x = torch.randn(3, 32, 4, 5, 6)
+    y = ops.to_channels_last(x.cuda())
+    assert torch.equal(y.cpu(), x.permute(0, 2, 3, 4, 1).contiguous())
+    assert torch.equal(ops.to_ncdhw(y).cpu(), x)
+
+
+def test_cyl_conv_known_answer(ops):
+    """calodiffusion/tests/test_cyl_conv.py embedded in channel 0 of a 32-channel problem (1x3x3 kernel -> zero d-taps)."""
+    g = gold("cyl_known_answer")
+    x = torch.zeros(1, 32, 1, 4, 3)
+    x[:, 0] = t(g["x"])[:, 0]
+    w = torch.zeros(32, 32, 3, 3, 3)
+    w[0, 0, 1] = 1.0  # all-ones 1x3x3 kernel in the central z plane
+    y = back(ops, ops.cyl_conv(cl(ops, x.numpy()), w.cuda(), None))
+    assert np.array_equal(y[0, 0, 0], g["cyl"][0, 0, 0])
+    assert np.count_nonzero(y[0, 1:]) == 0
+
+
+def test_conv_primitives(ops):
+    g = gold("primitives_conv")
+    tags = sorted({k.split(".")[0] for k in g.files})
+    for tag in tags:
+        w = t(g[f"{tag}.w"]).cuda()
+        b = t(g[f"{tag}.b"]).cuda() if f"{tag}.b" in g.files else None
+        if tag in ("c3_4_32", "c3_3_32"):
+            y = back(ops, ops.init_conv(t(g[f"{tag}.x"]).cuda(), w, b))
+        elif tag.startswith("c3") or tag.startswith("c1"):
+            if tag == "c1_32_1":
+                continue  # single-output head is covered by the fused head kernel in the model tests
+            y = back(ops, ops.cyl_conv(cl(ops, g[f"{tag}.x"]), w, b))
+        elif tag.startswith("down"):
+            zs = 2 if int(g[f"{tag}.cz"]) else 1
+            y = back(ops, ops.cyl_conv(cl(ops, g[f"{tag}.x"]), w, b, stride=(zs, 2, 2)))
+        else:
+            zs = 2 if int(g[f"{tag}.cz"]) else 1
+            e = g[f"{tag}.extra"]
+            y = back(ops, ops.cyl_conv_transpose(cl(ops, g[f"{tag}.x"]), w, b, int(w.shape[2]), zs, (0, int(e[1]), int(e[2]))))
+        assert y.shape == g[f"{tag}.y"].shape, (tag, y.shape, g[f"{tag}.y"].shape)
+        err = rel_l2(y, g[f"{tag}.y"])
+        assert err < TOL_OP, (tag, err)
+
+
+def test_concat_conv_equals_conv_of_concat(ops):
+    """The skip concat is never materialised: the conv reads two base pointers (models.py:741)."""
+    from oracle import torch_oracle as O
+    gen = torch.Generator().manual_seed(3)
+    a, b = torch.randn(2, 64, 5, 4, 3, generator=gen), torch.randn(2, 64, 5, 4, 3, generator=gen)
+    w, bias = torch.randn(32, 128, 3, 3, 3, generator=gen) * 0.05, torch.randn(32, generator=gen)
+    want = O.cyl_conv3d(torch.cat([a, b], 1), w, bias, padding=(1, 1, 1)).numpy()
+    y = back(ops, ops.cyl_conv(cl(ops, a.numpy()), w.cuda(), bias.cuda(), x1_cl=cl(ops, b.numpy())))
+    assert rel_l2(y, want) < TOL_OP
+    w1 = torch.randn(32, 128, 1, 1, 1, generator=gen) * 0.1
+    want = O.cyl_conv3d(torch.cat([a, b], 1), w1, bias).numpy()
+    y = back(ops, ops.cyl_conv(cl(ops, a.numpy()), w1.cuda(), bias.cuda(), x1_cl=cl(ops, b.numpy())))
+    assert rel_l2(y, want) < TOL_OP
+
+
+def test_group_norm(ops):
+    import torch.nn.functional as F
+    gen = torch.Generator().manual_seed(4)
+    for C, G, shp in ((32, 8, (2, 5, 6, 4)), (64, 8, (1, 23, 8, 4)), (96, 8, (1, 3, 3, 5)), (64, 1, (2, 7, 3, 5))):
+        x = torch.randn((shp[0], C) + shp[1:], generator=gen) * 3 + 1.5
+        gm, bt = torch.randn(C, generator=gen), torch.randn(C, generator=gen)
+        add, res = torch.randn(shp[0], C, generator=gen), torch.randn(x.shape, generator=gen)
+        want = F.silu(F.group_norm(x, G, gm, bt, 1e-5)) + add[:, :, None, None, None] + res
+        y = back(ops, ops.group_norm(cl(ops, x.numpy()), gm.cuda(), bt.cuda(), G, silu=True, add_bc=add.cuda(),
+                                     residual=cl(ops, res.numpy())))
+        assert rel_l2(y, want.numpy()) < TOL_OP, (C, G)
+
+
+def _sub(g, tag):
+    pre = f"{tag}.sd."
+    return {k[len(pre):]: t(g[k]).cuda() for k in g.files if k.startswith(pre)}
+
+
+def test_resnet_blocks(ops):
+    g = gold("primitives_blocks")
+    for tag in ("res_32_32", "res_32_64", "res_128_32", "res_nocond"):
+        cond = t(g[f"{tag}.cond"]).cuda() if f"{tag}.cond" in g.files else None
+        x = g[f"{tag}.x"]
+        if tag == "res_128_32":  # exercise the two-pointer concat path
+            y = ops.resnet_block(cl(ops, x[:, :64]), _sub(g, tag), cond, x1_cl=cl(ops, x[:, 64:]))
+        else:
+            y = ops.resnet_block(cl(ops, x), _sub(g, tag), cond)
+        err = rel_l2(back(ops, y), g[f"{tag}.y"])
+        assert err < TOL_OP, (tag, err)
+
+
+def test_linear_attention_blocks(ops):
+    g = gold("primitives_blocks")
+    for tag in ("attn_32", "attn_64", "attn_96"):
+        y = ops.linear_attention(cl(ops, g[f"{tag}.x"]), _sub(g, tag))
+        err = rel_l2(back(ops, y), g[f"{tag}.y"])
+        assert err < TOL_OP, (tag, err)
+
+
+def _model(name):
+    from calodiffusion_amd.calodiffusion import CaloDiffusion
+    from calodiffusion_amd.configs import load_config
+    cfg = load_config(name)
+    torch.manual_seed(1234)
+    m = CaloDiffusion(cfg, n_steps=cfg["NSTEPS"], loss_type=cfg["LOSS_TYPE"])
+    return m
+
+
+@pytest.mark.parametrize("name", ["tiny", "dataset2", "hgcal", "dataset3"])
+def test_denoise_matches_reference(name):
+    g = gold(f"model_{name}")
+    m = _model(name)
+    verify_checksums({k[6:]: v.cpu() for k, v in m.state_dict().items()}, g)
+    x, E = t(g["x"]).cuda(), t(g["E"]).cuda()
+    layers = t(g["layers"]).cuda() if "layers" in g.files else None
+    for i in range(3):
+        s = float(g[f"sigma_{i}"])
+        sig = torch.full((x.shape[0], 1, 1, 1, 1), s, device="cuda")
+        y = m.denoise(x * float(np.sqrt(1.0 + s * s)), E=E, sigma=sig, layers=layers)
+        err = rel_l2(y.cpu().numpy(), g[f"denoise_{i}"])
+        assert err < TOL_OP, (name, i, err)
+
+
+def test_unet_forward_d1_grid():
+    g = gold("unet_d1grid")
+    net = seeded_unet(d1grid_kwargs(), int(g["seed"])).cuda()
+    y = net(t(g["x"]).cuda(), cond=t(g["cond"]).cuda(), time=t(g["time"]).cuda())
+    assert rel_l2(y.cpu().numpy(), g["y"]) < TOL_OP
+
+
+def test_ddim_trajectories_dataset2():
+    g = gold("ddim_dataset2")
+    m = _model("dataset2")
+    start, E, layers = t(g["start"]).cuda(), t(g["E"]).cuda(), t(g["layers"]).cuda()
+    for n in (2, 10, 50, 400):
+        out = m.sample(E, layers, num_steps=n, start=start)
+        assert isinstance(out, np.ndarray) and out.dtype == np.float32 and out.shape == tuple(start.shape)
+        err = rel_l2(out, g[f"ddim_{n}"])
+        assert err < TOL_TRAJ, (n, err)
+    out, xs, x0s = m.sample(E, layers, num_steps=10, start=start, debug=True)
+    assert rel_l2(torch.stack(xs).cpu().numpy(), g["ddim_10_xs"]) < TOL_TRAJ
+    assert rel_l2(torch.stack(x0s).cpu().numpy(), g["ddim_10_x0s"]) < TOL_TRAJ
+    assert rel_l2(m.sample(E, layers, num_steps=10, start=start, sample_offset=3), g["ddim_10_off3"]) < TOL_TRAJ
+
+
+def test_graph_replay_equals_eager_bitwise():
+    m = _model("tiny")
+    g = gold("ddpm_tiny")
+    start, E, layers = t(g["start"]).cuda(), t(g["E"]).cuda(), t(g["layers"]).cuda()
+    from calodiffusion_amd import sample
+    m.sampler_algorithm = sample.DDim(m.config)
+    m.sampler_algorithm.use_graph = True
+    a = m.sample(E, layers, num_steps=20, start=start)
+    b = m.sample(E, layers, num_steps=20, start=start)  # cached graph
+    m.sampler_algorithm.use_graph = False
+    c = m.sample(E, layers, num_steps=20, start=start)
+    assert np.array_equal(a, b) and np.array_equal(a, c)
+    assert np.isfinite(a).all()
+
+
+def test_ddpm_tiny_with_reference_noise_stream():
+    g = gold("ddpm_tiny")
+    m = _model("tiny")
+    assert type(m.sampler_algorithm).__name__ == "DDPM"
+    start, E, layers = t(g["start"]).cuda(), t(g["E"]).cuda(), t(g["layers"]).cuda()
+    torch.manual_seed(int(g["noise_seed"]))
+    noise = torch.stack([torch.randn(start.shape) for _ in range(50)]).cuda()
+    m.sampler_algorithm.step_noise = noise
+    out, xs, x0s = m.sample(E, layers, num_steps=50, start=start, debug=True)
+    assert rel_l2(xs[10].cpu().numpy(), g["x_step10"]) < TOL_TRAJ
+    assert rel_l2(x0s[10].cpu().numpy(), g["x0_step10"]) < TOL_TRAJ
+    assert rel_l2(out, g["ddpm_50"]) < 5e-4  # 50 stochastic steps
+    # device Philox noise: runs, finite, and differs from the fixed-noise result
+    m.sampler_algorithm.step_noise = None
+    out2 = m.sample(E, layers, num_steps=50, start=start)
+    assert np.isfinite(out2).all() and not np.allclose(out2, out)
+
+
+def test_loss_values():
+    g = gold("loss_dataset2")
+    m = _model("dataset2")
+    loss = m.compute_loss(t(g["data"]).cuda(), t(g["E"]).cuda(), noise=t(g["noise"]).cuda(), layers=t(g["layers"]).cuda(),
+                          rnd_normal=t(g["rnd_normal"]).cuda())
+    assert loss.dim() == 0
+    assert abs(float(loss) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    g = gold("loss_dataset3")
+    m = _model("dataset3")
+    sig = m.loss_function.draw_sigma(t(g["data"]).cuda(), time=torch.from_numpy(g["time"]).cuda())
+    loss = m.loss_function.loss_function(m, t(g["data"]).cuda(), t(g["E"]).cuda(), sigma=sig, noise=t(g["noise"]).cuda(), layers=None)
+    assert abs(float(loss) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+
+
+def test_philox_stream_properties():
+    from calodiffusion_amd.engine import randn
+    a = randn((1 << 20,), "cuda", seed=1234, offset=0)
+    assert abs(float(a.mean())) < 5e-3 and abs(float(a.var()) - 1.0) < 5e-3
+    k = float(((a - a.mean()) ** 4).mean() / a.var() ** 2)
+    assert abs(k - 3.0) < 0.05
+    # element i depends only on (seed, offset + i): shards of one stream agree with the whole
+    b = randn((1000,), "cuda", seed=1234, offset=777)
+    assert torch.equal(b, a[777:1777])
+    assert torch.equal(randn((1 << 20,), "cuda", seed=1234, offset=0), a)
+    assert not torch.equal(randn((1000,), "cuda", seed=1235, offset=0), a[:1000])
+
+
+def test_full_size_properties_dataset2_batch64():
+    """BASELINE's headline size (B = 64): size-independent properties instead of a 64-sample oracle run."""
+    m = _model("dataset2")
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn((64, 1, 45, 16, 9), generator=gen).cuda()
+    E = torch.rand((64, 1), generator=gen).cuda()
+    layers = torch.randn((64, 46), generator=gen).cuda()
+    sig = torch.full((64,), 1.3, device="cuda")
+    y = m.denoise(x, E=E, sigma=sig, layers=layers)
+    assert torch.isfinite(y).all()
+    # (1) batch independence: no op mixes showers
+    y8 = m.denoise(x[5:13].contiguous(), E=E[5:13].contiguous(), sigma=sig[5:13].contiguous(), layers=layers[5:13].contiguous())
+    assert rel_l2(y8.cpu().numpy(), y[5:13].cpu().numpy()) < 2e-6
+    # (2) phi periodicity: Dataset-2 has no phi input channel, so rolling the input along phi rolls the output
+    yr = m.denoise(torch.roll(x, 5, dims=3).contiguous(), E=E, sigma=sig, layers=layers)
+    assert rel_l2(torch.roll(yr, -5, dims=3).cpu().numpy(), y.cpu().numpy()) < 2e-6
+    # (3) determinism
+    assert torch.equal(m.denoise(x, E=E, sigma=sig, layers=layers), y)
+    # (4) agreement with the oracle on two of the 64 showers
+    from oracle import torch_oracle as O
+    om = O.OracleModel(m.config, {k: v.cpu() for k, v in m.state_dict().items()})
+    with torch.no_grad():
+        want = om.denoise(x[[0, 63]].cpu(), E[[0, 63]].cpu(), sig[[0, 63]].cpu(), layers[[0, 63]].cpu())
+    assert rel_l2(y[[0, 63]].cpu().numpy(), want.numpy()) < TOL_OP
+
+
+def test_weight_update_is_picked_up():
+    m = _model("tiny")
+    g = gold("model_tiny")
+    x, E, layers = t(g["x"]).cuda(), t(g["E"]).cuda(), t(g["layers"]).cuda()
+    sig = torch.full((4,), 1.0, device="cuda")
+    y0 = m.denoise(x, E=E, sigma=sig, layers=layers)
+    with torch.no_grad():
+        m.model.final_conv[1].conv.bias.add_(0.5)
+    y1 = m.denoise(x, E=E, sigma=sig, layers=layers)
+    c_out = 1.0 * 1.0 / np.sqrt(2.0)
+    assert rel_l2((y1 - y0).cpu().numpy(), np.full(tuple(x.shape), 0.5 * c_out, dtype=np.float32)) < 1e-5

@@ -1,0 +1,123 @@
+"""CPU: host logic, the C-ABI library's export table, and the loud failure without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, gold, rel_l2
+from helpers import seeded_unet, t, verify_checksums
+from oracle import torch_oracle as O
+from calodiffusion_amd import engine, schedule, utils
+from calodiffusion_amd.calodiffusion import CaloDiffusion
+from calodiffusion_amd.configs import load_config
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "calodiff.h")).read()
+    declared = set(re.findall(r"\b(cd_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    lib = ctypes.CDLL(engine.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/calodiff.h but not exported"
+    assert declared == set(engine.EXPORTED_SYMBOLS)
+    engine.load_library()  # binds argtypes for all of them
+
+
+def test_step_table_matches_reference_loop_scalars():
+    """ddim_step_table == the scalars DDim.__call__ gathers per iteration (pinned through the oracle's tables,
+    themselves bit-identical to the reference's: test_oracle_golden.test_schedules_bitwise)."""
+    for n, eta, off in ((400, 0.0, 0), (50, 1.0, 0), (10, 0.0, 3), (2, 1.0, 0)):
+        tab = schedule.ddim_step_table(n, eta, off)
+        tb = O.ddim_tables(n)
+        ts = list(range(n - 1, -1, -1))[off:]
+        assert tab.shape == (len(ts), 4)
+        for i, tt in enumerate(ts):
+            a, ap = tb.alphas_cumprod[tt], tb.alphas_cumprod_prev[tt]
+            denom = tb.sqrt_alphas_cumprod[max(tt - 1, 0)]
+            sigma = tb.sqrt_one_minus_alphas_cumprod[tt] / tb.sqrt_alphas_cumprod[tt]
+            ds = eta * (((1 - ap) / (1 - a)) * (1 - a / ap)) ** 0.5
+            sp = (1.0 - ap - ds ** 2).sqrt() / denom * (1.0 if tt > 0 else 0.0)
+            want = np.array([float(sigma), float(sp), float(ds), float(denom)], dtype=np.float32)
+            assert np.array_equal(tab[i], want), (n, eta, tt)
+    # N = 400: sigma spans 2.57e4 .. 1.06e-2
+    tab = schedule.ddim_step_table(400, 0.0)
+    assert abs(tab[0, 0] / 2.57e4 - 1) < 0.01 and abs(tab[-1, 0] / 1.06e-2 - 1) < 0.01 and tab[-1, 1] == 0.0
+
+
+def test_coordinate_profiles_match_reference_images():
+    r, z, phi = utils.coordinate_profiles(2, (45, 16, 9))
+    ro, zo, po = O.rz_phi_profiles(2, (45, 16, 9))
+    assert np.array_equal(r, ro.numpy()) and np.array_equal(z, zo.numpy()) and np.array_equal(phi, po.numpy())
+    assert r[-1] == 1.0 and z[0] == 0.0 and abs(z[-1] - 44 / 45) < 1e-7 and phi[0] == 0.0 and phi[-1] == 1.0
+    with pytest.raises(ValueError):
+        utils.coordinate_profiles(2, (45, 16, 10))
+
+
+@pytest.mark.parametrize("name", ["dataset2", "dataset3", "hgcal", "tiny"])
+def test_parameter_container_reproduces_reference_init(name):
+    g = gold(f"model_{name}")
+    verify_checksums(seeded_unet(name, int(g["seed"])).state_dict(), g)
+
+
+def test_calodiffusion_surface_and_state_dict_roundtrip(tmp_path):
+    m = CaloDiffusion("dataset2", n_steps=400, loss_type="l2")
+    assert type(m.sampler_algorithm).__name__ == "DDim" and type(m.loss_function).__name__ == "hybrid_weight"
+    assert m.loss_function.sigma_data == 1.0 and m._data_shape == [1, 45, 16, 9] and m.nsteps == 400
+    sd = m.state_dict()
+    assert all(k.startswith("model.") for k in sd) and sum(v.numel() for v in sd.values()) == 2212785
+    # checkpoints written with a wrapper prefix load, as in the reference (calodiffusion.py:31-37)
+    wrapped = {"module." + k: v.clone() for k, v in sd.items()}
+    path = tmp_path / "ckpt.pth"
+    torch.save({"model_state_dict": wrapped}, path)
+    m2 = CaloDiffusion("dataset2", n_steps=400, loss_type="l2")
+    m2.load_state_dict(torch.load(path)["model_state_dict"])
+    for k in sd:
+        assert torch.equal(sd[k], m2.state_dict()[k])
+    with pytest.raises(ValueError):
+        cfg = dict(load_config("dataset2"))
+        cfg["SAMPLER"] = "NoSuchSampler"
+        CaloDiffusion(cfg)
+
+
+def test_unsupported_configurations_fail_at_construction():
+    cfg = dict(load_config("dataset2"))
+    cfg["TIME_EMBED"] = "sin"
+    with pytest.raises((KeyError, NotImplementedError)):
+        CaloDiffusion(cfg)
+    cfg = dict(load_config("dataset2"))
+    cfg["CYLINDRICAL"] = False
+    with pytest.raises(NotImplementedError):
+        CaloDiffusion(cfg)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_compute_fails_loudly_without_gpu():
+    m = CaloDiffusion("tiny", 50, "l2")
+    with pytest.raises(RuntimeError, match="no CPU fallback|GPU"):
+        m.denoise(torch.zeros(1, 1, 8, 8, 8), E=torch.zeros(1, 3), sigma=torch.ones(1), layers=torch.zeros(1, 9))
+    with pytest.raises(RuntimeError):
+        m.sample(torch.zeros(1, 3), torch.zeros(1, 9), num_steps=2)
+
+
+def test_shard_batch_partitions():
+    for n, w in ((64, 8), (10, 4), (3, 8), (128, 2)):
+        seen = []
+        for r in range(w):
+            s = utils.shard_batch(n, w, r)
+            seen += list(range(n))[s]
+        assert seen == list(range(n))
+
+
+def test_loss_sigma_draw_matches_oracle_formula():
+    m = CaloDiffusion("dataset2", 400, "l2")
+    rnd = torch.tensor([0.3, -1.1, 2.0])
+    s = m.loss_function.draw_sigma(torch.zeros(3, 1, 2, 2, 2), rnd_normal=rnd)
+    assert torch.equal(s, (rnd * 1.2 + (-1.2)).exp())
+    m3 = CaloDiffusion("dataset3", 400, "l2")
+    tt = torch.tensor([0, 137, 399])
+    s3 = m3.loss_function.draw_sigma(torch.zeros(3, 1, 2, 2, 2), time=tt)
+    tb = O.ddim_tables(400)
+    assert torch.equal(s3, tb.sqrt_one_minus_alphas_cumprod[tt] / tb.sqrt_alphas_cumprod[tt])

@@ -1,0 +1,146 @@
+"""CPU: the oracle (oracle/torch_oracle.py) against the golden vectors generated from the reference itself."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import gold, rel_l2
+from helpers import d1grid_kwargs, seeded_unet, t, verify_checksums
+from oracle import torch_oracle as O
+from calodiffusion_amd.configs import load_config
+
+TOL = 2e-6  # fp32 reorder noise floor of one denoise call is 5.5e-7
+
+
+def test_cyl_conv_known_answer():
+    """The reference's only known-answer fixture for this path: calodiffusion/tests/test_cyl_conv.py."""
+    g = gold("cyl_known_answer")
+    x = t(g["x"])
+    w = torch.ones(1, 1, 1, 3, 3)
+    y = O.cyl_conv3d(x, w, None, padding=(0, 1, 1))
+    assert np.array_equal(y.numpy(), g["cyl"])
+    # hand-computed: every phi row sees three identical rows [1,2,3] -> 3*(l+c+r) with zero padding in r
+    assert np.array_equal(g["cyl"][0, 0, 0], np.array([[9.0, 18.0, 15.0]] * 4, dtype=np.float32))
+    # plain zero padding differs on the two phi edge rows
+    assert np.array_equal(g["plain"][0, 0, 0, 0], np.array([6.0, 12.0, 10.0], dtype=np.float32))
+
+
+def test_schedules_bitwise():
+    g = gold("schedules")
+    for n in (2, 10, 50, 200, 400):
+        assert np.array_equal(O.cosine_beta_schedule(n).numpy(), g[f"betas_{n}"])
+        assert np.array_equal(O.ddim_tables(n).alphas_cumprod.numpy(), g[f"alphas_cumprod_{n}"])
+
+
+def test_conv_primitives():
+    g = gold("primitives_conv")
+    tags = sorted({k.split(".")[0] for k in g.files})
+    for tag in tags:
+        x, w = t(g[f"{tag}.x"]), t(g[f"{tag}.w"])
+        b = t(g[f"{tag}.b"]) if f"{tag}.b" in g.files else None
+        if tag.startswith("c3"):
+            y = O.cyl_conv3d(x, w, b, padding=(1, 1, 1))
+        elif tag.startswith("c1"):
+            y = O.cyl_conv3d(x, w, b)
+        elif tag.startswith("down"):
+            zs = 2 if int(g[f"{tag}.cz"]) else 1
+            y = O.cyl_conv3d(x, w, b, stride=(zs, 2, 2), padding=(1, 1, 1))
+        else:
+            zs = 2 if int(g[f"{tag}.cz"]) else 1
+            e = g[f"{tag}.extra"]
+            y = O.cyl_conv_transpose3d(x, w, b, (zs, 2, 2), (0, int(e[1]), int(e[2])))
+        assert y.shape == g[f"{tag}.y"].shape, tag
+        assert rel_l2(y.numpy(), g[f"{tag}.y"]) < TOL, tag
+
+
+def _sub(g, tag):
+    pre = f"{tag}.sd."
+    return {k[len(pre):]: t(g[k]) for k in g.files if k.startswith(pre)}
+
+
+def test_block_primitives():
+    g = gold("primitives_blocks")
+    for tag in ("res_32_32", "res_32_64", "res_128_32", "res_nocond"):
+        sd = {"blk." + k: v for k, v in _sub(g, tag).items()}
+        cond = t(g[f"{tag}.cond"]) if f"{tag}.cond" in g.files else None
+        y = O.resnet_block(sd, "blk", t(g[f"{tag}.x"]), cond, 8, True)
+        assert rel_l2(y.numpy(), g[f"{tag}.y"]) < TOL, tag
+    for tag in ("attn_32", "attn_64", "attn_96"):
+        sd = {"a." + k: v for k, v in _sub(g, tag).items()}
+        y = O.attn_residual(sd, "a", t(g[f"{tag}.x"]), True)
+        assert rel_l2(y.numpy(), g[f"{tag}.y"]) < TOL, tag
+
+
+@pytest.mark.parametrize("name", ["dataset2", "dataset3", "hgcal", "tiny"])
+def test_denoise_models(name):
+    g = gold(f"model_{name}")
+    cfg = load_config(name)
+    net = seeded_unet(name, int(g["seed"]))
+    verify_checksums(net.state_dict(), g)
+    m = O.OracleModel(cfg, net.state_dict())
+    x, E = t(g["x"]), t(g["E"])
+    layers = t(g["layers"]) if "layers" in g.files else None
+    with torch.no_grad():
+        for i in range(3):
+            s = float(g[f"sigma_{i}"])
+            sig = torch.full((x.shape[0],), s)
+            y = m.denoise(x * float(np.sqrt(1.0 + s * s)), E, sig, layers)
+            assert rel_l2(y.numpy(), g[f"denoise_{i}"]) < TOL, (name, i)
+
+
+def test_unet_d1_grid():
+    g = gold("unet_d1grid")
+    net = seeded_unet(d1grid_kwargs(), int(g["seed"]))
+    verify_checksums(net.state_dict(), g)
+    spec = O.UnetSpec(layer_sizes=[32, 32, 64, 96], channels=4, cond_size=7, data_shape=(5, 10, 30))
+    assert spec.up_kernel_z == [3, 3] and spec.up_out_pad == [(0, 1, 1), (0, 0, 0)]
+    with torch.no_grad():
+        y = O.cond_unet_forward(net.state_dict(), spec, t(g["x"]), t(g["cond"]), t(g["time"]))
+    assert rel_l2(y.numpy(), g["y"]) < TOL
+
+
+def test_ddim_trajectories():
+    g = gold("ddim_dataset2")
+    cfg = load_config("dataset2")
+    m = O.OracleModel(cfg, seeded_unet("dataset2").state_dict())
+    start, E, layers = t(g["start"]), t(g["E"]), t(g["layers"])
+    for n in (2, 10):
+        x, xs, x0s = m.ddim_sample(start, E, layers, n, keep=True)
+        assert rel_l2(x.numpy(), g[f"ddim_{n}"]) < 1e-5, n
+        if n == 10:
+            assert rel_l2(torch.stack(xs).numpy(), g["ddim_10_xs"]) < 1e-5
+            assert rel_l2(torch.stack(x0s).numpy(), g["ddim_10_x0s"]) < 1e-5
+    x, _, _ = m.ddim_sample(start, E, layers, 10, sample_offset=3)
+    assert rel_l2(x.numpy(), g["ddim_10_off3"]) < 1e-5
+
+
+def test_ddpm_tiny_with_seeded_noise():
+    g = gold("ddpm_tiny")
+    cfg = load_config("tiny")
+    m = O.OracleModel(cfg, seeded_unet("tiny").state_dict())
+    start, E, layers = t(g["start"]), t(g["E"]), t(g["layers"])
+    torch.manual_seed(int(g["noise_seed"]))
+    noise = [torch.randn(start.shape) for _ in range(50)]
+    x, xs, x0s = m.ddim_sample(start, E, layers, 50, eta=1.0, step_noise=noise, keep=True)
+    assert rel_l2(xs[10].numpy(), g["x_step10"]) < 1e-5
+    assert rel_l2(x0s[10].numpy(), g["x0_step10"]) < 1e-5
+    assert rel_l2(x.numpy(), g["ddpm_50"]) < 1e-4
+
+
+def test_loss_values():
+    g = gold("loss_dataset2")
+    m = O.OracleModel(load_config("dataset2"), seeded_unet("dataset2").state_dict())
+    with torch.no_grad():
+        loss = m.hybrid_l2_loss(t(g["data"]), t(g["E"]), t(g["noise"]), t(g["layers"]), rnd_normal=t(g["rnd_normal"]))
+    assert abs(float(loss) - float(g["loss"])) <= 2e-6 * abs(float(g["loss"]))
+    g = gold("loss_dataset3")
+    m = O.OracleModel(load_config("dataset3"), seeded_unet("dataset3").state_dict())
+    with torch.no_grad():
+        loss = m.hybrid_l2_loss(t(g["data"]), t(g["E"]), t(g["noise"]), None, time=torch.from_numpy(g["time"]))
+    assert abs(float(loss) - float(g["loss"])) <= 2e-6 * abs(float(g["loss"]))
+
+
+def test_work_accounting_matches_survey():
+    """Algorithmic FLOPs per sample-step reproduce SURVEY.md section 8d (5.44 G D2, 30.3 G D3, 6.47 G HGCal)."""
+    for name, want in (("dataset2", 5.44e9), ("dataset3", 30.3e9), ("hgcal", 6.47e9)):
+        w = O.algorithmic_work(O.spec_from_config(load_config(name)))
+        assert abs(w["flops"]["total"] - want) / want < 0.02, (name, w["flops"]["total"])
