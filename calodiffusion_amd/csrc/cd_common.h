@@ -127,7 +127,7 @@ void launch_gn_stats(const float* x, double* partials, int batch, int channels, 
                      hipStream_t s);
 void launch_gn_apply(const float* x, float* y, const double* partials, int nsplit, const float* gamma, const float* beta,
                      int batch, int channels, int64_t vox, int groups, int silu, const float* add_bc, int add_ld,
-                     const float* residual, hipStream_t s);
+                     const float* residual, hipStream_t s, const float* residual1 = nullptr, int res_c0 = 0);
 
 int attn_nsplit_for(int64_t vox, int batch);
 size_t attn_partial_floats(int batch, int nsplit);

@@ -83,7 +83,9 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        int channels, int64_t vox, int groups, int silu,
                                                        const float* __restrict__ add_bc, int add_ld,
-                                                       const float* __restrict__ residual, int blocks_per_sample) {
+                                                       const float* __restrict__ residual,
+                                                       const float* __restrict__ residual1, int res_c0,
+                                                       int blocks_per_sample) {
   __shared__ float sMean[64], sRstd[64];
   const int tid = threadIdx.x;
   const int b = blockIdx.x / blocks_per_sample, blk = blockIdx.x % blocks_per_sample;
@@ -124,7 +126,15 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
 #pragma unroll
       for (int e = 0; e < 4; ++e) t[e] += ad[e];
     }
-    if (residual) {
+    if (residual1) {
+      // identity shortcut of a block whose input is a (never materialised) channel concat of two tensors
+      const int64_t v = i / cols;
+      const int res_c1 = channels - res_c0;
+      const f32x4 rr = c < res_c0 ? *(const f32x4*)(residual + ((size_t)b * vox + v) * res_c0 + c)
+                                  : *(const f32x4*)(residual1 + ((size_t)b * vox + v) * res_c1 + (c - res_c0));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[e] += rr[e];
+    } else if (residual) {
       const f32x4 rr = *(const f32x4*)(residual + sbase + i * 4);
 #pragma unroll
       for (int e = 0; e < 4; ++e) t[e] += rr[e];
@@ -135,7 +145,7 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
 
 void launch_gn_apply(const float* x, float* y, const double* partials, int nsplit, const float* gamma, const float* beta,
                      int batch, int channels, int64_t vox, int groups, int silu, const float* add_bc, int add_ld,
-                     const float* residual, hipStream_t s) {
+                     const float* residual, hipStream_t s, const float* residual1, int res_c0) {
   CD_REQUIRE(groups <= 64, "group norm: at most 64 groups");
   const int64_t items = vox * (channels / 4);
   int bps = (int)((items + 2047) / 2048);  // >= 8 float4 per thread
@@ -144,7 +154,7 @@ void launch_gn_apply(const float* x, float* y, const double* partials, int nspli
   if (bps < 1) bps = 1;
   prof::Scope scope("gn_apply", s, 0, 4.0 * batch * (double)vox * channels * (2 + (residual ? 1 : 0)));
   hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)(batch * bps)), dim3(256), 0, s, x, y, partials, nsplit, gamma, beta,
-                     channels, vox, groups, silu, add_bc, add_ld, residual, bps);
+                     channels, vox, groups, silu, add_bc, add_ld, residual, residual1, res_c0, bps);
   CD_HIP(hipGetLastError());
 }
 

@@ -144,7 +144,8 @@ struct CdPlan {
   int* d_counter = nullptr;
   float* d_stepvals = nullptr;
 
-  // cached step graph
+  // cached step graph; captured on a private stream (the caller's may be the legacy null stream, which cannot capture)
+  hipStream_t cap_stream = nullptr;
   hipGraphExec_t graph_exec = nullptr;
   struct GraphKey {
     int batch = 0; const void* ws = nullptr; const void* cond = nullptr; const void* x = nullptr; int noisy = 0; uint64_t seed = 0, offset = 0;
@@ -420,8 +421,8 @@ float* res_block(Run& r, const ResP& w, const float* x0, int c0, const float* x1
     }
     ws->release(res);
   } else {
-    CD_REQUIRE(c1 == 0, "internal: identity residual on a concatenated input");
-    if (!r.dry()) launch_gn_apply(h2, h2, st, ns, w.n2g, w.n2b, r.B, w.cout, vox, G, 1, nullptr, 0, x0, r.s);
+    // identity shortcut; for a concatenated input the residual is read from its two sources (models.py:200,741)
+    if (!r.dry()) launch_gn_apply(h2, h2, st, ns, w.n2g, w.n2b, r.B, w.cout, vox, G, 1, nullptr, 0, x0, r.s, c1 ? x1 : nullptr, c0);
   }
   ws->release(st);
   return h2;
@@ -659,6 +660,7 @@ int cd_plan_destroy(CdPlan* plan) {
   return guarded([&] {
     if (!plan) return;
     destroy_graph(plan);
+    if (plan->cap_stream) hipStreamDestroy(plan->cap_stream);
     if (plan->arena) hipFree(plan->arena);
     if (plan->d_embed_layers) hipFree(plan->d_embed_layers);
     if (plan->d_coords) hipFree(plan->d_coords);
@@ -794,17 +796,16 @@ int cd_ddim_sample(CdPlan* plan, int batch, const float* start, const float* con
     char* sub = (char*)workspace + used;
     const size_t sub_bytes = workspace_bytes > used ? workspace_bytes - used : 0;
 
-    auto one_step = [&](int i, const float* noise_i, float* xs_i, float* x0s_i, bool philox_from_counter) {
-      launch_load_step(plan->d_table, plan->d_counter, plan->d_stepvals, sigma_b, batch, s);
+    auto one_step = [&](hipStream_t st, int i, const float* noise_i, float* xs_i, float* x0s_i) {
+      launch_load_step(plan->d_table, plan->d_counter, plan->d_stepvals, sigma_b, batch, st);
       plan->ws.reset(sub, sub_bytes, false);
-      forward_impl(plan, batch, x_out, cond, sigma_b, x0, false, s);
+      forward_impl(plan, batch, x_out, cond, sigma_b, x0, false, st);
       const float* nz = noise_i;
       if (!nz && noisy) {
-        (void)philox_from_counter;
-        launch_randn(noise_buf, n, seed, offset + (uint64_t)i * (uint64_t)n, s);
+        launch_randn(noise_buf, n, seed, offset + (uint64_t)i * (uint64_t)n, st);
         nz = noise_buf;
       }
-      launch_ddim_update(x_out, x0, nz, plan->d_stepvals, x_out, xs_i, x0s_i, n, s);
+      launch_ddim_update(x_out, x0, nz, plan->d_stepvals, x_out, xs_i, x0s_i, n, st);
     };
 
     // A hipGraph of one step can be replayed only if nothing in it depends on the host-side step index:
@@ -816,15 +817,17 @@ int cd_ddim_sample(CdPlan* plan, int batch, const float* start, const float* con
       if (!(plan->graph_exec && plan->graph_key == key)) {
         destroy_graph(plan);
         hipGraph_t graph = nullptr;
-        CD_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        if (!plan->cap_stream) CD_HIP(hipStreamCreateWithFlags(&plan->cap_stream, hipStreamNonBlocking));
+        hipStream_t cs = plan->cap_stream;
+        CD_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed));
         try {
-          one_step(0, nullptr, nullptr, nullptr, false);
+          one_step(cs, 0, nullptr, nullptr, nullptr);
         } catch (...) {
-          hipStreamEndCapture(s, &graph);
+          hipStreamEndCapture(cs, &graph);
           if (graph) hipGraphDestroy(graph);
           throw;
         }
-        CD_HIP(hipStreamEndCapture(s, &graph));
+        CD_HIP(hipStreamEndCapture(cs, &graph));
         hipError_t e = hipGraphInstantiate(&plan->graph_exec, graph, nullptr, nullptr, 0);
         hipGraphDestroy(graph);
         if (e != hipSuccess) {
@@ -836,8 +839,8 @@ int cd_ddim_sample(CdPlan* plan, int batch, const float* start, const float* con
       for (int i = 0; i < n_steps; ++i) CD_HIP(hipGraphLaunch(plan->graph_exec, s));
     } else {
       for (int i = 0; i < n_steps; ++i)
-        one_step(i, step_noise ? step_noise + (size_t)i * n : nullptr, xs ? xs + (size_t)i * n : nullptr,
-                 x0s ? x0s + (size_t)i * n : nullptr, false);
+        one_step(s, i, step_noise ? step_noise + (size_t)i * n : nullptr, xs ? xs + (size_t)i * n : nullptr,
+                 x0s ? x0s + (size_t)i * n : nullptr);
     }
   });
 }

@@ -253,9 +253,12 @@ def test_full_size_properties_dataset2_batch64():
     # (1) batch independence: no op mixes showers
     y8 = m.denoise(x[5:13].contiguous(), E=E[5:13].contiguous(), sigma=sig[5:13].contiguous(), layers=layers[5:13].contiguous())
     assert rel_l2(y8.cpu().numpy(), y[5:13].cpu().numpy()) < 2e-6
-    # (2) phi periodicity: Dataset-2 has no phi input channel, so rolling the input along phi rolls the output
+    # (2) phi periodicity: Dataset-2 has no phi input channel, so rolling the input along phi by a multiple of 4
+    #     (two stride-2 levels) rolls the output
+    yr = m.denoise(torch.roll(x, 4, dims=3).contiguous(), E=E, sigma=sig, layers=layers)
+    assert rel_l2(torch.roll(yr, -4, dims=3).cpu().numpy(), y.cpu().numpy()) < 2e-6
     yr = m.denoise(torch.roll(x, 5, dims=3).contiguous(), E=E, sigma=sig, layers=layers)
-    assert rel_l2(torch.roll(yr, -5, dims=3).cpu().numpy(), y.cpu().numpy()) < 2e-6
+    assert rel_l2(torch.roll(yr, -5, dims=3).cpu().numpy(), y.cpu().numpy()) > 1e-3  # odd shifts are NOT a symmetry
     # (3) determinism
     assert torch.equal(m.denoise(x, E=E, sigma=sig, layers=layers), y)
     # (4) agreement with the oracle on two of the 64 showers
