@@ -9,6 +9,10 @@
 // calodiffusion/models/models.py:25-96, 335-369: circular padding along phi (H), zero padding along z (D) and r (W).
 #include "cd_common.h"
 #include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <string>
+#include <vector>
 
 namespace cd {
 
@@ -246,6 +250,15 @@ ConvTile choose_conv_tile(const ConvGeom& g, int batch, int CT) {
     }
   }
   CD_REQUIRE(best.NW > 0, "no convolution tiling fits in LDS (grid too wide in r?)");
+  // experiment hook: CD_CONV_TILE="TZ,TH,NW,VT" overrides the choice for stride-1 3x3x3 convs
+  if (const char* ov = getenv("CD_CONV_TILE")) {
+    int tz, th, nw, vt;
+    if (sscanf(ov, "%d,%d,%d,%d", &tz, &th, &nw, &vt) == 4 && g.sz == 1 && g.kh == 3 && tz <= g.out.d && th <= g.out.h) {
+      const int IZ = tz - 1 + g.kd, IH = th - 1 + g.kh;
+      const size_t lds = ((size_t)IZ * IH * g.in.w * 36 + 36) * 4;
+      if (lds <= 160 * 1024 && nw * vt * 32 >= tz * th * g.out.w && vt <= max_vt) best = ConvTile{tz, th, nw, vt, lds};
+    }
+  }
   return best;
 }
 
@@ -261,6 +274,339 @@ void launch_conv_inst(const ConvKArgs& a, dim3 grid, int threads, size_t lds, hi
 }
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------------------
+// 3x3x3 stride-1 conv, "flat range" variant (the hot kernel: 92 % of the model's FLOPs).
+//
+// A workgroup owns R = 32*NT consecutive voxels of ONE sample in flattened (z, phi, r) order, so every MFMA row tile is
+// full whatever the grid extents are (45x16x9 has 144-voxel planes = 4.5 tiles).  It stages the z-planes that range
+// touches (+1 halo plane each side, zero-filled outside the tensor) as WHOLE planes: phi wraps by index arithmetic,
+// r edges are predicated to a zero slot, so no halo rows/columns are stored.  Input channels stream through LDS in
+// 16-channel sub-chunks (64 B per voxel, XOR-swizzled 16-B slots => conflict-free ds_read_b128 without padding):
+// ~46 KiB for R = 256 on Dataset-2, i.e. three workgroups per CU whose staging and MFMA phases overlap.
+// The 27 taps are fully unrolled: weight fragments (1-KiB wave loads, L1/L2 resident) and LDS fragments of tap t+1
+// are in flight while the 8*VT*CT MFMAs of tap t issue.
+// Sub-chunk k' of a 32-channel chunk = channels [8k', 8k'+8) (lane half 0) and [16+8k', 16+8k'+8) (lane half 1), so the
+// packed weight layout of cd_common.h is used unchanged (fragments q = 2k', 2k'+1).
+// ------------------------------------------------------------------------------------------------------------
+struct ConvFlatArgs {
+  const float* in0;
+  const float* in1;
+  int c0, c1;
+  const float* wpk;
+  const float* bias;
+  float* out;
+  int D, H, W;
+  int R;       // voxels per workgroup (multiple of 32)
+  int P;       // plane capacity of the LDS tile
+  int cout, CTtot;
+  int dbg;     // timing experiments only (CD_FLAT_DBG): 1 = skip staging, 2 = skip the MFMA taps
+};
+
+template <int VT, int CT>
+__global__ void __launch_bounds__(512, (VT * CT <= 2 ? 3 : 2)) conv3_flat_kernel(ConvFlatArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
+  const int b = blockIdx.y;
+  const int ct0 = blockIdx.z * CT;
+  const int HW = a.H * a.W;
+  const int vox = a.D * HW;
+  const int v0 = blockIdx.x * a.R;
+  const int vend = min(v0 + a.R, vox);
+  const int zA = v0 / HW - 1;
+  const int zB = (vend - 1) / HW + 1;
+  const int nstage = (zB - zA + 1) * HW;   // voxels staged per sub-chunk
+  const int NZ = a.P * HW;                 // index of the all-zero voxel
+  const int half = lane >> 5, col = lane & 31;
+  if (tid < 16) lds[NZ * 16 + tid] = 0.f;
+
+  // per-lane geometry of its voxel in each of the wave's VT row tiles
+  int nb[VT], rowm[VT], rowp[VT], ooff[VT];
+  unsigned wmask[VT];
+  bool any_valid = false;
+#pragma unroll
+  for (int vt = 0; vt < VT; ++vt) {
+    const int v = v0 + (wave * VT + vt) * 32 + col;
+    const bool valid = v < vend;
+    const int vv = valid ? v : v0;
+    const int r = vv % HW;
+    const int h = r / a.W, w = r - h * a.W;
+    nb[vt] = vv - zA * HW;
+    rowm[vt] = (h == 0 ? a.H - 1 : -1) * a.W;
+    rowp[vt] = (h == a.H - 1 ? -(a.H - 1) : 1) * a.W;
+    unsigned m = 0;
+    if (valid) m = (w > 0 ? 1u : 0u) | 2u | (w + 1 < a.W ? 4u : 0u);
+    wmask[vt] = m;
+    ooff[vt] = valid ? v * a.cout : -1;
+    any_valid |= valid;
+  }
+  const bool wave_active = __any(any_valid);
+
+  f32x16 acc[VT][CT];
+#pragma unroll
+  for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[vt][ct][r] = 0.f;
+
+  const int nsub = (a.c0 + a.c1) >> 4;
+  const int gbase = zA * HW;  // global voxel index of LDS voxel 0
+  const int nslots = nstage * 4;
+
+  // LDS image: voxel n = 64 B = two 32-B pairs; pair (lane half) hp sits at ((hp ^ (n>>2)) & 1): 2-way conflicts at most
+  // on the ds_read_b128 fragment reads, no padding.  A lane's two fragments are adjacent (immediate offset +16 B).
+  auto frag_addr = [&](int n) -> const float* { return lds + n * 16 + ((half ^ (n >> 2)) & 1) * 8; };
+  auto tap_voxel = [&](int vt, int tap) -> int {
+    const int dz = tap / 9 - 1, dh = (tap / 3) % 3 - 1, dw = tap % 3 - 1;
+    const int n = nb[vt] + dz * HW + (dh < 0 ? rowm[vt] : (dh > 0 ? rowp[vt] : 0)) + dw;
+    return ((wmask[vt] >> (dw + 1)) & 1u) ? n : NZ;
+  };
+
+  for (int sc = 0; sc < nsub; ++sc) {
+    const int chunk = sc >> 1, kq = sc & 1;
+    const float* src;
+    int ldc, coff;
+    if (chunk * 32 < a.c0) {
+      src = a.in0; ldc = a.c0; coff = chunk * 32;
+    } else {
+      src = a.in1; ldc = a.c1; coff = chunk * 32 - a.c0;
+    }
+    src += (size_t)b * vox * ldc + coff + kq * 8;
+    __syncthreads();
+    // stage: 4 independent 16-B loads in flight per thread before the first LDS write
+    for (int s0 = tid; s0 < ((a.dbg & 1) ? 0 : nslots); s0 += 4 * nthreads) {
+      f32x4 val[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int sidx = s0 + k * nthreads;
+        const int n = sidx >> 2, p = sidx & 3;
+        const int g = gbase + n;
+        val[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (sidx < nslots && g >= 0 && g < vox) val[k] = *(const f32x4*)(src + (size_t)g * ldc + (p >> 1) * 16 + (p & 1) * 4);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int sidx = s0 + k * nthreads;
+        const int n = sidx >> 2, p = sidx & 3;
+        if (sidx < nslots) *(f32x4*)(lds + n * 16 + ((((p >> 1) ^ (n >> 2)) & 1) * 2 + (p & 1)) * 4) = val[k];
+      }
+    }
+    __syncthreads();
+    if (!wave_active || (a.dbg & 2)) continue;
+
+    // keep the per-tap address arithmetic inside this loop (hoisting 27*VT addresses costs ~100 VGPRs)
+#pragma unroll
+    for (int vt = 0; vt < VT; ++vt) asm volatile("" : "+v"(nb[vt]));
+
+    const f32x4* wq = (const f32x4*)a.wpk + ((size_t)chunk * 27 * a.CTtot + ct0) * 256 + kq * 128 + lane;
+    // software pipeline over the 27 taps: fragments of tap t+1 are requested before the MFMAs of tap t issue
+    f32x4 bw[2][CT][2], av[2][VT][2];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      bw[0][ct][0] = wq[(size_t)ct * 256];
+      bw[0][ct][1] = wq[(size_t)ct * 256 + 64];
+    }
+#pragma unroll
+    for (int vt = 0; vt < VT; ++vt) {
+      const float* p = frag_addr(tap_voxel(vt, 0));
+      av[0][vt][0] = *(const f32x4*)p;
+      av[0][vt][1] = *(const f32x4*)(p + 4);
+    }
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) {
+      const int cur = tap & 1, nxt = cur ^ 1;
+      if (tap + 1 < 27) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          bw[nxt][ct][0] = wq[((size_t)(tap + 1) * a.CTtot + ct) * 256];
+          bw[nxt][ct][1] = wq[((size_t)(tap + 1) * a.CTtot + ct) * 256 + 64];
+        }
+#pragma unroll
+        for (int vt = 0; vt < VT; ++vt) {
+          const float* p = frag_addr(tap_voxel(vt, tap + 1));
+          av[nxt][vt][0] = *(const f32x4*)p;
+          av[nxt][vt][1] = *(const f32x4*)(p + 4);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the requests ahead of this tap's MFMAs (hipcc otherwise sinks them)
+#pragma unroll
+      for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[vt][ct] = MFMA32(av[cur][vt][0][e], bw[cur][ct][0][e], acc[vt][ct]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[vt][ct] = MFMA32(av[cur][vt][1][e], bw[cur][ct][1][e], acc[vt][ct]);
+        }
+    }
+  }
+
+  float* outb = a.out + (size_t)b * vox * a.cout;
+  float bv[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) bv[ct] = a.bias ? a.bias[(ct0 + ct) * 32 + col] : 0.f;
+#pragma unroll
+  for (int vt = 0; vt < VT; ++vt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int off = __shfl(ooff[vt], row, 64);
+      if (off >= 0) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) outb[off + (ct0 + ct) * 32 + col] = acc[vt][ct][r] + bv[ct];
+      }
+    }
+  }
+}
+
+namespace {
+template <int VT, int CT>
+void launch_flat_inst(const ConvFlatArgs& a, dim3 grid, int threads, size_t lds, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    CD_HIP(hipFuncSetAttribute((const void*)conv3_flat_kernel<VT, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv3_flat_kernel<VT, CT>), grid, dim3(threads), lds, s, a);
+  CD_HIP(hipGetLastError());
+}
+
+struct FlatTile {
+  int NT = 0, VT = 0;
+  size_t lds = 0;
+};
+
+// One-time on-device selection among candidate tilings of one conv geometry (all candidates give bit-identical
+// results: the per-output summation order does not depend on the tiling).  Never runs during stream capture.
+std::map<std::string, int>& tune_cache() {
+  static std::map<std::string, int> c;
+  return c;
+}
+template <typename F>
+int autotune(const std::string& key, int ncand, F&& run, hipStream_t s) {
+  auto it = tune_cache().find(key);
+  if (it != tune_cache().end()) return it->second;
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (getenv("CD_NO_AUTOTUNE") || hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone || prof::enabled())
+    return -1;  // caller falls back to its heuristic (not cached)
+  hipEvent_t e0, e1;
+  CD_HIP(hipEventCreate(&e0));
+  CD_HIP(hipEventCreate(&e1));
+  int best = 0;
+  float best_ms = 1e30f;
+  for (int i = 0; i < ncand; ++i) {
+    run(i);  // warm-up (also sets function attributes)
+    CD_HIP(hipEventRecord(e0, s));
+    run(i);
+    run(i);
+    CD_HIP(hipEventRecord(e1, s));
+    CD_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CD_HIP(hipEventElapsedTime(&ms, e0, e1));
+    if (ms < best_ms) { best_ms = ms; best = i; }
+  }
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  tune_cache()[key] = best;
+  if (getenv("CD_TUNE_VERBOSE")) std::fprintf(stderr, "[calodiff autotune] %s -> candidate %d (%.1f us)\n", key.c_str(), best, best_ms * 500.f);
+  return best;
+}
+
+// R = 32*NT voxels per workgroup.  Cost model: MFMA slot-time per CU round (tiles per SIMD, co-resident workgroups share
+// the 4 SIMDs), tail rounds over 256 CUs, staged bytes per output voxel (halo planes).
+FlatTile choose_flat_tile(Dims3 d, int batch, int CT) {
+  FlatTile best;
+  const int HW = d.h * d.w;
+  const int64_t vox = d.vox();
+  if (const char* ov = getenv("CD_FLAT_TILE")) {
+    int nt, vt;
+    if (sscanf(ov, "%d,%d", &nt, &vt) == 2 && nt % vt == 0 && nt / vt <= 8 && vt * CT <= 8) {
+      const int P = (32 * nt - 1) / HW + 4;
+      const size_t lds = ((size_t)P * HW + 1) * 64;
+      if (lds <= 160 * 1024) { best.NT = nt; best.VT = vt; best.lds = lds; return best; }
+    }
+  }
+  double best_cost = 1e300;
+  for (int NT = 1; NT <= 16; ++NT) {
+    if ((int64_t)32 * (NT - 1) >= vox) break;
+    const int P = (32 * NT - 1) / HW + 4;
+    const size_t lds = ((size_t)P * HW + 1) * 64;
+    if (lds > 80 * 1024) continue;  // keep at least two workgroups per CU
+    for (int VT = 1; VT <= 4; ++VT) {
+      if (NT % VT || NT / VT > 8 || VT * CT > 8) continue;
+      const int NW = NT / VT;
+      const long units = (long)batch * ((vox + 32 * NT - 1) / (32 * NT));
+      int bpc = (int)(160 * 1024 / lds);
+      while (bpc > 1 && bpc * NW > 16) --bpc;
+      long per_cu = (units + 255) / 256;  // workgroups each CU must run
+      // time ~ rounds * (MFMA slot-time of the co-resident set) ; a set of bpc workgroups has bpc*NT tiles on 4 SIMDs
+      const long rounds = (per_cu + bpc - 1) / bpc;
+      const int resident = (int)(per_cu < bpc ? per_cu : bpc);
+      double set_time = (double)((resident * NW + 3) / 4) * VT;  // waves per SIMD * tiles per wave
+      const double useful = (double)vox / (32.0 * NT * ((vox + 32 * NT - 1) / (32 * NT)));
+      const double halo = (double)P * HW / (32.0 * NT);
+      const double cost = rounds * set_time * (1.0 + 0.03 * halo) * (1.0 + 0.1 / (resident * NW)) / useful * 1.0;
+      if (cost < best_cost) { best_cost = cost; best.NT = NT; best.VT = VT; best.lds = lds; }
+    }
+  }
+  return best;
+}
+}  // namespace
+
+// returns false when the whole-plane LDS tile does not fit (wide grids such as Dataset-3's 50x18 planes)
+static bool try_launch_conv3_flat(const float* in0, int c0, const float* in1, int c1, const float* wpk, const float* bias,
+                                  float* out, int batch, int cout, Dims3 d, hipStream_t s) {
+  if (getenv("CD_NO_FLAT")) return false;
+  const int CTtot = cout / 32;
+  const int CT = CTtot <= 3 ? CTtot : 2;
+  if (CTtot % CT) return false;
+  const int HW = d.h * d.w;
+  auto launch = [&](int NT, int VT) -> bool {
+    ConvFlatArgs a;
+    a.in0 = in0; a.in1 = in1; a.c0 = c0; a.c1 = c1; a.wpk = wpk; a.bias = bias; a.out = out;
+    a.D = d.d; a.H = d.h; a.W = d.w; a.R = 32 * NT; a.P = (a.R - 1) / HW + 4; a.cout = cout; a.CTtot = CTtot;
+    a.dbg = getenv("CD_FLAT_DBG") ? atoi(getenv("CD_FLAT_DBG")) : 0;
+    const size_t lds = ((size_t)a.P * HW + 1) * 64;
+    dim3 grid((unsigned)((d.vox() + a.R - 1) / a.R), (unsigned)batch, (unsigned)(CTtot / CT));
+    const int threads = (NT / VT) * 64;
+#define CD_FLAT_CASE(V, C)                                 \
+  if (VT == V && CT == C) {                                \
+    launch_flat_inst<V, C>(a, grid, threads, lds, s);      \
+    return true;                                           \
+  }
+    CD_FLAT_CASE(1, 1) CD_FLAT_CASE(2, 1) CD_FLAT_CASE(3, 1) CD_FLAT_CASE(4, 1)
+    CD_FLAT_CASE(1, 2) CD_FLAT_CASE(2, 2) CD_FLAT_CASE(3, 2) CD_FLAT_CASE(4, 2)
+    CD_FLAT_CASE(1, 3) CD_FLAT_CASE(2, 3)
+#undef CD_FLAT_CASE
+    return false;
+  };
+  if (getenv("CD_FLAT_TILE")) {
+    const FlatTile t = choose_flat_tile(d, batch, CT);
+    return t.NT ? launch(t.NT, t.VT) : false;
+  }
+  // candidate tilings: (tiles per workgroup, tiles per wave)
+  static const int kCand[][2] = {{8, 2}, {4, 1}, {8, 1}, {12, 3}, {16, 2}, {16, 4}, {4, 2}, {6, 2}, {6, 3}, {2, 1},
+                                 {3, 1}, {1, 1}, {2, 2}, {12, 2}, {8, 4}, {6, 1}, {3, 3}};
+  std::vector<std::pair<int, int>> cand;
+  for (auto& c : kCand) {
+    const int NT = c[0], VT = c[1];
+    if (VT * CT > 8 || (CT == 3 && VT > 2)) continue;
+    if ((int64_t)32 * (NT - 1) >= d.vox()) continue;
+    const int P = (32 * NT - 1) / HW + 4;
+    if (((size_t)P * HW + 1) * 64 > 150 * 1024) continue;
+    cand.push_back({NT, VT});
+  }
+  if (cand.empty()) return false;
+  char key[160];
+  std::snprintf(key, sizeof key, "flat3 %dx%dx%d c%d+%d->%d b%d", d.d, d.h, d.w, c0, c1, cout, batch);
+  int pick = autotune(key, (int)cand.size(), [&](int i) { launch(cand[i].first, cand[i].second); }, s);
+  if (pick < 0) {
+    const FlatTile t = choose_flat_tile(d, batch, CT);
+    return t.NT ? launch(t.NT, t.VT) : false;
+  }
+  return launch(cand[pick].first, cand[pick].second);
+}
+
 void launch_conv_mfma(const float* in0, int c0, const float* in1, int c1, const float* wpk, const float* bias, float* out,
                       int batch, int cout, const ConvGeom& g, hipStream_t s) {
   CD_REQUIRE(c0 % 32 == 0 && c1 % 32 == 0 && c0 > 0, "conv: channel counts must be multiples of 32");
@@ -269,6 +615,14 @@ void launch_conv_mfma(const float* in0, int c0, const float* in1, int c1, const 
   const int CTtot = cout / 32;
   int CT = CTtot <= 3 ? CTtot : 2;
   CD_REQUIRE(CTtot % CT == 0, "conv: unsupported output channel count");
+  char cat[128];
+  std::snprintf(cat, sizeof cat, "conv%dx%dx%d_s%d C%d->%d @%dx%dx%d", g.kd, g.kh, g.kw, g.sh, c0 + c1, cout, g.in.d, g.in.h, g.in.w);
+  const double taps = (double)g.kd * g.kh * g.kw;
+  prof::Scope scope(cat, s, 2.0 * taps * (c0 + c1) * cout * (double)g.out.vox() * batch,
+                    4.0 * batch * ((double)g.in.vox() * (c0 + c1) + (double)g.out.vox() * cout));
+  if (g.kd == 3 && g.kh == 3 && g.kw == 3 && g.sz == 1 && g.sh == 1 && g.sw == 1 &&
+      try_launch_conv3_flat(in0, c0, in1, c1, wpk, bias, out, batch, cout, g.in, s))
+    return;
   const ConvTile t = choose_conv_tile(g, batch, CT);
   ConvKArgs a;
   a.in0 = in0; a.in1 = in1; a.c0 = c0; a.c1 = c1; a.wpk = wpk; a.bias = bias; a.out = out;
@@ -279,11 +633,6 @@ void launch_conv_mfma(const float* in0, int c0, const float* in1, int c1, const 
   a.cout = cout; a.CTtot = CTtot;
   dim3 grid((unsigned)(batch * a.nTZ * a.nTH), (unsigned)(CTtot / CT));
   const int threads = t.NW * 64;
-  char cat[128];
-  std::snprintf(cat, sizeof cat, "conv%dx%dx%d_s%d C%d->%d @%dx%dx%d", g.kd, g.kh, g.kw, g.sh, c0 + c1, cout, g.in.d, g.in.h, g.in.w);
-  const double taps = (double)g.kd * g.kh * g.kw;
-  prof::Scope scope(cat, s, 2.0 * taps * (c0 + c1) * cout * (double)g.out.vox() * batch,
-                    4.0 * batch * ((double)g.in.vox() * (c0 + c1) + (double)g.out.vox() * cout));
 #define CD_CONV_CASE(V, C)                                        \
   if (t.VT == V && CT == C) {                                     \
     launch_conv_inst<V, C>(a, grid, threads, t.lds, s);           \

@@ -817,6 +817,13 @@ int cd_ddim_sample(CdPlan* plan, int batch, const float* start, const float* con
       if (!(plan->graph_exec && plan->graph_key == key)) {
         destroy_graph(plan);
         hipGraph_t graph = nullptr;
+        // one eager pass first: per-geometry kernel tuning (and lazy function attributes) cannot happen during capture.
+        // It only writes x0 / scratch, which the replayed steps overwrite.
+        launch_load_step(plan->d_table, plan->d_counter, plan->d_stepvals, sigma_b, batch, s);
+        plan->ws.reset(sub, sub_bytes, false);
+        forward_impl(plan, batch, x_out, cond, sigma_b, x0, false, s);
+        CD_HIP(hipMemsetAsync(plan->d_counter, 0, sizeof(int), s));
+        CD_HIP(hipStreamSynchronize(s));
         if (!plan->cap_stream) CD_HIP(hipStreamCreateWithFlags(&plan->cap_stream, hipStreamNonBlocking));
         hipStream_t cs = plan->cap_stream;
         CD_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed));
