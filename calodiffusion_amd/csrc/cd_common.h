@@ -64,26 +64,28 @@ struct ConvGeom {
   int sz, sh, sw;   // strides
 };
 
-// optional GroupNorm(+SiLU)(+embedding) applied to the conv's input while it is staged into LDS
-struct NormPrologue {
-  const double* partials = nullptr;  // [B][G][nsplit][2]
-  int nsplit = 0, groups = 0;
-  const float* gamma = nullptr;
-  const float* beta = nullptr;
-  const float* add_bc = nullptr;  // [B][ld] or null
-  int add_ld = 0;
-  int silu = 0;
+// GroupNorm fusion around a conv (all optional):
+//   coef     [B][Cin][4] = {scale, shift, add, -}: y = act(scale*x + shift) + add applied to the input as it is staged
+//            (GroupNorm affine folded per sample and channel by launch_gn_finalize; `add` = the time/cond embedding);
+//   ch_part  [B][units][Cout][2] = per-workgroup {sum, sum of squares} of the conv output, units <= ceil(vox/32);
+//            *units is set to the number of workgroups per sample that wrote partials, or 0 if the chosen kernel
+//            cannot (the caller then runs launch_ch_stats on the output).
+struct ConvFusion {
+  const float* coef = nullptr;
+  int act = 0;
+  float* ch_part = nullptr;
+  int* units = nullptr;
 };
 
 void launch_pack_weights(const float* w_torch, float* wpk, int cout, int cin, int taps, bool transposed, hipStream_t s);
 void launch_pack_init_weights(const float* w_torch, float* wpk, int cout, int cin, hipStream_t s);
 
 void launch_conv_mfma(const float* in0, int c0, const float* in1, int c1, const float* wpk, const float* bias, float* out,
-                      int batch, int cout, const ConvGeom& g, hipStream_t s);
+                      int batch, int cout, const ConvGeom& g, hipStream_t s, const ConvFusion& fu = ConvFusion());
 void launch_conv_transpose_mfma(const float* in, int cin, const float* wpk, const float* bias, float* out, int batch,
                                 int cout, Dims3 din, Dims3 dout, int kz, int sz, hipStream_t s);
 
-enum A_Prologue { A_NONE = 0, A_GROUPNORM1 = 1, A_SOFTMAX32 = 2 };
+enum A_Prologue { A_NONE = 0, A_AFFINE = 1, A_SOFTMAX32 = 2 };
 struct PointwiseArgs {
   const float* in0 = nullptr;  // (B, vox, ld0) read at channel offset off0, c0 channels
   int ld0 = 0, off0 = 0, c0 = 0;
@@ -97,11 +99,10 @@ struct PointwiseArgs {
   int batch = 0, cout = 0;
   int64_t vox = 0;
   int prologue = A_NONE;
-  const double* gn_partials = nullptr;  // [B][1][nsplit][2]
-  int gn_nsplit = 0;
-  const float* gn_gamma = nullptr;
-  const float* gn_beta = nullptr;
+  const float* coef = nullptr;  // A_AFFINE: [B][Cin][4] {scale, shift, -, -} (a folded GroupNorm, see launch_gn_finalize)
+  float* ch_part = nullptr;     // optional channel partials of the output: [B][ceil(vox/128)][cout][2]
 };
+inline int pointwise_units(int64_t vox) { return (int)((vox + 127) / 128); }
 void launch_pointwise(const PointwiseArgs& a, hipStream_t s);
 
 struct InitConvArgs {
@@ -123,11 +124,16 @@ struct InitConvArgs {
 void launch_init_conv(const InitConvArgs& a, hipStream_t s);
 
 int gn_nsplit_for(int64_t vox, int batch);
-void launch_gn_stats(const float* x, double* partials, int batch, int channels, int64_t vox, int groups, int nsplit,
-                     hipStream_t s);
-void launch_gn_apply(const float* x, float* y, const double* partials, int nsplit, const float* gamma, const float* beta,
-                     int batch, int channels, int64_t vox, int groups, int silu, const float* add_bc, int add_ld,
-                     const float* residual, hipStream_t s, const float* residual1 = nullptr, int res_c0 = 0);
+// channel partials [B][nsplit][C][2] of a tensor whose producer has no stats epilogue
+void launch_ch_stats(const float* x, float* part, int batch, int channels, int64_t vox, int nsplit, hipStream_t s);
+// coef[B][C][4] = {rstd*gamma, beta - mean*rstd*gamma, add_bc[b][c] or 0, 0} from `units` channel partials per sample
+void launch_gn_finalize(const float* part, int units, const float* gamma, const float* beta, const float* add_bc, int add_ld,
+                        float* coef, int batch, int channels, int groups, int64_t vox, hipStream_t s);
+int gn_apply_blocks_per_sample(int batch, int channels, int64_t vox);
+// y = act(scale*x + shift) + add (+ residual; residual1/res_c0: shortcut read from a two-source channel concat);
+// part_out (optional): channel partials of y, [B][gn_apply_blocks_per_sample][C][2]
+void launch_gn_apply(const float* x, float* y, const float* coef, int batch, int channels, int64_t vox, int silu,
+                     const float* residual, const float* residual1, int res_c0, float* part_out, hipStream_t s);
 
 int attn_nsplit_for(int64_t vox, int batch);
 size_t attn_partial_floats(int batch, int nsplit);

@@ -80,6 +80,8 @@ struct ConvKArgs {
   int TZ, TH, nTZ, nTH;  // output tile (z, phi) extents and tile counts; tiles span the full r extent
   int IZ, IH;            // staged input tile extents (with halo)
   int cout, CTtot;
+  const float* coef;     // fused GroupNorm(+SiLU) of the input, see ConvFlatArgs
+  int act;
 };
 
 template <int VT, int CT>
@@ -153,7 +155,19 @@ __global__ void __launch_bounds__(512) conv_mfma_kernel(ConvKArgs a) {
       int gh = (gh0 + ih) % a.Hin;
       if (gh < 0) gh += a.Hin;
       f32x4 val = {0.f, 0.f, 0.f, 0.f};
-      if (gz >= 0 && gz < a.Din) val = *(const f32x4*)(src + ((size_t)(gz * a.Hin + gh) * a.Win + iw) * ldc + q * 4);
+      if (gz >= 0 && gz < a.Din) {
+        val = *(const f32x4*)(src + ((size_t)(gz * a.Hin + gh) * a.Win + iw) * ldc + q * 4);
+        if (a.coef) {
+          const float* cfp = a.coef + ((size_t)b * (a.c0 + a.c1) + chunk * 32 + q * 4) * 4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const f32x4 cf = *(const f32x4*)(cfp + e * 4);
+            float t = cf[0] * val[e] + cf[1];
+            if (a.act) t = t / (1.f + expf(-t));
+            val[e] = t + cf[2];
+          }
+        }
+      }
       *(f32x4*)(lds + vox * 36 + q * 4) = val;
     }
     __syncthreads();
@@ -300,6 +314,11 @@ struct ConvFlatArgs {
   int P;       // plane capacity of the LDS tile
   int cout, CTtot;
   int dbg;     // timing experiments only (CD_FLAT_DBG): 1 = skip staging, 2 = skip the MFMA taps
+  // fused GroupNorm: `coef` = per-(sample, input channel) {scale, shift, add, -} applied (with SiLU if `act`) while the
+  // input is staged; `ch_part` = per-(sample, workgroup, output channel) {sum, sum of squares} of this conv's output.
+  const float* coef;
+  int act;
+  float* ch_part;
 };
 
 template <int VT, int CT>
@@ -372,6 +391,13 @@ __global__ void __launch_bounds__(512, (VT * CT <= 2 ? 3 : 2)) conv3_flat_kernel
       src = a.in1; ldc = a.c1; coff = chunk * 32 - a.c0;
     }
     src += (size_t)b * vox * ldc + coff + kq * 8;
+    // this thread always stages the same 4 channels of a sub-chunk (slot index mod 4 is tid mod 4)
+    f32x4 cf[4];
+    if (a.coef) {
+      const int c = chunk * 32 + kq * 8 + ((tid & 3) >> 1) * 16 + (tid & 1) * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) cf[e] = *(const f32x4*)(a.coef + ((size_t)b * (a.c0 + a.c1) + c + e) * 4);
+    }
     __syncthreads();
     // stage: 4 independent 16-B loads in flight per thread before the first LDS write
     for (int s0 = tid; s0 < ((a.dbg & 1) ? 0 : nslots); s0 += 4 * nthreads) {
@@ -382,7 +408,17 @@ __global__ void __launch_bounds__(512, (VT * CT <= 2 ? 3 : 2)) conv3_flat_kernel
         const int n = sidx >> 2, p = sidx & 3;
         const int g = gbase + n;
         val[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (sidx < nslots && g >= 0 && g < vox) val[k] = *(const f32x4*)(src + (size_t)g * ldc + (p >> 1) * 16 + (p & 1) * 4);
+        if (sidx < nslots && g >= 0 && g < vox) {
+          val[k] = *(const f32x4*)(src + (size_t)g * ldc + (p >> 1) * 16 + (p & 1) * 4);
+          if (a.coef) {  // zero padding applies to the NORMALISED activation, so only in-range voxels are transformed
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float t = cf[e][0] * val[k][e] + cf[e][1];
+              if (a.act) t = t / (1.f + expf(-t));
+              val[k][e] = t + cf[e][2];
+            }
+          }
+        }
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -455,6 +491,46 @@ __global__ void __launch_bounds__(512, (VT * CT <= 2 ? 3 : 2)) conv3_flat_kernel
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) outb[off + (ct0 + ct) * 32 + col] = acc[vt][ct][r] + bv[ct];
       }
+    }
+  }
+  if (a.ch_part) {
+    // per-channel {sum, sum of squares} of this workgroup's outputs, reduced in a fixed order (deterministic)
+    float s1[CT], s2[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) s1[ct] = s2[ct] = 0.f;
+#pragma unroll
+    for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const bool ok = __shfl(ooff[vt], row, 64) >= 0;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          const float v = ok ? acc[vt][ct][r] + bv[ct] : 0.f;
+          s1[ct] += v;
+          s2[ct] += v * v;
+        }
+      }
+    __syncthreads();  // every wave is done with the LDS tile
+    const int nw = nthreads >> 6;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const float t1 = s1[ct] + __shfl_xor(s1[ct], 32, 64), t2 = s2[ct] + __shfl_xor(s2[ct], 32, 64);
+      if (half == 0) {
+        lds[((wave * CT + ct) * 32 + col) * 2] = t1;
+        lds[((wave * CT + ct) * 32 + col) * 2 + 1] = t2;
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < CT * 32; i += nthreads) {
+      float t1 = 0.f, t2 = 0.f;
+      for (int w = 0; w < nw; ++w) {
+        t1 += lds[((w * CT * 32) + i) * 2];
+        t2 += lds[((w * CT * 32) + i) * 2 + 1];
+      }
+      float* dst = a.ch_part + (((size_t)b * gridDim.x + blockIdx.x) * a.cout + ct0 * 32 + i) * 2;
+      dst[0] = t1;
+      dst[1] = t2;
     }
   }
 }
@@ -555,7 +631,7 @@ FlatTile choose_flat_tile(Dims3 d, int batch, int CT) {
 
 // returns false when the whole-plane LDS tile does not fit (wide grids such as Dataset-3's 50x18 planes)
 static bool try_launch_conv3_flat(const float* in0, int c0, const float* in1, int c1, const float* wpk, const float* bias,
-                                  float* out, int batch, int cout, Dims3 d, hipStream_t s) {
+                                  float* out, int batch, int cout, Dims3 d, hipStream_t s, const ConvFusion& fu) {
   if (getenv("CD_NO_FLAT")) return false;
   const int CTtot = cout / 32;
   const int CT = CTtot <= 3 ? CTtot : 2;
@@ -566,8 +642,12 @@ static bool try_launch_conv3_flat(const float* in0, int c0, const float* in1, in
     a.in0 = in0; a.in1 = in1; a.c0 = c0; a.c1 = c1; a.wpk = wpk; a.bias = bias; a.out = out;
     a.D = d.d; a.H = d.h; a.W = d.w; a.R = 32 * NT; a.P = (a.R - 1) / HW + 4; a.cout = cout; a.CTtot = CTtot;
     a.dbg = getenv("CD_FLAT_DBG") ? atoi(getenv("CD_FLAT_DBG")) : 0;
-    const size_t lds = ((size_t)a.P * HW + 1) * 64;
+    a.coef = fu.coef; a.act = fu.act; a.ch_part = fu.ch_part;
+    size_t lds = ((size_t)a.P * HW + 1) * 64;
+    const size_t red = (size_t)(NT / VT) * CT * 32 * 2 * 4;  // cross-wave reduction scratch of the stats epilogue
+    if (lds < red) lds = red;
     dim3 grid((unsigned)((d.vox() + a.R - 1) / a.R), (unsigned)batch, (unsigned)(CTtot / CT));
+    if (fu.units) *fu.units = (int)grid.x;
     const int threads = (NT / VT) * 64;
 #define CD_FLAT_CASE(V, C)                                 \
   if (VT == V && CT == C) {                                \
@@ -608,7 +688,9 @@ static bool try_launch_conv3_flat(const float* in0, int c0, const float* in1, in
 }
 
 void launch_conv_mfma(const float* in0, int c0, const float* in1, int c1, const float* wpk, const float* bias, float* out,
-                      int batch, int cout, const ConvGeom& g, hipStream_t s) {
+                      int batch, int cout, const ConvGeom& g, hipStream_t s, const ConvFusion& fu) {
+  CD_REQUIRE(!fu.coef || c1 == 0, "conv: a fused input normalisation needs a single (non-concatenated) source");
+  if (fu.units) *fu.units = 0;  // set by kernels that produce the output statistics themselves
   CD_REQUIRE(c0 % 32 == 0 && c1 % 32 == 0 && c0 > 0, "conv: channel counts must be multiples of 32");
   CD_REQUIRE(cout % 32 == 0, "conv: output channels must be a multiple of 32");
   CD_REQUIRE(g.kw <= 4, "conv: r kernel extent > 4 unsupported");
@@ -621,7 +703,7 @@ void launch_conv_mfma(const float* in0, int c0, const float* in1, int c1, const 
   prof::Scope scope(cat, s, 2.0 * taps * (c0 + c1) * cout * (double)g.out.vox() * batch,
                     4.0 * batch * ((double)g.in.vox() * (c0 + c1) + (double)g.out.vox() * cout));
   if (g.kd == 3 && g.kh == 3 && g.kw == 3 && g.sz == 1 && g.sh == 1 && g.sw == 1 &&
-      try_launch_conv3_flat(in0, c0, in1, c1, wpk, bias, out, batch, cout, g.in, s))
+      try_launch_conv3_flat(in0, c0, in1, c1, wpk, bias, out, batch, cout, g.in, s, fu))
     return;
   const ConvTile t = choose_conv_tile(g, batch, CT);
   ConvKArgs a;
@@ -630,7 +712,7 @@ void launch_conv_mfma(const float* in0, int c0, const float* in1, int c1, const 
   a.KD = g.kd; a.KH = g.kh; a.KW = g.kw; a.SZ = g.sz; a.SH = g.sh; a.SW = g.sw;
   a.TZ = t.TZ; a.TH = t.TH; a.nTZ = (g.out.d + t.TZ - 1) / t.TZ; a.nTH = (g.out.h + t.TH - 1) / t.TH;
   a.IZ = (t.TZ - 1) * g.sz + g.kd; a.IH = (t.TH - 1) * g.sh + g.kh;
-  a.cout = cout; a.CTtot = CTtot;
+  a.cout = cout; a.CTtot = CTtot; a.coef = fu.coef; a.act = fu.act;
   dim3 grid((unsigned)(batch * a.nTZ * a.nTH), (unsigned)(CTtot / CT));
   const int threads = t.NW * 64;
 #define CD_CONV_CASE(V, C)                                        \
@@ -837,19 +919,6 @@ __global__ void __launch_bounds__(256) pointwise_kernel(PointwiseArgs a, int CTt
   const int64_t n = n0 + col;
   const bool valid = n < a.vox;
 
-  float mean = 0.f, rstd = 1.f;
-  if (PRO == A_GROUPNORM1) {
-    double s1 = 0.0, s2 = 0.0;
-    const double* p = a.gn_partials + (size_t)b * a.gn_nsplit * 2;
-    for (int i = 0; i < a.gn_nsplit; ++i) { s1 += p[2 * i]; s2 += p[2 * i + 1]; }
-    const double cnt = (double)a.vox * (a.c0 + a.c1);
-    const double mu = s1 / cnt;
-    double var = s2 / cnt - mu * mu;
-    var = var < 0.0 ? 0.0 : var;
-    mean = (float)mu;
-    rstd = (float)(1.0 / sqrt(var + 1e-5));
-  }
-
   f32x16 acc[CT];
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct)
@@ -868,15 +937,15 @@ __global__ void __launch_bounds__(256) pointwise_kernel(PointwiseArgs a, int CTt
       av[q] = *(const f32x4*)(src + q * 4);
       if (!valid) av[q] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    if (PRO == A_GROUPNORM1) {
-      const int cbase = chunk * 32 + half * 16;
+    if (PRO == A_AFFINE) {
+      const float* cfp = a.coef + ((size_t)b * (a.c0 + a.c1) + chunk * 32 + half * 16) * 4;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 g = *(const f32x4*)(a.gn_gamma + cbase + q * 4);
-        const f32x4 bt = *(const f32x4*)(a.gn_beta + cbase + q * 4);
+      for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) av[q][e] = (av[q][e] - mean) * rstd * g[e] + bt[e];
-      }
+        for (int e = 0; e < 4; ++e) {
+          const f32x4 cf = *(const f32x4*)(cfp + (q * 4 + e) * 4);
+          av[q][e] = cf[0] * av[q][e] + cf[1];
+        }
     } else if (PRO == A_SOFTMAX32) {
       float m = av[0][0];
 #pragma unroll
@@ -929,6 +998,39 @@ __global__ void __launch_bounds__(256) pointwise_kernel(PointwiseArgs a, int CTt
       }
     }
   }
+  if (a.ch_part) {  // per-channel {sum, sum of squares} of this workgroup's 128 output voxels
+    __shared__ float red[4][CT * 32][2];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const int co = (ct0 + ct) * 32 + col;
+      const float bv = (a.bias && co < a.cout) ? a.bias[co] : 0.f;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (n0 + row < a.vox) {
+          float v = acc[ct][r] + bv;
+          if (a.residual && co < a.cout) v += a.residual[((size_t)b * a.vox + n0 + row) * a.cout + co];
+          s1 += v;
+          s2 += v * v;
+        }
+      }
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (half == 0) {
+        red[wave][ct * 32 + col][0] = s1;
+        red[wave][ct * 32 + col][1] = s2;
+      }
+    }
+    __syncthreads();
+    if (tid < CT * 32 && ct0 * 32 + tid < a.cout) {
+      const float t1 = (red[0][tid][0] + red[1][tid][0]) + (red[2][tid][0] + red[3][tid][0]);
+      const float t2 = (red[0][tid][1] + red[1][tid][1]) + (red[2][tid][1] + red[3][tid][1]);
+      float* dst = a.ch_part + (((size_t)b * gridDim.x + blockIdx.x) * a.cout + ct0 * 32 + tid) * 2;
+      dst[0] = t1;
+      dst[1] = t2;
+    }
+  }
 }
 
 void launch_pointwise(const PointwiseArgs& a, hipStream_t s) {
@@ -948,7 +1050,7 @@ void launch_pointwise(const PointwiseArgs& a, hipStream_t s) {
     return;                                                                                \
   }
   CD_PW_CASE(1, A_NONE) CD_PW_CASE(2, A_NONE) CD_PW_CASE(3, A_NONE)
-  CD_PW_CASE(1, A_GROUPNORM1) CD_PW_CASE(2, A_GROUPNORM1) CD_PW_CASE(3, A_GROUPNORM1)
+  CD_PW_CASE(1, A_AFFINE) CD_PW_CASE(2, A_AFFINE) CD_PW_CASE(3, A_AFFINE)
   CD_PW_CASE(1, A_SOFTMAX32) CD_PW_CASE(2, A_SOFTMAX32) CD_PW_CASE(3, A_SOFTMAX32)
 #undef CD_PW_CASE
   CD_REQUIRE(false, "pointwise conv: no kernel instance");

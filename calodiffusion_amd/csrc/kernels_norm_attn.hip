@@ -8,8 +8,14 @@ namespace cd {
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
 // ------------------------------------------------------------------------------------------------------------
-// GroupNorm statistics: per (sample, group) partial (sum, sum of squares) in fp64 over `nsplit` voxel ranges.
-// Consumers reduce the nsplit partials in a fixed order => bitwise deterministic statistics.
+// GroupNorm, split so that every piece fuses into a neighbour:
+//   statistics   per-(sample, unit, channel) {sum, sum of squares} partials in fp32.  Producers: the conv / pointwise
+//                epilogues, the apply kernel below (for a following PreNorm), or ch_stats_kernel for a tensor that
+//                comes from a kernel without a stats epilogue.  Partials are reduced in a fixed order in fp64
+//                => bitwise-deterministic statistics.
+//   finalize     folds mean / rstd / gamma / beta (+ the per-sample embedding that follows the activation) into
+//                per-(sample, channel) coefficients {scale, shift, add, 0}:  y = act(scale*x + shift) + add
+//   apply        either inside the consuming conv's LDS staging (ConvFusion::coef) or gn_apply_kernel.
 // ------------------------------------------------------------------------------------------------------------
 int gn_nsplit_for(int64_t vox, int batch) {
   // enough blocks to fill 256 CUs a few times over, but >= 256 voxels per block
@@ -21,140 +27,201 @@ int gn_nsplit_for(int64_t vox, int batch) {
   return (int)n;
 }
 
-__global__ void __launch_bounds__(256) gn_stats_kernel(const float* __restrict__ x, double* __restrict__ partials,
-                                                       int channels, int64_t vox, int groups, int nsplit) {
+__global__ void __launch_bounds__(256) ch_stats_kernel(const float* __restrict__ x, float* __restrict__ part, int channels,
+                                                       int64_t vox, int nsplit) {
   __shared__ double sP[256][2];
-  __shared__ double sC[64][2];
   const int tid = threadIdx.x;
   const int split = blockIdx.x, b = blockIdx.y;
-  const int cols = channels >> 2;           // float4 columns per voxel
-  const int rows = 256 / cols;              // voxels per pass
+  const int cols = channels >> 2;
+  const int rows = 256 / cols;
   const int64_t per = (vox + nsplit - 1) / nsplit;
   const int64_t v0 = split * per;
   const int64_t v1 = (v0 + per < vox) ? v0 + per : vox;
   const int colid = tid % cols, row = tid / cols;
-  float s1 = 0.f, s2 = 0.f;
+  // four channels per thread, kept separate
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
   if (row < rows) {
     const float* base = x + (size_t)b * vox * channels + colid * 4;
     for (int64_t v = v0 + row; v < v1; v += rows) {
       const f32x4 t = *(const f32x4*)(base + (size_t)v * channels);
-      s1 += (t[0] + t[1]) + (t[2] + t[3]);
-      s2 += (t[0] * t[0] + t[1] * t[1]) + (t[2] * t[2] + t[3] * t[3]);
+      s1 += t;
+      s2 += t * t;
     }
   }
-  sP[tid][0] = (double)s1;
-  sP[tid][1] = (double)s2;
-  __syncthreads();
-  if (tid < cols) {
+  float* dst = part + (((size_t)b * nsplit + split) * channels) * 2;
+  for (int e = 0; e < 4; ++e) {
+    sP[tid][0] = (double)s1[e];
+    sP[tid][1] = (double)s2[e];
+    __syncthreads();
+    if (tid < cols) {
+      double a1 = 0.0, a2 = 0.0;
+      for (int r = 0; r < rows; ++r) {
+        a1 += sP[r * cols + tid][0];
+        a2 += sP[r * cols + tid][1];
+      }
+      dst[(tid * 4 + e) * 2] = (float)a1;
+      dst[(tid * 4 + e) * 2 + 1] = (float)a2;
+    }
+    __syncthreads();
+  }
+}
+
+void launch_ch_stats(const float* x, float* part, int batch, int channels, int64_t vox, int nsplit, hipStream_t s) {
+  CD_REQUIRE(channels % 4 == 0 && channels <= 256, "channel stats: channels must be a multiple of 4 and <= 256");
+  prof::Scope scope("ch_stats", s, 0, 4.0 * batch * (double)vox * channels);
+  hipLaunchKernelGGL(ch_stats_kernel, dim3(nsplit, batch), dim3(256), 0, s, x, part, channels, vox, nsplit);
+  CD_HIP(hipGetLastError());
+}
+
+// one block per sample; thread c < channels writes coef[b][c]
+__global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restrict__ part, int units, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const float* __restrict__ add_bc,
+                                                          int add_ld, float* __restrict__ coef, int channels, int groups,
+                                                          int64_t vox) {
+  __shared__ double sS[256][2];
+  __shared__ double sC[256][2];
+  __shared__ float sMean[64], sRstd[64];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  // 256 threads = channels x slices; each slice sums every nsl-th unit, slices are then added in a fixed order
+  const int nsl = 256 / channels;
+  const int c = tid % channels, sl = tid / channels;
+  if (sl < nsl) {
+    const float* p = part + ((size_t)b * units * channels + c) * 2;
     double a1 = 0.0, a2 = 0.0;
-    for (int r = 0; r < rows; ++r) {
-      a1 += sP[r * cols + tid][0];
-      a2 += sP[r * cols + tid][1];
+    for (int u = sl; u < units; u += nsl) {
+      const float2 v = *(const float2*)(p + (size_t)u * channels * 2);
+      a1 += (double)v.x;
+      a2 += (double)v.y;
+    }
+    sS[tid][0] = a1;
+    sS[tid][1] = a2;
+  }
+  __syncthreads();
+  if (tid < channels) {
+    double a1 = 0.0, a2 = 0.0;
+    for (int k = 0; k < nsl; ++k) {
+      a1 += sS[k * channels + tid][0];
+      a2 += sS[k * channels + tid][1];
     }
     sC[tid][0] = a1;
     sC[tid][1] = a2;
   }
   __syncthreads();
+  const int cpg = channels / groups;
   if (tid < groups) {
-    const int cpg4 = cols / groups;  // float4 columns per group
     double a1 = 0.0, a2 = 0.0;
-    for (int c = 0; c < cpg4; ++c) {
-      a1 += sC[tid * cpg4 + c][0];
-      a2 += sC[tid * cpg4 + c][1];
+    for (int c = 0; c < cpg; ++c) {
+      a1 += sC[tid * cpg + c][0];
+      a2 += sC[tid * cpg + c][1];
     }
-    double* p = partials + (((size_t)b * groups + tid) * nsplit + split) * 2;
-    p[0] = a1;
-    p[1] = a2;
-  }
-}
-
-void launch_gn_stats(const float* x, double* partials, int batch, int channels, int64_t vox, int groups, int nsplit,
-                     hipStream_t s) {
-  CD_REQUIRE(channels % 4 == 0 && channels <= 256, "group norm: channels must be a multiple of 4 and <= 256");
-  CD_REQUIRE(channels % groups == 0 && (channels / groups) % 4 == 0, "group norm: channels per group must be a multiple of 4");
-  prof::Scope scope("gn_stats", s, 0, 4.0 * batch * (double)vox * channels);
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(nsplit, batch), dim3(256), 0, s, x, partials, channels, vox, groups, nsplit);
-  CD_HIP(hipGetLastError());
-}
-
-// y = act((x - mean) * rstd * gamma + beta) [+ add_bc[b][c]] [+ residual]
-__global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                       const double* __restrict__ partials, int nsplit,
-                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       int channels, int64_t vox, int groups, int silu,
-                                                       const float* __restrict__ add_bc, int add_ld,
-                                                       const float* __restrict__ residual,
-                                                       const float* __restrict__ residual1, int res_c0,
-                                                       int blocks_per_sample) {
-  __shared__ float sMean[64], sRstd[64];
-  const int tid = threadIdx.x;
-  const int b = blockIdx.x / blocks_per_sample, blk = blockIdx.x % blocks_per_sample;
-  if (tid < groups) {
-    const double* p = partials + ((size_t)b * groups + tid) * nsplit * 2;
-    double s1 = 0.0, s2 = 0.0;
-    for (int i = 0; i < nsplit; ++i) { s1 += p[2 * i]; s2 += p[2 * i + 1]; }
-    const double cnt = (double)vox * (channels / groups);
-    const double mu = s1 / cnt;
-    double var = s2 / cnt - mu * mu;
+    const double cnt = (double)vox * cpg;
+    const double mu = a1 / cnt;
+    double var = a2 / cnt - mu * mu;
     var = var < 0.0 ? 0.0 : var;
     sMean[tid] = (float)mu;
     sRstd[tid] = (float)(1.0 / sqrt(var + 1e-5));
   }
   __syncthreads();
-  const int cols = channels >> 2;
-  const int64_t total = vox * cols;  // float4 items of this sample
-  const int64_t per = (total + blocks_per_sample - 1) / blocks_per_sample;
-  const int64_t i0 = blk * per;
-  const int64_t i1 = (i0 + per < total) ? i0 + per : total;
-  const size_t sbase = (size_t)b * vox * channels;
-  const int cpg = channels / groups;
-  for (int64_t i = i0 + tid; i < i1; i += 256) {
-    const int c = (int)(i % cols) * 4;
-    const int g = c / cpg;
-    const float mu = sMean[g], rs = sRstd[g];
-    f32x4 t = *(const f32x4*)(x + sbase + i * 4);
-    const f32x4 gm = *(const f32x4*)(gamma + c);
-    const f32x4 bt = *(const f32x4*)(beta + c);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float v = (t[e] - mu) * rs * gm[e] + bt[e];
-      if (silu) v = v / (1.f + expf(-v));
-      t[e] = v;
-    }
-    if (add_bc) {
-      const f32x4 ad = *(const f32x4*)(add_bc + (size_t)b * add_ld + c);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) t[e] += ad[e];
-    }
-    if (residual1) {
-      // identity shortcut of a block whose input is a (never materialised) channel concat of two tensors
-      const int64_t v = i / cols;
-      const int res_c1 = channels - res_c0;
-      const f32x4 rr = c < res_c0 ? *(const f32x4*)(residual + ((size_t)b * vox + v) * res_c0 + c)
-                                  : *(const f32x4*)(residual1 + ((size_t)b * vox + v) * res_c1 + (c - res_c0));
-#pragma unroll
-      for (int e = 0; e < 4; ++e) t[e] += rr[e];
-    } else if (residual) {
-      const f32x4 rr = *(const f32x4*)(residual + sbase + i * 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) t[e] += rr[e];
-    }
-    *(f32x4*)(y + sbase + i * 4) = t;
+  if (tid < channels) {
+    const int g = tid / cpg;
+    const float sc = sRstd[g] * gamma[tid];
+    f32x4 o;
+    o[0] = sc;
+    o[1] = beta[tid] - sMean[g] * sc;
+    o[2] = add_bc ? add_bc[(size_t)b * add_ld + tid] : 0.f;
+    o[3] = 0.f;
+    *(f32x4*)(coef + ((size_t)b * channels + tid) * 4) = o;
   }
 }
 
-void launch_gn_apply(const float* x, float* y, const double* partials, int nsplit, const float* gamma, const float* beta,
-                     int batch, int channels, int64_t vox, int groups, int silu, const float* add_bc, int add_ld,
-                     const float* residual, hipStream_t s, const float* residual1, int res_c0) {
-  CD_REQUIRE(groups <= 64, "group norm: at most 64 groups");
-  const int64_t items = vox * (channels / 4);
-  int bps = (int)((items + 2047) / 2048);  // >= 8 float4 per thread
-  const int want = (4096 + batch - 1) / batch;
+void launch_gn_finalize(const float* part, int units, const float* gamma, const float* beta, const float* add_bc, int add_ld,
+                        float* coef, int batch, int channels, int groups, int64_t vox, hipStream_t s) {
+  CD_REQUIRE(channels <= 256 && groups <= 64 && channels % groups == 0, "group norm: <= 256 channels, <= 64 groups");
+  prof::Scope scope("gn_finalize", s, 0, 0);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(batch), dim3(256), 0, s, part, units, gamma, beta, add_bc, add_ld, coef, channels,
+                     groups, vox);
+  CD_HIP(hipGetLastError());
+}
+
+// y = act(scale*x + shift) + add [+ residual]; optionally emits the channel partials of y (for a following PreNorm)
+__global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                       const float* __restrict__ coef, int channels, int64_t vox, int silu,
+                                                       const float* __restrict__ residual,
+                                                       const float* __restrict__ residual1, int res_c0,
+                                                       int blocks_per_sample, float* __restrict__ part_out) {
+  __shared__ double sP[256][2];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x / blocks_per_sample, blk = blockIdx.x % blocks_per_sample;
+  const int cols = channels >> 2;
+  const int rows = 256 / cols;
+  const int64_t vper = (vox + blocks_per_sample - 1) / blocks_per_sample;
+  const int64_t v0 = blk * vper;
+  const int64_t v1 = (v0 + vper < vox) ? v0 + vper : vox;
+  const int colid = tid % cols, row = tid / cols;
+  const int c = colid * 4;
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  if (row < rows) {
+    f32x4 cf[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) cf[e] = *(const f32x4*)(coef + ((size_t)b * channels + c + e) * 4);
+    const size_t sbase = (size_t)b * vox * channels;
+    const int res_c1 = channels - res_c0;
+    for (int64_t v = v0 + row; v < v1; v += rows) {
+      f32x4 t = *(const f32x4*)(x + sbase + (size_t)v * channels + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float u = cf[e][0] * t[e] + cf[e][1];
+        if (silu) u = u / (1.f + expf(-u));
+        t[e] = u + cf[e][2];
+      }
+      if (residual1) {
+        // identity shortcut of a block whose input is a (never materialised) channel concat of two tensors
+        t += c < res_c0 ? *(const f32x4*)(residual + ((size_t)b * vox + v) * res_c0 + c)
+                        : *(const f32x4*)(residual1 + ((size_t)b * vox + v) * res_c1 + (c - res_c0));
+      } else if (residual) {
+        t += *(const f32x4*)(residual + sbase + (size_t)v * channels + c);
+      }
+      *(f32x4*)(y + sbase + (size_t)v * channels + c) = t;
+      s1 += t;
+      s2 += t * t;
+    }
+  }
+  if (part_out) {
+    float* dst = part_out + (((size_t)b * blocks_per_sample + blk) * channels) * 2;
+    for (int e = 0; e < 4; ++e) {
+      sP[tid][0] = (double)s1[e];
+      sP[tid][1] = (double)s2[e];
+      __syncthreads();
+      if (tid < cols) {
+        double a1 = 0.0, a2 = 0.0;
+        for (int r = 0; r < rows; ++r) {
+          a1 += sP[r * cols + tid][0];
+          a2 += sP[r * cols + tid][1];
+        }
+        dst[(tid * 4 + e) * 2] = (float)a1;
+        dst[(tid * 4 + e) * 2 + 1] = (float)a2;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+int gn_apply_blocks_per_sample(int batch, int channels, int64_t vox) {
+  const int rows = 256 / (channels / 4);
+  int64_t bps = (vox + (int64_t)rows * 8 - 1) / ((int64_t)rows * 8);  // >= 8 float4 per thread
+  const int64_t want = (4096 + batch - 1) / batch;
   if (bps > want) bps = want;
   if (bps < 1) bps = 1;
+  return (int)bps;
+}
+
+void launch_gn_apply(const float* x, float* y, const float* coef, int batch, int channels, int64_t vox, int silu,
+                     const float* residual, const float* residual1, int res_c0, float* part_out, hipStream_t s) {
+  CD_REQUIRE(channels % 4 == 0 && channels <= 256, "group norm: channels must be a multiple of 4 and <= 256");
+  const int bps = gn_apply_blocks_per_sample(batch, channels, vox);
   prof::Scope scope("gn_apply", s, 0, 4.0 * batch * (double)vox * channels * (2 + (residual ? 1 : 0)));
-  hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)(batch * bps)), dim3(256), 0, s, x, y, partials, nsplit, gamma, beta,
-                     channels, vox, groups, silu, add_bc, add_ld, residual, residual1, res_c0, bps);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)(batch * bps)), dim3(256), 0, s, x, y, coef, channels, vox, silu, residual,
+                     residual1, res_c0, bps, part_out);
   CD_HIP(hipGetLastError());
 }
 

@@ -385,31 +385,68 @@ AttnP resolve(const CdPlan* p, const AttnW& w) {
   return a;
 }
 
-double* gn_stats(Run& r, const float* x, int C, int64_t vox, int G, int* nsplit_out) {
+// channel partials of a tensor from a standalone pass (producer without a stats epilogue)
+float* stats_pass(Run& r, const float* x, int C, int64_t vox, int* units) {
   const int ns = gn_nsplit_for(vox, r.B);
-  double* part = r.ws->get<double>((size_t)r.B * G * ns * 2);
-  if (!r.dry()) launch_gn_stats(x, part, r.B, C, vox, G, ns, r.s);
-  *nsplit_out = ns;
+  float* part = r.ws->get<float>((size_t)r.B * ns * C * 2);
+  if (!r.dry()) launch_ch_stats(x, part, r.B, C, vox, ns, r.s);
+  *units = ns;
   return part;
 }
 
-// ResnetBlock.forward (models.py:191-200): block1 -> (+ mlp(cond)) -> block2 -> + res_conv(x)
-float* res_block(Run& r, const ResP& w, const float* x0, int c0, const float* x1, int c1, Dims3 dims) {
+// conv + channel partials of its output (fused epilogue when the kernel supports it); input optionally normalised
+// on the fly by `coef_in` (+SiLU).  Returns the partial buffer (caller releases) and sets *units.
+float* conv3_with_stats(Run& r, const float* x0, int c0, const float* x1, int c1, const float* wpk, const float* bias, float* out,
+                        int cout, Dims3 dims, const float* coef_in, int* units) {
+  const int64_t vox = dims.vox();
+  const int cap = (int)((vox + 31) / 32);
+  float* part = r.ws->get<float>((size_t)r.B * cap * cout * 2);
+  int u = 0;
+  if (!r.dry()) {
+    ConvGeom g{dims, dims, 3, 3, 3, 1, 1, 1};
+    ConvFusion fu;
+    fu.coef = coef_in; fu.act = 1; fu.ch_part = part; fu.units = &u;
+    launch_conv_mfma(x0, c0, x1, c1, wpk, bias, out, r.B, cout, g, r.s, fu);
+    if (u == 0) {  // kernel without a stats epilogue: separate pass, same buffer (nsplit <= cap)
+      u = gn_nsplit_for(vox, r.B);
+      if (u > cap) u = cap;
+      launch_ch_stats(out, part, r.B, cout, vox, u, r.s);
+    }
+  }
+  *units = u;
+  return part;
+}
+
+// ResnetBlock.forward (models.py:191-200): block1 -> (+ mlp(cond)) -> block2 -> + res_conv(x).
+//   conv1 (stats epilogue) -> finalize -> conv2 normalises h1 while staging it (stats epilogue) -> finalize ->
+//   one elementwise pass: silu(gn(h2)) + shortcut.  `part_out`/`units_out` (optional): channel partials of the block
+//   output for a following PreNorm.
+float* res_block(Run& r, const ResP& w, const float* x0, int c0, const float* x1, int c1, Dims3 dims,
+                 float** part_out = nullptr, int* units_out = nullptr) {
   Arena* ws = r.ws;
   CD_REQUIRE(c0 + c1 == w.cin, "internal: resnet block input width mismatch");
   const int64_t vox = dims.vox();
   const int G = r.groups;
-  ConvGeom g{dims, dims, 3, 3, 3, 1, 1, 1};
+  int u1 = 0, u2 = 0;
   float* h1 = ws->get<float>((size_t)r.B * vox * w.cout);
-  if (!r.dry()) launch_conv_mfma(x0, c0, x1, c1, w.c1w, w.c1b, h1, r.B, w.cout, g, r.s);
-  int ns;
-  double* st = gn_stats(r, h1, w.cout, vox, G, &ns);
-  if (!r.dry()) launch_gn_apply(h1, h1, st, ns, w.n1g, w.n1b, r.B, w.cout, vox, G, 1, w.emb, w.emb_ld, nullptr, r.s);
-  ws->release(st);
+  float* p1 = conv3_with_stats(r, x0, c0, x1, c1, w.c1w, w.c1b, h1, w.cout, dims, nullptr, &u1);
+  float* coef1 = ws->get<float>((size_t)r.B * w.cout * 4);
+  if (!r.dry()) launch_gn_finalize(p1, u1, w.n1g, w.n1b, w.emb, w.emb_ld, coef1, r.B, w.cout, G, vox, r.s);
+  ws->release(p1);
   float* h2 = ws->get<float>((size_t)r.B * vox * w.cout);
-  if (!r.dry()) launch_conv_mfma(h1, w.cout, nullptr, 0, w.c2w, w.c2b, h2, r.B, w.cout, g, r.s);
+  float* p2 = conv3_with_stats(r, h1, w.cout, nullptr, 0, w.c2w, w.c2b, h2, w.cout, dims, coef1, &u2);
   ws->release(h1);
-  st = gn_stats(r, h2, w.cout, vox, G, &ns);
+  ws->release(coef1);
+  float* coef2 = ws->get<float>((size_t)r.B * w.cout * 4);
+  if (!r.dry()) launch_gn_finalize(p2, u2, w.n2g, w.n2b, nullptr, 0, coef2, r.B, w.cout, G, vox, r.s);
+  ws->release(p2);
+  float* po = nullptr;
+  if (part_out) {
+    const int bps = gn_apply_blocks_per_sample(r.B, w.cout, vox);
+    po = ws->get<float>((size_t)r.B * bps * w.cout * 2);
+    *part_out = po;
+    *units_out = bps;
+  }
   if (w.has_res) {
     float* res = ws->get<float>((size_t)r.B * vox * w.cout);
     if (!r.dry()) {
@@ -417,32 +454,39 @@ float* res_block(Run& r, const ResP& w, const float* x0, int c0, const float* x1
       a.in0 = x0; a.ld0 = c0; a.off0 = 0; a.c0 = c0; a.in1 = x1; a.ld1 = c1; a.c1 = c1;
       a.wpk = w.rw; a.bias = w.rb; a.out = res; a.batch = r.B; a.cout = w.cout; a.vox = vox;
       launch_pointwise(a, r.s);
-      launch_gn_apply(h2, h2, st, ns, w.n2g, w.n2b, r.B, w.cout, vox, G, 1, nullptr, 0, res, r.s);
+      launch_gn_apply(h2, h2, coef2, r.B, w.cout, vox, 1, res, nullptr, 0, po, r.s);
     }
     ws->release(res);
   } else {
-    // identity shortcut; for a concatenated input the residual is read from its two sources (models.py:200,741)
-    if (!r.dry()) launch_gn_apply(h2, h2, st, ns, w.n2g, w.n2b, r.B, w.cout, vox, G, 1, nullptr, 0, x0, r.s, c1 ? x1 : nullptr, c0);
+    // identity shortcut; for a concatenated input it is read from the two sources (models.py:200,741)
+    if (!r.dry()) launch_gn_apply(h2, h2, coef2, r.B, w.cout, vox, 1, x0, c1 ? x1 : nullptr, c0, po, r.s);
   }
-  ws->release(st);
+  ws->release(coef2);
   return h2;
 }
 
-// Residual(PreNorm(LinearAttention)) (models.py:111-117, 281-329)
-float* attn_block(Run& r, const AttnP& w, const float* x, Dims3 dims) {
+// Residual(PreNorm(LinearAttention)) (models.py:111-117, 281-329).  xpart/xunits: channel partials of x if its producer
+// emitted them (else a stats pass runs here).
+float* attn_block(Run& r, const AttnP& w, const float* x, Dims3 dims, float* xpart = nullptr, int xunits = 0) {
   Arena* ws = r.ws;
   const int64_t vox = dims.vox();
   const int C = w.c;
-  int ns;
-  double* st = gn_stats(r, x, C, vox, 1, &ns);
+  float* own = nullptr;
+  if (!xpart) {
+    own = stats_pass(r, x, C, vox, &xunits);
+    xpart = own;
+  }
+  float* coefn = ws->get<float>((size_t)r.B * C * 4);
+  if (!r.dry()) launch_gn_finalize(xpart, xunits, w.ng, w.nb, nullptr, 0, coefn, r.B, C, 1, vox, r.s);
+  if (own) ws->release(own);
   float* qkv = ws->get<float>((size_t)r.B * vox * 96);
   if (!r.dry()) {
     PointwiseArgs a;
     a.in0 = x; a.ld0 = C; a.c0 = C; a.wpk = w.qkv; a.out = qkv; a.batch = r.B; a.cout = 96; a.vox = vox;
-    a.prologue = A_GROUPNORM1; a.gn_partials = st; a.gn_nsplit = ns; a.gn_gamma = w.ng; a.gn_beta = w.nb;
+    a.prologue = A_AFFINE; a.coef = coefn;
     launch_pointwise(a, r.s);
   }
-  ws->release(st);
+  ws->release(coefn);
   const int nsp = attn_nsplit_for(vox, r.B);
   float* part = ws->get<float>(attn_partial_floats(r.B, nsp));
   const int CT = (C + 31) / 32;
@@ -452,18 +496,24 @@ float* attn_block(Run& r, const AttnP& w, const float* x, Dims3 dims) {
     launch_attn_combine(part, nsp, w.ow, C, wpb, r.B, 0.17677669529663689f /* 32^-1/2 */, r.s);
   }
   float* y = ws->get<float>((size_t)r.B * vox * C);
+  const int yu = pointwise_units(vox);
+  float* ypart = ws->get<float>((size_t)r.B * yu * C * 2);
   if (!r.dry()) {
     PointwiseArgs a;
     a.in0 = qkv; a.ld0 = 96; a.off0 = 0; a.c0 = 32; a.wpk = wpb; a.w_batch_stride = (int64_t)CT * 1024; a.bias = w.ob;
-    a.out = y; a.batch = r.B; a.cout = C; a.vox = vox; a.prologue = A_SOFTMAX32;
+    a.out = y; a.batch = r.B; a.cout = C; a.vox = vox; a.prologue = A_SOFTMAX32; a.ch_part = ypart;
     launch_pointwise(a, r.s);
   }
   ws->release(part);
   ws->release(wpb);
   ws->release(qkv);
-  st = gn_stats(r, y, C, vox, 1, &ns);
-  if (!r.dry()) launch_gn_apply(y, y, st, ns, w.gg, w.gb, r.B, C, vox, 1, 0, nullptr, 0, x, r.s);
-  ws->release(st);
+  float* coefg = ws->get<float>((size_t)r.B * C * 4);
+  if (!r.dry()) {
+    launch_gn_finalize(ypart, yu, w.gg, w.gb, nullptr, 0, coefg, r.B, C, 1, vox, r.s);
+    launch_gn_apply(y, y, coefg, r.B, C, vox, 0, x, nullptr, 0, nullptr, r.s);
+  }
+  ws->release(ypart);
+  ws->release(coefg);
   return y;
 }
 
@@ -480,11 +530,14 @@ float* unet_body(CdPlan* p, Run& r, const float* emb, float* h) {
     float* t = res_block(r, resolve(p, p->downs[i].r1, emb), x, cx, nullptr, 0, dims);
     r.ws->release(x);
     x = t; cx = p->downs[i].r1.cout;
-    t = res_block(r, resolve(p, p->downs[i].r2, emb), x, cx, nullptr, 0, dims);
+    float* xp = nullptr;
+    int xu = 0;
+    t = res_block(r, resolve(p, p->downs[i].r2, emb), x, cx, nullptr, 0, dims, d.block_attn ? &xp : nullptr, &xu);
     r.ws->release(x);
     x = t;
     if (d.block_attn) {
-      t = attn_block(r, resolve(p, p->downs[i].attn), x, dims);
+      t = attn_block(r, resolve(p, p->downs[i].attn), x, dims, xp, xu);
+      r.ws->release(xp);
       r.ws->release(x);
       x = t;
     }
@@ -503,11 +556,14 @@ float* unet_body(CdPlan* p, Run& r, const float* emb, float* h) {
     }
   }
   const Dims3 md = p->shapes[nres - 1];
-  float* t = res_block(r, resolve(p, p->mid1, emb), x, cx, nullptr, 0, md);
+  float* mp = nullptr;
+  int mu = 0;
+  float* t = res_block(r, resolve(p, p->mid1, emb), x, cx, nullptr, 0, md, d.mid_attn ? &mp : nullptr, &mu);
   // x aliases skips[nres-1]: keep it alive for the concat
   x = t;
   if (d.mid_attn) {
-    t = attn_block(r, resolve(p, p->mid_attn), x, md);
+    t = attn_block(r, resolve(p, p->mid_attn), x, md, mp, mu);
+    r.ws->release(mp);
     r.ws->release(x);
     x = t;
   }
@@ -524,11 +580,14 @@ float* unet_body(CdPlan* p, Run& r, const float* emb, float* h) {
     r.ws->release(x);
     r.ws->release(skips[lv]);
     x = t; cx = p->ups[i].r1.cout;
-    t = res_block(r, resolve(p, p->ups[i].r2, emb), x, cx, nullptr, 0, dims);
+    float* up = nullptr;
+    int uu = 0;
+    t = res_block(r, resolve(p, p->ups[i].r2, emb), x, cx, nullptr, 0, dims, d.block_attn ? &up : nullptr, &uu);
     r.ws->release(x);
     x = t;
     if (d.block_attn) {
-      t = attn_block(r, resolve(p, p->ups[i].attn), x, dims);
+      t = attn_block(r, resolve(p, p->ups[i].attn), x, dims, up, uu);
+      r.ws->release(up);
       r.ws->release(x);
       x = t;
     }
@@ -949,9 +1008,11 @@ int cd_op_group_norm(const float* x, float* y, const float* gamma, const float* 
     CD_REQUIRE(x && y && gamma && beta && scratch, "null argument");
     hipStream_t s = (hipStream_t)stream;
     const int ns = gn_nsplit_for(voxels, batch);
-    double* part = (double*)scratch;
-    launch_gn_stats(x, part, batch, channels, voxels, groups, ns, s);
-    launch_gn_apply(x, y, part, ns, gamma, beta, batch, channels, voxels, groups, silu, add_bc, channels, residual, s);
+    float* part = (float*)scratch;
+    float* coef = part + (size_t)batch * ns * channels * 2;
+    launch_ch_stats(x, part, batch, channels, voxels, ns, s);
+    launch_gn_finalize(part, ns, gamma, beta, add_bc, channels, coef, batch, channels, groups, voxels, s);
+    launch_gn_apply(x, y, coef, batch, channels, voxels, silu, residual, nullptr, 0, nullptr, s);
   });
 }
 
