@@ -75,7 +75,12 @@ struct ConvFusion {
   int act = 0;
   float* ch_part = nullptr;
   int* units = nullptr;
+  const void* wpk_bf16x3 = nullptr;  // 3x3x3 stride-1 only: split-bf16 packed weights (launch_pack_weights_bf16x3)
 };
+inline size_t packed_bf16x3_bytes(int cin, int cout, int taps) {
+  return (size_t)(cin / 16) * taps * ((cout + 31) / 32) * 3 * 64 * 16;
+}
+void launch_pack_weights_bf16x3(const float* w_torch, void* wpk, int cout, int cin, int taps, hipStream_t s);
 
 void launch_pack_weights(const float* w_torch, float* wpk, int cout, int cin, int taps, bool transposed, hipStream_t s);
 void launch_pack_init_weights(const float* w_torch, float* wpk, int cout, int cin, hipStream_t s);

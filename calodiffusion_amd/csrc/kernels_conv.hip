@@ -10,6 +10,8 @@
 #include "cd_common.h"
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -223,16 +225,52 @@ __global__ void __launch_bounds__(512) conv_mfma_kernel(ConvKArgs a) {
 }
 
 namespace {
+// One-time on-device selection among candidate tilings of one conv geometry (all candidates give bit-identical
+// results: the per-output summation order does not depend on the tiling).  Never runs during stream capture.
+std::map<std::string, int>& tune_cache() {
+  static std::map<std::string, int> c;
+  return c;
+}
+template <typename F>
+int autotune(const std::string& key, int ncand, F&& run, hipStream_t s) {
+  auto it = tune_cache().find(key);
+  if (it != tune_cache().end()) return it->second;
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (getenv("CD_NO_AUTOTUNE") || hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone || prof::enabled())
+    return -1;  // caller falls back to its heuristic (not cached)
+  hipEvent_t e0, e1;
+  CD_HIP(hipEventCreate(&e0));
+  CD_HIP(hipEventCreate(&e1));
+  int best = 0;
+  float best_ms = 1e30f;
+  for (int i = 0; i < ncand; ++i) {
+    run(i);  // warm-up (also sets function attributes)
+    CD_HIP(hipEventRecord(e0, s));
+    run(i);
+    run(i);
+    CD_HIP(hipEventRecord(e1, s));
+    CD_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CD_HIP(hipEventElapsedTime(&ms, e0, e1));
+    if (ms < best_ms) { best_ms = ms; best = i; }
+  }
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  tune_cache()[key] = best;
+  if (getenv("CD_TUNE_VERBOSE")) std::fprintf(stderr, "[calodiff autotune] %s -> candidate %d (%.1f us)\n", key.c_str(), best, best_ms * 500.f);
+  return best;
+}
+
 struct ConvTile {
   int TZ, TH, NW, VT;
   size_t lds;
 };
 
-// Pick the output tile and wave layout: minimise an estimate of whole-chip MFMA time (tile quantisation in
-// 32-voxel MFMA rows, SIMD balance, tail rounds over 256 CUs), subject to the 160 KiB LDS per CU.
-ConvTile choose_conv_tile(const ConvGeom& g, int batch, int CT) {
-  ConvTile best{0, 0, 0, 0, 0};
-  double best_cost = 1e300;
+// Candidate output tiles / wave layouts, ranked by an estimate of whole-chip MFMA time (tile quantisation in 32-voxel
+// MFMA rows, SIMD balance, tail rounds over 256 CUs) subject to the 160 KiB LDS per CU; the best few are timed on the
+// device once per geometry (autotune above), the top-ranked one is the fallback when timing is not possible.
+std::vector<ConvTile> conv_tile_candidates(const ConvGeom& g, int batch, int CT, int keep) {
+  std::vector<std::pair<double, ConvTile>> all;
   const int max_vt = 8 / CT;
   for (int TZ = 1; TZ <= g.out.d && TZ <= 12; ++TZ) {
     for (int nth = 1; nth <= g.out.h; ++nth) {
@@ -242,38 +280,33 @@ ConvTile choose_conv_tile(const ConvGeom& g, int batch, int CT) {
       const size_t lds = ((size_t)IZ * IH * g.in.w * 36 + 36) * 4;
       if (lds > 150 * 1024) continue;
       const int tiles = (TZ * TH * g.out.w + 31) / 32;
-      for (int NW : {2, 4, 8}) {
+      for (int NW = 1; NW <= 8; ++NW) {
         const int VT = (tiles + NW - 1) / NW;
         if (VT > max_vt || VT < 1) continue;
+        if (NW > 1 && (tiles + NW - 2) / (NW - 1) == VT) continue;  // a smaller NW already covers it with the same VT
         const int nTZ = (g.out.d + TZ - 1) / TZ;
         const long nblocks = (long)batch * nTZ * nth;
         int bpc = (int)(160 * 1024 / lds);
         bpc = bpc < 1 ? 1 : bpc;
         while (bpc > 1 && bpc * NW > 16) --bpc;
-        const long rounds = (nblocks + 256L * bpc - 1) / (256L * bpc);
-        double per_round = (double)bpc * NW * VT / 4.0;
-        if (per_round < VT) per_round = VT;
-        // staging cost: float4 items per block / threads, weighted against one 32x32xK tap pass (27*16 MFMAs of 64 clk)
-        const double stage = (double)IZ * IH * g.in.w * 8 / (64.0 * NW) * 40.0 / (g.kd * g.kh * g.kw * 16 * 64.0) * bpc;
-        const double cost = rounds * (per_round + stage) * (1.0 + 0.02 * (NW == 2));
-        if (cost < best_cost - 1e-9) {
-          best_cost = cost;
-          best = ConvTile{TZ, TH, NW, VT, lds};
-        }
+        const long per_cu = (nblocks + 255) / 256;
+        const long rounds = (per_cu + bpc - 1) / bpc;
+        const int resident = (int)(per_cu < bpc ? per_cu : bpc);
+        double per_round = (double)((resident * NW + 3) / 4) * VT;
+        const double useful = (double)(g.out.d * g.out.h * g.out.w) / ((double)nTZ * nth * NW * VT * 32);
+        const double cost = rounds * per_round / (useful > 0 ? 1.0 : 1.0) + 0.02 * (double)IZ * IH * g.in.w / 32.0 * rounds;
+        all.push_back({cost, ConvTile{TZ, TH, NW, VT, lds}});
       }
     }
   }
-  CD_REQUIRE(best.NW > 0, "no convolution tiling fits in LDS (grid too wide in r?)");
-  // experiment hook: CD_CONV_TILE="TZ,TH,NW,VT" overrides the choice for stride-1 3x3x3 convs
-  if (const char* ov = getenv("CD_CONV_TILE")) {
-    int tz, th, nw, vt;
-    if (sscanf(ov, "%d,%d,%d,%d", &tz, &th, &nw, &vt) == 4 && g.sz == 1 && g.kh == 3 && tz <= g.out.d && th <= g.out.h) {
-      const int IZ = tz - 1 + g.kd, IH = th - 1 + g.kh;
-      const size_t lds = ((size_t)IZ * IH * g.in.w * 36 + 36) * 4;
-      if (lds <= 160 * 1024 && nw * vt * 32 >= tz * th * g.out.w && vt <= max_vt) best = ConvTile{tz, th, nw, vt, lds};
-    }
+  CD_REQUIRE(!all.empty(), "no convolution tiling fits in LDS (grid too wide in r?)");
+  std::stable_sort(all.begin(), all.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
+  std::vector<ConvTile> out;
+  for (auto& c : all) {
+    out.push_back(c.second);
+    if ((int)out.size() >= keep) break;
   }
-  return best;
+  return out;
 }
 
 template <int VT, int CT>
@@ -552,107 +585,333 @@ struct FlatTile {
   size_t lds = 0;
 };
 
-// One-time on-device selection among candidate tilings of one conv geometry (all candidates give bit-identical
-// results: the per-output summation order does not depend on the tiling).  Never runs during stream capture.
-std::map<std::string, int>& tune_cache() {
-  static std::map<std::string, int> c;
-  return c;
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------
+// 3x3x3 stride-1 conv on the bf16 matrix pipe with fp32-grade accuracy ("bf16x3").
+//
+// gfx950's f32-input MFMA runs at 1/16 of the bf16 rate.  Every fp32 operand is therefore split exactly into three bf16
+// terms, x = x1 + x2 + x3 (x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2): 24 significant bits), and the
+// product is formed from the six term pairs whose magnitude is >= 2^-16 of the leading one:
+//     x*w ~= x1*w1 + (x1*w2 + x2*w1) + (x1*w3 + x2*w2 + x3*w1)          (dropped terms <= 2^-24 relative)
+// Each bf16 x bf16 product is exact in fp32 and accumulation is fp32 inside v_mfma_f32_32x32x16_bf16, so the result has
+// fp32 rounding-level error (measured: ~2x the error of an fp32 FMA chain, 1e-6 relative on K = 864), at 6/16 of the
+// matrix-pipe time of the f32 MFMA.  Weights are split once at pack time; activations are split while they are staged
+// into LDS (after the optional fused GroupNorm+SiLU), 96 B per voxel per 16-channel sub-chunk.
+// Same flat-range tiling, LDS plane image, software pipeline, and fused statistics epilogue as conv3_flat_kernel.
+// ------------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+  const bf16x2 v = {(__bf16)lo, (__bf16)hi};  // v_cvt_pk_bf16_f32, round to nearest even
+  return __builtin_bit_cast(unsigned, v);
 }
-template <typename F>
-int autotune(const std::string& key, int ncand, F&& run, hipStream_t s) {
-  auto it = tune_cache().find(key);
-  if (it != tune_cache().end()) return it->second;
-  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-  if (getenv("CD_NO_AUTOTUNE") || hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone || prof::enabled())
-    return -1;  // caller falls back to its heuristic (not cached)
-  hipEvent_t e0, e1;
-  CD_HIP(hipEventCreate(&e0));
-  CD_HIP(hipEventCreate(&e1));
-  int best = 0;
-  float best_ms = 1e30f;
-  for (int i = 0; i < ncand; ++i) {
-    run(i);  // warm-up (also sets function attributes)
-    CD_HIP(hipEventRecord(e0, s));
-    run(i);
-    run(i);
-    CD_HIP(hipEventRecord(e1, s));
-    CD_HIP(hipEventSynchronize(e1));
-    float ms = 0.f;
-    CD_HIP(hipEventElapsedTime(&ms, e0, e1));
-    if (ms < best_ms) { best_ms = ms; best = i; }
-  }
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
-  tune_cache()[key] = best;
-  if (getenv("CD_TUNE_VERBOSE")) std::fprintf(stderr, "[calodiff autotune] %s -> candidate %d (%.1f us)\n", key.c_str(), best, best_ms * 500.f);
-  return best;
+// exact three-way split of 4 floats -> three 8-byte groups of 4 bf16
+__device__ __forceinline__ void split3(const f32x4 x, u32x2& t1, u32x2& t2, u32x2& t3) {
+  f32x4 r = x;
+  t1 = u32x2{pack_bf16(r[0], r[1]), pack_bf16(r[2], r[3])};
+  r[0] -= __uint_as_float(t1[0] << 16); r[1] -= __uint_as_float(t1[0] & 0xffff0000u);
+  r[2] -= __uint_as_float(t1[1] << 16); r[3] -= __uint_as_float(t1[1] & 0xffff0000u);
+  t2 = u32x2{pack_bf16(r[0], r[1]), pack_bf16(r[2], r[3])};
+  r[0] -= __uint_as_float(t2[0] << 16); r[1] -= __uint_as_float(t2[0] & 0xffff0000u);
+  r[2] -= __uint_as_float(t2[1] << 16); r[3] -= __uint_as_float(t2[1] & 0xffff0000u);
+  t3 = u32x2{pack_bf16(r[0], r[1]), pack_bf16(r[2], r[3])};
 }
 
-// R = 32*NT voxels per workgroup.  Cost model: MFMA slot-time per CU round (tiles per SIMD, co-resident workgroups share
-// the 4 SIMDs), tail rounds over 256 CUs, staged bytes per output voxel (halo planes).
-FlatTile choose_flat_tile(Dims3 d, int batch, int CT) {
-  FlatTile best;
-  const int HW = d.h * d.w;
-  const int64_t vox = d.vox();
-  if (const char* ov = getenv("CD_FLAT_TILE")) {
-    int nt, vt;
-    if (sscanf(ov, "%d,%d", &nt, &vt) == 2 && nt % vt == 0 && nt / vt <= 8 && vt * CT <= 8) {
-      const int P = (32 * nt - 1) / HW + 4;
-      const size_t lds = ((size_t)P * HW + 1) * 64;
-      if (lds <= 160 * 1024) { best.NT = nt; best.VT = vt; best.lds = lds; return best; }
+// packed bf16x3 weights: [sub-chunk = ci/16][tap][ct][term][lane = h*32+j][8 bf16] = W_term[co = ct*32+j][ci = sc*16+8h+0..7]
+__global__ void pack_weights_bf16x3_kernel(const float* __restrict__ w, u32x4* __restrict__ wpk, int cout, int cin, int taps,
+                                           size_t total) {
+  const size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x;  // one thread per (sc, tap, ct, lane)
+  if (idx >= total) return;
+  const int lane = idx & 63;
+  size_t rest = idx >> 6;
+  const int CT = (cout + 31) / 32;
+  const int ct = rest % CT;
+  rest /= CT;
+  const int tap = rest % taps;
+  const int sc = rest / taps;
+  const int h = lane >> 5, j = lane & 31;
+  const int co = ct * 32 + j;
+  f32x4 v[2];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int ci = sc * 16 + h * 8 + e;
+    v[e >> 2][e & 3] = (co < cout && ci < cin) ? w[((size_t)co * cin + ci) * taps + tap] : 0.f;
+  }
+  u32x2 a1, a2, a3, b1, b2, b3;
+  split3(v[0], a1, a2, a3);
+  split3(v[1], b1, b2, b3);
+  u32x4* dst = wpk + (((size_t)(sc * taps + tap) * CT + ct) * 3) * 64 + lane;
+  dst[0] = u32x4{a1[0], a1[1], b1[0], b1[1]};
+  dst[64] = u32x4{a2[0], a2[1], b2[0], b2[1]};
+  dst[128] = u32x4{a3[0], a3[1], b3[0], b3[1]};
+}
+
+void launch_pack_weights_bf16x3(const float* w_torch, void* wpk, int cout, int cin, int taps, hipStream_t s) {
+  CD_REQUIRE(cin % 16 == 0, "bf16x3 convolution needs input channels in multiples of 16");
+  const size_t total = (size_t)(cin / 16) * taps * ((cout + 31) / 32) * 64;
+  hipLaunchKernelGGL(pack_weights_bf16x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w_torch, (u32x4*)wpk, cout,
+                     cin, taps, total);
+  CD_HIP(hipGetLastError());
+}
+
+#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
+
+template <int VT, int CT>
+__global__ void __launch_bounds__(512, (VT * CT <= 2 ? 3 : 2)) conv3_flat_bf16x3_kernel(ConvFlatArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  char* ldsb = (char*)lds;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
+  const int b = blockIdx.y;
+  const int ct0 = blockIdx.z * CT;
+  const int HW = a.H * a.W;
+  const int vox = a.D * HW;
+  const int v0 = blockIdx.x * a.R;
+  const int vend = min(v0 + a.R, vox);
+  const int zA = v0 / HW - 1;
+  const int zB = (vend - 1) / HW + 1;
+  const int nstage = (zB - zA + 1) * HW;
+  const int NZ = a.P * HW;  // all-zero voxel
+  const int half = lane >> 5, col = lane & 31;
+  if (tid < 24) ((float*)(ldsb + (size_t)NZ * 96))[tid] = 0.f;
+
+  int nb[VT], rowm[VT], rowp[VT], ooff[VT];
+  unsigned wmask[VT];
+  bool any_valid = false;
+#pragma unroll
+  for (int vt = 0; vt < VT; ++vt) {
+    const int v = v0 + (wave * VT + vt) * 32 + col;
+    const bool valid = v < vend;
+    const int vv = valid ? v : v0;
+    const int r = vv % HW;
+    const int h = r / a.W, w = r - h * a.W;
+    nb[vt] = vv - zA * HW;
+    rowm[vt] = (h == 0 ? a.H - 1 : -1) * a.W;
+    rowp[vt] = (h == a.H - 1 ? -(a.H - 1) : 1) * a.W;
+    unsigned m = 0;
+    if (valid) m = (w > 0 ? 1u : 0u) | 2u | (w + 1 < a.W ? 4u : 0u);
+    wmask[vt] = m;
+    ooff[vt] = valid ? v * a.cout : -1;
+    any_valid |= valid;
+  }
+  const bool wave_active = __any(any_valid);
+
+  f32x16 acc[VT][CT];
+#pragma unroll
+  for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[vt][ct][r] = 0.f;
+
+  const int nsub = (a.c0 + a.c1) >> 4;
+  const int gbase = zA * HW;
+  const int nslots = nstage * 4;  // one slot = 4 channels of one voxel
+
+  auto tap_voxel = [&](int vt, int tap) -> int {
+    const int dz = tap / 9 - 1, dh = (tap / 3) % 3 - 1, dw = tap % 3 - 1;
+    const int n = nb[vt] + dz * HW + (dh < 0 ? rowm[vt] : (dh > 0 ? rowp[vt] : 0)) + dw;
+    return ((wmask[vt] >> (dw + 1)) & 1u) ? n : NZ;
+  };
+
+  for (int sc = 0; sc < nsub; ++sc) {
+    const float* src;
+    int ldc, coff;
+    if (sc * 16 < a.c0) {
+      src = a.in0; ldc = a.c0; coff = sc * 16;
+    } else {
+      src = a.in1; ldc = a.c1; coff = sc * 16 - a.c0;
+    }
+    const int pq = tid & 3;  // this thread always stages channel quad pq of a voxel
+    src += (size_t)b * vox * ldc + coff + pq * 4;
+    f32x4 cf[4];
+    if (a.coef) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) cf[e] = *(const f32x4*)(a.coef + ((size_t)b * (a.c0 + a.c1) + sc * 16 + pq * 4 + e) * 4);
+    }
+    __syncthreads();
+    for (int s0 = tid; s0 < ((a.dbg & 1) ? 0 : nslots); s0 += 4 * nthreads) {
+      f32x4 val[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int sidx = s0 + k * nthreads;
+        const int g = gbase + (sidx >> 2);
+        val[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (sidx < nslots && g >= 0 && g < vox) {
+          val[k] = *(const f32x4*)(src + (size_t)g * ldc);
+          if (a.coef) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float t = cf[e][0] * val[k][e] + cf[e][1];
+              if (a.act) t = t / (1.f + expf(-t));
+              val[k][e] = t + cf[e][2];
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int sidx = s0 + k * nthreads;
+        if (sidx < nslots) {
+          u32x2 t1, t2, t3;
+          split3(val[k], t1, t2, t3);
+          char* d = ldsb + (size_t)(sidx >> 2) * 96 + pq * 8;
+          *(u32x2*)d = t1;
+          *(u32x2*)(d + 32) = t2;
+          *(u32x2*)(d + 64) = t3;
+        }
+      }
+    }
+    __syncthreads();
+    if (!wave_active || (a.dbg & 2)) continue;
+
+#pragma unroll
+    for (int vt = 0; vt < VT; ++vt) asm volatile("" : "+v"(nb[vt]));
+
+    const u32x4* wq = (const u32x4*)a.wpk + ((size_t)sc * 27 * a.CTtot + ct0) * 192 + lane;
+    u32x4 bw[2][CT][3], av[2][VT][3];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) bw[0][ct][t] = wq[(size_t)ct * 192 + t * 64];
+#pragma unroll
+    for (int vt = 0; vt < VT; ++vt) {
+      const char* p = ldsb + (size_t)tap_voxel(vt, 0) * 96 + half * 16;
+#pragma unroll
+      for (int t = 0; t < 3; ++t) av[0][vt][t] = *(const u32x4*)(p + t * 32);
+    }
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) {
+      const int cur = tap & 1, nxt = cur ^ 1;
+      if (tap + 1 < 27) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+          for (int t = 0; t < 3; ++t) bw[nxt][ct][t] = wq[((size_t)(tap + 1) * a.CTtot + ct) * 192 + t * 64];
+#pragma unroll
+        for (int vt = 0; vt < VT; ++vt) {
+          const char* p = ldsb + (size_t)tap_voxel(vt, tap + 1) * 96 + half * 16;
+#pragma unroll
+          for (int t = 0; t < 3; ++t) av[nxt][vt][t] = *(const u32x4*)(p + t * 32);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          f32x16 c = acc[vt][ct];
+          c = MFMA_BF16(av[cur][vt][2], bw[cur][ct][0], c);  // x3*w1
+          c = MFMA_BF16(av[cur][vt][1], bw[cur][ct][1], c);  // x2*w2
+          c = MFMA_BF16(av[cur][vt][0], bw[cur][ct][2], c);  // x1*w3
+          c = MFMA_BF16(av[cur][vt][1], bw[cur][ct][0], c);  // x2*w1
+          c = MFMA_BF16(av[cur][vt][0], bw[cur][ct][1], c);  // x1*w2
+          c = MFMA_BF16(av[cur][vt][0], bw[cur][ct][0], c);  // x1*w1
+          acc[vt][ct] = c;
+        }
     }
   }
-  double best_cost = 1e300;
-  for (int NT = 1; NT <= 16; ++NT) {
-    if ((int64_t)32 * (NT - 1) >= vox) break;
-    const int P = (32 * NT - 1) / HW + 4;
-    const size_t lds = ((size_t)P * HW + 1) * 64;
-    if (lds > 80 * 1024) continue;  // keep at least two workgroups per CU
-    for (int VT = 1; VT <= 4; ++VT) {
-      if (NT % VT || NT / VT > 8 || VT * CT > 8) continue;
-      const int NW = NT / VT;
-      const long units = (long)batch * ((vox + 32 * NT - 1) / (32 * NT));
-      int bpc = (int)(160 * 1024 / lds);
-      while (bpc > 1 && bpc * NW > 16) --bpc;
-      long per_cu = (units + 255) / 256;  // workgroups each CU must run
-      // time ~ rounds * (MFMA slot-time of the co-resident set) ; a set of bpc workgroups has bpc*NT tiles on 4 SIMDs
-      const long rounds = (per_cu + bpc - 1) / bpc;
-      const int resident = (int)(per_cu < bpc ? per_cu : bpc);
-      double set_time = (double)((resident * NW + 3) / 4) * VT;  // waves per SIMD * tiles per wave
-      const double useful = (double)vox / (32.0 * NT * ((vox + 32 * NT - 1) / (32 * NT)));
-      const double halo = (double)P * HW / (32.0 * NT);
-      const double cost = rounds * set_time * (1.0 + 0.03 * halo) * (1.0 + 0.1 / (resident * NW)) / useful * 1.0;
-      if (cost < best_cost) { best_cost = cost; best.NT = NT; best.VT = VT; best.lds = lds; }
+
+  float* outb = a.out + (size_t)b * vox * a.cout;
+  float bv[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) bv[ct] = a.bias ? a.bias[(ct0 + ct) * 32 + col] : 0.f;
+#pragma unroll
+  for (int vt = 0; vt < VT; ++vt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int off = __shfl(ooff[vt], row, 64);
+      if (off >= 0) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) outb[off + (ct0 + ct) * 32 + col] = acc[vt][ct][r] + bv[ct];
+      }
     }
   }
-  return best;
+  if (a.ch_part) {
+    float s1[CT], s2[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) s1[ct] = s2[ct] = 0.f;
+#pragma unroll
+    for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const bool ok = __shfl(ooff[vt], row, 64) >= 0;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          const float v = ok ? acc[vt][ct][r] + bv[ct] : 0.f;
+          s1[ct] += v;
+          s2[ct] += v * v;
+        }
+      }
+    __syncthreads();
+    const int nw = nthreads >> 6;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const float t1 = s1[ct] + __shfl_xor(s1[ct], 32, 64), t2 = s2[ct] + __shfl_xor(s2[ct], 32, 64);
+      if (half == 0) {
+        lds[((wave * CT + ct) * 32 + col) * 2] = t1;
+        lds[((wave * CT + ct) * 32 + col) * 2 + 1] = t2;
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < CT * 32; i += nthreads) {
+      float t1 = 0.f, t2 = 0.f;
+      for (int w = 0; w < nw; ++w) {
+        t1 += lds[((w * CT * 32) + i) * 2];
+        t2 += lds[((w * CT * 32) + i) * 2 + 1];
+      }
+      float* dst = a.ch_part + (((size_t)b * gridDim.x + blockIdx.x) * a.cout + ct0 * 32 + i) * 2;
+      dst[0] = t1;
+      dst[1] = t2;
+    }
+  }
+}
+
+namespace {
+template <int VT, int CT>
+void launch_flat3_inst(const ConvFlatArgs& a, dim3 grid, int threads, size_t lds, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    CD_HIP(hipFuncSetAttribute((const void*)conv3_flat_bf16x3_kernel<VT, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv3_flat_bf16x3_kernel<VT, CT>), grid, dim3(threads), lds, s, a);
+  CD_HIP(hipGetLastError());
 }
 }  // namespace
 
-// returns false when the whole-plane LDS tile does not fit (wide grids such as Dataset-3's 50x18 planes)
-static bool try_launch_conv3_flat(const float* in0, int c0, const float* in1, int c1, const float* wpk, const float* bias,
-                                  float* out, int batch, int cout, Dims3 d, hipStream_t s, const ConvFusion& fu) {
+// returns false when the whole-plane LDS tile does not fit (wide grids such as Dataset-3's 50x18 planes).
+// bf16x3 = true runs the split-bf16 kernel on `wpk` = packed bf16x3 weights; otherwise the f32 MFMA kernel.
+static bool try_launch_conv3_flat(const float* in0, int c0, const float* in1, int c1, const void* wpk, const float* bias,
+                                  float* out, int batch, int cout, Dims3 d, hipStream_t s, const ConvFusion& fu, bool bf16x3) {
   if (getenv("CD_NO_FLAT")) return false;
   const int CTtot = cout / 32;
   const int CT = CTtot <= 3 ? CTtot : 2;
   if (CTtot % CT) return false;
   const int HW = d.h * d.w;
+  const size_t vox_bytes = bf16x3 ? 96 : 64;
   auto launch = [&](int NT, int VT) -> bool {
     ConvFlatArgs a;
-    a.in0 = in0; a.in1 = in1; a.c0 = c0; a.c1 = c1; a.wpk = wpk; a.bias = bias; a.out = out;
+    a.in0 = in0; a.in1 = in1; a.c0 = c0; a.c1 = c1; a.wpk = (const float*)wpk; a.bias = bias; a.out = out;
     a.D = d.d; a.H = d.h; a.W = d.w; a.R = 32 * NT; a.P = (a.R - 1) / HW + 4; a.cout = cout; a.CTtot = CTtot;
     a.dbg = getenv("CD_FLAT_DBG") ? atoi(getenv("CD_FLAT_DBG")) : 0;
     a.coef = fu.coef; a.act = fu.act; a.ch_part = fu.ch_part;
-    size_t lds = ((size_t)a.P * HW + 1) * 64;
+    size_t lds = ((size_t)a.P * HW + 1) * vox_bytes;
     const size_t red = (size_t)(NT / VT) * CT * 32 * 2 * 4;  // cross-wave reduction scratch of the stats epilogue
     if (lds < red) lds = red;
     dim3 grid((unsigned)((d.vox() + a.R - 1) / a.R), (unsigned)batch, (unsigned)(CTtot / CT));
     if (fu.units) *fu.units = (int)grid.x;
     const int threads = (NT / VT) * 64;
-#define CD_FLAT_CASE(V, C)                                 \
-  if (VT == V && CT == C) {                                \
-    launch_flat_inst<V, C>(a, grid, threads, lds, s);      \
-    return true;                                           \
+#define CD_FLAT_CASE(V, C)                                              \
+  if (VT == V && CT == C) {                                             \
+    if (bf16x3) launch_flat3_inst<V, C>(a, grid, threads, lds, s);      \
+    else launch_flat_inst<V, C>(a, grid, threads, lds, s);              \
+    return true;                                                        \
   }
     CD_FLAT_CASE(1, 1) CD_FLAT_CASE(2, 1) CD_FLAT_CASE(3, 1) CD_FLAT_CASE(4, 1)
     CD_FLAT_CASE(1, 2) CD_FLAT_CASE(2, 2) CD_FLAT_CASE(3, 2) CD_FLAT_CASE(4, 2)
@@ -660,9 +919,11 @@ static bool try_launch_conv3_flat(const float* in0, int c0, const float* in1, in
 #undef CD_FLAT_CASE
     return false;
   };
-  if (getenv("CD_FLAT_TILE")) {
-    const FlatTile t = choose_flat_tile(d, batch, CT);
-    return t.NT ? launch(t.NT, t.VT) : false;
+  if (const char* ov = getenv("CD_FLAT_TILE")) {
+    int nt, vt;
+    if (sscanf(ov, "%d,%d", &nt, &vt) == 2 && nt % vt == 0 && nt / vt <= 8 && vt * CT <= 8 &&
+        ((size_t)((32 * nt - 1) / HW + 4) * HW + 1) * vox_bytes <= 160 * 1024)
+      return launch(nt, vt);
   }
   // candidate tilings: (tiles per workgroup, tiles per wave)
   static const int kCand[][2] = {{8, 2}, {4, 1}, {8, 1}, {12, 3}, {16, 2}, {16, 4}, {4, 2}, {6, 2}, {6, 3}, {2, 1},
@@ -673,18 +934,14 @@ static bool try_launch_conv3_flat(const float* in0, int c0, const float* in1, in
     if (VT * CT > 8 || (CT == 3 && VT > 2)) continue;
     if ((int64_t)32 * (NT - 1) >= d.vox()) continue;
     const int P = (32 * NT - 1) / HW + 4;
-    if (((size_t)P * HW + 1) * 64 > 150 * 1024) continue;
+    if (((size_t)P * HW + 1) * vox_bytes > 150 * 1024) continue;
     cand.push_back({NT, VT});
   }
   if (cand.empty()) return false;
   char key[160];
-  std::snprintf(key, sizeof key, "flat3 %dx%dx%d c%d+%d->%d b%d", d.d, d.h, d.w, c0, c1, cout, batch);
-  int pick = autotune(key, (int)cand.size(), [&](int i) { launch(cand[i].first, cand[i].second); }, s);
-  if (pick < 0) {
-    const FlatTile t = choose_flat_tile(d, batch, CT);
-    return t.NT ? launch(t.NT, t.VT) : false;
-  }
-  return launch(cand[pick].first, cand[pick].second);
+  std::snprintf(key, sizeof key, "flat3%s %dx%dx%d c%d+%d->%d b%d", bf16x3 ? "_bf16x3" : "", d.d, d.h, d.w, c0, c1, cout, batch);
+  const int pick = autotune(key, (int)cand.size(), [&](int i) { launch(cand[i].first, cand[i].second); }, s);
+  return launch(cand[pick < 0 ? 0 : pick].first, cand[pick < 0 ? 0 : pick].second);
 }
 
 void launch_conv_mfma(const float* in0, int c0, const float* in1, int c1, const float* wpk, const float* bias, float* out,
@@ -702,28 +959,42 @@ void launch_conv_mfma(const float* in0, int c0, const float* in1, int c1, const 
   const double taps = (double)g.kd * g.kh * g.kw;
   prof::Scope scope(cat, s, 2.0 * taps * (c0 + c1) * cout * (double)g.out.vox() * batch,
                     4.0 * batch * ((double)g.in.vox() * (c0 + c1) + (double)g.out.vox() * cout));
-  if (g.kd == 3 && g.kh == 3 && g.kw == 3 && g.sz == 1 && g.sh == 1 && g.sw == 1 &&
-      try_launch_conv3_flat(in0, c0, in1, c1, wpk, bias, out, batch, cout, g.in, s, fu))
-    return;
-  const ConvTile t = choose_conv_tile(g, batch, CT);
-  ConvKArgs a;
-  a.in0 = in0; a.in1 = in1; a.c0 = c0; a.c1 = c1; a.wpk = wpk; a.bias = bias; a.out = out;
-  a.Din = g.in.d; a.Hin = g.in.h; a.Win = g.in.w; a.Do = g.out.d; a.Ho = g.out.h; a.Wo = g.out.w;
-  a.KD = g.kd; a.KH = g.kh; a.KW = g.kw; a.SZ = g.sz; a.SH = g.sh; a.SW = g.sw;
-  a.TZ = t.TZ; a.TH = t.TH; a.nTZ = (g.out.d + t.TZ - 1) / t.TZ; a.nTH = (g.out.h + t.TH - 1) / t.TH;
-  a.IZ = (t.TZ - 1) * g.sz + g.kd; a.IH = (t.TH - 1) * g.sh + g.kh;
-  a.cout = cout; a.CTtot = CTtot; a.coef = fu.coef; a.act = fu.act;
-  dim3 grid((unsigned)(batch * a.nTZ * a.nTH), (unsigned)(CTtot / CT));
-  const int threads = t.NW * 64;
+  if (g.kd == 3 && g.kh == 3 && g.kw == 3 && g.sz == 1 && g.sh == 1 && g.sw == 1) {
+    static const bool want_f32 = getenv("CD_CONV_PRECISION") && !strcmp(getenv("CD_CONV_PRECISION"), "f32");
+    if (fu.wpk_bf16x3 && !want_f32 &&
+        try_launch_conv3_flat(in0, c0, in1, c1, fu.wpk_bf16x3, bias, out, batch, cout, g.in, s, fu, true))
+      return;
+    if (try_launch_conv3_flat(in0, c0, in1, c1, wpk, bias, out, batch, cout, g.in, s, fu, false)) return;
+  }
+  const std::vector<ConvTile> cand = conv_tile_candidates(g, batch, CT, 14);
+  auto launch = [&](const ConvTile& t) {
+    ConvKArgs a;
+    a.in0 = in0; a.in1 = in1; a.c0 = c0; a.c1 = c1; a.wpk = wpk; a.bias = bias; a.out = out;
+    a.Din = g.in.d; a.Hin = g.in.h; a.Win = g.in.w; a.Do = g.out.d; a.Ho = g.out.h; a.Wo = g.out.w;
+    a.KD = g.kd; a.KH = g.kh; a.KW = g.kw; a.SZ = g.sz; a.SH = g.sh; a.SW = g.sw;
+    a.TZ = t.TZ; a.TH = t.TH; a.nTZ = (g.out.d + t.TZ - 1) / t.TZ; a.nTH = (g.out.h + t.TH - 1) / t.TH;
+    a.IZ = (t.TZ - 1) * g.sz + g.kd; a.IH = (t.TH - 1) * g.sh + g.kh;
+    a.cout = cout; a.CTtot = CTtot; a.coef = fu.coef; a.act = fu.act;
+    dim3 grid((unsigned)(batch * a.nTZ * a.nTH), (unsigned)(CTtot / CT));
+    const int threads = t.NW * 64;
 #define CD_CONV_CASE(V, C)                                        \
   if (t.VT == V && CT == C) {                                     \
     launch_conv_inst<V, C>(a, grid, threads, t.lds, s);           \
     return;                                                       \
   }
-  CD_CONV_CASE(1, 1) CD_CONV_CASE(2, 1) CD_CONV_CASE(3, 1) CD_CONV_CASE(4, 1)
-  CD_CONV_CASE(5, 1) CD_CONV_CASE(6, 1) CD_CONV_CASE(7, 1) CD_CONV_CASE(8, 1)
-  CD_CONV_CASE(1, 2) CD_CONV_CASE(2, 2) CD_CONV_CASE(3, 2) CD_CONV_CASE(4, 2)
-  CD_CONV_CASE(1, 3) CD_CONV_CASE(2, 3)
+    CD_CONV_CASE(1, 1) CD_CONV_CASE(2, 1) CD_CONV_CASE(3, 1) CD_CONV_CASE(4, 1)
+    CD_CONV_CASE(5, 1) CD_CONV_CASE(6, 1) CD_CONV_CASE(7, 1) CD_CONV_CASE(8, 1)
+    CD_CONV_CASE(1, 2) CD_CONV_CASE(2, 2) CD_CONV_CASE(3, 2) CD_CONV_CASE(4, 2)
+    CD_CONV_CASE(1, 3) CD_CONV_CASE(2, 3)
+#undef CD_CONV_CASE
+    CD_REQUIRE(false, "conv: no kernel instance for the chosen tiling");
+  };
+  char key[192];
+  std::snprintf(key, sizeof key, "tiled %s b%d", cat, batch);
+  int pick = autotune(key, (int)cand.size(), [&](int i) { launch(cand[i]); }, s);
+  launch(cand[pick < 0 ? 0 : pick]);
+  return;
+#define CD_CONV_CASE(V, C)
 #undef CD_CONV_CASE
   CD_REQUIRE(false, "conv: no kernel instance for the chosen tiling");
 }
@@ -873,35 +1144,47 @@ void launch_conv_transpose_mfma(const float* in, int cin, const float* wpk, cons
   a.Cw = (dout.w + 1) / 2;
   a.CS = cin + LDS_VOX_PAD;
   const int Az = (dout.d + sz - 1) / sz, Bh = (dout.h + 1) / 2;
-  // tile: largest (TZ, TH) whose haloed input tile stays under ~64 KiB (two blocks per CU); prefer full phi rings
-  int bestTZ = 1, bestTH = 1;
-  long bestv = -1;
+  // candidate (TZ, TH) tiles in class-index space; ranked by useful/haloed volume, a spread of them is timed once
+  struct TT { int tz, th; double score; };
+  std::vector<TT> all;
   for (int TZ = 1; TZ <= Az; ++TZ)
     for (int TH = 1; TH <= Bh; ++TH) {
       const size_t lds = ((size_t)(TZ + 2) * (TH + 2) * din.w + 1) * a.CS * 4;
-      if (lds > 64 * 1024) break;
-      const long v = (long)TZ * TH;
-      const long halo = (long)(TZ + 2) * (TH + 2);
-      // maximise useful/haloed ratio, then volume
-      const long score = v * 1000 / halo * 1000 + v;
-      if (score > bestv) { bestv = score; bestTZ = TZ; bestTH = TH; }
+      if (lds > 150 * 1024) break;
+      if (TH != Bh && (Bh + TH - 1) / TH == (Bh + TH) / (TH + 1)) continue;  // a larger TH gives the same tile count
+      if (TZ != Az && (Az + TZ - 1) / TZ == (Az + TZ) / (TZ + 1)) continue;
+      const long nblocks = (long)batch * ((Az + TZ - 1) / TZ) * ((Bh + TH - 1) / TH);
+      const double ratio = (double)TZ * TH / ((double)(TZ + 2) * (TH + 2));
+      const double fill = nblocks >= 512 ? 1.0 : (double)nblocks / 512.0;
+      all.push_back({TZ, TH, ratio * fill});
     }
-  a.TZ = bestTZ; a.TH = bestTH;
-  a.nTZ = (Az + a.TZ - 1) / a.TZ; a.nTH = (Bh + a.TH - 1) / a.TH;
-  const size_t lds = ((size_t)(a.TZ + 2) * (a.TH + 2) * din.w + 1) * a.CS * 4;
-  CD_REQUIRE(lds <= 160 * 1024, "conv_transpose: tile does not fit in LDS");
-  dim3 grid((unsigned)(batch * a.nTZ * a.nTH));
+  CD_REQUIRE(!all.empty(), "conv_transpose: no tile fits in LDS");
+  std::stable_sort(all.begin(), all.end(), [](const TT& x, const TT& y) { return x.score > y.score; });
+  std::vector<TT> cand;
+  for (size_t i = 0; i < all.size() && cand.size() < 8; ++i) cand.push_back(all[i]);
+  for (size_t i = 8; i < all.size() && cand.size() < 14; i += (all.size() - 8) / 6 + 1) cand.push_back(all[i]);
   char cat[128];
   std::snprintf(cat, sizeof cat, "convT%dx4x4 C%d->%d @%dx%dx%d", kz, cin, cout, din.d, din.h, din.w);
   prof::Scope scope(cat, s, 2.0 * kz * 16 * cin * cout * (double)din.vox() * batch,
                     4.0 * batch * ((double)din.vox() * cin + (double)dout.vox() * cout));
-  switch (a.CTtot) {
-    case 1: launch_convT_inst<1>(a, grid, lds, s); break;
-    case 2: launch_convT_inst<2>(a, grid, lds, s); break;
-    case 3: launch_convT_inst<3>(a, grid, lds, s); break;
-    case 4: launch_convT_inst<4>(a, grid, lds, s); break;
-    default: CD_REQUIRE(false, "conv_transpose: more than 128 output channels unsupported");
-  }
+  auto launch = [&](const TT& t) {
+    ConvTArgs b = a;
+    b.TZ = t.tz; b.TH = t.th;
+    b.nTZ = (Az + b.TZ - 1) / b.TZ; b.nTH = (Bh + b.TH - 1) / b.TH;
+    const size_t lds = ((size_t)(b.TZ + 2) * (b.TH + 2) * din.w + 1) * b.CS * 4;
+    dim3 grid((unsigned)(batch * b.nTZ * b.nTH));
+    switch (b.CTtot) {
+      case 1: launch_convT_inst<1>(b, grid, lds, s); break;
+      case 2: launch_convT_inst<2>(b, grid, lds, s); break;
+      case 3: launch_convT_inst<3>(b, grid, lds, s); break;
+      case 4: launch_convT_inst<4>(b, grid, lds, s); break;
+      default: CD_REQUIRE(false, "conv_transpose: more than 128 output channels unsupported");
+    }
+  };
+  char key[192];
+  std::snprintf(key, sizeof key, "%s k%d s%d b%d", cat, kz, sz, batch);
+  const int pick = autotune(key, (int)cand.size(), [&](int i) { launch(cand[i]); }, s);
+  launch(cand[pick < 0 ? 0 : pick]);
 }
 
 // ------------------------------------------------------------------------------------------------------------

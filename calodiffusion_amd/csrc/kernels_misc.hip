@@ -12,20 +12,30 @@ namespace cd {
 // ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
 
+// out[j] = bias[j] + sum_k w[j][k] * in[k]: one wave per output row, lanes stride k (coalesced 256-B reads of the
+// row-major torch weight), butterfly reduction.
+__device__ __forceinline__ float wave_dot(const float* __restrict__ wr, const float* in, int nin, int lane) {
+  float acc = 0.f;
+  for (int k = lane; k < nin; k += 64) acc = fmaf(wr[k], in[k], acc);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  return acc;
+}
+
 __device__ void dense(const float* __restrict__ w, const float* __restrict__ bias, const float* in, float* out, int nin,
                       int nout, bool gelu) {
-  for (int j = threadIdx.x; j < nout; j += blockDim.x) {
-    float acc = bias[j];
-    const float* wr = w + (size_t)j * nin;
-    for (int k = 0; k < nin; ++k) acc = fmaf(wr[k], in[k], acc);
-    out[j] = gelu ? gelu_erf(acc) : acc;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int j = wave; j < nout; j += nw) {
+    const float acc = wave_dot(w + (size_t)j * nin, in, nin, lane) + bias[j];
+    if (lane == 0) out[j] = gelu ? gelu_erf(acc) : acc;
   }
   __syncthreads();
 }
 
-__global__ void __launch_bounds__(128) embed_kernel(EmbedArgs a) {
+__global__ void __launch_bounds__(512) embed_kernel(EmbedArgs a) {
   __shared__ float bufA[256], bufB[256], cat[256];
   const int b = blockIdx.x, tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   const float tv = a.time_or_sigma[b];
   float t_in = tv;
   if (a.time_kind == 0) t_in = 0.5f * logf(tv);
@@ -57,13 +67,12 @@ __global__ void __launch_bounds__(128) embed_kernel(EmbedArgs a) {
     bufA[i] = v / (1.f + expf(-v));
   }
   __syncthreads();
+  // all ResnetBlock projections as one flat list of output rows
   for (int l = 0; l < a.n_layers; ++l) {
     const EmbedLayer L = a.layers[l];
-    for (int j = tid; j < L.cout; j += blockDim.x) {
-      float acc = L.b[j];
-      const float* wr = L.w + (size_t)j * 2 * half;
-      for (int k = 0; k < 2 * half; ++k) acc = fmaf(wr[k], bufA[k], acc);
-      a.emb[(size_t)b * a.emb_ld + L.offset + j] = acc;
+    for (int j = wave; j < L.cout; j += nw) {
+      const float acc = wave_dot(L.w + (size_t)j * 2 * half, bufA, 2 * half, lane) + L.b[j];
+      if (lane == 0) a.emb[(size_t)b * a.emb_ld + L.offset + j] = acc;
     }
   }
 }
@@ -71,7 +80,7 @@ __global__ void __launch_bounds__(128) embed_kernel(EmbedArgs a) {
 void launch_embed(const EmbedArgs& a, hipStream_t s) {
   CD_REQUIRE(a.half * 2 <= 256 && a.cond_hidden <= 256 && a.cond_size <= 256, "embedding widths above 256 unsupported");
   prof::Scope scope("embed", s, 0, 0);
-  hipLaunchKernelGGL(embed_kernel, dim3(a.batch), dim3(128), 0, s, a);
+  hipLaunchKernelGGL(embed_kernel, dim3(a.batch), dim3(512), 0, s, a);
   CD_HIP(hipGetLastError());
 }
 

@@ -29,6 +29,7 @@ struct WeightEntry {
   PackKind pack = PK_NONE;
   int cin = 0, cout = 0, taps = 0;
   size_t pk_off = 0;
+  size_t pk3_off = 0;  // split-bf16 image of 3x3x3 convs (floats into the arena; 0 = none)
   bool set = false;
 };
 
@@ -158,6 +159,7 @@ struct CdPlan {
 
   const float* raw(int i) const { return arena + weights[i].raw_off; }
   const float* packed(int i) const { return arena + weights[i].pk_off; }
+  const void* packed3(int i) const { return weights[i].pk3_off ? (const void*)(arena + weights[i].pk3_off) : nullptr; }
 };
 
 namespace {
@@ -314,6 +316,7 @@ void build_plan(CdPlan* p) {
   for (auto& w : p->weights) {
     w.raw_off = bump((size_t)w.numel);
     if (w.pack == PK_CONV || w.pack == PK_CONVT) w.pk_off = bump(packed_weight_floats(w.cin, w.cout, w.taps));
+    if (w.pack == PK_CONV && w.taps == 27) w.pk3_off = bump(packed_bf16x3_bytes(w.cin, w.cout, 27) / 4);
     else if (w.pack == PK_INIT) w.pk_off = bump((size_t)w.numel);
   }
   p->arena_floats = off;
@@ -358,6 +361,7 @@ struct ResP {
   int cin = 0, cout = 0;
   bool has_res = false;
   const float *c1w = nullptr, *c1b = nullptr, *n1g = nullptr, *n1b = nullptr;
+  const void *c1w3 = nullptr, *c2w3 = nullptr;  // split-bf16 images of the two 3x3x3 convs
   const float *c2w = nullptr, *c2b = nullptr, *n2g = nullptr, *n2b = nullptr;
   const float *rw = nullptr, *rb = nullptr;
   const float* emb = nullptr;  // (B, emb_ld) slice for this block, or null
@@ -371,6 +375,7 @@ struct AttnP {
 ResP resolve(const CdPlan* p, const ResW& w, const float* emb) {
   ResP r;
   r.cin = w.cin; r.cout = w.cout; r.has_res = w.has_res;
+  r.c1w3 = p->packed3(w.c1w); r.c2w3 = p->packed3(w.c2w);
   r.c1w = p->packed(w.c1w); r.c1b = p->raw(w.c1b); r.n1g = p->raw(w.n1g); r.n1b = p->raw(w.n1b);
   r.c2w = p->packed(w.c2w); r.c2b = p->raw(w.c2b); r.n2g = p->raw(w.n2g); r.n2b = p->raw(w.n2b);
   if (w.has_res) { r.rw = p->packed(w.rw); r.rb = p->raw(w.rb); }
@@ -396,8 +401,8 @@ float* stats_pass(Run& r, const float* x, int C, int64_t vox, int* units) {
 
 // conv + channel partials of its output (fused epilogue when the kernel supports it); input optionally normalised
 // on the fly by `coef_in` (+SiLU).  Returns the partial buffer (caller releases) and sets *units.
-float* conv3_with_stats(Run& r, const float* x0, int c0, const float* x1, int c1, const float* wpk, const float* bias, float* out,
-                        int cout, Dims3 dims, const float* coef_in, int* units) {
+float* conv3_with_stats(Run& r, const float* x0, int c0, const float* x1, int c1, const float* wpk, const void* wpk3,
+                        const float* bias, float* out, int cout, Dims3 dims, const float* coef_in, int* units) {
   const int64_t vox = dims.vox();
   const int cap = (int)((vox + 31) / 32);
   float* part = r.ws->get<float>((size_t)r.B * cap * cout * 2);
@@ -405,7 +410,7 @@ float* conv3_with_stats(Run& r, const float* x0, int c0, const float* x1, int c1
   if (!r.dry()) {
     ConvGeom g{dims, dims, 3, 3, 3, 1, 1, 1};
     ConvFusion fu;
-    fu.coef = coef_in; fu.act = 1; fu.ch_part = part; fu.units = &u;
+    fu.coef = coef_in; fu.act = 1; fu.ch_part = part; fu.units = &u; fu.wpk_bf16x3 = wpk3;
     launch_conv_mfma(x0, c0, x1, c1, wpk, bias, out, r.B, cout, g, r.s, fu);
     if (u == 0) {  // kernel without a stats epilogue: separate pass, same buffer (nsplit <= cap)
       u = gn_nsplit_for(vox, r.B);
@@ -429,12 +434,12 @@ float* res_block(Run& r, const ResP& w, const float* x0, int c0, const float* x1
   const int G = r.groups;
   int u1 = 0, u2 = 0;
   float* h1 = ws->get<float>((size_t)r.B * vox * w.cout);
-  float* p1 = conv3_with_stats(r, x0, c0, x1, c1, w.c1w, w.c1b, h1, w.cout, dims, nullptr, &u1);
+  float* p1 = conv3_with_stats(r, x0, c0, x1, c1, w.c1w, w.c1w3, w.c1b, h1, w.cout, dims, nullptr, &u1);
   float* coef1 = ws->get<float>((size_t)r.B * w.cout * 4);
   if (!r.dry()) launch_gn_finalize(p1, u1, w.n1g, w.n1b, w.emb, w.emb_ld, coef1, r.B, w.cout, G, vox, r.s);
   ws->release(p1);
   float* h2 = ws->get<float>((size_t)r.B * vox * w.cout);
-  float* p2 = conv3_with_stats(r, h1, w.cout, nullptr, 0, w.c2w, w.c2b, h2, w.cout, dims, coef1, &u2);
+  float* p2 = conv3_with_stats(r, h1, w.cout, nullptr, 0, w.c2w, w.c2w3, w.c2b, h2, w.cout, dims, coef1, &u2);
   ws->release(h1);
   ws->release(coef1);
   float* coef2 = ws->get<float>((size_t)r.B * w.cout * 4);
@@ -756,6 +761,7 @@ int cd_plan_set_weight(CdPlan* plan, const char* name, const float* dev_ptr, int
     hipStream_t s = (hipStream_t)stream;
     CD_HIP(hipMemcpyAsync(plan->arena + w.raw_off, dev_ptr, sizeof(float) * (size_t)numel, hipMemcpyDeviceToDevice, s));
     if (w.pack == PK_CONV) launch_pack_weights(plan->arena + w.raw_off, plan->arena + w.pk_off, w.cout, w.cin, w.taps, false, s);
+    if (w.pk3_off) launch_pack_weights_bf16x3(plan->arena + w.raw_off, plan->arena + w.pk3_off, w.cout, w.cin, w.taps, s);
     else if (w.pack == PK_CONVT) launch_pack_weights(plan->arena + w.raw_off, plan->arena + w.pk_off, w.cout, w.cin, w.taps, true, s);
     else if (w.pack == PK_INIT) launch_pack_init_weights(plan->arena + w.raw_off, plan->arena + w.pk_off, w.cout, w.cin, s);
     w.set = true;
@@ -936,7 +942,7 @@ int cd_loss_hybrid_l2(CdPlan* plan, int batch, const float* data, const float* n
 // ---- primitives -----------------------------------------------------------------------------------------------
 size_t cd_op_scratch_bytes(int batch, int max_channels, int64_t max_voxels) {
   // packed weights of the largest supported conv (256 x 256 x 64 taps) + norm partials + one activation
-  return (size_t)256 * 256 * 64 * 4 + (size_t)batch * 64 * 64 * 16 + (size_t)batch * max_channels * max_voxels * 4 + (1 << 20);
+  return (size_t)256 * 256 * 64 * 4 * 3 + (size_t)batch * 64 * 64 * 16 + (size_t)batch * max_channels * max_voxels * 4 + (1 << 20);
 }
 
 int cd_op_to_channels_last(const float* ncdhw, float* ndhwc, int batch, int channels, int64_t voxels, void* stream) {
@@ -967,7 +973,13 @@ int cd_op_cyl_conv(const float* x0, int c0, const float* x1, int c1, const float
       g.in = din;
       g.kd = kernel[0]; g.kh = kernel[1]; g.kw = kernel[2]; g.sz = stride[0]; g.sh = stride[1]; g.sw = stride[2];
       g.out = Dims3{(din.d + 2 - g.kd) / g.sz + 1, (din.h + 2 - g.kh) / g.sh + 1, (din.w + 2 - g.kw) / g.sw + 1};
-      launch_conv_mfma(x0, c0, x1, c1, wpk, bias, y, batch, cout, g, s);
+      ConvFusion fu;
+      if (taps == 27 && g.sz == 1 && g.sh == 1 && g.sw == 1) {
+        float* w3 = wpk + packed_weight_floats(c0 + c1, cout, taps);
+        launch_pack_weights_bf16x3(w, w3, cout, c0 + c1, 27, s);
+        fu.wpk_bf16x3 = w3;
+      }
+      launch_conv_mfma(x0, c0, x1, c1, wpk, bias, y, batch, cout, g, s, fu);
     }
   });
 }
@@ -1029,8 +1041,13 @@ int cd_op_resnet_block(const float* x0, int c0, const float* x1, int c1, const f
     float* p2 = ws.get<float>(packed_weight_floats(cout, cout, 27));
     launch_pack_weights(w[0], p1, cout, cin, 27, false, s);
     launch_pack_weights(w[4], p2, cout, cout, 27, false, s);
+    float* q1 = ws.get<float>(packed_bf16x3_bytes(cin, cout, 27) / 4);
+    float* q2 = ws.get<float>(packed_bf16x3_bytes(cout, cout, 27) / 4);
+    launch_pack_weights_bf16x3(w[0], q1, cout, cin, 27, s);
+    launch_pack_weights_bf16x3(w[4], q2, cout, cout, 27, s);
     ResP r;
     r.cin = cin; r.cout = cout; r.has_res = w[10] != nullptr;
+    r.c1w3 = q1; r.c2w3 = q2;
     r.c1w = p1; r.c1b = w[1]; r.n1g = w[2]; r.n1b = w[3]; r.c2w = p2; r.c2b = w[5]; r.n2g = w[6]; r.n2b = w[7];
     if (r.has_res) {
       float* p3 = ws.get<float>(packed_weight_floats(cin, cout, 1));
