@@ -342,8 +342,9 @@ struct ConvFlatArgs {
   const float* wpk;
   const float* bias;
   float* out;
-  int D, H, W;
-  int R;       // voxels per workgroup (multiple of 32)
+  int D, H, W;     // input extents
+  int Do, Ho, Wo;  // output extents (== input for stride 1)
+  int R;       // output voxels per workgroup (multiple of 32)
   int P;       // plane capacity of the LDS tile
   int cout, CTtot;
   int dbg;     // timing experiments only (CD_FLAT_DBG): 1 = skip staging, 2 = skip the MFMA taps
@@ -660,25 +661,32 @@ void launch_pack_weights_bf16x3(const float* w_torch, void* wpk, int cout, int c
 
 #define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
 
-template <int VT, int CT>
+// Geometry is a template parameter: (KD,KH,KW) taps, z stride SZ, phi/r stride SXY; padding is always (1, circular 1, 1).
+// Instantiated for the 3x3x3 stride-1 conv and the (3,4,4) down-sampling conv with z stride 2 or 1.
+template <int VT, int CT, int KD, int KH, int KW, int SZ, int SXY>
 __global__ void __launch_bounds__(512, (VT * CT <= 2 ? 3 : 2)) conv3_flat_bf16x3_kernel(ConvFlatArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   char* ldsb = (char*)lds;
+  constexpr int T = KD * KH * KW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
   const int b = blockIdx.y;
   const int ct0 = blockIdx.z * CT;
-  const int HW = a.H * a.W;
-  const int vox = a.D * HW;
+  const int HW = a.H * a.W;          // input plane
+  const int vox = a.D * HW;          // input voxels per sample
+  const int HWo = a.Ho * a.Wo;
+  const int voxo = a.Do * HWo;       // output voxels per sample
   const int v0 = blockIdx.x * a.R;
-  const int vend = min(v0 + a.R, vox);
-  const int zA = v0 / HW - 1;
-  const int zB = (vend - 1) / HW + 1;
+  const int vend = min(v0 + a.R, voxo);
+  const int zA = (v0 / HWo) * SZ - 1;                   // first staged input plane (may be -1: zero plane)
+  const int zB = ((vend - 1) / HWo) * SZ + KD - 2;      // last staged input plane
   const int nstage = (zB - zA + 1) * HW;
   const int NZ = a.P * HW;  // all-zero voxel
   const int half = lane >> 5, col = lane & 31;
   if (tid < 24) ((float*)(ldsb + (size_t)NZ * 96))[tid] = 0.f;
 
-  int nb[VT], rowm[VT], rowp[VT], ooff[VT];
+  // per-lane geometry of its output voxel in each of the wave's VT row tiles: LDS index of the (kz=0, kh=1, kw=1) tap,
+  // phi-row offsets with wrap-around for each kh, r-validity bit for each kw
+  int nb[VT], rowoff[VT][KH], ooff[VT];
   unsigned wmask[VT];
   bool any_valid = false;
 #pragma unroll
@@ -686,13 +694,24 @@ __global__ void __launch_bounds__(512, (VT * CT <= 2 ? 3 : 2)) conv3_flat_bf16x3
     const int v = v0 + (wave * VT + vt) * 32 + col;
     const bool valid = v < vend;
     const int vv = valid ? v : v0;
-    const int r = vv % HW;
-    const int h = r / a.W, w = r - h * a.W;
-    nb[vt] = vv - zA * HW;
-    rowm[vt] = (h == 0 ? a.H - 1 : -1) * a.W;
-    rowp[vt] = (h == a.H - 1 ? -(a.H - 1) : 1) * a.W;
+    const int oz = vv / HWo;
+    const int r = vv - oz * HWo;
+    const int oh = r / a.Wo, ow = r - oh * a.Wo;
+    const int ih0 = oh * SXY, iw0 = ow * SXY;
+    nb[vt] = (oz * SZ - 1 - zA) * HW + ih0 * a.W + iw0;
     unsigned m = 0;
-    if (valid) m = (w > 0 ? 1u : 0u) | 2u | (w + 1 < a.W ? 4u : 0u);
+#pragma unroll
+    for (int kh = 0; kh < KH; ++kh) {
+      int ih = ih0 + kh - 1;
+      ih = ih < 0 ? ih + a.H : (ih >= a.H ? ih - a.H : ih);
+      ih = ih >= a.H ? ih - a.H : ih;  // H == 2 with a 4-wide kernel wraps twice
+      rowoff[vt][kh] = (ih - ih0) * a.W;
+    }
+#pragma unroll
+    for (int kw = 0; kw < KW; ++kw) {
+      const int iw = iw0 + kw - 1;
+      if (valid && iw >= 0 && iw < a.W) m |= 1u << kw;
+    }
     wmask[vt] = m;
     ooff[vt] = valid ? v * a.cout : -1;
     any_valid |= valid;
@@ -712,9 +731,9 @@ __global__ void __launch_bounds__(512, (VT * CT <= 2 ? 3 : 2)) conv3_flat_bf16x3
   const int nslots = nstage * 4;  // one slot = 4 channels of one voxel
 
   auto tap_voxel = [&](int vt, int tap) -> int {
-    const int dz = tap / 9 - 1, dh = (tap / 3) % 3 - 1, dw = tap % 3 - 1;
-    const int n = nb[vt] + dz * HW + (dh < 0 ? rowm[vt] : (dh > 0 ? rowp[vt] : 0)) + dw;
-    return ((wmask[vt] >> (dw + 1)) & 1u) ? n : NZ;
+    const int kz = tap / (KH * KW), kh = (tap / KW) % KH, kw = tap % KW;
+    const int n = nb[vt] + kz * HW + rowoff[vt][kh] + kw - 1;
+    return ((wmask[vt] >> kw) & 1u) ? n : NZ;
   };
 
   for (int sc = 0; sc < nsub; ++sc) {
@@ -771,7 +790,7 @@ __global__ void __launch_bounds__(512, (VT * CT <= 2 ? 3 : 2)) conv3_flat_bf16x3
 #pragma unroll
     for (int vt = 0; vt < VT; ++vt) asm volatile("" : "+v"(nb[vt]));
 
-    const u32x4* wq = (const u32x4*)a.wpk + ((size_t)sc * 27 * a.CTtot + ct0) * 192 + lane;
+    const u32x4* wq = (const u32x4*)a.wpk + ((size_t)sc * T * a.CTtot + ct0) * 192 + lane;
     u32x4 bw[2][CT][3], av[2][VT][3];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
@@ -784,9 +803,9 @@ __global__ void __launch_bounds__(512, (VT * CT <= 2 ? 3 : 2)) conv3_flat_bf16x3
       for (int t = 0; t < 3; ++t) av[0][vt][t] = *(const u32x4*)(p + t * 32);
     }
 #pragma unroll
-    for (int tap = 0; tap < 27; ++tap) {
+    for (int tap = 0; tap < T; ++tap) {
       const int cur = tap & 1, nxt = cur ^ 1;
-      if (tap + 1 < 27) {
+      if (tap + 1 < T) {
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -815,7 +834,7 @@ __global__ void __launch_bounds__(512, (VT * CT <= 2 ? 3 : 2)) conv3_flat_bf16x3
     }
   }
 
-  float* outb = a.out + (size_t)b * vox * a.cout;
+  float* outb = a.out + (size_t)b * voxo * a.cout;
   float bv[CT];
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) bv[ct] = a.bias ? a.bias[(ct0 + ct) * 32 + col] : 0.f;
@@ -873,45 +892,62 @@ __global__ void __launch_bounds__(512, (VT * CT <= 2 ? 3 : 2)) conv3_flat_bf16x3
 }
 
 namespace {
-template <int VT, int CT>
-void launch_flat3_inst(const ConvFlatArgs& a, dim3 grid, int threads, size_t lds, hipStream_t s) {
+template <int VT, int CT, int KD, int KH, int KW, int SZ, int SXY>
+void launch_flat3_geo(const ConvFlatArgs& a, dim3 grid, int threads, size_t lds, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    CD_HIP(hipFuncSetAttribute((const void*)conv3_flat_bf16x3_kernel<VT, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CD_HIP(hipFuncSetAttribute((const void*)conv3_flat_bf16x3_kernel<VT, CT, KD, KH, KW, SZ, SXY>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv3_flat_bf16x3_kernel<VT, CT>), grid, dim3(threads), lds, s, a);
+  hipLaunchKernelGGL((conv3_flat_bf16x3_kernel<VT, CT, KD, KH, KW, SZ, SXY>), grid, dim3(threads), lds, s, a);
   CD_HIP(hipGetLastError());
+}
+// geo: 0 = 3x3x3 stride 1, 1 = (3,4,4) stride (2,2,2), 2 = (3,4,4) stride (1,2,2)
+template <int VT, int CT>
+void launch_flat3_inst(const ConvFlatArgs& a, dim3 grid, int threads, size_t lds, hipStream_t s, int geo = 0) {
+  if (geo == 0) launch_flat3_geo<VT, CT, 3, 3, 3, 1, 1>(a, grid, threads, lds, s);
+  else if (geo == 1) launch_flat3_geo<VT, CT, 3, 4, 4, 2, 2>(a, grid, threads, lds, s);
+  else launch_flat3_geo<VT, CT, 3, 4, 4, 1, 2>(a, grid, threads, lds, s);
 }
 }  // namespace
 
 // returns false when the whole-plane LDS tile does not fit (wide grids such as Dataset-3's 50x18 planes).
-// bf16x3 = true runs the split-bf16 kernel on `wpk` = packed bf16x3 weights; otherwise the f32 MFMA kernel.
+// bf16x3 = true runs the split-bf16 kernel on `wpk` = packed bf16x3 weights; otherwise the f32 MFMA kernel
+// (stride-1 3x3x3 only).
 static bool try_launch_conv3_flat(const float* in0, int c0, const float* in1, int c1, const void* wpk, const float* bias,
-                                  float* out, int batch, int cout, Dims3 d, hipStream_t s, const ConvFusion& fu, bool bf16x3) {
+                                  float* out, int batch, int cout, const ConvGeom& g, hipStream_t s, const ConvFusion& fu,
+                                  bool bf16x3) {
   if (getenv("CD_NO_FLAT")) return false;
+  int geo = -1;
+  if (g.kd == 3 && g.kh == 3 && g.kw == 3 && g.sz == 1 && g.sh == 1 && g.sw == 1) geo = 0;
+  else if (g.kd == 3 && g.kh == 4 && g.kw == 4 && g.sh == 2 && g.sw == 2 && (g.sz == 1 || g.sz == 2)) geo = g.sz == 2 ? 1 : 2;
+  if (geo < 0 || (geo != 0 && !bf16x3)) return false;
+  const Dims3 d = g.in;
   const int CTtot = cout / 32;
   const int CT = CTtot <= 3 ? CTtot : 2;
   if (CTtot % CT) return false;
-  const int HW = d.h * d.w;
+  const int HW = d.h * d.w, HWo = g.out.h * g.out.w;
   const size_t vox_bytes = bf16x3 ? 96 : 64;
+  auto planes = [&](int NT) { return ((32 * NT - 1) / HWo + 1) * g.sz + g.kd; };
   auto launch = [&](int NT, int VT) -> bool {
     ConvFlatArgs a;
     a.in0 = in0; a.in1 = in1; a.c0 = c0; a.c1 = c1; a.wpk = (const float*)wpk; a.bias = bias; a.out = out;
-    a.D = d.d; a.H = d.h; a.W = d.w; a.R = 32 * NT; a.P = (a.R - 1) / HW + 4; a.cout = cout; a.CTtot = CTtot;
+    a.D = d.d; a.H = d.h; a.W = d.w; a.Do = g.out.d; a.Ho = g.out.h; a.Wo = g.out.w;
+    a.R = 32 * NT; a.P = planes(NT); a.cout = cout; a.CTtot = CTtot;
     a.dbg = getenv("CD_FLAT_DBG") ? atoi(getenv("CD_FLAT_DBG")) : 0;
     a.coef = fu.coef; a.act = fu.act; a.ch_part = fu.ch_part;
     size_t lds = ((size_t)a.P * HW + 1) * vox_bytes;
     const size_t red = (size_t)(NT / VT) * CT * 32 * 2 * 4;  // cross-wave reduction scratch of the stats epilogue
     if (lds < red) lds = red;
-    dim3 grid((unsigned)((d.vox() + a.R - 1) / a.R), (unsigned)batch, (unsigned)(CTtot / CT));
+    dim3 grid((unsigned)((g.out.vox() + a.R - 1) / a.R), (unsigned)batch, (unsigned)(CTtot / CT));
     if (fu.units) *fu.units = (int)grid.x;
     const int threads = (NT / VT) * 64;
-#define CD_FLAT_CASE(V, C)                                              \
-  if (VT == V && CT == C) {                                             \
-    if (bf16x3) launch_flat3_inst<V, C>(a, grid, threads, lds, s);      \
-    else launch_flat_inst<V, C>(a, grid, threads, lds, s);              \
-    return true;                                                        \
+#define CD_FLAT_CASE(V, C)                                                   \
+  if (VT == V && CT == C) {                                                  \
+    if (bf16x3) launch_flat3_inst<V, C>(a, grid, threads, lds, s, geo);      \
+    else launch_flat_inst<V, C>(a, grid, threads, lds, s);                   \
+    return true;                                                             \
   }
     CD_FLAT_CASE(1, 1) CD_FLAT_CASE(2, 1) CD_FLAT_CASE(3, 1) CD_FLAT_CASE(4, 1)
     CD_FLAT_CASE(1, 2) CD_FLAT_CASE(2, 2) CD_FLAT_CASE(3, 2) CD_FLAT_CASE(4, 2)
@@ -922,7 +958,7 @@ static bool try_launch_conv3_flat(const float* in0, int c0, const float* in1, in
   if (const char* ov = getenv("CD_FLAT_TILE")) {
     int nt, vt;
     if (sscanf(ov, "%d,%d", &nt, &vt) == 2 && nt % vt == 0 && nt / vt <= 8 && vt * CT <= 8 &&
-        ((size_t)((32 * nt - 1) / HW + 4) * HW + 1) * vox_bytes <= 160 * 1024)
+        ((size_t)planes(nt) * HW + 1) * vox_bytes <= 160 * 1024)
       return launch(nt, vt);
   }
   // candidate tilings: (tiles per workgroup, tiles per wave)
@@ -932,14 +968,14 @@ static bool try_launch_conv3_flat(const float* in0, int c0, const float* in1, in
   for (auto& c : kCand) {
     const int NT = c[0], VT = c[1];
     if (VT * CT > 8 || (CT == 3 && VT > 2)) continue;
-    if ((int64_t)32 * (NT - 1) >= d.vox()) continue;
-    const int P = (32 * NT - 1) / HW + 4;
-    if (((size_t)P * HW + 1) * vox_bytes > 150 * 1024) continue;
+    if ((int64_t)32 * (NT - 1) >= g.out.vox()) continue;
+    if (((size_t)planes(NT) * HW + 1) * vox_bytes > 150 * 1024) continue;
     cand.push_back({NT, VT});
   }
   if (cand.empty()) return false;
-  char key[160];
-  std::snprintf(key, sizeof key, "flat3%s %dx%dx%d c%d+%d->%d b%d", bf16x3 ? "_bf16x3" : "", d.d, d.h, d.w, c0, c1, cout, batch);
+  char key[192];
+  std::snprintf(key, sizeof key, "flat%s g%d %dx%dx%d c%d+%d->%d b%d", bf16x3 ? "_bf16x3" : "_f32", geo, d.d, d.h, d.w, c0, c1,
+                cout, batch);
   const int pick = autotune(key, (int)cand.size(), [&](int i) { launch(cand[i].first, cand[i].second); }, s);
   return launch(cand[pick < 0 ? 0 : pick].first, cand[pick < 0 ? 0 : pick].second);
 }
@@ -959,12 +995,11 @@ void launch_conv_mfma(const float* in0, int c0, const float* in1, int c1, const 
   const double taps = (double)g.kd * g.kh * g.kw;
   prof::Scope scope(cat, s, 2.0 * taps * (c0 + c1) * cout * (double)g.out.vox() * batch,
                     4.0 * batch * ((double)g.in.vox() * (c0 + c1) + (double)g.out.vox() * cout));
-  if (g.kd == 3 && g.kh == 3 && g.kw == 3 && g.sz == 1 && g.sh == 1 && g.sw == 1) {
+  {
     static const bool want_f32 = getenv("CD_CONV_PRECISION") && !strcmp(getenv("CD_CONV_PRECISION"), "f32");
-    if (fu.wpk_bf16x3 && !want_f32 &&
-        try_launch_conv3_flat(in0, c0, in1, c1, fu.wpk_bf16x3, bias, out, batch, cout, g.in, s, fu, true))
+    if (fu.wpk_bf16x3 && !want_f32 && try_launch_conv3_flat(in0, c0, in1, c1, fu.wpk_bf16x3, bias, out, batch, cout, g, s, fu, true))
       return;
-    if (try_launch_conv3_flat(in0, c0, in1, c1, wpk, bias, out, batch, cout, g.in, s, fu, false)) return;
+    if (try_launch_conv3_flat(in0, c0, in1, c1, wpk, bias, out, batch, cout, g, s, fu, false)) return;
   }
   const std::vector<ConvTile> cand = conv_tile_candidates(g, batch, CT, 14);
   auto launch = [&](const ConvTile& t) {

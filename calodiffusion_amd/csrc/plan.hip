@@ -316,7 +316,7 @@ void build_plan(CdPlan* p) {
   for (auto& w : p->weights) {
     w.raw_off = bump((size_t)w.numel);
     if (w.pack == PK_CONV || w.pack == PK_CONVT) w.pk_off = bump(packed_weight_floats(w.cin, w.cout, w.taps));
-    if (w.pack == PK_CONV && w.taps == 27) w.pk3_off = bump(packed_bf16x3_bytes(w.cin, w.cout, 27) / 4);
+    if (w.pack == PK_CONV && (w.taps == 27 || w.taps == 48)) w.pk3_off = bump(packed_bf16x3_bytes(w.cin, w.cout, w.taps) / 4);
     else if (w.pack == PK_INIT) w.pk_off = bump((size_t)w.numel);
   }
   p->arena_floats = off;
@@ -552,7 +552,9 @@ float* unet_body(CdPlan* p, Run& r, const float* emb, float* h) {
       float* y = r.ws->get<float>((size_t)r.B * nd.vox() * cx);
       if (!r.dry()) {
         ConvGeom g{dims, nd, 3, 4, 4, zs, 2, 2};
-        launch_conv_mfma(x, cx, nullptr, 0, p->packed(p->downs[i].sw), p->raw(p->downs[i].sb), y, r.B, cx, g, r.s);
+        ConvFusion fu;
+        fu.wpk_bf16x3 = p->packed3(p->downs[i].sw);
+        launch_conv_mfma(x, cx, nullptr, 0, p->packed(p->downs[i].sw), p->raw(p->downs[i].sb), y, r.B, cx, g, r.s, fu);
       }
       x = y;
     } else {
@@ -974,9 +976,9 @@ int cd_op_cyl_conv(const float* x0, int c0, const float* x1, int c1, const float
       g.kd = kernel[0]; g.kh = kernel[1]; g.kw = kernel[2]; g.sz = stride[0]; g.sh = stride[1]; g.sw = stride[2];
       g.out = Dims3{(din.d + 2 - g.kd) / g.sz + 1, (din.h + 2 - g.kh) / g.sh + 1, (din.w + 2 - g.kw) / g.sw + 1};
       ConvFusion fu;
-      if (taps == 27 && g.sz == 1 && g.sh == 1 && g.sw == 1) {
+      if (taps == 27 || taps == 48) {
         float* w3 = wpk + packed_weight_floats(c0 + c1, cout, taps);
-        launch_pack_weights_bf16x3(w, w3, cout, c0 + c1, 27, s);
+        launch_pack_weights_bf16x3(w, w3, cout, c0 + c1, taps, s);
         fu.wpk_bf16x3 = w3;
       }
       launch_conv_mfma(x0, c0, x1, c1, wpk, bias, y, batch, cout, g, s, fu);
