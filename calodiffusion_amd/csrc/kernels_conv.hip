@@ -252,6 +252,7 @@ int autotune(const std::string& key, int ncand, F&& run, hipStream_t s) {
     CD_HIP(hipEventSynchronize(e1));
     float ms = 0.f;
     CD_HIP(hipEventElapsedTime(&ms, e0, e1));
+    if (getenv("CD_TUNE_VERBOSE") && atoi(getenv("CD_TUNE_VERBOSE")) > 1) std::fprintf(stderr, "[calodiff autotune]   %s cand %d: %.1f us\n", key.c_str(), i, ms * 500.f);
     if (ms < best_ms) { best_ms = ms; best = i; }
   }
   hipEventDestroy(e0);
@@ -791,44 +792,44 @@ __global__ void __launch_bounds__(512, (VT * CT <= 2 ? 3 : 2)) conv3_flat_bf16x3
     for (int vt = 0; vt < VT; ++vt) asm volatile("" : "+v"(nb[vt]));
 
     const u32x4* wq = (const u32x4*)a.wpk + ((size_t)sc * T * a.CTtot + ct0) * 192 + lane;
-    u32x4 bw[2][CT][3], av[2][VT][3];
+    // Register rings: weight fragments (L1/L2) are requested WD taps ahead, LDS fragments AD taps ahead.
+    constexpr int WD = 1, AD = 1;  // deeper rings were measured: they cost occupancy (VGPRs) and gain nothing
+    u32x4 bw[WD + 1][CT][3], av[AD + 1][VT][3];
+    auto load_w = [&](int tap) {
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
+      for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-      for (int t = 0; t < 3; ++t) bw[0][ct][t] = wq[(size_t)ct * 192 + t * 64];
+        for (int t = 0; t < 3; ++t) bw[tap % (WD + 1)][ct][t] = wq[((size_t)tap * a.CTtot + ct) * 192 + t * 64];
+    };
+    auto load_a = [&](int tap) {
 #pragma unroll
-    for (int vt = 0; vt < VT; ++vt) {
-      const char* p = ldsb + (size_t)tap_voxel(vt, 0) * 96 + half * 16;
+      for (int vt = 0; vt < VT; ++vt) {
+        const char* p = ldsb + (size_t)tap_voxel(vt, tap) * 96 + half * 16;
 #pragma unroll
-      for (int t = 0; t < 3; ++t) av[0][vt][t] = *(const u32x4*)(p + t * 32);
-    }
+        for (int t = 0; t < 3; ++t) av[tap % (AD + 1)][vt][t] = *(const u32x4*)(p + t * 32);
+      }
+    };
+#pragma unroll
+    for (int t0 = 0; t0 < WD; ++t0) load_w(t0);
+#pragma unroll
+    for (int t0 = 0; t0 < AD; ++t0) load_a(t0);
 #pragma unroll
     for (int tap = 0; tap < T; ++tap) {
-      const int cur = tap & 1, nxt = cur ^ 1;
-      if (tap + 1 < T) {
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-          for (int t = 0; t < 3; ++t) bw[nxt][ct][t] = wq[((size_t)(tap + 1) * a.CTtot + ct) * 192 + t * 64];
-#pragma unroll
-        for (int vt = 0; vt < VT; ++vt) {
-          const char* p = ldsb + (size_t)tap_voxel(vt, tap + 1) * 96 + half * 16;
-#pragma unroll
-          for (int t = 0; t < 3; ++t) av[nxt][vt][t] = *(const u32x4*)(p + t * 32);
-        }
-      }
+      if (tap + WD < T) load_w(tap + WD);
+      if (tap + AD < T) load_a(tap + AD);
       __builtin_amdgcn_sched_barrier(0);
+      const int wc = tap % (WD + 1), ac = tap % (AD + 1);
 #pragma unroll
       for (int vt = 0; vt < VT; ++vt)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
           f32x16 c = acc[vt][ct];
-          c = MFMA_BF16(av[cur][vt][2], bw[cur][ct][0], c);  // x3*w1
-          c = MFMA_BF16(av[cur][vt][1], bw[cur][ct][1], c);  // x2*w2
-          c = MFMA_BF16(av[cur][vt][0], bw[cur][ct][2], c);  // x1*w3
-          c = MFMA_BF16(av[cur][vt][1], bw[cur][ct][0], c);  // x2*w1
-          c = MFMA_BF16(av[cur][vt][0], bw[cur][ct][1], c);  // x1*w2
-          c = MFMA_BF16(av[cur][vt][0], bw[cur][ct][0], c);  // x1*w1
+          c = MFMA_BF16(av[ac][vt][2], bw[wc][ct][0], c);  // x3*w1
+          c = MFMA_BF16(av[ac][vt][1], bw[wc][ct][1], c);  // x2*w2
+          c = MFMA_BF16(av[ac][vt][0], bw[wc][ct][2], c);  // x1*w3
+          c = MFMA_BF16(av[ac][vt][1], bw[wc][ct][0], c);  // x2*w1
+          c = MFMA_BF16(av[ac][vt][0], bw[wc][ct][1], c);  // x1*w2
+          c = MFMA_BF16(av[ac][vt][0], bw[wc][ct][0], c);  // x1*w1
           acc[vt][ct] = c;
         }
     }
@@ -891,6 +892,278 @@ __global__ void __launch_bounds__(512, (VT * CT <= 2 ? 3 : 2)) conv3_flat_bf16x3
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Warp-specialised, persistent variant of the bf16x3 flat conv.
+//
+// One workgroup per CU loops over its share of (sample, voxel-range) units.  NLW loader waves stage the NEXT
+// 16-channel sub-chunk (global -> fused GroupNorm/SiLU -> exact bf16 split -> LDS buffer B) on the vector ALU while NMW
+// matrix waves run the taps of the CURRENT sub-chunk out of LDS buffer A on the matrix pipe; one barrier per phase swaps
+// the buffers.  Staging (VALU / LDS-write bound) and MFMAs (matrix-pipe bound) therefore overlap inside a CU instead of
+// alternating, and the pipeline runs seamlessly across units (the first sub-chunk of unit u+1 is staged during the last
+// phase of unit u).  Each matrix wave owns one 32-voxel row tile of the unit (R = 32*NMW voxels); the per-unit channel
+// statistics are handed to the loader waves through a small LDS scratch and written by them one phase later.
+// ------------------------------------------------------------------------------------------------------------
+template <int CT, int KD, int KH, int KW, int SZ, int SXY>
+__global__ void __launch_bounds__(768) conv_flat_ws_kernel(ConvFlatArgs a, int nlw, int units_per_sample, int total_units) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int T = KD * KH * KW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nmw = (blockDim.x >> 6) - nlw;
+  const bool loader = wave < nlw;
+  const int ct0 = blockIdx.z * CT;
+  const int HW = a.H * a.W, vox = a.D * HW;
+  const int HWo = a.Ho * a.Wo, voxo = a.Do * HWo;
+  const int NZ = a.P * HW;
+  const size_t buf_bytes = ((size_t)NZ + 1) * 96;
+  char* bufp[2] = {(char*)lds, (char*)lds + buf_bytes};
+  float* scratch = (float*)((char*)lds + 2 * buf_bytes);  // [nmw][CT*32][2]
+  const int half = lane >> 5, col = lane & 31;
+  const int nsub = (a.c0 + a.c1) >> 4;
+  if (tid < 48) ((float*)(bufp[tid / 24] + (size_t)NZ * 96))[tid % 24] = 0.f;
+
+  // units of this workgroup: u = blockIdx.x + k*gridDim.x
+  const int my_units = (total_units - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int nph = my_units * nsub;
+
+  // ---- loader side ------------------------------------------------------------------------------------------
+  auto stage = [&](int ph, char* dst) {
+    const int u = blockIdx.x + (ph / nsub) * gridDim.x, sc = ph % nsub;
+    const int b = u / units_per_sample, ux = u - b * units_per_sample;
+    const int v0 = ux * a.R, vend = min(v0 + a.R, voxo);
+    const int zA = (v0 / HWo) * SZ - 1, zB = ((vend - 1) / HWo) * SZ + KD - 2;
+    const int nslots = (zB - zA + 1) * HW * 4, gbase = zA * HW;
+    const float* src;
+    int ldc, coff;
+    if (sc * 16 < a.c0) {
+      src = a.in0; ldc = a.c0; coff = sc * 16;
+    } else {
+      src = a.in1; ldc = a.c1; coff = sc * 16 - a.c0;
+    }
+    const int pq = tid & 3, nth = nlw * 64;
+    src += (size_t)b * vox * ldc + coff + pq * 4;
+    f32x4 cf[4];
+    if (a.coef) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) cf[e] = *(const f32x4*)(a.coef + ((size_t)b * (a.c0 + a.c1) + sc * 16 + pq * 4 + e) * 4);
+    }
+    // all loads of a batch are issued before the first conversion: with only nlw waves loading, memory-level
+    // parallelism (bytes in flight per CU), not issue rate, sets the staging time
+    constexpr int LB = 12;
+    for (int s0 = tid; s0 < nslots; s0 += LB * nth) {
+      f32x4 val[LB];
+#pragma unroll
+      for (int k = 0; k < LB; ++k) {
+        const int sidx = s0 + k * nth;
+        const int g = gbase + (sidx >> 2);
+        val[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (sidx < nslots && g >= 0 && g < vox) {
+          val[k] = *(const f32x4*)(src + (size_t)g * ldc);
+          if (a.coef) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float t = cf[e][0] * val[k][e] + cf[e][1];
+              if (a.act) t = t / (1.f + expf(-t));
+              val[k][e] = t + cf[e][2];
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < LB; ++k) {
+        const int sidx = s0 + k * nth;
+        if (sidx < nslots) {
+          u32x2 t1, t2, t3;
+          split3(val[k], t1, t2, t3);
+          char* d = dst + (size_t)(sidx >> 2) * 96 + pq * 8;
+          *(u32x2*)d = t1;
+          *(u32x2*)(d + 32) = t2;
+          *(u32x2*)(d + 64) = t3;
+        }
+      }
+    }
+  };
+
+  if (loader) stage(0, bufp[0]);
+  __syncthreads();
+
+  // ---- matrix-wave state --------------------------------------------------------------------------------------
+  f32x16 acc[CT];
+  int nb = 0, ooff = -1, rowoff[KH];
+  unsigned wmask = 0;
+  int cur_b = 0;
+
+  for (int ph = 0; ph < nph; ++ph) {
+    const int cur = ph & 1;
+    const int sc = ph % nsub;
+    if (loader) {
+      if (ph + 1 < nph) stage(ph + 1, bufp[cur ^ 1]);
+      // statistics of the unit that finished in the previous phase
+      if (a.ch_part && sc == 0 && ph > 0) {
+        const int u = blockIdx.x + (ph / nsub - 1) * gridDim.x;
+        for (int i = tid; i < CT * 32; i += nlw * 64) {
+          float t1 = 0.f, t2 = 0.f;
+          for (int w = 0; w < nmw; ++w) {
+            t1 += scratch[((w * CT * 32) + i) * 2];
+            t2 += scratch[((w * CT * 32) + i) * 2 + 1];
+          }
+          float* dst = a.ch_part + ((size_t)u * a.cout + ct0 * 32 + i) * 2;  // u = b*units_per_sample + ux
+          dst[0] = t1;
+          dst[1] = t2;
+        }
+      }
+    } else {
+      const int mw = wave - nlw;
+      if (sc == 0) {
+        const int u = blockIdx.x + (ph / nsub) * gridDim.x;
+        cur_b = u / units_per_sample;
+        const int ux = u - cur_b * units_per_sample;
+        const int v0 = ux * a.R, vend = min(v0 + a.R, voxo);
+        const int zA = (v0 / HWo) * SZ - 1;
+        const int v = v0 + mw * 32 + col;
+        const bool valid = v < vend;
+        const int vv = valid ? v : v0;
+        const int oz = vv / HWo;
+        const int r = vv - oz * HWo;
+        const int oh = r / a.Wo, ow = r - oh * a.Wo;
+        const int ih0 = oh * SXY, iw0 = ow * SXY;
+        nb = (oz * SZ - 1 - zA) * HW + ih0 * a.W + iw0;
+        unsigned m = 0;
+#pragma unroll
+        for (int kh = 0; kh < KH; ++kh) {
+          int ih = ih0 + kh - 1;
+          ih = ih < 0 ? ih + a.H : (ih >= a.H ? ih - a.H : ih);
+          ih = ih >= a.H ? ih - a.H : ih;
+          rowoff[kh] = (ih - ih0) * a.W;
+        }
+#pragma unroll
+        for (int kw = 0; kw < KW; ++kw) {
+          const int iw = iw0 + kw - 1;
+          if (valid && iw >= 0 && iw < a.W) m |= 1u << kw;
+        }
+        wmask = m;
+        ooff = valid ? v * a.cout : -1;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+          for (int r2 = 0; r2 < 16; ++r2) acc[ct][r2] = 0.f;
+      }
+      if (__any(ooff >= 0)) {
+        const char* ldsb = bufp[cur];
+        auto tap_ptr = [&](int tap) -> const char* {
+          const int kz = tap / (KH * KW), kh = (tap / KW) % KH, kw = tap % KW;
+          const int n = nb + kz * HW + rowoff[kh] + kw - 1;
+          return ldsb + (size_t)(((wmask >> kw) & 1u) ? n : NZ) * 96 + half * 16;
+        };
+        asm volatile("" : "+v"(nb));
+        const u32x4* wq = (const u32x4*)a.wpk + ((size_t)sc * T * a.CTtot + ct0) * 192 + lane;
+        u32x4 bw[2][CT][3], av[2][3];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+          for (int t = 0; t < 3; ++t) bw[0][ct][t] = wq[(size_t)ct * 192 + t * 64];
+        {
+          const char* p = tap_ptr(0);
+#pragma unroll
+          for (int t = 0; t < 3; ++t) av[0][t] = *(const u32x4*)(p + t * 32);
+        }
+#pragma unroll
+        for (int tap = 0; tap < T; ++tap) {
+          const int c = tap & 1, nx = c ^ 1;
+          if (tap + 1 < T) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+              for (int t = 0; t < 3; ++t) bw[nx][ct][t] = wq[((size_t)(tap + 1) * a.CTtot + ct) * 192 + t * 64];
+            const char* p = tap_ptr(tap + 1);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) av[nx][t] = *(const u32x4*)(p + t * 32);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) {
+            f32x16 cc = acc[ct];
+            cc = MFMA_BF16(av[c][2], bw[c][ct][0], cc);
+            cc = MFMA_BF16(av[c][1], bw[c][ct][1], cc);
+            cc = MFMA_BF16(av[c][0], bw[c][ct][2], cc);
+            cc = MFMA_BF16(av[c][1], bw[c][ct][0], cc);
+            cc = MFMA_BF16(av[c][0], bw[c][ct][1], cc);
+            cc = MFMA_BF16(av[c][0], bw[c][ct][0], cc);
+            acc[ct] = cc;
+          }
+        }
+      }
+      if (sc == nsub - 1) {
+        float* outb = a.out + (size_t)cur_b * voxo * a.cout;
+        float bv[CT], s1[CT], s2[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          bv[ct] = a.bias ? a.bias[(ct0 + ct) * 32 + col] : 0.f;
+          s1[ct] = s2[ct] = 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+          const int off = __shfl(ooff, row, 64);
+          if (off >= 0) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+              const float v = acc[ct][r] + bv[ct];
+              outb[off + (ct0 + ct) * 32 + col] = v;
+              s1[ct] += v;
+              s2[ct] += v * v;
+            }
+          }
+        }
+        if (a.ch_part) {
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) {
+            const float t1 = s1[ct] + __shfl_xor(s1[ct], 32, 64), t2 = s2[ct] + __shfl_xor(s2[ct], 32, 64);
+            if (half == 0) {
+              scratch[((mw * CT + ct) * 32 + col) * 2] = t1;
+              scratch[((mw * CT + ct) * 32 + col) * 2 + 1] = t2;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // statistics of the last unit
+  if (loader && a.ch_part && nph > 0) {
+    const int u = blockIdx.x + (my_units - 1) * gridDim.x;
+    for (int i = tid; i < CT * 32; i += nlw * 64) {
+      float t1 = 0.f, t2 = 0.f;
+      for (int w = 0; w < nmw; ++w) {
+        t1 += scratch[((w * CT * 32) + i) * 2];
+        t2 += scratch[((w * CT * 32) + i) * 2 + 1];
+      }
+      float* dst = a.ch_part + ((size_t)u * a.cout + ct0 * 32 + i) * 2;
+      dst[0] = t1;
+      dst[1] = t2;
+    }
+  }
+}
+
+namespace {
+template <int CT, int KD, int KH, int KW, int SZ, int SXY>
+void launch_ws_geo(const ConvFlatArgs& a, dim3 grid, int threads, size_t lds, int nlw, int ups, int total, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    CD_HIP(hipFuncSetAttribute((const void*)conv_flat_ws_kernel<CT, KD, KH, KW, SZ, SXY>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_flat_ws_kernel<CT, KD, KH, KW, SZ, SXY>), grid, dim3(threads), lds, s, a, nlw, ups, total);
+  CD_HIP(hipGetLastError());
+}
+template <int CT>
+void launch_ws_inst(const ConvFlatArgs& a, dim3 grid, int threads, size_t lds, int nlw, int ups, int total, hipStream_t s, int geo) {
+  if (geo == 0) launch_ws_geo<CT, 3, 3, 3, 1, 1>(a, grid, threads, lds, nlw, ups, total, s);
+  else if (geo == 1) launch_ws_geo<CT, 3, 4, 4, 2, 2>(a, grid, threads, lds, nlw, ups, total, s);
+  else launch_ws_geo<CT, 3, 4, 4, 1, 2>(a, grid, threads, lds, nlw, ups, total, s);
+}
+}  // namespace
+
 namespace {
 template <int VT, int CT, int KD, int KH, int KW, int SZ, int SXY>
 void launch_flat3_geo(const ConvFlatArgs& a, dim3 grid, int threads, size_t lds, hipStream_t s) {
@@ -931,6 +1204,28 @@ static bool try_launch_conv3_flat(const float* in0, int c0, const float* in1, in
   const size_t vox_bytes = bf16x3 ? 96 : 64;
   auto planes = [&](int NT) { return ((32 * NT - 1) / HWo + 1) * g.sz + g.kd; };
   auto launch = [&](int NT, int VT) -> bool {
+    if (VT < 0) {  // warp-specialised persistent kernel
+      const int NLW = -VT;
+      ConvFlatArgs a;
+      a.in0 = in0; a.in1 = in1; a.c0 = c0; a.c1 = c1; a.wpk = (const float*)wpk; a.bias = bias; a.out = out;
+      a.D = d.d; a.H = d.h; a.W = d.w; a.Do = g.out.d; a.Ho = g.out.h; a.Wo = g.out.w;
+      a.R = 32 * NT; a.P = planes(NT); a.cout = cout; a.CTtot = CTtot; a.dbg = 0;
+      a.coef = fu.coef; a.act = fu.act; a.ch_part = fu.ch_part;
+      const size_t lds = 2 * ((size_t)a.P * HW + 1) * 96 + (size_t)NT * CT * 64 * 4;
+      const int ups = (int)((g.out.vox() + a.R - 1) / a.R);
+      const int total = ups * batch;
+      const int nblk = total < 256 ? total : 256;
+      dim3 grid((unsigned)nblk, 1, (unsigned)(CTtot / CT));
+      if (fu.units) *fu.units = ups;
+      const int threads = (NT + NLW) * 64;
+      switch (CT) {
+        case 1: launch_ws_inst<1>(a, grid, threads, lds, NLW, ups, total, s, geo); break;
+        case 2: launch_ws_inst<2>(a, grid, threads, lds, NLW, ups, total, s, geo); break;
+        case 3: launch_ws_inst<3>(a, grid, threads, lds, NLW, ups, total, s, geo); break;
+        default: return false;
+      }
+      return true;
+    }
     ConvFlatArgs a;
     a.in0 = in0; a.in1 = in1; a.c0 = c0; a.c1 = c1; a.wpk = (const float*)wpk; a.bias = bias; a.out = out;
     a.D = d.d; a.H = d.h; a.W = d.w; a.Do = g.out.d; a.Ho = g.out.h; a.Wo = g.out.w;
@@ -971,6 +1266,17 @@ static bool try_launch_conv3_flat(const float* in0, int c0, const float* in1, in
     if ((int64_t)32 * (NT - 1) >= g.out.vox()) continue;
     if (((size_t)planes(NT) * HW + 1) * vox_bytes > 150 * 1024) continue;
     cand.push_back({NT, VT});
+  }
+  if (bf16x3 && !getenv("CD_NO_WS")) {
+    // warp-specialised persistent variants: (matrix waves, -loader waves); two LDS buffers + statistics scratch
+    static const int kWs[][2] = {{8, 4}, {8, 2}, {4, 2}, {4, 4}, {8, 3}, {6, 2}, {2, 2}, {3, 1}, {1, 1}, {2, 1}};
+    for (auto& c : kWs) {
+      const int NMW = c[0], NLW = c[1];
+      if ((int64_t)32 * (NMW - 1) >= g.out.vox()) continue;
+      const size_t lds = 2 * ((size_t)planes(NMW) * HW + 1) * 96 + (size_t)NMW * CT * 64 * 4;
+      if (lds > 160 * 1024 - 256) continue;
+      cand.push_back({NMW, -NLW});
+    }
   }
   if (cand.empty()) return false;
   char key[192];
