@@ -1198,12 +1198,14 @@ static bool try_launch_conv3_flat(const float* in0, int c0, const float* in1, in
   if (geo < 0 || (geo != 0 && !bf16x3)) return false;
   const Dims3 d = g.in;
   const int CTtot = cout / 32;
-  const int CT = CTtot <= 3 ? CTtot : 2;
-  if (CTtot % CT) return false;
+  const int CTmax = CTtot <= 3 ? CTtot : 2;
+  if (CTtot % CTmax) return false;
   const int HW = d.h * d.w, HWo = g.out.h * g.out.w;
   const size_t vox_bytes = bf16x3 ? 96 : 64;
   auto planes = [&](int NT) { return ((32 * NT - 1) / HWo + 1) * g.sz + g.kd; };
-  auto launch = [&](int NT, int VT) -> bool {
+  // CT = output-channel tiles per workgroup: CTmax shares one staged input tile between them; 1 spreads them over
+  // gridDim.z (shorter MFMA chains: wins on the deep, latency-bound levels)
+  auto launch = [&](int NT, int VT, int CT) -> bool {
     if (VT < 0) {  // warp-specialised persistent kernel
       const int NLW = -VT;
       ConvFlatArgs a;
@@ -1252,20 +1254,26 @@ static bool try_launch_conv3_flat(const float* in0, int c0, const float* in1, in
   };
   if (const char* ov = getenv("CD_FLAT_TILE")) {
     int nt, vt;
-    if (sscanf(ov, "%d,%d", &nt, &vt) == 2 && nt % vt == 0 && nt / vt <= 8 && vt * CT <= 8 &&
+    if (sscanf(ov, "%d,%d", &nt, &vt) == 2 && nt % vt == 0 && nt / vt <= 8 && vt * CTmax <= 8 &&
         ((size_t)planes(nt) * HW + 1) * vox_bytes <= 160 * 1024)
-      return launch(nt, vt);
+      return launch(nt, vt, CTmax);
   }
   // candidate tilings: (tiles per workgroup, tiles per wave)
   static const int kCand[][2] = {{8, 2}, {4, 1}, {8, 1}, {12, 3}, {16, 2}, {16, 4}, {4, 2}, {6, 2}, {6, 3}, {2, 1},
                                  {3, 1}, {1, 1}, {2, 2}, {12, 2}, {8, 4}, {6, 1}, {3, 3}};
-  std::vector<std::pair<int, int>> cand;
-  for (auto& c : kCand) {
-    const int NT = c[0], VT = c[1];
-    if (VT * CT > 8 || (CT == 3 && VT > 2)) continue;
-    if ((int64_t)32 * (NT - 1) >= g.out.vox()) continue;
-    if (((size_t)planes(NT) * HW + 1) * vox_bytes > 150 * 1024) continue;
-    cand.push_back({NT, VT});
+  struct Cand { int nt, vt, ct; };
+  std::vector<Cand> cand;
+  const bool small = g.out.vox() * batch <= 64 * 1024;  // deep levels: also try one output tile per workgroup
+  for (int pass = 0; pass < (small && CTmax > 1 ? 2 : 1); ++pass) {
+    const int CT = pass == 0 ? CTmax : 1;
+    for (auto& c : kCand) {
+      const int NT = c[0], VT = c[1];
+      if (VT * CT > 8 || (CT == 3 && VT > 2)) continue;
+      if ((int64_t)32 * (NT - 1) >= g.out.vox()) continue;
+      if (((size_t)planes(NT) * HW + 1) * vox_bytes > 150 * 1024) continue;
+      if (pass == 1 && NT > 4) continue;
+      cand.push_back({NT, VT, CT});
+    }
   }
   if (bf16x3 && !getenv("CD_NO_WS")) {
     // warp-specialised persistent variants: (matrix waves, -loader waves); two LDS buffers + statistics scratch
@@ -1273,17 +1281,18 @@ static bool try_launch_conv3_flat(const float* in0, int c0, const float* in1, in
     for (auto& c : kWs) {
       const int NMW = c[0], NLW = c[1];
       if ((int64_t)32 * (NMW - 1) >= g.out.vox()) continue;
-      const size_t lds = 2 * ((size_t)planes(NMW) * HW + 1) * 96 + (size_t)NMW * CT * 64 * 4;
+      const size_t lds = 2 * ((size_t)planes(NMW) * HW + 1) * 96 + (size_t)NMW * CTmax * 64 * 4;
       if (lds > 160 * 1024 - 256) continue;
-      cand.push_back({NMW, -NLW});
+      cand.push_back({NMW, -NLW, CTmax});
     }
   }
   if (cand.empty()) return false;
   char key[192];
   std::snprintf(key, sizeof key, "flat%s g%d %dx%dx%d c%d+%d->%d b%d", bf16x3 ? "_bf16x3" : "_f32", geo, d.d, d.h, d.w, c0, c1,
                 cout, batch);
-  const int pick = autotune(key, (int)cand.size(), [&](int i) { launch(cand[i].first, cand[i].second); }, s);
-  return launch(cand[pick < 0 ? 0 : pick].first, cand[pick < 0 ? 0 : pick].second);
+  const int pick = autotune(key, (int)cand.size(), [&](int i) { launch(cand[i].nt, cand[i].vt, cand[i].ct); }, s);
+  const Cand& c = cand[pick < 0 ? 0 : pick];
+  return launch(c.nt, c.vt, c.ct);
 }
 
 void launch_conv_mfma(const float* in0, int c0, const float* in1, int c1, const float* wpk, const float* bias, float* out,

@@ -67,12 +67,24 @@ __global__ void __launch_bounds__(512) embed_kernel(EmbedArgs a) {
     bufA[i] = v / (1.f + expf(-v));
   }
   __syncthreads();
-  // all ResnetBlock projections as one flat list of output rows
+  // all ResnetBlock projections: a wave owns 4 output rows at a time so that 4 independent weight-row loads are in flight
+  const int nin = 2 * half;
   for (int l = 0; l < a.n_layers; ++l) {
     const EmbedLayer L = a.layers[l];
-    for (int j = wave; j < L.cout; j += nw) {
-      const float acc = wave_dot(L.w + (size_t)j * 2 * half, bufA, 2 * half, lane) + L.b[j];
-      if (lane == 0) a.emb[(size_t)b * a.emb_ld + L.offset + j] = acc;
+    for (int j0 = wave * 4; j0 < L.cout; j0 += nw * 4) {
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int k = lane; k < nin; k += 64) {
+        const float xv = bufA[k];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (j0 + r < L.cout) acc[r] = fmaf(L.w[(size_t)(j0 + r) * nin + k], xv, acc[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc[r] += __shfl_xor(acc[r], o, 64);
+        if (lane == 0 && j0 + r < L.cout) a.emb[(size_t)b * a.emb_ld + L.offset + j0 + r] = acc[r] + L.b[j0 + r];
+      }
     }
   }
 }
