@@ -136,6 +136,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the roofline and cpu_baseline legs")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel breakdown to stderr")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg only")
     args = ap.parse_args()
 
     rank, local_rank, world = dist_info()
@@ -203,8 +204,9 @@ def main():
         if args.breakdown:
             print(json.dumps(breakdown, indent=1), file=sys.stderr)
         result["kernel_breakdown_ms_per_denoise"] = {k: v["ms_per_step"] for k, v in list(breakdown.items())[:8]}
-        result["cpu_baseline"] = cpu_baseline(cfg, args.sample_steps)
-        result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
+        if not args.no_cpu:
+            result["cpu_baseline"] = cpu_baseline(cfg, args.sample_steps)
+            result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

@@ -270,7 +270,7 @@ struct ConvTile {
 // Candidate output tiles / wave layouts, ranked by an estimate of whole-chip MFMA time (tile quantisation in 32-voxel
 // MFMA rows, SIMD balance, tail rounds over 256 CUs) subject to the 160 KiB LDS per CU; the best few are timed on the
 // device once per geometry (autotune above), the top-ranked one is the fallback when timing is not possible.
-std::vector<ConvTile> conv_tile_candidates(const ConvGeom& g, int batch, int CT, int keep) {
+std::vector<ConvTile> conv_tile_candidates(const ConvGeom& g, int batch, int CT, int keep, int vox_bytes = 144) {
   std::vector<std::pair<double, ConvTile>> all;
   const int max_vt = 8 / CT;
   for (int TZ = 1; TZ <= g.out.d && TZ <= 12; ++TZ) {
@@ -278,7 +278,7 @@ std::vector<ConvTile> conv_tile_candidates(const ConvGeom& g, int batch, int CT,
       const int TH = (g.out.h + nth - 1) / nth;
       if (nth > 1 && (g.out.h + nth - 2) / (nth - 1) == TH) continue;  // same TH as previous nth
       const int IZ = (TZ - 1) * g.sz + g.kd, IH = (TH - 1) * g.sh + g.kh;
-      const size_t lds = ((size_t)IZ * IH * g.in.w * 36 + 36) * 4;
+      const size_t lds = ((size_t)IZ * IH * g.in.w + 1) * vox_bytes;
       if (lds > 150 * 1024) continue;
       const int tiles = (TZ * TH * g.out.w + 31) / 32;
       for (int NW = 1; NW <= 8; ++NW) {
@@ -1185,6 +1185,227 @@ void launch_flat3_inst(const ConvFlatArgs& a, dim3 grid, int threads, size_t lds
 }
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------------------
+// (TZ, TH) halo-tiled bf16x3 conv: same split-bf16 arithmetic as conv3_flat_bf16x3_kernel for grids whose z-planes are
+// too wide for the whole-plane LDS image (Dataset-3 level 0: 50x18 = 900-voxel planes).  Tile geometry as in
+// conv_mfma_kernel: output tile (TZ, TH, full r), staged input tile with phi halo rows (wrapped) and z halo planes
+// (zero-filled); 96 B per voxel per 16-channel sub-chunk; runtime tap loop.
+// ------------------------------------------------------------------------------------------------------------
+struct ConvTiled3Args {
+  ConvKArgs k;       // geometry / tiling / pointers (wpk = packed bf16x3 weights)
+  float* ch_part;    // optional channel statistics of the output: [B][nTZ*nTH][cout][2]
+};
+
+template <int VT, int CT>
+__global__ void __launch_bounds__(512, (VT * CT <= 2 ? 3 : 2)) conv_tiled_bf16x3_kernel(ConvTiled3Args args) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  char* ldsb = (char*)lds;
+  const ConvKArgs& a = args.k;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
+  int bid = blockIdx.x;
+  const int thi = bid % a.nTH;
+  bid /= a.nTH;
+  const int tzi = bid % a.nTZ;
+  const int b = bid / a.nTZ;
+  const int ct0 = blockIdx.y * CT;
+  const int oz0 = tzi * a.TZ, oh0 = thi * a.TH;
+  const int tileVox = a.IZ * a.IH * a.Win;
+  const int ZERO = tileVox * 96;  // byte offset of the all-zero voxel
+  const int half = lane >> 5, col = lane & 31;
+  if (tid < 24) ((float*)(ldsb + ZERO))[tid] = 0.f;
+
+  int abase[VT], ooff[VT];
+  unsigned wmask[VT];
+  bool any_valid = false;
+#pragma unroll
+  for (int vt = 0; vt < VT; ++vt) {
+    const int v = (wave * VT + vt) * 32 + col;
+    const int ow = v % a.Wo;
+    const int t = v / a.Wo;
+    const int oh = t % a.TH, oz = t / a.TH;
+    const bool valid = (oz < a.TZ) && (oz0 + oz < a.Do) && (oh0 + oh < a.Ho);
+    abase[vt] = ((oz * a.SZ * a.IH + oh * a.SH) * a.Win + ow * a.SW - 1) * 96 + half * 16;
+    unsigned m = 0;
+    for (int kw = 0; kw < a.KW; ++kw) {
+      const int iw = ow * a.SW + kw - 1;
+      if (valid && iw >= 0 && iw < a.Win) m |= 1u << kw;
+    }
+    wmask[vt] = m;
+    ooff[vt] = valid ? (((oz0 + oz) * a.Ho + oh0 + oh) * a.Wo + ow) * a.cout : -1;
+    any_valid |= valid;
+  }
+  const bool wave_active = __any(any_valid);
+
+  f32x16 acc[VT][CT];
+#pragma unroll
+  for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[vt][ct][r] = 0.f;
+
+  const int nsub = (a.c0 + a.c1) >> 4;
+  const int T = a.KD * a.KH * a.KW;
+  const int gz0 = oz0 * a.SZ - 1, gh0 = oh0 * a.SH - 1;
+  const int items = tileVox * 4;
+  const size_t in_vox = (size_t)a.Din * a.Hin * a.Win;
+
+  for (int sc = 0; sc < nsub; ++sc) {
+    const float* src;
+    int ldc, coff;
+    if (sc * 16 < a.c0) {
+      src = a.in0; ldc = a.c0; coff = sc * 16;
+    } else {
+      src = a.in1; ldc = a.c1; coff = sc * 16 - a.c0;
+    }
+    const int pq = tid & 3;
+    src += (size_t)b * in_vox * ldc + coff + pq * 4;
+    f32x4 cf[4];
+    if (a.coef) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) cf[e] = *(const f32x4*)(a.coef + ((size_t)b * (a.c0 + a.c1) + sc * 16 + pq * 4 + e) * 4);
+    }
+    __syncthreads();
+    for (int i0 = tid; i0 < items; i0 += 4 * nthreads) {
+      f32x4 val[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int idx = i0 + k * nthreads;
+        val[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (idx < items) {
+          const int vox = idx >> 2;
+          const int iw = vox % a.Win;
+          const int r = vox / a.Win;
+          const int ih = r % a.IH, iz = r / a.IH;
+          const int gz = gz0 + iz;
+          int gh = (gh0 + ih) % a.Hin;
+          if (gh < 0) gh += a.Hin;
+          if (gz >= 0 && gz < a.Din) {
+            val[k] = *(const f32x4*)(src + ((size_t)(gz * a.Hin + gh) * a.Win + iw) * ldc);
+            if (a.coef) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                float t = cf[e][0] * val[k][e] + cf[e][1];
+                if (a.act) t = t / (1.f + expf(-t));
+                val[k][e] = t + cf[e][2];
+              }
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int idx = i0 + k * nthreads;
+        if (idx < items) {
+          u32x2 t1, t2, t3;
+          split3(val[k], t1, t2, t3);
+          char* d = ldsb + (size_t)(idx >> 2) * 96 + pq * 8;
+          *(u32x2*)d = t1;
+          *(u32x2*)(d + 32) = t2;
+          *(u32x2*)(d + 64) = t3;
+        }
+      }
+    }
+    __syncthreads();
+    if (!wave_active) continue;
+
+    const u32x4* wq = (const u32x4*)a.wpk + ((size_t)sc * T * a.CTtot + ct0) * 192 + lane;
+    for (int kd = 0; kd < a.KD; ++kd) {
+      for (int kh = 0; kh < a.KH; ++kh) {
+        const int rowoff = (kd * a.IH + kh) * a.Win * 96;
+        for (int kw = 0; kw < a.KW; ++kw) {
+          const int tap = (kd * a.KH + kh) * a.KW + kw;
+          u32x4 bw[CT][3];
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) bw[ct][t] = wq[((size_t)tap * a.CTtot + ct) * 192 + t * 64];
+#pragma unroll
+          for (int vt = 0; vt < VT; ++vt) {
+            const int off = ((wmask[vt] >> kw) & 1u) ? abase[vt] + rowoff + kw * 96 : ZERO + half * 16;
+            u32x4 av[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) av[t] = *(const u32x4*)(ldsb + off + t * 32);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+              f32x16 c = acc[vt][ct];
+              c = MFMA_BF16(av[2], bw[ct][0], c);
+              c = MFMA_BF16(av[1], bw[ct][1], c);
+              c = MFMA_BF16(av[0], bw[ct][2], c);
+              c = MFMA_BF16(av[1], bw[ct][0], c);
+              c = MFMA_BF16(av[0], bw[ct][1], c);
+              c = MFMA_BF16(av[0], bw[ct][0], c);
+              acc[vt][ct] = c;
+            }
+          }
+        }
+      }
+    }
+  }
+
+  float* outb = a.out + (size_t)b * a.Do * a.Ho * a.Wo * a.cout;
+  float bv[CT], s1[CT], s2[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    bv[ct] = a.bias ? a.bias[(ct0 + ct) * 32 + col] : 0.f;
+    s1[ct] = s2[ct] = 0.f;
+  }
+#pragma unroll
+  for (int vt = 0; vt < VT; ++vt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int off = __shfl(ooff[vt], row, 64);
+      if (off >= 0) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          const float v = acc[vt][ct][r] + bv[ct];
+          outb[off + (ct0 + ct) * 32 + col] = v;
+          s1[ct] += v;
+          s2[ct] += v * v;
+        }
+      }
+    }
+  }
+  if (args.ch_part) {
+    __syncthreads();
+    const int nw = nthreads >> 6;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const float t1 = s1[ct] + __shfl_xor(s1[ct], 32, 64), t2 = s2[ct] + __shfl_xor(s2[ct], 32, 64);
+      if (half == 0) {
+        lds[((wave * CT + ct) * 32 + col) * 2] = t1;
+        lds[((wave * CT + ct) * 32 + col) * 2 + 1] = t2;
+      }
+    }
+    __syncthreads();
+    const int unit = tzi * a.nTH + thi, units = a.nTZ * a.nTH;
+    for (int i = tid; i < CT * 32; i += nthreads) {
+      float t1 = 0.f, t2 = 0.f;
+      for (int w = 0; w < nw; ++w) {
+        t1 += lds[((w * CT * 32) + i) * 2];
+        t2 += lds[((w * CT * 32) + i) * 2 + 1];
+      }
+      float* dst = args.ch_part + (((size_t)b * units + unit) * a.cout + ct0 * 32 + i) * 2;
+      dst[0] = t1;
+      dst[1] = t2;
+    }
+  }
+}
+
+namespace {
+template <int VT, int CT>
+void launch_tiled3_inst(const ConvTiled3Args& a, dim3 grid, int threads, size_t lds, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    CD_HIP(hipFuncSetAttribute((const void*)conv_tiled_bf16x3_kernel<VT, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_tiled_bf16x3_kernel<VT, CT>), grid, dim3(threads), lds, s, a);
+  CD_HIP(hipGetLastError());
+}
+}  // namespace
+
 // returns false when the whole-plane LDS tile does not fit (wide grids such as Dataset-3's 50x18 planes).
 // bf16x3 = true runs the split-bf16 kernel on `wpk` = packed bf16x3 weights; otherwise the f32 MFMA kernel
 // (stride-1 3x3x3 only).
@@ -1315,6 +1536,50 @@ void launch_conv_mfma(const float* in0, int c0, const float* in1, int c1, const 
     if (fu.wpk_bf16x3 && !want_f32 && try_launch_conv3_flat(in0, c0, in1, c1, fu.wpk_bf16x3, bias, out, batch, cout, g, s, fu, true))
       return;
     if (try_launch_conv3_flat(in0, c0, in1, c1, wpk, bias, out, batch, cout, g, s, fu, false)) return;
+  }
+  {
+    static const bool want_f32 = getenv("CD_CONV_PRECISION") && !strcmp(getenv("CD_CONV_PRECISION"), "f32");
+    if (fu.wpk_bf16x3 && !want_f32) {
+      const std::vector<ConvTile> cand3 = conv_tile_candidates(g, batch, CT, 14, 96);
+      auto launch3 = [&](const ConvTile& t) {
+        ConvTiled3Args a3;
+        ConvKArgs& a = a3.k;
+        a.in0 = in0; a.in1 = in1; a.c0 = c0; a.c1 = c1; a.wpk = (const float*)fu.wpk_bf16x3; a.bias = bias; a.out = out;
+        a.Din = g.in.d; a.Hin = g.in.h; a.Win = g.in.w; a.Do = g.out.d; a.Ho = g.out.h; a.Wo = g.out.w;
+        a.KD = g.kd; a.KH = g.kh; a.KW = g.kw; a.SZ = g.sz; a.SH = g.sh; a.SW = g.sw;
+        a.TZ = t.TZ; a.TH = t.TH; a.nTZ = (g.out.d + t.TZ - 1) / t.TZ; a.nTH = (g.out.h + t.TH - 1) / t.TH;
+        a.IZ = (t.TZ - 1) * g.sz + g.kd; a.IH = (t.TH - 1) * g.sh + g.kh;
+        a.cout = cout; a.CTtot = CTtot; a.coef = fu.coef; a.act = fu.act;
+        const int units = a.nTZ * a.nTH;
+        const int64_t cap = (g.out.vox() + 31) / 32;  // capacity of the caller's partial buffer (units per sample)
+        a3.ch_part = (fu.ch_part && units <= cap) ? fu.ch_part : nullptr;
+        if (fu.units) *fu.units = a3.ch_part ? units : 0;
+        dim3 grid((unsigned)(batch * a.nTZ * a.nTH), (unsigned)(CTtot / CT));
+        size_t lds = t.lds;
+        const size_t red = (size_t)t.NW * CT * 32 * 2 * 4;
+        if (lds < red) lds = red;
+#define CD_T3_CASE(V, C)                                              \
+  if (t.VT == V && CT == C) {                                         \
+    launch_tiled3_inst<V, C>(a3, grid, t.NW * 64, lds, s);            \
+    return;                                                           \
+  }
+        CD_T3_CASE(1, 1) CD_T3_CASE(2, 1) CD_T3_CASE(3, 1) CD_T3_CASE(4, 1)
+        CD_T3_CASE(1, 2) CD_T3_CASE(2, 2) CD_T3_CASE(3, 2) CD_T3_CASE(4, 2)
+        CD_T3_CASE(1, 3) CD_T3_CASE(2, 3)
+#undef CD_T3_CASE
+        CD_REQUIRE(false, "conv: no bf16x3 tiled kernel instance for the chosen tiling");
+      };
+      std::vector<ConvTile> ok;
+      for (auto& t : cand3)
+        if (t.VT <= 4 && !(CT == 3 && t.VT > 2)) ok.push_back(t);
+      if (!ok.empty()) {
+        char key3[192];
+        std::snprintf(key3, sizeof key3, "tiled_bf16x3 %s b%d", cat, batch);
+        const int pick3 = autotune(key3, (int)ok.size(), [&](int i) { launch3(ok[i]); }, s);
+        launch3(ok[pick3 < 0 ? 0 : pick3]);
+        return;
+      }
+    }
   }
   const std::vector<ConvTile> cand = conv_tile_candidates(g, batch, CT, 14);
   auto launch = [&](const ConvTile& t) {

@@ -80,6 +80,22 @@ def test_conv_primitives(ops):
         assert err < TOL_OP, (tag, err)
 
 
+def test_halo_tiled_kernels_match_too(ops, monkeypatch):
+    """Grids whose planes do not fit the whole-plane LDS image (Dataset-3 level 0) take the (TZ, TH) halo-tiled kernels;
+    force them on the small golden cases."""
+    monkeypatch.setenv("CD_NO_FLAT", "1")
+    g = gold("primitives_conv")
+    for tag in ("c3_32_32", "c3_64_32", "c3_96_64", "down_d2", "down_odd", "down_noz"):
+        w = t(g[f"{tag}.w"]).cuda()
+        b = t(g[f"{tag}.b"]).cuda()
+        stride = (1, 1, 1)
+        if tag.startswith("down"):
+            stride = (2 if int(g[f"{tag}.cz"]) else 1, 2, 2)
+        y = back(ops, ops.cyl_conv(cl(ops, g[f"{tag}.x"]), w, b, stride=stride))
+        err = rel_l2(y, g[f"{tag}.y"])
+        assert err < TOL_OP, (tag, err)
+
+
 def test_concat_conv_equals_conv_of_concat(ops):
     """The skip concat is never materialised: the conv reads two base pointers (models.py:741)."""
     from oracle import torch_oracle as O
