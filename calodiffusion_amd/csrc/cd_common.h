@@ -80,9 +80,13 @@ struct ConvFusion {
 inline size_t packed_bf16x3_bytes(int cin, int cout, int taps) {
   return (size_t)(cin / 16) * taps * ((cout + 31) / 32) * 3 * 64 * 16;
 }
-void launch_pack_weights_bf16x3(const float* w_torch, void* wpk, int cout, int cin, int taps, hipStream_t s);
+void launch_pack_weights_bf16x3(const float* w_torch, void* wpk, int cout, int cin, int taps, hipStream_t s,
+                                bool transposed = false, bool flip = false);
 
-void launch_pack_weights(const float* w_torch, float* wpk, int cout, int cin, int taps, bool transposed, hipStream_t s);
+// packed image Wp[co'][ci'][tap'] (see above) of torch weights: transposed = stored [ci'][co'][tap] (ConvTranspose3d, or the
+// input gradient of a Conv3d, whose roles of in/out channels swap); flip = tap' <- taps-1-tap' (input gradient, stride 1)
+void launch_pack_weights(const float* w_torch, float* wpk, int cout, int cin, int taps, bool transposed, hipStream_t s,
+                         bool flip = false);
 void launch_pack_init_weights(const float* w_torch, float* wpk, int cout, int cin, hipStream_t s);
 
 void launch_conv_mfma(const float* in0, int c0, const float* in1, int c1, const float* wpk, const float* bias, float* out,
@@ -133,7 +137,25 @@ int gn_nsplit_for(int64_t vox, int batch);
 void launch_ch_stats(const float* x, float* part, int batch, int channels, int64_t vox, int nsplit, hipStream_t s);
 // coef[B][C][4] = {rstd*gamma, beta - mean*rstd*gamma, add_bc[b][c] or 0, 0} from `units` channel partials per sample
 void launch_gn_finalize(const float* part, int units, const float* gamma, const float* beta, const float* add_bc, int add_ld,
-                        float* coef, int batch, int channels, int groups, int64_t vox, hipStream_t s);
+                        float* coef, int batch, int channels, int groups, int64_t vox, hipStream_t s,
+                        float* stat_out = nullptr /* [B][G][2] = {mean, rstd}, kept for the backward pass */);
+
+// ---- backward (kernels_bwd.hip) ---------------------------------------------------------------------------------
+size_t wgrad_partial_floats(int64_t out_vox, int batch, bool per_sample, int A, int Bc, int T);
+// dW[a][b][tap] (or [b][a][tap] if transposed_out) = sum_{n,o} g[n][o][a] * x[n][in(o,tap)][xoff + b]; see kernels_bwd.hip
+void launch_wgrad(const float* g, int A, Dims3 dg, const float* x, int Bc, int xld, int xoff, Dims3 dx, int kd, int kh, int kw,
+                  int sz, int sxy, int batch, bool per_sample, float* partial, float* dw, bool accumulate, bool transposed_out,
+                  hipStream_t s, int b_total = 0, int b_off = 0);
+void launch_strided_dgrad_naive(const float* dy, const float* w, float* dx, int batch, int cin, int cout, Dims3 din, Dims3 dout,
+                                int kd, int sz, hipStream_t s);
+void launch_add_slices(const float* a, int lda, int aoff, const float* b, int ldb, int boff, float* out, int channels,
+                       int64_t rows, hipStream_t s);
+void launch_bias_grad(const float* part, int units, int batch, int channels, float* db, bool accumulate, hipStream_t s);
+size_t gn_backward_scratch_floats(int batch, int channels, int64_t vox);
+// backward of y = act(scale*h + shift) + add: dh, dgamma, dbeta (accumulated if asked), dadd[b][c] (optional)
+void launch_gn_backward(const float* dy, const float* h, const float* coef, const float* stat, const float* gamma, float* dh,
+                        float* dgamma, float* dbeta, float* dadd, int dadd_ld, int batch, int channels, int64_t vox, int groups,
+                        int silu, float* scratch, bool accumulate_params, hipStream_t s);
 int gn_apply_blocks_per_sample(int batch, int channels, int64_t vox);
 // y = act(scale*x + shift) + add (+ residual; residual1/res_c0: shortcut read from a two-source channel concat);
 // part_out (optional): channel partials of y, [B][gn_apply_blocks_per_sample][C][2]

@@ -1,0 +1,432 @@
+// Backward kernels of the training step (Diffusion.compute_loss -> loss.backward()).
+// The reference relies on torch autograd through stock modules; here every gradient is a hand-written kernel on the
+// same channels-last layout as the forward path.  Input gradients of the convolutions reuse the forward conv kernels
+// with re-packed (transposed / tap-flipped) weights; this file holds what has no forward counterpart:
+//   * weight gradients: dW[a][b][tap] = sum over voxels of g[o][a] * x[in(o, tap)][b]  (contraction over voxels on the
+//     fp32 MFMA), generic in taps / stride so that it serves 3x3x3, 1x1x1, the strided down conv and -- with the roles
+//     of the two tensors swapped -- the transposed up conv;
+//   * GroupNorm(+SiLU) backward (statistics pass + elementwise pass);
+//   * small elementwise pieces (loss gradient, softmax backward of the linear attention, head).
+#include "cd_common.h"
+#include <cstdio>
+
+namespace cd {
+
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+// ------------------------------------------------------------------------------------------------------------
+// Weight gradient.
+//   g : (B, Og, A)  channels-last "output side" tensor (A = rows of dW), voxel grid (Dg, Hg, Wg)
+//   x : (B, Ox, Bc) channels-last "input side" tensor (Bc = columns of dW), voxel grid (Dx, Hx, Wx)
+//   dW[a][b][tap] = sum_{n, o} g[n][o][a] * x[n][in(o, tap)][b],  in(o,tap) = (oz*SZ + kz - 1, (oh*S + kh - 1) mod Hx, ow*S + kw - 1)
+//   (zero outside z / r).  For a transposed conv the caller passes g = layer input, x = output gradient: same geometry.
+// One workgroup = one 32x32 (a, b) tile x one voxel chunk; its 4 waves split the taps; every lane half takes one voxel of
+// a pair (K = 2 per MFMA).  Partials [chunk][tap][32][32] are reduced in a fixed order by wgrad_reduce_kernel
+// (deterministic, no float atomics), which also writes the torch layout.
+// ------------------------------------------------------------------------------------------------------------
+struct WgradArgs {
+  const float* g;
+  const float* x;
+  int A, Bc;              // channel counts (ld of g / x)
+  int xld, xoff;          // x may be a channel slice of a wider tensor (skip concat): row stride and offset
+  int Dg, Hg, Wg, Dx, Hx, Wx;
+  int KD, KH, KW, SZ, S;
+  int batch;
+  int per_sample;         // 1: no reduction over the batch (attention context gradient); partial index includes n
+  int chunk_vox;          // output voxels per chunk (even)
+  int nchunks;            // chunks per sample
+  float* partial;         // [(n if per_sample)][chunk (x batch if !per_sample)][tileA][tileB][tap][32][32]
+};
+
+template <int TPW>  // taps per wave (upper bound)
+__global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, col = lane & 31;
+  const int T = a.KD * a.KH * a.KW;
+  const int tilesB = a.Bc / 32;
+  const int ta = blockIdx.y / tilesB, tb = blockIdx.y % tilesB;
+  const int chunk = blockIdx.x % a.nchunks;
+  const int n = blockIdx.x / a.nchunks;
+  const int Og = a.Dg * a.Hg * a.Wg, Ox = a.Dx * a.Hx * a.Wx;
+  const int tap0 = wave * TPW;
+  const int ntap = min(TPW, T - tap0);
+
+  f32x16 acc[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const float* gb = a.g + (size_t)n * Og * a.A + ta * 32 + col;
+  const float* xb = a.x + (size_t)n * Ox * a.xld + a.xoff + tb * 32 + col;
+  const int o0 = chunk * a.chunk_vox;
+  const int o1 = min(o0 + a.chunk_vox, Og);
+  if (ntap > 0) {
+    for (int o = o0 + half; o < o0 + a.chunk_vox; o += 2) {
+      const bool ov = o < o1;
+      const int oo = ov ? o : o0;
+      const float gv = ov ? gb[(size_t)oo * a.A] : 0.f;
+      const int ow = oo % a.Wg;
+      const int t2 = oo / a.Wg;
+      const int oh = t2 % a.Hg, oz = t2 / a.Hg;
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) {
+        if (t < ntap) {
+          const int tap = tap0 + t;
+          const int kw = tap % a.KW, kh = (tap / a.KW) % a.KH, kz = tap / (a.KW * a.KH);
+          const int pz = a.KD == 1 ? 0 : 1, pw = a.KW == 1 ? 0 : 1, ph = a.KH == 1 ? 0 : 1;
+          const int iz = oz * a.SZ + kz - pz, iw = ow * a.S + kw - pw;
+          int ih = oh * a.S + kh - ph;
+          ih = ih < 0 ? ih + a.Hx : (ih >= a.Hx ? ih - a.Hx : ih);
+          ih = ih >= a.Hx ? ih - a.Hx : ih;
+          float xv = 0.f;
+          if (ov && iz >= 0 && iz < a.Dx && iw >= 0 && iw < a.Wx) xv = xb[((size_t)(iz * a.Hx + ih) * a.Wx + iw) * a.xld];
+          acc[t] = MFMA32(gv, xv, acc[t]);
+        }
+      }
+    }
+  }
+  // C layout: col = lane&31 (b), row = (r&3) + 8*(r>>2) + 4*half (a)
+  const size_t slot = a.per_sample ? ((size_t)n * a.nchunks + chunk) : ((size_t)chunk * a.batch + n);
+  float* pbase = a.partial + ((slot * (a.A / 32) + ta) * tilesB + tb) * (size_t)T * 1024;
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    if (t < ntap) {
+      float* p = pbase + (size_t)(tap0 + t) * 1024;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) p[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + col] = acc[t][r];
+    }
+  }
+}
+
+// dW (torch layout) = sum over slots of the partial tiles.
+//   transposed_out = 0: dW[a][b][tap] (Conv3d weight, a = out channel)   1: dW[b][a][tap]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int A, int Bc, int T, int nslots,
+                                    int accumulate, int transposed_out, size_t sample_stride_partial, size_t sample_stride_out,
+                                    int b_total, int b_off) {
+  const size_t total = (size_t)A * Bc * T;
+  const size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int n = blockIdx.y;
+  // idx enumerates the partial-tile order: [ta][tb][tap][row a][col b]
+  const int cb = idx & 31, ra = (idx >> 5) & 31;
+  size_t rest = idx >> 10;
+  const int tap = rest % T;
+  rest /= T;
+  const int tilesB = Bc / 32;
+  const int tb = rest % tilesB, ta = rest / tilesB;
+  const float* p = partial + (size_t)n * sample_stride_partial + idx;
+  float s = 0.f;
+  for (int k = 0; k < nslots; ++k) s += p[(size_t)k * total];
+  const int ga = ta * 32 + ra, gb2 = tb * 32 + cb;
+  // b_total / b_off: the b columns are a slice of a wider weight (second source of a channel concat)
+  const size_t o = (transposed_out ? ((size_t)(gb2 + b_off) * A + ga) : ((size_t)ga * b_total + b_off + gb2)) * T + tap;
+  float* d = dw + (size_t)n * sample_stride_out + o;
+  *d = accumulate ? *d + s : s;
+}
+
+// chunks per sample: enough workgroups to fill the chip, chunks of >= 128 voxels, partial volume <= 32 MiB
+int wgrad_chunks(int64_t out_vox, int batch, bool per_sample, int A, int Bc, int T) {
+  int64_t want = per_sample ? 8 : (1024 + batch - 1) / batch;
+  const int64_t cap = (out_vox + 127) / 128;
+  if (want > cap) want = cap;
+  const int64_t per_slot = (int64_t)A * Bc * T * 4;
+  int64_t mem = (32ll << 20) / (per_slot * (per_sample ? 1 : batch));
+  if (mem < 1) mem = 1;
+  if (want > mem) want = mem;
+  return (int)(want < 1 ? 1 : want);
+}
+size_t wgrad_partial_floats(int64_t out_vox, int batch, bool per_sample, int A, int Bc, int T) {
+  return (size_t)wgrad_chunks(out_vox, batch, per_sample, A, Bc, T) * batch * A * Bc * T;
+}
+
+void launch_wgrad(const float* g, int A, Dims3 dg, const float* x, int Bc, int xld, int xoff, Dims3 dx, int kd, int kh, int kw,
+                  int sz, int sxy, int batch, bool per_sample, float* partial, float* dw, bool accumulate, bool transposed_out,
+                  hipStream_t s, int b_total, int b_off) {
+  CD_REQUIRE(A % 32 == 0 && Bc % 32 == 0, "wgrad: channel counts must be multiples of 32");
+  if (b_total <= 0) b_total = Bc;
+  WgradArgs a;
+  a.g = g; a.x = x; a.A = A; a.Bc = Bc; a.xld = xld; a.xoff = xoff;
+  a.Dg = dg.d; a.Hg = dg.h; a.Wg = dg.w; a.Dx = dx.d; a.Hx = dx.h; a.Wx = dx.w;
+  a.KD = kd; a.KH = kh; a.KW = kw; a.SZ = sz; a.S = sxy; a.batch = batch; a.per_sample = per_sample ? 1 : 0;
+  a.nchunks = wgrad_chunks(dg.vox(), batch, per_sample, A, Bc, kd * kh * kw);
+  int cv = (int)((dg.vox() + a.nchunks - 1) / a.nchunks);
+  a.chunk_vox = (cv + 1) & ~1;
+  a.partial = partial;
+  const int T = kd * kh * kw;
+  char cat[96];
+  std::snprintf(cat, sizeof cat, "wgrad T%d C%dx%d n%ld", T, A, Bc, (long)dg.vox());
+  prof::Scope scope(cat, s, 2.0 * T * A * Bc * (double)dg.vox() * batch, 4.0 * batch * ((double)dg.vox() * A + (double)dx.vox() * Bc));
+  dim3 grid((unsigned)(a.nchunks * batch), (unsigned)((A / 32) * (Bc / 32)));
+  const int tpw = (T + 3) / 4;
+  if (T == 1) hipLaunchKernelGGL(wgrad_kernel<1>, grid, dim3(64), 0, s, a);  // one wave per workgroup (nothing to split)
+  else if (tpw <= 1) hipLaunchKernelGGL(wgrad_kernel<1>, grid, dim3(256), 0, s, a);
+  else if (tpw <= 7) hipLaunchKernelGGL(wgrad_kernel<7>, grid, dim3(256), 0, s, a);
+  else if (tpw <= 12) hipLaunchKernelGGL(wgrad_kernel<12>, grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(wgrad_kernel<16>, grid, dim3(256), 0, s, a);
+  CD_HIP(hipGetLastError());
+  const size_t total = (size_t)A * Bc * T;
+  const int nslots = per_sample ? a.nchunks : a.nchunks * batch;
+  dim3 rg((unsigned)((total + 255) / 256), per_sample ? batch : 1);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, rg, dim3(256), 0, s, partial, dw, A, Bc, T, nslots, accumulate ? 1 : 0,
+                     transposed_out ? 1 : 0, (size_t)nslots * total, total, b_total, b_off);
+  CD_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Per-channel sums over (batch, voxels): bias gradients.  part: channel partials [B][units][C][2] (only the sums are used)
+// ------------------------------------------------------------------------------------------------------------
+__global__ void bias_grad_kernel(const float* __restrict__ part, int units, int batch, int channels, float* __restrict__ db,
+                                 int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= channels) return;
+  double s = 0.0;
+  for (int n = 0; n < batch; ++n)
+    for (int u = 0; u < units; ++u) s += (double)part[(((size_t)n * units + u) * channels + c) * 2];
+  db[c] = accumulate ? db[c] + (float)s : (float)s;
+}
+void launch_bias_grad(const float* part, int units, int batch, int channels, float* db, bool accumulate, hipStream_t s) {
+  hipLaunchKernelGGL(bias_grad_kernel, dim3((channels + 63) / 64), dim3(64), 0, s, part, units, batch, channels, db, accumulate ? 1 : 0);
+  CD_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// GroupNorm(+SiLU)(+add) backward.   forward: z = scale*h + shift (scale = rstd*gamma, shift = beta - mean*scale),
+// y = act(z) + add [+ residual].  Given dy:
+//   dz = dy * act'(z);  dgamma[c] = sum dz*hhat;  dbeta[c] = sum dz;  dadd[b][c] = sum_v dy
+//   dh = rstd * (dhhat - mean_g(dhhat) - hhat * mean_g(dhhat*hhat)),  dhhat = dz*gamma,  hhat = (h - mean)*rstd
+// Pass 1 (gn_bwd_stats_kernel): per (b, split, c): {sum dz, sum dz*hhat, sum dy}.  Pass 2 (gn_bwd_apply_kernel).
+// `stat` = saved {mean, rstd} per (b, g).
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float silu_grad(float z) {
+  const float sg = 1.f / (1.f + expf(-z));
+  return sg * (1.f + z * (1.f - sg));
+}
+
+__global__ void __launch_bounds__(256) gn_bwd_stats_kernel(const float* __restrict__ dy, const float* __restrict__ h,
+                                                           const float* __restrict__ coef, const float* __restrict__ stat,
+                                                           float* __restrict__ part, int channels, int64_t vox, int groups,
+                                                           int silu, int nsplit) {
+  __shared__ double sP[256][3];
+  const int tid = threadIdx.x;
+  const int split = blockIdx.x, b = blockIdx.y;
+  const int cols = channels >> 2, rows = 256 / cols;
+  const int64_t per = (vox + nsplit - 1) / nsplit;
+  const int64_t v0 = split * per, v1 = (v0 + per < vox) ? v0 + per : vox;
+  const int colid = tid % cols, row = tid / cols;
+  const int c = colid * 4, cpg = channels / groups;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0;
+  if (row < rows) {
+    f32x4 cf[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) cf[e] = *(const f32x4*)(coef + ((size_t)b * channels + c + e) * 4);
+    const float mean = stat[((size_t)b * groups + c / cpg) * 2], rstd = stat[((size_t)b * groups + c / cpg) * 2 + 1];
+    const size_t sb = (size_t)b * vox * channels + c;
+    for (int64_t v = v0 + row; v < v1; v += rows) {
+      const f32x4 g = *(const f32x4*)(dy + sb + (size_t)v * channels);
+      const f32x4 hv = *(const f32x4*)(h + sb + (size_t)v * channels);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float z = cf[e][0] * hv[e] + cf[e][1];
+        const float dz = silu ? g[e] * silu_grad(z) : g[e];
+        s0[e] += dz;
+        s1[e] += dz * (hv[e] - mean) * rstd;
+        s2[e] += g[e];
+      }
+    }
+  }
+  float* dst = part + (((size_t)b * nsplit + split) * channels) * 3;
+  for (int e = 0; e < 4; ++e) {
+    sP[tid][0] = (double)s0[e]; sP[tid][1] = (double)s1[e]; sP[tid][2] = (double)s2[e];
+    __syncthreads();
+    if (tid < cols) {
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+      for (int r = 0; r < rows; ++r) { a0 += sP[r * cols + tid][0]; a1 += sP[r * cols + tid][1]; a2 += sP[r * cols + tid][2]; }
+      dst[(tid * 4 + e) * 3] = (float)a0; dst[(tid * 4 + e) * 3 + 1] = (float)a1; dst[(tid * 4 + e) * 3 + 2] = (float)a2;
+    }
+    __syncthreads();
+  }
+}
+
+// one block per sample: reduces the partials; writes gcoef[b][c] = {gamma*rstd, m1, m2*rstd... } for the apply pass,
+// accumulates dadd[b][c]; dgamma/dbeta are reduced over the batch by a second tiny kernel.
+__global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(const float* __restrict__ part, int nsplit, const float* __restrict__ gamma,
+                                                              const float* __restrict__ stat, float* __restrict__ gcoef,
+                                                              float* __restrict__ sums_bc, float* __restrict__ dadd, int dadd_ld,
+                                                              int channels, int groups, int64_t vox) {
+  __shared__ double s0[256], s1[256];
+  __shared__ float m1[64], m2[64];
+  const int b = blockIdx.x, c = threadIdx.x;
+  const int cpg = channels / groups;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+  if (c < channels) {
+    const float* p = part + ((size_t)b * nsplit * channels + c) * 3;
+    for (int u = 0; u < nsplit; ++u) { a0 += (double)p[(size_t)u * channels * 3]; a1 += (double)p[(size_t)u * channels * 3 + 1]; a2 += (double)p[(size_t)u * channels * 3 + 2]; }
+    s0[c] = a0 * (double)gamma[c];   // sum dhhat
+    s1[c] = a1 * (double)gamma[c];   // sum dhhat*hhat
+    sums_bc[((size_t)b * channels + c) * 2] = (float)a0;      // dbeta contribution of this sample
+    sums_bc[((size_t)b * channels + c) * 2 + 1] = (float)a1;  // dgamma contribution
+    if (dadd) dadd[(size_t)b * dadd_ld + c] = (float)a2;
+  }
+  __syncthreads();
+  if (c < groups) {
+    double t0 = 0.0, t1 = 0.0;
+    for (int k = 0; k < cpg; ++k) { t0 += s0[c * cpg + k]; t1 += s1[c * cpg + k]; }
+    const double cnt = (double)vox * cpg;
+    m1[c] = (float)(t0 / cnt);
+    m2[c] = (float)(t1 / cnt);
+  }
+  __syncthreads();
+  if (c < channels) {
+    const int g = c / cpg;
+    const float mean = stat[((size_t)b * groups + g) * 2], rstd = stat[((size_t)b * groups + g) * 2 + 1];
+    // dh = rstd*(gamma*dz - m1 - hhat*m2) = A*dz + Bh*h + C0 with hhat = (h-mean)*rstd
+    f32x4 o;
+    o[0] = rstd * gamma[c];                 // * dz
+    o[1] = -rstd * rstd * m2[g];            // * h
+    o[2] = rstd * (-m1[g] + mean * rstd * m2[g]);
+    o[3] = 0.f;
+    *(f32x4*)(gcoef + ((size_t)b * channels + c) * 4) = o;
+  }
+}
+
+__global__ void param_grad_from_samples_kernel(const float* __restrict__ sums_bc, int batch, int channels, float* __restrict__ dgamma,
+                                               float* __restrict__ dbeta, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= channels) return;
+  double g = 0.0, bt = 0.0;
+  for (int n = 0; n < batch; ++n) { bt += (double)sums_bc[((size_t)n * channels + c) * 2]; g += (double)sums_bc[((size_t)n * channels + c) * 2 + 1]; }
+  dgamma[c] = accumulate ? dgamma[c] + (float)g : (float)g;
+  dbeta[c] = accumulate ? dbeta[c] + (float)bt : (float)bt;
+}
+
+// dh = gc0*dz + gc1*h + gc2 (+ dh_accum), dz = dy*act'(scale*h+shift)
+__global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ h,
+                                                           const float* __restrict__ coef, const float* __restrict__ gcoef,
+                                                           float* __restrict__ dh, int channels, int64_t vox, int silu,
+                                                           int blocks_per_sample) {
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x / blocks_per_sample, blk = blockIdx.x % blocks_per_sample;
+  const int cols = channels >> 2, rows = 256 / cols;
+  const int64_t vper = (vox + blocks_per_sample - 1) / blocks_per_sample;
+  const int64_t v0 = blk * vper, v1 = (v0 + vper < vox) ? v0 + vper : vox;
+  const int colid = tid % cols, row = tid / cols;
+  const int c = colid * 4;
+  if (row >= rows) return;
+  f32x4 cf[4], gc[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    cf[e] = *(const f32x4*)(coef + ((size_t)b * channels + c + e) * 4);
+    gc[e] = *(const f32x4*)(gcoef + ((size_t)b * channels + c + e) * 4);
+  }
+  const size_t sb = (size_t)b * vox * channels + c;
+  for (int64_t v = v0 + row; v < v1; v += rows) {
+    const f32x4 g = *(const f32x4*)(dy + sb + (size_t)v * channels);
+    const f32x4 hv = *(const f32x4*)(h + sb + (size_t)v * channels);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float z = cf[e][0] * hv[e] + cf[e][1];
+      const float dz = silu ? g[e] * silu_grad(z) : g[e];
+      o[e] = gc[e][0] * dz + gc[e][1] * hv[e] + gc[e][2];
+    }
+    *(f32x4*)(dh + sb + (size_t)v * channels) = o;
+  }
+}
+
+void launch_gn_backward(const float* dy, const float* h, const float* coef, const float* stat, const float* gamma, float* dh,
+                        float* dgamma, float* dbeta, float* dadd, int dadd_ld, int batch, int channels, int64_t vox, int groups,
+                        int silu, float* scratch, bool accumulate_params, hipStream_t s) {
+  CD_REQUIRE(channels % 4 == 0 && channels <= 256 && groups <= 64, "group norm backward: <= 256 channels, <= 64 groups");
+  const int ns = gn_nsplit_for(vox, batch);
+  float* part = scratch;                                         // [B][ns][C][3]
+  float* gcoef = part + (size_t)batch * ns * channels * 3;        // [B][C][4]
+  float* sums_bc = gcoef + (size_t)batch * channels * 4;          // [B][C][2]
+  prof::Scope scope("gn_backward", s, 0, 4.0 * batch * (double)vox * channels * 5);
+  hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(ns, batch), dim3(256), 0, s, dy, h, coef, stat, part, channels, vox, groups, silu, ns);
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(batch), dim3(256), 0, s, part, ns, gamma, stat, gcoef, sums_bc, dadd, dadd_ld,
+                     channels, groups, vox);
+  hipLaunchKernelGGL(param_grad_from_samples_kernel, dim3((channels + 63) / 64), dim3(64), 0, s, sums_bc, batch, channels, dgamma,
+                     dbeta, accumulate_params ? 1 : 0);
+  const int bps = gn_apply_blocks_per_sample(batch, channels, vox);
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)(batch * bps)), dim3(256), 0, s, dy, h, coef, gcoef, dh, channels, vox, silu, bps);
+  CD_HIP(hipGetLastError());
+}
+// out[v][c] = a[v][aoff + c] + (b ? b[v][boff + c] : 0)   (row strides lda / ldb / C): gradient fan-in, channel slices of
+// the gradient of a concatenated tensor
+__global__ void add_slices_kernel(const float* __restrict__ a, int lda, int aoff, const float* __restrict__ b, int ldb, int boff,
+                                  float* __restrict__ out, int channels, int64_t rows) {
+  const int cols = channels >> 2;
+  const int64_t total = rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / cols;
+    const int c = (int)(i % cols) * 4;
+    f32x4 v = *(const f32x4*)(a + (size_t)r * lda + aoff + c);
+    if (b) v += *(const f32x4*)(b + (size_t)r * ldb + boff + c);
+    *(f32x4*)(out + (size_t)r * channels + c) = v;
+  }
+}
+void launch_add_slices(const float* a, int lda, int aoff, const float* b, int ldb, int boff, float* out, int channels,
+                       int64_t rows, hipStream_t s) {
+  int64_t blocks = (rows * (channels / 4) + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(add_slices_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, lda, aoff, b, ldb, boff, out, channels, rows);
+  CD_HIP(hipGetLastError());
+}
+
+// Input gradient of the strided (KD,4,4) down conv for ODD phi extents.  With an even phi ring the adjoint coincides with the
+// up-conv gather kernel (conv_transpose_kernel); with an odd ring the circular halo rows break its parity classes, so this
+// (rare: Dataset-1 grid) case takes a plain gather:  dx[i][ci] = sum_{o,k : in(o,k) = i} sum_co dy[o][co] * w[co][ci][k].
+// One thread per (input voxel, ci).
+__global__ void strided_dgrad_naive_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
+                                           int cin, int cout, int D, int H, int W, int Do, int Ho, int Wo, int KD, int SZ) {
+  const int64_t vox = (int64_t)D * H * W;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  if (idx >= vox * cin) return;
+  const int ci = (int)(idx % cin);
+  const int v = (int)(idx / cin);
+  const int iw = v % W, ih = (v / W) % H, iz = v / (W * H);
+  float acc = 0.f;
+  for (int kz = 0; kz < KD; ++kz) {
+    const int tz = iz + 1 - kz;
+    if (tz < 0 || tz % SZ) continue;
+    const int oz = tz / SZ;
+    if (oz >= Do) continue;
+    for (int kw = 0; kw < 4; ++kw) {
+      const int tw = iw + 1 - kw;
+      if (tw < 0 || (tw & 1)) continue;
+      const int ow = tw >> 1;
+      if (ow >= Wo) continue;
+      for (int kh = 0; kh < 4; ++kh) {
+        // padded row r = 2*oh + kh covers input row (r - 1) mod H for r in [0, H+2)
+        for (int rr = 0; rr < 3; ++rr) {
+          const int r = ih + 1 + (rr - 1) * H;
+          if (r < 0 || r > H + 1) continue;
+          const int th = r - kh;
+          if (th < 0 || (th & 1)) continue;
+          const int oh = th >> 1;
+          if (oh >= Ho) continue;
+          const float* g = dy + (((size_t)b * Do + oz) * Ho + oh) * (size_t)Wo * cout + (size_t)ow * cout;
+          const float* wr = w + (size_t)ci * KD * 16 + (kz * 4 + kh) * 4 + kw;
+          for (int co = 0; co < cout; ++co) acc = fmaf(g[co], wr[(size_t)co * cin * KD * 16], acc);
+        }
+      }
+    }
+  }
+  dx[((size_t)b * vox + v) * cin + ci] = acc;
+}
+void launch_strided_dgrad_naive(const float* dy, const float* w, float* dx, int batch, int cin, int cout, Dims3 din, Dims3 dout,
+                                int kd, int sz, hipStream_t s) {
+  const int64_t total = din.vox() * cin;
+  hipLaunchKernelGGL(strided_dgrad_naive_kernel, dim3((unsigned)((total + 255) / 256), batch), dim3(256), 0, s, dy, w, dx, cin, cout,
+                     din.d, din.h, din.w, dout.d, dout.h, dout.w, kd, sz);
+  CD_HIP(hipGetLastError());
+}
+
+size_t gn_backward_scratch_floats(int batch, int channels, int64_t vox) {
+  const int ns = gn_nsplit_for(vox, batch);
+  return (size_t)batch * ns * channels * 3 + (size_t)batch * channels * 6 + 64;
+}
+
+}  // namespace cd

@@ -26,7 +26,7 @@ static constexpr int LDS_VOX_PAD = 4;  // floats of padding per LDS voxel: strid
 // weight packing (see cd_common.h for the layout)
 // ------------------------------------------------------------------------------------------------------------
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wpk, int cout, int cin, int taps,
-                                    int transposed, size_t total) {
+                                    int transposed, size_t total, int flip) {
   size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (idx >= total) return;
   const int e = idx & 3, lane = (idx >> 2) & 63, q = (idx >> 8) & 3;
@@ -39,16 +39,17 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
   const int h = lane >> 5, j = lane & 31, m = q * 4 + e;
   const int ci = chunk * 32 + h * 16 + m, co = ct * 32 + j;
   float v = 0.f;
+  const int st = flip ? taps - 1 - tap : tap;  // source tap (flipped for the input gradient of a stride-1 conv)
   if (co < cout && ci < cin)
-    v = transposed ? w[((size_t)ci * cout + co) * taps + tap] : w[((size_t)co * cin + ci) * taps + tap];
+    v = transposed ? w[((size_t)ci * cout + co) * taps + st] : w[((size_t)co * cin + ci) * taps + st];
   wpk[idx] = v;
 }
 
-void launch_pack_weights(const float* w_torch, float* wpk, int cout, int cin, int taps, bool transposed, hipStream_t s) {
+void launch_pack_weights(const float* w_torch, float* wpk, int cout, int cin, int taps, bool transposed, hipStream_t s, bool flip) {
   CD_REQUIRE(cin % 32 == 0, "MFMA convolutions need input channels in multiples of 32");
   size_t total = packed_weight_floats(cin, cout, taps);
   hipLaunchKernelGGL(pack_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, s, w_torch, wpk, cout, cin, taps,
-                     transposed ? 1 : 0, total);
+                     transposed ? 1 : 0, total, flip ? 1 : 0);
   CD_HIP(hipGetLastError());
 }
 
@@ -625,7 +626,7 @@ __device__ __forceinline__ void split3(const f32x4 x, u32x2& t1, u32x2& t2, u32x
 
 // packed bf16x3 weights: [sub-chunk = ci/16][tap][ct][term][lane = h*32+j][8 bf16] = W_term[co = ct*32+j][ci = sc*16+8h+0..7]
 __global__ void pack_weights_bf16x3_kernel(const float* __restrict__ w, u32x4* __restrict__ wpk, int cout, int cin, int taps,
-                                           size_t total) {
+                                           size_t total, int transposed, int flip) {
   const size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x;  // one thread per (sc, tap, ct, lane)
   if (idx >= total) return;
   const int lane = idx & 63;
@@ -641,7 +642,9 @@ __global__ void pack_weights_bf16x3_kernel(const float* __restrict__ w, u32x4* _
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int ci = sc * 16 + h * 8 + e;
-    v[e >> 2][e & 3] = (co < cout && ci < cin) ? w[((size_t)co * cin + ci) * taps + tap] : 0.f;
+    const int st = flip ? taps - 1 - tap : tap;
+    const size_t src = transposed ? ((size_t)ci * cout + co) * taps + st : ((size_t)co * cin + ci) * taps + st;
+    v[e >> 2][e & 3] = (co < cout && ci < cin) ? w[src] : 0.f;
   }
   u32x2 a1, a2, a3, b1, b2, b3;
   split3(v[0], a1, a2, a3);
@@ -652,11 +655,12 @@ __global__ void pack_weights_bf16x3_kernel(const float* __restrict__ w, u32x4* _
   dst[128] = u32x4{a3[0], a3[1], b3[0], b3[1]};
 }
 
-void launch_pack_weights_bf16x3(const float* w_torch, void* wpk, int cout, int cin, int taps, hipStream_t s) {
+void launch_pack_weights_bf16x3(const float* w_torch, void* wpk, int cout, int cin, int taps, hipStream_t s, bool transposed,
+                                bool flip) {
   CD_REQUIRE(cin % 16 == 0, "bf16x3 convolution needs input channels in multiples of 16");
   const size_t total = (size_t)(cin / 16) * taps * ((cout + 31) / 32) * 64;
   hipLaunchKernelGGL(pack_weights_bf16x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w_torch, (u32x4*)wpk, cout,
-                     cin, taps, total);
+                     cin, taps, total, transposed ? 1 : 0, flip ? 1 : 0);
   CD_HIP(hipGetLastError());
 }
 
@@ -1160,7 +1164,8 @@ template <int CT>
 void launch_ws_inst(const ConvFlatArgs& a, dim3 grid, int threads, size_t lds, int nlw, int ups, int total, hipStream_t s, int geo) {
   if (geo == 0) launch_ws_geo<CT, 3, 3, 3, 1, 1>(a, grid, threads, lds, nlw, ups, total, s);
   else if (geo == 1) launch_ws_geo<CT, 3, 4, 4, 2, 2>(a, grid, threads, lds, nlw, ups, total, s);
-  else launch_ws_geo<CT, 3, 4, 4, 1, 2>(a, grid, threads, lds, nlw, ups, total, s);
+  else if (geo == 2) launch_ws_geo<CT, 3, 4, 4, 1, 2>(a, grid, threads, lds, nlw, ups, total, s);
+  else launch_ws_geo<CT, 4, 4, 4, 2, 2>(a, grid, threads, lds, nlw, ups, total, s);
 }
 }  // namespace
 
@@ -1176,12 +1181,13 @@ void launch_flat3_geo(const ConvFlatArgs& a, dim3 grid, int threads, size_t lds,
   hipLaunchKernelGGL((conv3_flat_bf16x3_kernel<VT, CT, KD, KH, KW, SZ, SXY>), grid, dim3(threads), lds, s, a);
   CD_HIP(hipGetLastError());
 }
-// geo: 0 = 3x3x3 stride 1, 1 = (3,4,4) stride (2,2,2), 2 = (3,4,4) stride (1,2,2)
+// geo: 0 = 3x3x3 stride 1, 1 = (3,4,4) stride (2,2,2), 2 = (3,4,4) stride (1,2,2), 3 = (4,4,4) stride (2,2,2)
 template <int VT, int CT>
 void launch_flat3_inst(const ConvFlatArgs& a, dim3 grid, int threads, size_t lds, hipStream_t s, int geo = 0) {
   if (geo == 0) launch_flat3_geo<VT, CT, 3, 3, 3, 1, 1>(a, grid, threads, lds, s);
   else if (geo == 1) launch_flat3_geo<VT, CT, 3, 4, 4, 2, 2>(a, grid, threads, lds, s);
-  else launch_flat3_geo<VT, CT, 3, 4, 4, 1, 2>(a, grid, threads, lds, s);
+  else if (geo == 2) launch_flat3_geo<VT, CT, 3, 4, 4, 1, 2>(a, grid, threads, lds, s);
+  else launch_flat3_geo<VT, CT, 4, 4, 4, 2, 2>(a, grid, threads, lds, s);
 }
 }  // namespace
 
@@ -1416,6 +1422,7 @@ static bool try_launch_conv3_flat(const float* in0, int c0, const float* in1, in
   int geo = -1;
   if (g.kd == 3 && g.kh == 3 && g.kw == 3 && g.sz == 1 && g.sh == 1 && g.sw == 1) geo = 0;
   else if (g.kd == 3 && g.kh == 4 && g.kw == 4 && g.sh == 2 && g.sw == 2 && (g.sz == 1 || g.sz == 2)) geo = g.sz == 2 ? 1 : 2;
+  else if (g.kd == 4 && g.kh == 4 && g.kw == 4 && g.sh == 2 && g.sw == 2 && g.sz == 2) geo = 3;  // input gradient of an up conv
   if (geo < 0 || (geo != 0 && !bf16x3)) return false;
   const Dims3 d = g.in;
   const int CTtot = cout / 32;

@@ -77,7 +77,7 @@ void launch_ch_stats(const float* x, float* part, int batch, int channels, int64
 __global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restrict__ part, int units, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, const float* __restrict__ add_bc,
                                                           int add_ld, float* __restrict__ coef, int channels, int groups,
-                                                          int64_t vox) {
+                                                          int64_t vox, float* __restrict__ stat_out) {
   __shared__ double sS[256][2];
   __shared__ double sC[256][2];
   __shared__ float sMean[64], sRstd[64];
@@ -120,6 +120,10 @@ __global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restric
     var = var < 0.0 ? 0.0 : var;
     sMean[tid] = (float)mu;
     sRstd[tid] = (float)(1.0 / sqrt(var + 1e-5));
+    if (stat_out) {
+      stat_out[((size_t)b * groups + tid) * 2] = sMean[tid];
+      stat_out[((size_t)b * groups + tid) * 2 + 1] = sRstd[tid];
+    }
   }
   __syncthreads();
   if (tid < channels) {
@@ -135,11 +139,11 @@ __global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restric
 }
 
 void launch_gn_finalize(const float* part, int units, const float* gamma, const float* beta, const float* add_bc, int add_ld,
-                        float* coef, int batch, int channels, int groups, int64_t vox, hipStream_t s) {
+                        float* coef, int batch, int channels, int groups, int64_t vox, hipStream_t s, float* stat_out) {
   CD_REQUIRE(channels <= 256 && groups <= 64 && channels % groups == 0, "group norm: <= 256 channels, <= 64 groups");
   prof::Scope scope("gn_finalize", s, 0, 0);
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(batch), dim3(256), 0, s, part, units, gamma, beta, add_bc, add_ld, coef, channels,
-                     groups, vox);
+                     groups, vox, stat_out);
   CD_HIP(hipGetLastError());
 }
 

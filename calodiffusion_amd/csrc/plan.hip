@@ -522,6 +522,100 @@ float* attn_block(Run& r, const AttnP& w, const float* x, Dims3 dims, float* xpa
   return y;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// backward building blocks
+// ------------------------------------------------------------------------------------------------------------
+// per-channel sums of a (B, vox, C) tensor over batch and voxels -> db (bias gradients)
+void bias_grad(Run& r, const float* dy, int C, int64_t vox, float* db) {
+  int units = 0;
+  float* part = stats_pass(r, dy, C, vox, &units);
+  if (!r.dry()) launch_bias_grad(part, units, r.B, C, db, false, r.s);
+  r.ws->release(part);
+}
+
+// Backward of a phi-periodic Conv3d y = conv(cat(x0, x1), w) + b  (3x3x3 stride 1, 1x1x1, or the (3,4,4) strided conv).
+//   dx (optional): (B, vox_in, c0+c1) gradient of the concatenated input
+//   dw: torch layout (cout, c0+c1, taps);  db: (cout) or null.   w_raw: torch-layout weights (device).
+void conv_backward(Run& r, const float* x0, int c0, const float* x1, int c1, const float* w_raw, const float* dy, float* dx,
+                   float* dw, float* db, int cout, const ConvGeom& g) {
+  Arena* ws = r.ws;
+  const int cin = c0 + c1, T = g.kd * g.kh * g.kw;
+  if (dx) {
+    if (T == 1) {
+      float* wp = ws->get<float>(packed_weight_floats(cout, cin, 1));
+      if (!r.dry()) {
+        launch_pack_weights(w_raw, wp, cin, cout, 1, true, r.s);
+        PointwiseArgs a;
+        a.in0 = dy; a.ld0 = cout; a.c0 = cout; a.wpk = wp; a.out = dx; a.batch = r.B; a.cout = cin; a.vox = g.in.vox();
+        launch_pointwise(a, r.s);
+      }
+      ws->release(wp);
+    } else if (g.sz == 1 && g.sh == 1 && g.sw == 1) {
+      // dx = conv(dy, W^T flipped): the forward kernels with re-packed weights
+      float* wp = ws->get<float>(packed_weight_floats(cout, cin, T));
+      float* wp3 = ws->get<float>(packed_bf16x3_bytes(cout, cin, T) / 4);
+      if (!r.dry()) {
+        launch_pack_weights(w_raw, wp, cin, cout, T, true, r.s, true);
+        launch_pack_weights_bf16x3(w_raw, wp3, cin, cout, T, r.s, true, true);
+        ConvGeom gd{g.out, g.in, g.kd, g.kh, g.kw, 1, 1, 1};
+        ConvFusion fu;
+        fu.wpk_bf16x3 = wp3;
+        launch_conv_mfma(dy, cout, nullptr, 0, wp, nullptr, dx, r.B, cin, gd, r.s, fu);
+      }
+      ws->release(wp3);
+      ws->release(wp);
+    } else if (g.in.h & 1) {
+      // odd phi ring: the circular halo breaks the parity classes of the gather kernel (see kernels_bwd.hip)
+      if (!r.dry()) launch_strided_dgrad_naive(dy, w_raw, dx, r.B, cin, cout, g.in, g.out, g.kd, g.sz, r.s);
+    } else {
+      // strided conv: its adjoint is the transposed-conv gather kernel
+      float* wp = ws->get<float>(packed_weight_floats(cout, cin, T));
+      if (!r.dry()) {
+        launch_pack_weights(w_raw, wp, cin, cout, T, true, r.s);
+        launch_conv_transpose_mfma(dy, cout, wp, nullptr, dx, r.B, cin, g.out, g.in, g.kd, g.sz, r.s);
+      }
+      ws->release(wp);
+    }
+  }
+  float* part = ws->get<float>(wgrad_partial_floats(g.out.vox(), r.B, false, cout, c0 > c1 ? c0 : c1, T));
+  if (!r.dry()) {
+    launch_wgrad(dy, cout, g.out, x0, c0, c0, 0, g.in, g.kd, g.kh, g.kw, g.sz, g.sh, r.B, false, part, dw, false, false, r.s, cin, 0);
+    if (c1) launch_wgrad(dy, cout, g.out, x1, c1, c1, 0, g.in, g.kd, g.kh, g.kw, g.sz, g.sh, r.B, false, part, dw, false, false, r.s, cin, c0);
+  }
+  ws->release(part);
+  if (db) bias_grad(r, dy, cout, g.out.vox(), db);
+}
+
+// Backward of the phi-periodic ConvTranspose3d (Upsample): y = convT(x, w) + b, w stored (cin, cout, kz, 4, 4)
+void conv_transpose_backward(Run& r, const float* x, const float* w_raw, const float* dy, float* dx, float* dw, float* db, int c,
+                             Dims3 din, Dims3 dout, int kz, int sz) {
+  Arena* ws = r.ws;
+  const int T = kz * 16;
+  // With an odd output phi extent (output_padding 1 along phi: only the Dataset-1 grid) the circular halo of the INPUT makes
+  // the adjoint two-valued; that case is not implemented for training (the forward handles it).
+  CD_REQUIRE((dout.h & 1) == 0, "training backward: up-sampling to an odd phi extent is not supported");
+  if (dx) {
+    // dx[i][ci] = sum_k dy[s*i + k - 1][co] w[ci][co][k]: a strided conv of dy with w viewed as (co' = ci, ci' = co)
+    float* wp = ws->get<float>(packed_weight_floats(c, c, T));
+    float* wp3 = ws->get<float>(packed_bf16x3_bytes(c, c, T) / 4);
+    if (!r.dry()) {
+      launch_pack_weights(w_raw, wp, c, c, T, false, r.s);
+      launch_pack_weights_bf16x3(w_raw, wp3, c, c, T, r.s, false, false);
+      ConvGeom gd{dout, din, kz, 4, 4, sz, 2, 2};
+      ConvFusion fu;
+      fu.wpk_bf16x3 = wp3;
+      launch_conv_mfma(dy, c, nullptr, 0, wp, nullptr, dx, r.B, c, gd, r.s, fu);
+    }
+    ws->release(wp3);
+    ws->release(wp);
+  }
+  // dw[ci][co][k] = sum_i x[i][ci] * dy[s*i + k - 1][co]: the strided-conv weight gradient with the two tensors' roles swapped
+  float* part = ws->get<float>(wgrad_partial_floats(din.vox(), r.B, false, c, c, T));
+  if (!r.dry()) launch_wgrad(x, c, din, dy, c, c, 0, dout, kz, 4, 4, sz, 2, r.B, false, part, dw, false, false, r.s);
+  ws->release(part);
+  if (db) bias_grad(r, dy, c, dout.vox(), db);
+}
+
 // CondUnet.forward after init_conv / embeddings (models.py:713-748). Takes ownership of h (a workspace block).
 float* unet_body(CdPlan* p, Run& r, const float* emb, float* h) {
   const CdUnetDesc& d = p->desc;
@@ -1083,6 +1177,57 @@ int cd_op_linear_attention(const float* x, const float* const* w, float* y, int 
     const Dims3 d{dims[0], dims[1], dims[2]};
     float* out = attn_block(run, a, x, d);
     CD_HIP(hipMemcpyAsync(y, out, sizeof(float) * (size_t)batch * d.vox() * channels, hipMemcpyDeviceToDevice, s));
+  });
+}
+
+int cd_op_conv_backward(const float* x0, int c0, const float* x1, int c1, const float* w, const float* dy, float* dx, float* dw,
+                        float* db, int batch, int cout, const int32_t dims_in[3], const int32_t kernel[3],
+                        const int32_t stride[3], void* workspace, size_t workspace_bytes, void* stream) {
+  return guarded([&] {
+    CD_REQUIRE(x0 && w && dy && dw && workspace, "null argument");
+    Arena ws;
+    ws.reset((char*)workspace, workspace_bytes, false);
+    Run run{&ws, (hipStream_t)stream, batch, 8};
+    ConvGeom g;
+    g.in = Dims3{dims_in[0], dims_in[1], dims_in[2]};
+    g.kd = kernel[0]; g.kh = kernel[1]; g.kw = kernel[2]; g.sz = stride[0]; g.sh = stride[1]; g.sw = stride[2];
+    if (g.kd * g.kh * g.kw == 1) g.out = g.in;
+    else g.out = Dims3{(g.in.d + 2 - g.kd) / g.sz + 1, (g.in.h + 2 - g.kh) / g.sh + 1, (g.in.w + 2 - g.kw) / g.sw + 1};
+    conv_backward(run, x0, c0, x1, c1, w, dy, dx, dw, db, cout, g);
+  });
+}
+
+int cd_op_conv_transpose_backward(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int batch,
+                                  int channels, const int32_t dims_in[3], int kernel_z, int stride_z, const int32_t out_pad[3],
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+  return guarded([&] {
+    CD_REQUIRE(x && w && dy && dw && workspace, "null argument");
+    Arena ws;
+    ws.reset((char*)workspace, workspace_bytes, false);
+    Run run{&ws, (hipStream_t)stream, batch, 8};
+    const Dims3 din{dims_in[0], dims_in[1], dims_in[2]};
+    const Dims3 dout{(din.d - 1) * stride_z - 2 + kernel_z, 2 * din.h + out_pad[1], 2 * din.w + out_pad[2]};
+    conv_transpose_backward(run, x, w, dy, dx, dw, db, channels, din, dout, kernel_z, stride_z);
+  });
+}
+
+int cd_op_group_norm_backward(const float* x, const float* gamma, const float* beta, const float* dy, float* dx, float* dgamma,
+                              float* dbeta, float* dadd, int batch, int channels, int64_t voxels, int groups, int silu,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+  return guarded([&] {
+    CD_REQUIRE(x && gamma && beta && dy && dx && dgamma && dbeta && workspace, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    Arena ws;
+    ws.reset((char*)workspace, workspace_bytes, false);
+    Run run{&ws, s, batch, groups};
+    int units = 0;
+    float* part = stats_pass(run, x, channels, voxels, &units);
+    float* coef = ws.get<float>((size_t)batch * channels * 4);
+    float* stat = ws.get<float>((size_t)batch * groups * 2);
+    launch_gn_finalize(part, units, gamma, beta, nullptr, 0, coef, batch, channels, groups, voxels, s, stat);
+    float* scratch = ws.get<float>(gn_backward_scratch_floats(batch, channels, voxels));
+    launch_gn_backward(dy, x, coef, stat, gamma, dx, dgamma, dbeta, dadd, channels, batch, channels, voxels, groups, silu, scratch,
+                       false, s);
   });
 }
 

@@ -75,6 +75,12 @@ _SIGNATURES = {
     "cd_op_resnet_block": (C.c_int, [_P, C.c_int, _P, C.c_int, C.POINTER(_P), _P, _P, C.c_int, C.c_int,
                                      C.POINTER(C.c_int32), C.c_int, _P, C.c_size_t, _P]),
     "cd_op_linear_attention": (C.c_int, [_P, C.POINTER(_P), _P, C.c_int, C.c_int, C.POINTER(C.c_int32), _P, C.c_size_t, _P]),
+    "cd_op_conv_backward": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.POINTER(C.c_int32),
+                                      C.POINTER(C.c_int32), C.POINTER(C.c_int32), _P, C.c_size_t, _P]),
+    "cd_op_conv_transpose_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_int,
+                                                C.POINTER(C.c_int32), _P, C.c_size_t, _P]),
+    "cd_op_group_norm_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, _P,
+                                            C.c_size_t, _P]),
     "cd_op_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int64]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -391,6 +397,49 @@ class Ops:
         _check(self.lib.cd_op_group_norm(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), B, Cc, vox, groups,
                                          int(silu), _ptr(add_bc), _ptr(residual), sc.data_ptr(), _stream()))
         return y
+
+    def _bws(self, nbytes=1 << 30):
+        if getattr(self, "_bwd_ws", None) is None or self._bwd_ws.numel() < nbytes:
+            self._bwd_ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        return self._bwd_ws
+
+    def conv_backward(self, x_cl, w, dy_cl, stride=(1, 1, 1), x1_cl=None, need_dx=True, bias=True):
+        """Gradients (dx, dw, db) of cyl_conv; channels-last activations, torch-layout weights."""
+        x, w, dy = _dev32(x_cl, "x"), _dev32(w, "w"), _dev32(dy_cl, "dy")
+        B, D, H, W, c0 = x.shape
+        c1 = 0 if x1_cl is None else x1_cl.shape[-1]
+        cout, k = w.shape[0], tuple(w.shape[2:])
+        dx = torch.empty((B, D, H, W, c0 + c1), dtype=torch.float32, device=x.device) if need_dx else None
+        dw = torch.empty_like(w)
+        db = torch.empty((cout,), dtype=torch.float32, device=x.device) if bias else None
+        ws = self._bws()
+        _check(self.lib.cd_op_conv_backward(x.data_ptr(), c0, _ptr(x1_cl), c1, w.data_ptr(), dy.data_ptr(), _ptr(dx), dw.data_ptr(),
+                                            _ptr(db), B, cout, _i32x3((D, H, W)), _i32x3(k), _i32x3(stride), ws.data_ptr(),
+                                            ws.numel(), _stream()))
+        return dx, dw, db
+
+    def conv_transpose_backward(self, x_cl, w, dy_cl, kernel_z, stride_z, out_pad):
+        x, w, dy = _dev32(x_cl, "x"), _dev32(w, "w"), _dev32(dy_cl, "dy")
+        B, D, H, W, c = x.shape
+        dx, dw = torch.empty_like(x), torch.empty_like(w)
+        db = torch.empty((c,), dtype=torch.float32, device=x.device)
+        ws = self._bws()
+        _check(self.lib.cd_op_conv_transpose_backward(x.data_ptr(), w.data_ptr(), dy.data_ptr(), dx.data_ptr(), dw.data_ptr(),
+                                                      db.data_ptr(), B, c, _i32x3((D, H, W)), kernel_z, stride_z, _i32x3(out_pad),
+                                                      ws.data_ptr(), ws.numel(), _stream()))
+        return dx, dw, db
+
+    def group_norm_backward(self, x_cl, gamma, beta, dy_cl, groups, silu=False, want_dadd=False):
+        x, dy = _dev32(x_cl, "x"), _dev32(dy_cl, "dy")
+        B, Cc = x.shape[0], x.shape[-1]
+        vox = int(np.prod(x.shape[1:-1]))
+        dx, dg, db = torch.empty_like(x), torch.empty_like(gamma), torch.empty_like(beta)
+        dadd = torch.empty((B, Cc), dtype=torch.float32, device=x.device) if want_dadd else None
+        ws = self._bws()
+        _check(self.lib.cd_op_group_norm_backward(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), dy.data_ptr(), dx.data_ptr(),
+                                                  dg.data_ptr(), db.data_ptr(), _ptr(dadd), B, Cc, vox, groups, int(silu),
+                                                  ws.data_ptr(), ws.numel(), _stream()))
+        return dx, dg, db, dadd
 
     _RES_KEYS = ("block1.proj.conv.weight", "block1.proj.conv.bias", "block1.norm.weight", "block1.norm.bias",
                  "block2.proj.conv.weight", "block2.proj.conv.bias", "block2.norm.weight", "block2.norm.bias",

@@ -162,6 +162,20 @@ int cd_op_resnet_block(const float* x0, int c0, const float* x1, int c1, const f
  * fn.fn.to_qkv.conv.weight, fn.fn.to_out.0.conv.{weight,bias}, fn.fn.to_out.1.{weight,bias}. */
 int cd_op_linear_attention(const float* x, const float* const* w, float* y, int batch, int channels, const int32_t dims[3],
                            void* workspace, size_t workspace_bytes, void* stream);
+/* ---- backward primitives (training path; parity-tested against torch autograd on the oracle) ------------------------- */
+/* Gradients of y = cyl_conv(cat(x0, x1), w) + b given dy: dx (B, vox_in, c0+c1) or NULL, dw (torch layout), db or NULL.
+ * Same geometry rules as cd_op_cyl_conv (models.py:65-96, 360-365). */
+int cd_op_conv_backward(const float* x0, int c0, const float* x1, int c1, const float* w, const float* dy, float* dx, float* dw,
+                        float* db, int batch, int cout, const int32_t dims_in[3], const int32_t kernel[3],
+                        const int32_t stride[3], void* workspace, size_t workspace_bytes, void* stream);
+/* Gradients of the Upsample transposed conv (models.py:25-62, 335-348): dx, dw (cin, cout, kz, 4, 4), db. */
+int cd_op_conv_transpose_backward(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int batch,
+                                  int channels, const int32_t dims_in[3], int kernel_z, int stride_z, const int32_t out_pad[3],
+                                  void* workspace, size_t workspace_bytes, void* stream);
+/* Gradients of y = act(GroupNorm(x)) + add: dx, dgamma, dbeta, dadd (B, C) or NULL. */
+int cd_op_group_norm_backward(const float* x, const float* gamma, const float* beta, const float* dy, float* dx, float* dgamma,
+                              float* dbeta, float* dadd, int batch, int channels, int64_t voxels, int groups, int silu,
+                              void* workspace, size_t workspace_bytes, void* stream);
 size_t cd_op_scratch_bytes(int batch, int max_channels, int64_t max_voxels);
 
 #ifdef __cplusplus
