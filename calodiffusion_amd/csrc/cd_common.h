@@ -94,7 +94,7 @@ void launch_conv_mfma(const float* in0, int c0, const float* in1, int c1, const 
 void launch_conv_transpose_mfma(const float* in, int cin, const float* wpk, const float* bias, float* out, int batch,
                                 int cout, Dims3 din, Dims3 dout, int kz, int sz, hipStream_t s);
 
-enum A_Prologue { A_NONE = 0, A_AFFINE = 1, A_SOFTMAX32 = 2 };
+enum A_Prologue { A_NONE = 0, A_AFFINE = 1, A_SOFTMAX32 = 2, A_EXPNORM = 3 };
 struct PointwiseArgs {
   const float* in0 = nullptr;  // (B, vox, ld0) read at channel offset off0, c0 channels
   int ld0 = 0, off0 = 0, c0 = 0;
@@ -108,7 +108,9 @@ struct PointwiseArgs {
   int batch = 0, cout = 0;
   int64_t vox = 0;
   int prologue = A_NONE;
-  const float* coef = nullptr;  // A_AFFINE: [B][Cin][4] {scale, shift, -, -} (a folded GroupNorm, see launch_gn_finalize)
+  const float* coef = nullptr;  // A_AFFINE: [B][Cin][4] {scale, shift, -, -} (a folded GroupNorm, see launch_gn_finalize);
+                                // A_EXPNORM: [B][Cin][2] {max, 1/sum}: a <- exp(a - max)/sum (the voxel softmax of k)
+  int out_ld = 0, out_off = 0;  // output row stride / channel offset (0 = cout, packed)
   float* ch_part = nullptr;     // optional channel partials of the output: [B][ceil(vox/128)][cout][2]
 };
 inline int pointwise_units(int64_t vox) { return (int)((vox + 127) / 128); }
@@ -148,6 +150,22 @@ void launch_wgrad(const float* g, int A, Dims3 dg, const float* x, int Bc, int x
                   hipStream_t s, int b_total = 0, int b_off = 0);
 void launch_strided_dgrad_naive(const float* dy, const float* w, float* dx, int batch, int cin, int cout, Dims3 din, Dims3 dout,
                                 int kd, int sz, hipStream_t s);
+void launch_softmax32(const float* qkv, float* qs, int64_t rows, hipStream_t s);
+void launch_softmax32_bwd(const float* qs, const float* dqs, float* dqkv, int64_t rows, hipStream_t s);
+void launch_ksoftmax_bwd(const float* qkv, const float* dks, const float* kstat, const float* ctx, const float* dctx, float dscale,
+                         float* dqkv, int batch, int64_t vox, hipStream_t s);
+void launch_pack_sample32(const float* m, float* wpk, int batch, bool transpose, float scale, hipStream_t s);
+int head_bwd_blocks(int batch, int64_t vox);
+void launch_head_loss_bwd(const float* x0, const float* data, const float* scal, const float* h, const float* wh, float* dh,
+                          float* part, float* dwh, float* dbh, int batch, int64_t vox, hipStream_t s);
+struct LinearWgradJob {
+  const float* delta;  // (B, delta_ld) rows, nout used
+  const float* in;     // (B, in_ld) rows, nin used
+  float* dw;           // (nout, nin)
+  float* db;           // (nout)
+  int nout, nin, delta_ld, in_ld;
+};
+void launch_linear_wgrad(const LinearWgradJob* jobs_dev, int njobs, int max_elems, int batch, hipStream_t s);
 void launch_add_slices(const float* a, int lda, int aoff, const float* b, int ldb, int boff, float* out, int channels,
                        int64_t rows, hipStream_t s);
 void launch_bias_grad(const float* part, int units, int batch, int channels, float* db, bool accumulate, hipStream_t s);
@@ -166,7 +184,8 @@ int attn_nsplit_for(int64_t vox, int batch);
 size_t attn_partial_floats(int batch, int nsplit);
 void launch_attn_context(const float* qkv, float* partials, int batch, int64_t vox, int nsplit, hipStream_t s);
 void launch_attn_combine(const float* partials, int nsplit, const float* w_out /*torch (C,32)*/, int cout, float* wpk_b,
-                         int batch, float scale, hipStream_t s);
+                         int batch, float scale, hipStream_t s, float* ctx_out = nullptr /* [B][32][32] unscaled context */,
+                         float* kstat_out = nullptr /* [B][32][2] = {max, 1/sum} of the k softmax */);
 
 struct EmbedLayer {
   const float* w;  // (cout, 128) torch layout
@@ -220,5 +239,38 @@ void launch_loss_partial(const float* x0, const float* data, const float* sigma_
 void launch_loss_final(const double* partial, const float* sigma_b, double* loss, int batch, int64_t per, hipStream_t s);
 void launch_transpose_to_cl(const float* ncdhw, float* ndhwc, int batch, int channels, int64_t vox, hipStream_t s);
 void launch_transpose_to_planar(const float* ndhwc, float* ncdhw, int batch, int channels, int64_t vox, hipStream_t s);
+
+size_t init_wgrad_partial_floats(int batch, int64_t vox, int cin, int cout);
+void launch_init_wgrad(const InitConvArgs& a, const float* g, float* part, float* dw, hipStream_t s);
+// per-sample record the embedding backward leaves for the Linear weight gradients
+struct EmbedTapeLayout {
+  int t_in, a1t, a2t, a1c, a2c, sc;      // inputs of the Linears (time: 1, q, half; cond: cond(copied), hidden, half; proj: 2*half)
+  int cond_in;
+  int d1t, d2t, d3t, d1c, d2c, d3c;      // deltas at the Linear outputs
+  int total;
+};
+__host__ __device__ inline EmbedTapeLayout embed_tape_layout(int cond_size, int hidden, int half) {
+  EmbedTapeLayout L;
+  int o = 0;
+  const int q = half / 2;
+  L.t_in = o; o += 1;
+  L.a1t = o; o += q;
+  L.a2t = o; o += half;
+  L.cond_in = o; o += cond_size;
+  L.a1c = o; o += hidden;
+  L.a2c = o; o += half;
+  L.sc = o; o += 2 * half;
+  L.d1t = o; o += q;
+  L.d2t = o; o += half;
+  L.d3t = o; o += half;
+  L.d1c = o; o += hidden;
+  L.d2c = o; o += half;
+  L.d3c = o; o += half;
+  L.total = (o + 3) & ~3;
+  return L;
+}
+
+size_t embed_tape_floats(int cond_size, int hidden, int half);
+void launch_embed_bwd(const EmbedArgs& a, const float* demb, float* tape, hipStream_t s);
 
 }  // namespace cd

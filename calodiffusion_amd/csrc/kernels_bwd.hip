@@ -424,6 +424,407 @@ void launch_strided_dgrad_naive(const float* dy, const float* w, float* dx, int 
   CD_HIP(hipGetLastError());
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Linear attention backward helpers (forward: kernels_norm_attn.hip; reference LinearAttention.forward models.py:301-318)
+// ------------------------------------------------------------------------------------------------------------
+// qs[n][d] = softmax over the 32 channels of q (q = channels [0,32) of the (B, n, 96) qkv tensor); one thread per voxel
+__global__ void softmax32_kernel(const float* __restrict__ qkv, float* __restrict__ qs, int64_t rows) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows) return;
+  const f32x4* src = (const f32x4*)(qkv + (size_t)i * 96);
+  f32x4 v[8];
+  float m = -3.0e38f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    v[k] = src[k];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) m = fmaxf(m, v[k][e]);
+  }
+  float ssum = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[k][e] = expf(v[k][e] - m);
+      ssum += v[k][e];
+    }
+  const float inv = 1.f / ssum;
+  f32x4* dst = (f32x4*)(qs + (size_t)i * 32);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) dst[k] = v[k] * inv;
+}
+void launch_softmax32(const float* qkv, float* qs, int64_t rows, hipStream_t s) {
+  hipLaunchKernelGGL(softmax32_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, qkv, qs, rows);
+  CD_HIP(hipGetLastError());
+}
+
+// dq[n][d] = qs*(dqs - sum_d' qs*dqs)  written into channels [0,32) of dqkv (row stride 96)
+__global__ void softmax32_bwd_kernel(const float* __restrict__ qs, const float* __restrict__ dqs, float* __restrict__ dqkv,
+                                     int64_t rows) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows) return;
+  const f32x4* a = (const f32x4*)(qs + (size_t)i * 32);
+  const f32x4* g = (const f32x4*)(dqs + (size_t)i * 32);
+  f32x4 av[8], gv[8];
+  float dot = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    av[k] = a[k];
+    gv[k] = g[k];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dot += av[k][e] * gv[k][e];
+  }
+  f32x4* dst = (f32x4*)(dqkv + (size_t)i * 96);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) dst[k] = av[k] * (gv[k] - dot);
+}
+void launch_softmax32_bwd(const float* qs, const float* dqs, float* dqkv, int64_t rows, hipStream_t s) {
+  hipLaunchKernelGGL(softmax32_bwd_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, qs, dqs, dqkv, rows);
+  CD_HIP(hipGetLastError());
+}
+
+// dk[n][d] = ks*(dks - r[d]),  ks = exp(k - M[d])/S[d],  r[d] = dscale * sum_e dctx[d][e]*ctx[d][e];  written to dqkv channels [32,64)
+// kstat[b][d] = {M, 1/S};  ctx, dctx: [b][32][32] (row d, col e), both WITHOUT the q scale.
+__global__ void __launch_bounds__(256) ksoftmax_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dks,
+                                                           const float* __restrict__ kstat, const float* __restrict__ ctx,
+                                                           const float* __restrict__ dctx, float dscale, float* __restrict__ dqkv,
+                                                           int64_t vox) {
+  __shared__ float sR[32], sM[32], sI[32];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  if (tid < 32) {
+    float r = 0.f;
+    for (int e = 0; e < 32; ++e) r += dctx[((size_t)b * 32 + tid) * 32 + e] * ctx[((size_t)b * 32 + tid) * 32 + e];
+    sR[tid] = r * dscale;
+    sM[tid] = kstat[((size_t)b * 32 + tid) * 2];
+    sI[tid] = kstat[((size_t)b * 32 + tid) * 2 + 1];
+  }
+  __syncthreads();
+  const int64_t total = vox * 8;  // float4 items
+  for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t n = i >> 3;
+    const int c = (int)(i & 7) * 4;
+    const f32x4 kv = *(const f32x4*)(qkv + ((size_t)b * vox + n) * 96 + 32 + c);
+    const f32x4 g = *(const f32x4*)(dks + ((size_t)b * vox + n) * 32 + c);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = expf(kv[e] - sM[c + e]) * sI[c + e] * (g[e] - sR[c + e]);
+    *(f32x4*)(dqkv + ((size_t)b * vox + n) * 96 + 32 + c) = o;
+  }
+}
+void launch_ksoftmax_bwd(const float* qkv, const float* dks, const float* kstat, const float* ctx, const float* dctx, float dscale,
+                         float* dqkv, int batch, int64_t vox, hipStream_t s) {
+  int64_t bx = (vox * 8 + 255) / 256;
+  if (bx > 256) bx = 256;
+  hipLaunchKernelGGL(ksoftmax_bwd_kernel, dim3((unsigned)bx, batch), dim3(256), 0, s, qkv, dks, kstat, ctx, dctx, dscale, dqkv, vox);
+  CD_HIP(hipGetLastError());
+}
+
+// per-sample 32x32 matrix -> packed 1x1 MFMA weights:  W[co][ci] = scale * (transpose ? m[co][ci] : m[ci][co])
+__global__ void pack_sample32_kernel(const float* __restrict__ m, float* __restrict__ wpk, int transpose, float scale) {
+  const int b = blockIdx.x;
+  for (int i = threadIdx.x; i < 1024; i += blockDim.x) {
+    const int e4 = i & 3, lane = (i >> 2) & 63, q = (i >> 8) & 3;
+    const int co = lane & 31, ci = (lane >> 5) * 16 + q * 4 + e4;
+    wpk[(size_t)b * 1024 + i] = scale * (transpose ? m[((size_t)b * 32 + co) * 32 + ci] : m[((size_t)b * 32 + ci) * 32 + co]);
+  }
+}
+void launch_pack_sample32(const float* m, float* wpk, int batch, bool transpose, float scale, hipStream_t s) {
+  hipLaunchKernelGGL(pack_sample32_kernel, dim3(batch), dim3(256), 0, s, m, wpk, transpose ? 1 : 0, scale);
+  CD_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Head + loss backward (forward: head_kernel; loss.py:103-104,176):
+//   L = sum_b w_b sum_v (x0 - data)^2 / (mean(w) * B * per),  x0 = c_skip*x + c_out*F,  F = sum_c Wh[c]*h[v][c] + bh
+//   dF = 2 w_b (x0 - data) c_out[b] / (mean(w) B per);  dh[v][c] = dF*Wh[c];  dWh[c] = sum dF*h[v][c];  dbh = sum dF
+// part: [blocks][33] partial sums (32 weights + bias)
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) head_loss_bwd_kernel(const float* __restrict__ x0, const float* __restrict__ data,
+                                                            const float* __restrict__ scal, const float* __restrict__ h,
+                                                            const float* __restrict__ wh, float* __restrict__ dh,
+                                                            float* __restrict__ part, int batch, int64_t vox) {
+  __shared__ float sW[32];
+  __shared__ float sAcc[8][33];
+  __shared__ float sNorm;
+  const int tid = threadIdx.x, sub = tid & 7, grp = tid >> 3;
+  if (tid < 32) sW[tid] = wh[tid];
+  if (tid == 0) {
+    double wsum = 0.0;
+    for (int b = 0; b < batch; ++b) {
+      const float sg = scal[b * 4 + 3];
+      wsum += (double)(1.0f + 1.0f / (sg * sg));
+    }
+    sNorm = (float)(2.0 / ((wsum / batch) * (double)batch * (double)vox));
+  }
+  __syncthreads();
+  const int64_t total = (int64_t)batch * vox;
+  f32x4 aw = {0.f, 0.f, 0.f, 0.f};
+  float ab = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 32 + grp; i < total; i += (int64_t)gridDim.x * 32) {
+    const int b = (int)(i / vox);
+    const float sg = scal[b * 4 + 3];
+    const float dF = sNorm * (1.0f + 1.0f / (sg * sg)) * (x0[i] - data[i]) * scal[b * 4 + 2];
+    const f32x4 hv = *(const f32x4*)(h + (size_t)i * 32 + sub * 4);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o[e] = dF * sW[sub * 4 + e];
+      aw[e] += dF * hv[e];
+    }
+    *(f32x4*)(dh + (size_t)i * 32 + sub * 4) = o;
+    if (sub == 0) ab += dF;
+  }
+  // reduce over the 32 voxel groups of the block: lanes with equal `sub` hold the same channels
+#pragma unroll
+  for (int o = 8; o < 64; o <<= 1) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) aw[e] += __shfl_xor(aw[e], o, 64);
+    ab += __shfl_xor(ab, o, 64);
+  }
+  const int wave = tid >> 6, lane = tid & 63;
+  if (lane < 8) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sAcc[wave * 2][lane * 4 + e] = aw[e];
+    if (lane == 0) sAcc[wave * 2][32] = ab;
+  }
+  __syncthreads();
+  if (tid < 33) part[(size_t)blockIdx.x * 33 + tid] = sAcc[0][tid] + sAcc[2][tid] + sAcc[4][tid] + sAcc[6][tid];
+}
+__global__ void head_grad_reduce_kernel(const float* __restrict__ part, int nblocks, float* __restrict__ dwh, float* __restrict__ dbh) {
+  const int c = threadIdx.x;
+  if (c >= 33) return;
+  double s = 0.0;
+  for (int k = 0; k < nblocks; ++k) s += (double)part[(size_t)k * 33 + c];
+  if (c < 32) dwh[c] = (float)s;
+  else dbh[0] = (float)s;
+}
+int head_bwd_blocks(int batch, int64_t vox) {
+  int64_t n = ((int64_t)batch * vox + 255) / 256;
+  return (int)(n > 1024 ? 1024 : (n < 1 ? 1 : n));
+}
+void launch_head_loss_bwd(const float* x0, const float* data, const float* scal, const float* h, const float* wh, float* dh,
+                          float* part, float* dwh, float* dbh, int batch, int64_t vox, hipStream_t s) {
+  const int nb = head_bwd_blocks(batch, vox);
+  hipLaunchKernelGGL(head_loss_bwd_kernel, dim3(nb), dim3(256), 0, s, x0, data, scal, h, wh, dh, part, batch, vox);
+  hipLaunchKernelGGL(head_grad_reduce_kernel, dim3(1), dim3(64), 0, s, part, nb, dwh, dbh);
+  CD_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// init conv weight gradient (few input channels, coordinate channels synthesised as in init_conv_kernel):
+//   dW[co][ci][tap] = sum_{b,v} g[b][v][co] * xin[b][in(v,tap)][ci]
+// lane = output channel; a wave walks a voxel range with 27*CIN accumulators per lane; partials [b][chunk][tap*CIN+ci][32]
+// ------------------------------------------------------------------------------------------------------------
+template <int CIN>
+__global__ void __launch_bounds__(256) init_wgrad_kernel(InitConvArgs a, const float* __restrict__ g, float* __restrict__ part,
+                                                         int chunk_vox, int nchunks) {
+  __shared__ float red[4][27 * CIN][32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int co = lane & 31, half = lane >> 5;
+  const int chunk = blockIdx.x, b = blockIdx.y, ct = blockIdx.z;
+  const int D = a.dims.d, H = a.dims.h, W = a.dims.w;
+  const int64_t vox = a.dims.vox();
+  const float sc = a.scale_b ? a.scale_b[(size_t)b * a.scale_stride] : 1.f;
+  float acc[27 * CIN];
+#pragma unroll
+  for (int i = 0; i < 27 * CIN; ++i) acc[i] = 0.f;
+  const int v0 = chunk * chunk_vox, v1 = min((int64_t)(v0 + chunk_vox), vox);
+  for (int v = v0 + wave * 2 + half; v < v1; v += 8) {
+    const float gv = g[((size_t)b * vox + v) * a.cout + ct * 32 + co];
+    const int w = v % W, h = (v / W) % H, z = v / (W * H);
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd) {
+      const int zz = z + kd - 1;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        int hh = h + kh - 1;
+        hh = hh < 0 ? hh + H : (hh >= H ? hh - H : hh);
+        hh = hh % H;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int ww = w + kw - 1;
+          const bool inb = zz >= 0 && zz < D && ww >= 0 && ww < W;
+#pragma unroll
+          for (int ci = 0; ci < CIN; ++ci) {
+            float xv = 0.f;
+            if (inb) {
+              if (ci < a.cx) {
+                xv = a.x[(((size_t)b * a.cx + ci) * D + zz) * H * W + (size_t)hh * W + ww];
+                if (ci == 0) xv *= sc;
+              } else {
+                const int k = ci - a.cx;
+                if (a.use_rz) xv = (k == 0) ? a.r_w[ww] : (k == 1 ? a.z_d[zz] : a.phi_h[hh]);
+                else xv = a.phi_h[hh];
+              }
+            }
+            acc[((kd * 3 + kh) * 3 + kw) * CIN + ci] = fmaf(gv, xv, acc[((kd * 3 + kh) * 3 + kw) * CIN + ci]);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 27 * CIN; ++i) {
+    const float t = acc[i] + __shfl_xor(acc[i], 32, 64);
+    if (half == 0) red[wave][i][co] = t;
+  }
+  __syncthreads();
+  float* dst = part + ((((size_t)b * nchunks + chunk) * gridDim.z + ct) * 27 * CIN) * 32;
+  for (int i = tid; i < 27 * CIN * 32; i += 256) {
+    const int r = i >> 5, c = i & 31;
+    dst[i] = (red[0][r][c] + red[1][r][c]) + (red[2][r][c] + red[3][r][c]);
+  }
+}
+__global__ void init_wgrad_reduce_kernel(const float* __restrict__ part, int nslots, int ctiles, int cin, int cout, float* __restrict__ dw) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // over cout*cin*27
+  if (idx >= cout * cin * 27) return;
+  const int tap = idx % 27, ci = (idx / 27) % cin, co = idx / (27 * cin);
+  const int ct = co / 32, c = co % 32;
+  double s = 0.0;
+  for (int k = 0; k < nslots; ++k) s += (double)part[((((size_t)k * ctiles + ct) * 27 * cin) + tap * cin + ci) * 32 + c];
+  dw[idx] = (float)s;
+}
+size_t init_wgrad_partial_floats(int batch, int64_t vox, int cin, int cout) {
+  const int nchunks = (int)((vox + 1023) / 1024);
+  return (size_t)batch * nchunks * (cout / 32) * 27 * cin * 32;
+}
+void launch_init_wgrad(const InitConvArgs& a, const float* g, float* part, float* dw, hipStream_t s) {
+  const int64_t vox = a.dims.vox();
+  const int nchunks = (int)((vox + 1023) / 1024);
+  dim3 grid(nchunks, a.batch, a.cout / 32);
+  switch (a.cin) {
+    case 1: hipLaunchKernelGGL(init_wgrad_kernel<1>, grid, dim3(256), 0, s, a, g, part, 1024, nchunks); break;
+    case 2: hipLaunchKernelGGL(init_wgrad_kernel<2>, grid, dim3(256), 0, s, a, g, part, 1024, nchunks); break;
+    case 3: hipLaunchKernelGGL(init_wgrad_kernel<3>, grid, dim3(256), 0, s, a, g, part, 1024, nchunks); break;
+    case 4: hipLaunchKernelGGL(init_wgrad_kernel<4>, grid, dim3(256), 0, s, a, g, part, 1024, nchunks); break;
+    default: CD_REQUIRE(false, "init conv wgrad: 1..4 input channels");
+  }
+  const int total = a.cout * a.cin * 27;
+  hipLaunchKernelGGL(init_wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, part, a.batch * nchunks, a.cout / 32, a.cin,
+                     a.cout, dw);
+  CD_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Conditioning MLPs backward (forward: embed_kernel).  One block per sample recomputes the tiny forward, back-propagates
+// demb (gradient of every ResnetBlock projection output) down to the first layers and leaves, per sample, each Linear's
+// input activation and output delta in `tape`; linear_wgrad_kernel then forms dW = sum_b delta x input, db = sum_b delta.
+// tape row layout per sample (floats): see EmbedTapeLayout.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_erf_b(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad(float x) {
+  return 0.5f * (1.f + erff(x * 0.70710678118654752440f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
+}
+// y = W x + b (pre-activation) for all outputs; block-cooperative (thread per output row, serial dot: tiny sizes)
+__device__ void dense_pre(const float* __restrict__ w, const float* __restrict__ bias, const float* in, float* pre, int nin, int nout) {
+  for (int j = threadIdx.x; j < nout; j += blockDim.x) {
+    float acc = bias[j];
+    for (int k = 0; k < nin; ++k) acc = fmaf(w[(size_t)j * nin + k], in[k], acc);
+    pre[j] = acc;
+  }
+  __syncthreads();
+}
+// din[k] = sum_j W[j][k] * dout[j]
+__device__ void dense_bwd_in(const float* __restrict__ w, const float* dout, float* din, int nin, int nout) {
+  for (int k = threadIdx.x; k < nin; k += blockDim.x) {
+    float acc = 0.f;
+    for (int j = 0; j < nout; ++j) acc = fmaf(w[(size_t)j * nin + k], dout[j], acc);
+    din[k] = acc;
+  }
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(256) embed_bwd_kernel(EmbedArgs a, const float* __restrict__ demb, float* __restrict__ tape) {
+  __shared__ float p1t[128], p2t[128], p1c[256], p2c[128], cat[256], sc[256], dcat[256], tmpA[256], tmpB[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int half = a.half, q = half / 2, hid = a.cond_hidden;
+  const EmbedTapeLayout L = embed_tape_layout(a.cond_size, hid, half);
+  float* T = tape + (size_t)b * L.total;
+  const float tv = a.time_or_sigma[b];
+  float t_in = tv;
+  if (a.time_kind == 0) t_in = 0.5f * logf(tv);
+  else if (a.time_kind == 1) t_in = tv / sqrtf(1.f + tv * tv);
+  // ---- forward recompute (pre-activations kept) ----
+  if (tid == 0) { tmpA[0] = t_in; T[L.t_in] = t_in; }
+  __syncthreads();
+  dense_pre(a.tw1, a.tb1, tmpA, p1t, 1, q);
+  for (int i = tid; i < q; i += blockDim.x) { tmpB[i] = gelu_erf_b(p1t[i]); T[L.a1t + i] = tmpB[i]; }
+  __syncthreads();
+  dense_pre(a.tw2, a.tb2, tmpB, p2t, q, half);
+  for (int i = tid; i < half; i += blockDim.x) { tmpA[i] = gelu_erf_b(p2t[i]); T[L.a2t + i] = tmpA[i]; }
+  __syncthreads();
+  dense_pre(a.tw3, a.tb3, tmpA, cat, half, half);
+  for (int i = tid; i < a.cond_size; i += blockDim.x) { tmpA[i] = a.cond[(size_t)b * a.cond_size + i]; T[L.cond_in + i] = tmpA[i]; }
+  __syncthreads();
+  dense_pre(a.cw1, a.cb1, tmpA, p1c, a.cond_size, hid);
+  for (int i = tid; i < hid; i += blockDim.x) { tmpB[i] = gelu_erf_b(p1c[i]); T[L.a1c + i] = tmpB[i]; }
+  __syncthreads();
+  dense_pre(a.cw2, a.cb2, tmpB, p2c, hid, half);
+  for (int i = tid; i < half; i += blockDim.x) { tmpA[i] = gelu_erf_b(p2c[i]); T[L.a2c + i] = tmpA[i]; }
+  __syncthreads();
+  dense_pre(a.cw3, a.cb3, tmpA, cat + half, half, half);
+  for (int i = tid; i < 2 * half; i += blockDim.x) {
+    const float v = cat[i];
+    sc[i] = v / (1.f + expf(-v));
+    T[L.sc + i] = sc[i];
+  }
+  __syncthreads();
+  // ---- backward: dsc = sum_l W_l^T demb_l ; dcat = dsc * silu'(cat) ----
+  for (int k = tid; k < 2 * half; k += blockDim.x) {
+    float acc = 0.f;
+    for (int l = 0; l < a.n_layers; ++l) {
+      const EmbedLayer Ly = a.layers[l];
+      const float* d = demb + (size_t)b * a.emb_ld + Ly.offset;
+      for (int j = 0; j < Ly.cout; ++j) acc = fmaf(Ly.w[(size_t)j * 2 * half + k], d[j], acc);
+    }
+    const float v = cat[k];
+    const float sg = 1.f / (1.f + expf(-v));
+    dcat[k] = acc * sg * (1.f + v * (1.f - sg));
+  }
+  __syncthreads();
+  // time branch: cat[0:half] = W3 a2t + b3
+  for (int i = tid; i < half; i += blockDim.x) T[L.d3t + i] = dcat[i];
+  dense_bwd_in(a.tw3, dcat, tmpA, half, half);                       // d a2t
+  for (int i = tid; i < half; i += blockDim.x) { tmpA[i] *= gelu_grad(p2t[i]); T[L.d2t + i] = tmpA[i]; }
+  __syncthreads();
+  dense_bwd_in(a.tw2, tmpA, tmpB, q, half);                          // d a1t
+  for (int i = tid; i < q; i += blockDim.x) { tmpB[i] *= gelu_grad(p1t[i]); T[L.d1t + i] = tmpB[i]; }
+  __syncthreads();
+  // cond branch: cat[half:] = W3c a2c + b3c
+  for (int i = tid; i < half; i += blockDim.x) T[L.d3c + i] = dcat[half + i];
+  dense_bwd_in(a.cw3, dcat + half, tmpA, half, half);
+  for (int i = tid; i < half; i += blockDim.x) { tmpA[i] *= gelu_grad(p2c[i]); T[L.d2c + i] = tmpA[i]; }
+  __syncthreads();
+  dense_bwd_in(a.cw2, tmpA, tmpB, hid, half);
+  for (int i = tid; i < hid; i += blockDim.x) { tmpB[i] *= gelu_grad(p1c[i]); T[L.d1c + i] = tmpB[i]; }
+}
+size_t embed_tape_floats(int cond_size, int hidden, int half) { return (size_t)embed_tape_layout(cond_size, hidden, half).total; }
+void launch_embed_bwd(const EmbedArgs& a, const float* demb, float* tape, hipStream_t s) {
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(a.batch), dim3(256), 0, s, a, demb, tape);
+  CD_HIP(hipGetLastError());
+}
+
+// dW[j][k] = sum_b delta[b][j] * in[b][k],  db[j] = sum_b delta[b][j];  blockIdx.y = job
+__global__ void linear_wgrad_kernel(const LinearWgradJob* __restrict__ jobs, int batch) {
+  const LinearWgradJob J = jobs[blockIdx.y];
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < J.nout * J.nin) {
+    const int j = idx / J.nin, k = idx % J.nin;
+    float s = 0.f;
+    for (int b = 0; b < batch; ++b) s = fmaf(J.delta[(size_t)b * J.delta_ld + j], J.in[(size_t)b * J.in_ld + k], s);
+    J.dw[idx] = s;
+  }
+  if (idx < J.nout) {
+    float s = 0.f;
+    for (int b = 0; b < batch; ++b) s += J.delta[(size_t)b * J.delta_ld + idx];
+    J.db[idx] = s;
+  }
+}
+void launch_linear_wgrad(const LinearWgradJob* jobs_dev, int njobs, int max_elems, int batch, hipStream_t s) {
+  hipLaunchKernelGGL(linear_wgrad_kernel, dim3((max_elems + 255) / 256, njobs), dim3(256), 0, s, jobs_dev, batch);
+  CD_HIP(hipGetLastError());
+}
+
 size_t gn_backward_scratch_floats(int batch, int channels, int64_t vox) {
   const int ns = gn_nsplit_for(vox, batch);
   return (size_t)batch * ns * channels * 3 + (size_t)batch * channels * 6 + 64;

@@ -1851,6 +1851,12 @@ __global__ void __launch_bounds__(256) pointwise_kernel(PointwiseArgs a, int CTt
           const f32x4 cf = *(const f32x4*)(cfp + (q * 4 + e) * 4);
           av[q][e] = cf[0] * av[q][e] + cf[1];
         }
+    } else if (PRO == A_EXPNORM) {
+      const float* cfp = a.coef + ((size_t)b * (a.c0 + a.c1) + chunk * 32 + half * 16) * 2;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) av[q][e] = valid ? expf(av[q][e] - cfp[(q * 4 + e) * 2]) * cfp[(q * 4 + e) * 2 + 1] : 0.f;
     } else if (PRO == A_SOFTMAX32) {
       float m = av[0][0];
 #pragma unroll
@@ -1898,7 +1904,7 @@ __global__ void __launch_bounds__(256) pointwise_kernel(PointwiseArgs a, int CTt
           const size_t o = ((size_t)b * a.vox + nr) * a.cout + co;
           float v = acc[ct][r] + (a.bias ? a.bias[co] : 0.f);
           if (a.residual) v += a.residual[o];
-          a.out[o] = v;
+          a.out[((size_t)b * a.vox + nr) * (a.out_ld ? a.out_ld : a.cout) + a.out_off + co] = v;
         }
       }
     }
@@ -1957,6 +1963,7 @@ void launch_pointwise(const PointwiseArgs& a, hipStream_t s) {
   CD_PW_CASE(1, A_NONE) CD_PW_CASE(2, A_NONE) CD_PW_CASE(3, A_NONE)
   CD_PW_CASE(1, A_AFFINE) CD_PW_CASE(2, A_AFFINE) CD_PW_CASE(3, A_AFFINE)
   CD_PW_CASE(1, A_SOFTMAX32) CD_PW_CASE(2, A_SOFTMAX32) CD_PW_CASE(3, A_SOFTMAX32)
+  CD_PW_CASE(1, A_EXPNORM) CD_PW_CASE(2, A_EXPNORM) CD_PW_CASE(3, A_EXPNORM)
 #undef CD_PW_CASE
   CD_REQUIRE(false, "pointwise conv: no kernel instance");
 }

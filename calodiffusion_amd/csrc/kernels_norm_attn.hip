@@ -310,7 +310,8 @@ void launch_attn_context(const float* qkv, float* partials, int batch, int64_t v
 
 __global__ void __launch_bounds__(256) attn_combine_kernel(const float* __restrict__ partials, int nsplit,
                                                            const float* __restrict__ w_out, int cout,
-                                                           float* __restrict__ wpk_b, float scale) {
+                                                           float* __restrict__ wpk_b, float scale, float* __restrict__ ctx_out,
+                                                           float* __restrict__ kstat_out) {
   __shared__ float sM[32], sInv[32];
   __shared__ float sCtx[1024];
   const int tid = threadIdx.x, b = blockIdx.x;
@@ -322,6 +323,10 @@ __global__ void __launch_bounds__(256) attn_combine_kernel(const float* __restri
     for (int i = 0; i < nsplit; ++i) S += p[(size_t)i * 1088 + 32 + tid] * expf(p[(size_t)i * 1088 + tid] - M);
     sM[tid] = M;
     sInv[tid] = scale / S;
+    if (kstat_out) {
+      kstat_out[((size_t)b * 32 + tid) * 2] = M;
+      kstat_out[((size_t)b * 32 + tid) * 2 + 1] = 1.f / S;
+    }
   }
   __syncthreads();
   for (int i = tid; i < 1024; i += 256) {
@@ -329,6 +334,7 @@ __global__ void __launch_bounds__(256) attn_combine_kernel(const float* __restri
     float c = 0.f;
     for (int k = 0; k < nsplit; ++k) c += p[(size_t)k * 1088 + 64 + i] * expf(p[(size_t)k * 1088 + d] - sM[d]);
     sCtx[i] = c * sInv[d];
+    if (ctx_out) ctx_out[(size_t)b * 1024 + i] = sCtx[i] / scale;
   }
   __syncthreads();
   // W'[c][d] = sum_e W_out[c][e] * ctx[d][e]; packed: ((ct*4+q)*64 + h*32+j)*4+e4 with c = ct*32+j, d = h*16 + 4q + e4
@@ -345,9 +351,10 @@ __global__ void __launch_bounds__(256) attn_combine_kernel(const float* __restri
 }
 
 void launch_attn_combine(const float* partials, int nsplit, const float* w_out, int cout, float* wpk_b, int batch,
-                         float scale, hipStream_t s) {
+                         float scale, hipStream_t s, float* ctx_out, float* kstat_out) {
   prof::Scope scope("attn_combine", s, 0, 0);
-  hipLaunchKernelGGL(attn_combine_kernel, dim3(batch), dim3(256), 0, s, partials, nsplit, w_out, cout, wpk_b, scale);
+  hipLaunchKernelGGL(attn_combine_kernel, dim3(batch), dim3(256), 0, s, partials, nsplit, w_out, cout, wpk_b, scale, ctx_out,
+                     kstat_out);
   CD_HIP(hipGetLastError());
 }
 

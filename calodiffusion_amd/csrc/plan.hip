@@ -30,6 +30,7 @@ struct WeightEntry {
   int cin = 0, cout = 0, taps = 0;
   size_t pk_off = 0;
   size_t pk3_off = 0;  // split-bf16 image of 3x3x3 convs (floats into the arena; 0 = none)
+  size_t grad_off = 0; // floats into the flat gradient buffer of cd_train_step
   bool set = false;
 };
 
@@ -154,6 +155,11 @@ struct CdPlan {
       return batch == o.batch && ws == o.ws && cond == o.cond && x == o.x && noisy == o.noisy && seed == o.seed && offset == o.offset;
     }
   } graph_key;
+
+  // training: flat gradient layout and the device job list of the small Linear weight gradients
+  size_t grad_floats = 0;
+  std::vector<LinearWgradJob> lin_jobs_host;
+  LinearWgradJob* d_lin_jobs = nullptr;
 
   Arena ws;
 
@@ -320,6 +326,13 @@ void build_plan(CdPlan* p) {
     else if (w.pack == PK_INIT) w.pk_off = bump((size_t)w.numel);
   }
   p->arena_floats = off;
+  size_t goff = 0;
+  for (auto& w : p->weights) {
+    w.grad_off = goff;
+    goff += ((size_t)w.numel + 63) & ~(size_t)63;
+  }
+  p->grad_floats = goff;
+  CD_HIP(hipMalloc((void**)&p->d_lin_jobs, sizeof(LinearWgradJob) * 64));
   CD_HIP(hipMalloc((void**)&p->arena, off * sizeof(float)));
   CD_HIP(hipMemset(p->arena, 0, off * sizeof(float)));
 
@@ -760,6 +773,8 @@ void forward_impl(CdPlan* p, int B, const float* x, const float* cond, const flo
   r.ws->release(emb);
 }
 
+#include "train.inc"
+
 template <typename F>
 int guarded(F&& f) {
   try {
@@ -827,6 +842,7 @@ int cd_plan_destroy(CdPlan* plan) {
     if (plan->d_table) hipFree(plan->d_table);
     if (plan->d_counter) hipFree(plan->d_counter);
     if (plan->d_stepvals) hipFree(plan->d_stepvals);
+    if (plan->d_lin_jobs) hipFree(plan->d_lin_jobs);
     delete plan;
   });
 }
@@ -1010,6 +1026,37 @@ int cd_ddim_sample(CdPlan* plan, int batch, const float* start, const float* con
         one_step(s, i, step_noise ? step_noise + (size_t)i * n : nullptr, xs ? xs + (size_t)i * n : nullptr,
                  x0s ? x0s + (size_t)i * n : nullptr);
     }
+  });
+}
+
+int cd_plan_grad_layout(const CdPlan* plan, int idx, int64_t* offset, int64_t* total_floats) {
+  return guarded([&] {
+    CD_REQUIRE(plan, "null argument");
+    if (total_floats) *total_floats = (int64_t)plan->grad_floats;
+    if (offset) {
+      CD_REQUIRE(idx >= 0 && idx < (int)plan->weights.size(), "weight index out of range");
+      *offset = (int64_t)plan->weights[idx].grad_off;
+    }
+  });
+}
+
+int cd_plan_train_workspace_bytes(CdPlan* plan, int batch, size_t* bytes) {
+  return guarded([&] {
+    CD_REQUIRE(plan && bytes && batch > 0, "bad argument");
+    plan->ws.reset(nullptr, 0, true);
+    train_step_impl(plan, batch, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    *bytes = plan->ws.high() + 4096;
+  });
+}
+
+int cd_train_step(CdPlan* plan, int batch, const float* data, const float* noise, const float* sigma, const float* cond,
+                  double* loss_out, float* grads, void* workspace, size_t workspace_bytes, void* stream) {
+  return guarded([&] {
+    CD_REQUIRE(plan && data && noise && sigma && cond && loss_out && grads && workspace && batch > 0, "bad argument");
+    CD_REQUIRE(plan->desc.objective == CD_OBJ_HYBRID, "cd_train_step implements the hybrid_weight objective");
+    check_ready(plan, true);
+    plan->ws.reset((char*)workspace, workspace_bytes, false);
+    train_step_impl(plan, batch, data, noise, sigma, cond, loss_out, grads, (hipStream_t)stream);
   });
 }
 

@@ -61,6 +61,9 @@ _SIGNATURES = {
     "cd_ddim_sample": (C.c_int, [_P, C.c_int, _P, _P, C.POINTER(CdStep), C.c_int, _P, C.c_uint64, C.c_uint64, _P, _P, _P,
                                  C.c_int, _P, C.c_size_t, _P]),
     "cd_randn": (C.c_int, [_P, C.c_int64, C.c_uint64, C.c_uint64, _P]),
+    "cd_plan_grad_layout": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "cd_plan_train_workspace_bytes": (C.c_int, [_P, C.c_int, C.POINTER(C.c_size_t)]),
+    "cd_train_step": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "cd_profile_begin": (C.c_int, []),
     "cd_profile_end": (C.c_int, [C.c_char_p, C.c_int]),
     "cd_loss_hybrid_l2": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
@@ -287,6 +290,54 @@ class UnetEngine:
                                        int(offset), x_out.data_ptr(), _ptr(xs), _ptr(x0s), int(bool(use_graph)),
                                        ws.data_ptr(), ws.numel(), _stream()))
         return x_out, xs, x0s
+
+    # ------------------------------------------------------------------ training
+    def grad_layout(self):
+        """{state_dict name: (offset, numel)} into the flat gradient buffer, and its total length."""
+        if getattr(self, "_grad_layout", None) is None:
+            n = C.c_int()
+            _check(self.lib.cd_plan_num_weights(self.plan, C.byref(n)))
+            buf = C.create_string_buffer(256)
+            numel, off, total = C.c_int64(), C.c_int64(), C.c_int64()
+            lay = {}
+            for i in range(n.value):
+                _check(self.lib.cd_plan_weight_name(self.plan, i, buf, 256, C.byref(numel)))
+                _check(self.lib.cd_plan_grad_layout(self.plan, i, C.byref(off), C.byref(total)))
+                lay[buf.value.decode()] = (off.value, numel.value)
+            self._grad_layout = (lay, total.value)
+        return self._grad_layout
+
+    def train_workspace(self, batch: int) -> torch.Tensor:
+        ws = getattr(self, "_tws", {}).get(batch)
+        if ws is None:
+            nbytes = C.c_size_t()
+            _check(self.lib.cd_plan_train_workspace_bytes(self.plan, batch, C.byref(nbytes)))
+            ws = torch.empty(nbytes.value, dtype=torch.uint8, device=self.device)
+            self._tws = {batch: ws}
+        return ws
+
+    def train_step(self, data, noise, sigma, cond):
+        """hybrid_weight/l2 loss and the gradient of every parameter (flat fp32 buffer, see grad_layout)."""
+        data, noise, cond = _dev32(data, "data"), _dev32(noise, "noise"), _dev32(cond, "cond")
+        sigma = _dev32(sigma, "sigma").reshape(-1)
+        B = data.shape[0]
+        self.sync_weights()
+        ws = self.train_workspace(B)
+        _, total = self.grad_layout()
+        flat = torch.empty(total, dtype=torch.float32, device=data.device)
+        loss = torch.empty((), dtype=torch.float64, device=data.device)
+        _check(self.lib.cd_train_step(self.plan, B, data.data_ptr(), noise.data_ptr(), sigma.data_ptr(), cond.data_ptr(),
+                                      loss.data_ptr(), flat.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+        return loss, flat
+
+    def param_grads(self, flat):
+        """Views of the flat gradient buffer, one per parameter of the bound CondUnet, in .parameters() order."""
+        lay, _ = self.grad_layout()
+        out = []
+        for name, p in self.unet.named_parameters():
+            off, numel = lay[name]
+            out.append(flat[off:off + numel].view(p.shape))
+        return out
 
     def loss_hybrid_l2(self, data, noise, sigma, cond):
         data, noise, cond = _dev32(data, "data"), _dev32(noise, "noise"), _dev32(cond, "cond")

@@ -54,6 +54,22 @@ class Loss:
         raise NotImplementedError
 
 
+class _TrainStep(torch.autograd.Function):
+    """Loss value and parameter gradients from ONE call into the HIP library (cd_train_step); autograd only sees a
+    node whose backward hands the pre-computed gradients (scaled by the incoming gradient) to the parameters."""
+
+    @staticmethod
+    def forward(ctx, engine, data, noise, sigma, cond, *params):
+        loss, flat = engine.train_step(data, noise, sigma, cond)
+        ctx.engine, ctx.flat = engine, flat
+        return loss.to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        grads = ctx.engine.param_grads(ctx.flat)
+        return (None, None, None, None, None) + tuple(g * grad_out for g in grads)
+
+
 class hybrid_weight(Loss):
     """x0-prediction with weight 1 + sigma^-2 (models/loss.py:163-179); value computed by cd_loss_hybrid_l2."""
 
@@ -63,4 +79,9 @@ class hybrid_weight(Loss):
     def loss_function(self, model, data, E, sigma=None, noise=None, layers=None):
         if self.loss_type != "l2":
             raise NotImplementedError("the HIP path implements LOSS_TYPE 'l2' (the only one the shipped configs use)")
-        return model.engine().loss_hybrid_l2(data, noise, sigma, model.cond_tensor(E, layers))
+        cond = model.cond_tensor(E, layers)
+        params = list(model.model.parameters())
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            # training: TrainDiffusion.training_loop calls loss.backward(); optimizer.step() on the result
+            return _TrainStep.apply(model.engine(), data, noise, sigma, cond, *params)
+        return model.engine().loss_hybrid_l2(data, noise, sigma, cond)

@@ -124,6 +124,17 @@ int cd_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream
 int cd_loss_hybrid_l2(CdPlan* plan, int batch, const float* data, const float* noise, const float* sigma,
                       const float* cond, double* loss_out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- training step ----------------------------------------------------------------------------------------------- */
+/* Body of TrainDiffusion.training_loop (train/train_diffusion.py:52-63) up to loss.backward(): the hybrid_weight/l2 loss
+ * (as cd_loss_hybrid_l2) AND the gradient of that loss with respect to every parameter, written to `grads`, a flat fp32
+ * buffer laid out as cd_plan_grad_layout reports (tensor idx of cd_plan_weight_name starts at *offset, torch layout;
+ * *total_floats = size of the buffer).  Workspace: cd_plan_train_workspace_bytes (the forward's activations are kept
+ * until the backward has consumed them). */
+int cd_plan_grad_layout(const CdPlan* plan, int idx, int64_t* offset, int64_t* total_floats);
+int cd_plan_train_workspace_bytes(CdPlan* plan, int batch, size_t* bytes);
+int cd_train_step(CdPlan* plan, int batch, const float* data, const float* noise, const float* sigma, const float* cond,
+                  double* loss_out, float* grads, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- measurement ---------------------------------------------------------------------------------------------- */
 /* Per-launch timing with HIP events on the launch stream (eager mode; graphs are bypassed while active).
  * cd_profile_end synchronises the device and writes a JSON object
