@@ -135,6 +135,47 @@ def roofline_leg(model, cfg, batch, E, layers):
     return roof, breakdown
 
 
+def train_bench(args, model, cfg, E, layers, rank, world):
+    """Training throughput (BASELINE configs[2]): zero_grad -> compute_loss -> backward -> Adam.step per iteration, as
+    TrainDiffusion.training_loop does; data-parallel replicas with one flat gradient all-reduce per step."""
+    B = args.batch
+    g = torch.Generator().manual_seed(4321 + rank)
+    shape = [B] + list(cfg["SHAPE_PAD"][1:])
+    data = torch.randn(shape, generator=g).cuda()
+    noise = torch.randn(shape, generator=g).cuda()
+    rnd = torch.randn((B,), generator=g).cuda()
+    opt = torch.optim.Adam(model.parameters(), lr=float(cfg["LR"]))
+
+    def step():
+        opt.zero_grad()
+        loss = model.compute_loss(data, E, noise=noise, layers=layers, rnd_normal=rnd)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0)
+    result = {"metric": f"training samples/sec ({args.config}, hybrid_weight l2, Adam)", "value": world * args.steps * B / dt,
+              "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+              "config": {"workload": f"{args.config} training step, batch {B} per GPU", "global_batch": B * world,
+                         "parallelism": f"data-parallel x{world}, one flat fp32 gradient all-reduce per step",
+                         "final_loss": float(loss)}}
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -147,6 +188,8 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the roofline and cpu_baseline legs")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel breakdown to stderr")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg only")
+    ap.add_argument("--mode", default="sample", choices=["sample", "train"],
+                    help="train: BASELINE configs[2], a step = one training iteration (fwd + bwd + grad all-reduce + Adam)")
     args = ap.parse_args()
 
     rank, local_rank, world = dist_info()
@@ -172,6 +215,9 @@ def main():
     # disjoint slices of one Philox stream per rank: (start + per-step noise) * steps per sample() call
     model.noise_offset = rank * (args.steps + args.warmup + 4) * (args.sample_steps + 2) * B * vox
     E, layers = synthetic_inputs(cfg, B, rank, "cuda")
+
+    if args.mode == "train":
+        return train_bench(args, model, cfg, E, layers, rank, world)
 
     def one_pass():
         out = model.sample(E, layers, num_steps=args.sample_steps)  # returns a host ndarray (final D2H included)

@@ -4,7 +4,7 @@ from __future__ import annotations
 import torch
 
 from . import schedule
-from .utils import subsample_alphas
+from .utils import allreduce_mean_, subsample_alphas
 
 
 class Loss:
@@ -61,6 +61,7 @@ class _TrainStep(torch.autograd.Function):
     @staticmethod
     def forward(ctx, engine, data, noise, sigma, cond, *params):
         loss, flat = engine.train_step(data, noise, sigma, cond)
+        allreduce_mean_(flat)  # data parallel: identical replicas, one flat-buffer all-reduce per step
         ctx.engine, ctx.flat = engine, flat
         return loss.to(torch.float32)
 

@@ -82,3 +82,14 @@ def shard_batch(n: int, world_size: int, rank: int) -> slice:
     base, rem = divmod(n, world_size)
     lo = rank * base + min(rank, rem)
     return slice(lo, lo + base + (1 if rank < rem else 0))
+
+
+def allreduce_mean_(flat: torch.Tensor) -> torch.Tensor:
+    """Data-parallel gradient exchange: ONE sum all-reduce of the flat fp32 gradient buffer (8.85 MB for Dataset-2) over
+    the default process group (RCCL over xGMI on GPUs, gloo in the CPU tests), then the mean.  No-op outside a
+    multi-process job.  This is the only collective of the training path."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(dist.get_world_size())
+    return flat

@@ -48,6 +48,31 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+def _grad_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from calodiffusion_amd.utils import allreduce_mean_
+    g = torch.Generator().manual_seed(100 + rank)
+    flat = torch.randn(2212785, generator=g)  # Dataset-2 parameter count: the flat gradient buffer of one rank
+    np.save(os.path.join(out_dir, f"g{rank}.npy"), flat.numpy())
+    allreduce_mean_(flat)
+    np.save(os.path.join(out_dir, f"r{rank}.npy"), flat.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_is_the_mean_over_ranks(tmp_path):
+    world = 2
+    mp.spawn(_grad_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mean = sum(np.load(tmp_path / f"g{r}.npy") for r in range(world)) / world
+    for r in range(world):
+        assert np.allclose(np.load(tmp_path / f"r{r}.npy"), mean, rtol=0, atol=1e-7)
+    # outside a process group it is the identity
+    from calodiffusion_amd.utils import allreduce_mean_
+    x = torch.arange(5.0)
+    assert torch.equal(allreduce_mean_(x.clone()), x)
+
+
 def test_sharded_sampling_equals_single_process(tmp_path):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
