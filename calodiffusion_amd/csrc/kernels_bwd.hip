@@ -9,6 +9,7 @@
 //   * small elementwise pieces (loss gradient, softmax backward of the linear attention, head).
 #include "cd_common.h"
 #include <cstdio>
+#include <cstdlib>
 
 namespace cd {
 
@@ -38,8 +39,8 @@ struct WgradArgs {
   float* partial;         // [(n if per_sample)][chunk (x batch if !per_sample)][tileA][tileB][tap][32][32]
 };
 
-template <int TPW>  // taps per wave (upper bound)
-__global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
+template <int TPW>  // taps per wave (upper bound); blockDim = 64 * ceil(T / TPW)
+__global__ void __launch_bounds__(1024) wgrad_kernel(WgradArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, col = lane & 31;
   const int T = a.KD * a.KH * a.KW;
@@ -99,6 +100,147 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Weight gradient of the stride-1 3x3x3 conv, LDS-staged and persistent (the hot backward kernel).
+// A workgroup loops over (sample, 256-voxel flat range) units; per unit it stages the output-gradient rows [R][32] and
+// the input z-planes the range touches (+1 halo plane each side, zero outside) as [voxel][32] fp32, plus a per-voxel
+// record (LDS index, phi/r edge flags).  Its waves split the 27 taps; a wave keeps one 32x32 accumulator per tap in
+// registers across ALL its units and writes ONE partial per workgroup (grid = CU count => 256 partial slots instead of one
+// per voxel chunk).  K = 2 voxels per v_mfma_f32_32x32x2_f32: lane half h takes voxel 2p+h, lanes are channels, so both
+// LDS operand reads are conflict-free 128-B rows.
+// ------------------------------------------------------------------------------------------------------------
+struct WgradFlatArgs {
+  const float* g;   // (B, vox, A)
+  const float* x;   // (B, vox, xld) read at channel offset xoff
+  int A, xld, xoff;
+  int D, H, W;
+  int R, P;         // voxels per unit, plane capacity
+  int units_per_sample, total_units;
+  float* partial;   // [gridDim.x][tilesA][tilesB][27][32][32]
+  int tilesB;
+};
+
+template <int TPW>
+__global__ void __launch_bounds__(64 * ((27 + TPW - 1) / TPW)) wgrad_flat_kernel(WgradFlatArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int NW = (27 + TPW - 1) / TPW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, col = lane & 31;
+  const int ta = blockIdx.y / a.tilesB, tb = blockIdx.y % a.tilesB;
+  const int HW = a.H * a.W, vox = a.D * HW;
+  float* gL = lds;                                   // [R][32]
+  float* xL = lds + a.R * 32;                        // [P*HW][32]
+  int* tbl = (int*)(xL + (size_t)a.P * HW * 32);     // [R]
+
+  // this wave's taps
+  int toff[TPW], tdh[TPW], tdw[TPW];
+  int ntap = 0;
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int tap = wave + t * NW;
+    const int dz = tap / 9 - 1, dh = (tap / 3) % 3 - 1, dw = tap % 3 - 1;
+    toff[t] = dz * HW + dh * a.W + dw;
+    tdh[t] = dh;
+    tdw[t] = dw;
+    if (tap < 27) ntap = t + 1;
+  }
+  f32x16 acc[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  for (int u = blockIdx.x; u < a.total_units; u += gridDim.x) {
+    const int n = u / a.units_per_sample, ux = u - n * a.units_per_sample;
+    const int v0 = ux * a.R, vend = min(v0 + a.R, vox);
+    const int zA = v0 / HW - 1, zB = (vend - 1) / HW + 1;
+    const int nstage = (zB - zA + 1) * HW, gbase = zA * HW;
+    __syncthreads();  // previous unit fully consumed
+    {
+      const float* gs = a.g + ((size_t)n * vox + v0) * a.A + ta * 32;
+      for (int i0 = tid; i0 < a.R * 8; i0 += 4 * blockDim.x) {
+        f32x4 val[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int i = i0 + k * blockDim.x;
+          val[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (i < a.R * 8 && v0 + (i >> 3) < vend) val[k] = *(const f32x4*)(gs + (size_t)(i >> 3) * a.A + (i & 7) * 4);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int i = i0 + k * blockDim.x;
+          if (i < a.R * 8) *(f32x4*)(gL + (i >> 3) * 32 + (i & 7) * 4) = val[k];
+        }
+      }
+      const float* xs = a.x + (size_t)n * vox * a.xld + a.xoff + tb * 32;
+      for (int i0 = tid; i0 < nstage * 8; i0 += 4 * blockDim.x) {
+        f32x4 val[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int i = i0 + k * blockDim.x;
+          const int gv = gbase + (i >> 3);
+          val[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (i < nstage * 8 && gv >= 0 && gv < vox) val[k] = *(const f32x4*)(xs + (size_t)gv * a.xld + (i & 7) * 4);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int i = i0 + k * blockDim.x;
+          if (i < nstage * 8) *(f32x4*)(xL + (i >> 3) * 32 + (i & 7) * 4) = val[k];
+        }
+      }
+      for (int v = tid; v < a.R; v += blockDim.x) {
+        const int gv = v0 + v;
+        int rec = -1;
+        if (gv < vend) {
+          const int r = gv % HW;
+          const int h = r / a.W, w = r - h * a.W;
+          rec = (gv - gbase) | (w == 0 ? 1 << 20 : 0) | (w == a.W - 1 ? 1 << 21 : 0) | (h == 0 ? 1 << 22 : 0) |
+                (h == a.H - 1 ? 1 << 23 : 0);
+        }
+        tbl[v] = rec;
+      }
+    }
+    __syncthreads();
+    // 4 voxel pairs per trip: all their LDS operands are requested before the first MFMA of the group issues
+    constexpr int UP = 4;
+    for (int p0 = 0; p0 < a.R; p0 += 2 * UP) {
+      float gv[UP], xv[UP][TPW];
+#pragma unroll
+      for (int k = 0; k < UP; ++k) {
+        const int p = p0 + 2 * k;
+        const int rec = p < a.R ? tbl[p + half] : -1;
+        gv[k] = p < a.R ? gL[(p + half) * 32 + col] : 0.f;
+        const int nb = rec & 0xfffff;
+        const bool vvalid = rec >= 0;
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+          int nidx = nb + toff[t];
+          if (tdh[t] < 0 && (rec & (1 << 22))) nidx += HW;        // wrap phi: row -1 -> H-1
+          if (tdh[t] > 0 && (rec & (1 << 23))) nidx -= HW;        // row H -> 0
+          const bool ok = vvalid && t < ntap && !(tdw[t] < 0 && (rec & (1 << 20))) && !(tdw[t] > 0 && (rec & (1 << 21)));
+          xv[k][t] = ok ? xL[nidx * 32 + col] : 0.f;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < UP; ++k)
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+          if (t < ntap) acc[t] = MFMA32(gv[k], xv[k][t], acc[t]);
+    }
+  }
+  float* pbase = a.partial + (((size_t)blockIdx.x * (a.A / 32) + ta) * a.tilesB + tb) * (size_t)27 * 1024;
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int tap = wave + t * NW;
+    if (tap < 27) {
+      float* pp = pbase + (size_t)tap * 1024;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pp[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + col] = acc[t][r];
+    }
+  }
+}
+
 // dW (torch layout) = sum over slots of the partial tiles.
 //   transposed_out = 0: dW[a][b][tap] (Conv3d weight, a = out channel)   1: dW[b][a][tap]
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int A, int Bc, int T, int nslots,
@@ -116,8 +258,18 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __
   const int tilesB = Bc / 32;
   const int tb = rest % tilesB, ta = rest / tilesB;
   const float* p = partial + (size_t)n * sample_stride_partial + idx;
-  float s = 0.f;
-  for (int k = 0; k < nslots; ++k) s += p[(size_t)k * total];
+  // 16 independent loads in flight per thread (the slot loop is latency-bound otherwise); fixed summation order
+  float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int k = 0;
+  for (; k + 16 <= nslots; k += 16) {
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = p[(size_t)(k + j) * total];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc8[j & 7] += v[j];
+  }
+  for (; k < nslots; ++k) acc8[k & 7] += p[(size_t)k * total];
+  const float s = ((acc8[0] + acc8[1]) + (acc8[2] + acc8[3])) + ((acc8[4] + acc8[5]) + (acc8[6] + acc8[7]));
   const int ga = ta * 32 + ra, gb2 = tb * 32 + cb;
   // b_total / b_off: the b columns are a slice of a wider weight (second source of a channel concat)
   const size_t o = (transposed_out ? ((size_t)(gb2 + b_off) * A + ga) : ((size_t)ga * b_total + b_off + gb2)) * T + tap;
@@ -127,8 +279,9 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __
 
 // chunks per sample: enough workgroups to fill the chip, chunks of >= 128 voxels, partial volume <= 32 MiB
 int wgrad_chunks(int64_t out_vox, int batch, bool per_sample, int A, int Bc, int T) {
-  int64_t want = per_sample ? 8 : (1024 + batch - 1) / batch;
-  const int64_t cap = (out_vox + 127) / 128;
+  int64_t want = per_sample ? 8 : (512 + batch - 1) / batch;
+  if (T == 1) want = per_sample ? 32 : (4096 + batch - 1) / batch;  // single-wave workgroups, 4 KiB partials: use many
+  const int64_t cap = (out_vox + (T == 1 ? 63 : 127)) / (T == 1 ? 64 : 128);
   if (want > cap) want = cap;
   const int64_t per_slot = (int64_t)A * Bc * T * 4;
   int64_t mem = (32ll << 20) / (per_slot * (per_sample ? 1 : batch));
@@ -137,7 +290,9 @@ int wgrad_chunks(int64_t out_vox, int batch, bool per_sample, int A, int Bc, int
   return (int)(want < 1 ? 1 : want);
 }
 size_t wgrad_partial_floats(int64_t out_vox, int batch, bool per_sample, int A, int Bc, int T) {
-  return (size_t)wgrad_chunks(out_vox, batch, per_sample, A, Bc, T) * batch * A * Bc * T;
+  size_t slots = (size_t)wgrad_chunks(out_vox, batch, per_sample, A, Bc, T) * batch;
+  if (T == 27 && slots < 256) slots = 256;  // the persistent stride-1 kernel writes one partial per workgroup
+  return slots * A * Bc * T;
 }
 
 void launch_wgrad(const float* g, int A, Dims3 dg, const float* x, int Bc, int xld, int xoff, Dims3 dx, int kd, int kh, int kw,
@@ -149,6 +304,46 @@ void launch_wgrad(const float* g, int A, Dims3 dg, const float* x, int Bc, int x
   a.g = g; a.x = x; a.A = A; a.Bc = Bc; a.xld = xld; a.xoff = xoff;
   a.Dg = dg.d; a.Hg = dg.h; a.Wg = dg.w; a.Dx = dx.d; a.Hx = dx.h; a.Wx = dx.w;
   a.KD = kd; a.KH = kh; a.KW = kw; a.SZ = sz; a.S = sxy; a.batch = batch; a.per_sample = per_sample ? 1 : 0;
+  const int Tt = kd * kh * kw;
+  if (Tt == 27 && sz == 1 && sxy == 1 && !per_sample && dg.vox() == dx.vox() && !getenv("CD_NO_WGRAD_FLAT")) {
+    // LDS-staged persistent kernel
+    const int HW = dg.h * dg.w;
+    int R = 256;
+    while (R > 32 && (int64_t)(R / 2) >= dg.vox()) R /= 2;
+    int P = (R - 1) / HW + 4;
+    size_t lds = ((size_t)R * 32 + (size_t)P * HW * 32 + R) * 4;
+    while (lds > 150 * 1024 && R > 32) {
+      R /= 2;
+      P = (R - 1) / HW + 4;
+      lds = ((size_t)R * 32 + (size_t)P * HW * 32 + R) * 4;
+    }
+    if (lds <= 150 * 1024) {
+      WgradFlatArgs f;
+      f.g = g; f.x = x; f.A = A; f.xld = xld; f.xoff = xoff; f.D = dg.d; f.H = dg.h; f.W = dg.w; f.R = R; f.P = P;
+      f.units_per_sample = (int)((dg.vox() + R - 1) / R);
+      f.total_units = f.units_per_sample * batch;
+      f.partial = partial; f.tilesB = Bc / 32;
+      const int tiles = (A / 32) * (Bc / 32);
+      int nblk = 256 / tiles;  // partial slots: one per workgroup
+      if (nblk < 32) nblk = 32;
+      if (nblk > f.total_units) nblk = f.total_units;
+      char cat[96];
+      std::snprintf(cat, sizeof cat, "wgrad T27 C%dx%d n%ld", A, Bc, (long)dg.vox());
+      prof::Scope scope(cat, s, 2.0 * 27 * A * Bc * (double)dg.vox() * batch, 4.0 * batch * (double)dg.vox() * (A + Bc));
+      static bool attr_set = false;
+      if (!attr_set) {
+        CD_HIP(hipFuncSetAttribute((const void*)wgrad_flat_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(wgrad_flat_kernel<4>, dim3(nblk, tiles), dim3(64 * 7), lds, s, f);
+      CD_HIP(hipGetLastError());
+      const size_t total = (size_t)A * Bc * 27;
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256), 1), dim3(256), 0, s, partial, dw, A, Bc, 27, nblk,
+                         accumulate ? 1 : 0, transposed_out ? 1 : 0, (size_t)nblk * total, total, b_total, b_off);
+      CD_HIP(hipGetLastError());
+      return;
+    }
+  }
   a.nchunks = wgrad_chunks(dg.vox(), batch, per_sample, A, Bc, kd * kh * kw);
   int cv = (int)((dg.vox() + a.nchunks - 1) / a.nchunks);
   a.chunk_vox = (cv + 1) & ~1;
@@ -158,12 +353,11 @@ void launch_wgrad(const float* g, int A, Dims3 dg, const float* x, int Bc, int x
   std::snprintf(cat, sizeof cat, "wgrad T%d C%dx%d n%ld", T, A, Bc, (long)dg.vox());
   prof::Scope scope(cat, s, 2.0 * T * A * Bc * (double)dg.vox() * batch, 4.0 * batch * ((double)dg.vox() * A + (double)dx.vox() * Bc));
   dim3 grid((unsigned)(a.nchunks * batch), (unsigned)((A / 32) * (Bc / 32)));
-  const int tpw = (T + 3) / 4;
+  // few taps per wave => small accumulator footprint => many resident waves to hide the operand-load latency
   if (T == 1) hipLaunchKernelGGL(wgrad_kernel<1>, grid, dim3(64), 0, s, a);  // one wave per workgroup (nothing to split)
-  else if (tpw <= 1) hipLaunchKernelGGL(wgrad_kernel<1>, grid, dim3(256), 0, s, a);
-  else if (tpw <= 7) hipLaunchKernelGGL(wgrad_kernel<7>, grid, dim3(256), 0, s, a);
-  else if (tpw <= 12) hipLaunchKernelGGL(wgrad_kernel<12>, grid, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(wgrad_kernel<16>, grid, dim3(256), 0, s, a);
+  else if (T <= 4) hipLaunchKernelGGL(wgrad_kernel<1>, grid, dim3(64 * T), 0, s, a);
+  else if (T <= 27) hipLaunchKernelGGL(wgrad_kernel<3>, grid, dim3(64 * ((T + 2) / 3)), 0, s, a);
+  else hipLaunchKernelGGL(wgrad_kernel<4>, grid, dim3(64 * ((T + 3) / 4)), 0, s, a);
   CD_HIP(hipGetLastError());
   const size_t total = (size_t)A * Bc * T;
   const int nslots = per_sample ? a.nchunks : a.nchunks * batch;
@@ -176,17 +370,26 @@ void launch_wgrad(const float* g, int A, Dims3 dg, const float* x, int Bc, int x
 // ------------------------------------------------------------------------------------------------------------
 // Per-channel sums over (batch, voxels): bias gradients.  part: channel partials [B][units][C][2] (only the sums are used)
 // ------------------------------------------------------------------------------------------------------------
-__global__ void bias_grad_kernel(const float* __restrict__ part, int units, int batch, int channels, float* __restrict__ db,
-                                 int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= channels) return;
+__global__ void __launch_bounds__(256) bias_grad_kernel(const float* __restrict__ part, int units, int batch, int channels,
+                                                        float* __restrict__ db, int accumulate) {
+  // block = 8 channels x 32 slices of the (batch x units) partial rows; fixed-order tree => deterministic
+  __shared__ double sh[32][8];
+  const int cl = threadIdx.x & 7, sl = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + cl;
+  const int rows = batch * units;
   double s = 0.0;
-  for (int n = 0; n < batch; ++n)
-    for (int u = 0; u < units; ++u) s += (double)part[(((size_t)n * units + u) * channels + c) * 2];
-  db[c] = accumulate ? db[c] + (float)s : (float)s;
+  if (c < channels)
+    for (int r = sl; r < rows; r += 32) s += (double)part[((size_t)r * channels + c) * 2];
+  sh[sl][cl] = s;
+  __syncthreads();
+  if (sl == 0 && c < channels) {
+    double t = 0.0;
+    for (int k = 0; k < 32; ++k) t += sh[k][cl];
+    db[c] = accumulate ? db[c] + (float)t : (float)t;
+  }
 }
 void launch_bias_grad(const float* part, int units, int batch, int channels, float* db, bool accumulate, hipStream_t s) {
-  hipLaunchKernelGGL(bias_grad_kernel, dim3((channels + 63) / 64), dim3(64), 0, s, part, units, batch, channels, db, accumulate ? 1 : 0);
+  hipLaunchKernelGGL(bias_grad_kernel, dim3((channels + 7) / 8), dim3(256), 0, s, part, units, batch, channels, db, accumulate ? 1 : 0);
   CD_HIP(hipGetLastError());
 }
 

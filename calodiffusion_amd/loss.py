@@ -67,8 +67,9 @@ class _TrainStep(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
-        grads = ctx.engine.param_grads(ctx.flat)
-        return (None, None, None, None, None) + tuple(g * grad_out for g in grads)
+        # one scaling of the flat buffer, then per-parameter views (no per-tensor kernels)
+        grads = ctx.engine.param_grads(ctx.flat * grad_out.to(ctx.flat.dtype))
+        return (None, None, None, None, None) + tuple(grads)
 
 
 class hybrid_weight(Loss):
