@@ -166,6 +166,7 @@ struct LinearWgradJob {
   int nout, nin, delta_ld, in_ld;
 };
 void launch_linear_wgrad(const LinearWgradJob* jobs_dev, int njobs, int max_elems, int batch, hipStream_t s);
+void launch_fold_phi(const float* src, float* dst, int batch, Dims3 d, int C, hipStream_t s);
 void launch_add_slices(const float* a, int lda, int aoff, const float* b, int ldb, int boff, float* out, int channels,
                        int64_t rows, hipStream_t s);
 void launch_bias_grad(const float* part, int units, int batch, int channels, float* db, bool accumulate, hipStream_t s);

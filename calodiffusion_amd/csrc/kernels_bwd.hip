@@ -1028,6 +1028,32 @@ void launch_linear_wgrad(const LinearWgradJob* jobs_dev, int njobs, int max_elem
   CD_HIP(hipGetLastError());
 }
 
+// Up-sampling to an ODD phi extent (output_padding 1 along phi): the forward's last phi row duplicates row 0 (both read
+// the same wrapped inputs), so its adjoint first folds the gradient of row H-1 into row 0 and then proceeds on the even
+// ring of H-1 rows.  dst: (B, D, H-1, W, C) <- src: (B, D, H, W, C)
+__global__ void fold_phi_kernel(const float* __restrict__ src, float* __restrict__ dst, int D, int H, int W, int C, int batch) {
+  const int c4 = C >> 2;
+  const int64_t total = (int64_t)batch * D * (H - 1) * W * c4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int q = (int)(i % c4);
+    int64_t r = i / c4;
+    const int w = (int)(r % W);
+    r /= W;
+    const int h = (int)(r % (H - 1));
+    const int64_t bz = r / (H - 1);
+    const float* s0 = src + (((size_t)bz * H + h) * W + w) * C + q * 4;
+    f32x4 v = *(const f32x4*)s0;
+    if (h == 0) v += *(const f32x4*)(src + (((size_t)bz * H + (H - 1)) * W + w) * C + q * 4);
+    *(f32x4*)(dst + (size_t)i * 4) = v;
+  }
+}
+void launch_fold_phi(const float* src, float* dst, int batch, Dims3 d, int C, hipStream_t s) {
+  int64_t blocks = ((int64_t)batch * d.d * (d.h - 1) * d.w * (C / 4) + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(fold_phi_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, dst, d.d, d.h, d.w, C, batch);
+  CD_HIP(hipGetLastError());
+}
+
 size_t gn_backward_scratch_floats(int batch, int channels, int64_t vox) {
   const int ns = gn_nsplit_for(vox, batch);
   return (size_t)batch * ns * channels * 3 + (size_t)batch * channels * 6 + 64;

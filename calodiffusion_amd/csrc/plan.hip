@@ -604,9 +604,17 @@ void conv_transpose_backward(Run& r, const float* x, const float* w_raw, const f
                              Dims3 din, Dims3 dout, int kz, int sz) {
   Arena* ws = r.ws;
   const int T = kz * 16;
-  // With an odd output phi extent (output_padding 1 along phi: only the Dataset-1 grid) the circular halo of the INPUT makes
-  // the adjoint two-valued; that case is not implemented for training (the forward handles it).
-  CD_REQUIRE((dout.h & 1) == 0, "training backward: up-sampling to an odd phi extent is not supported");
+  // Odd output phi extent (output_padding 1 along phi: Dataset-3 level 1, Dataset-1 grid): the forward's last phi row
+  // duplicates row 0, so fold its gradient into row 0 and continue on the even ring (kernels_bwd.hip: fold_phi_kernel).
+  float* folded = nullptr;
+  const float* dy_full = dy;
+  const Dims3 dout_full = dout;
+  if (dout.h & 1) {
+    folded = ws->get<float>((size_t)r.B * dout.d * (dout.h - 1) * dout.w * c);
+    if (!r.dry()) launch_fold_phi(dy, folded, r.B, dout, c, r.s);
+    dy = folded;
+    dout.h -= 1;
+  }
   if (dx) {
     // dx[i][ci] = sum_k dy[s*i + k - 1][co] w[ci][co][k]: a strided conv of dy with w viewed as (co' = ci, ci' = co)
     float* wp = ws->get<float>(packed_weight_floats(c, c, T));
@@ -626,7 +634,8 @@ void conv_transpose_backward(Run& r, const float* x, const float* w_raw, const f
   float* part = ws->get<float>(wgrad_partial_floats(din.vox(), r.B, false, c, c, T));
   if (!r.dry()) launch_wgrad(x, c, din, dy, c, c, 0, dout, kz, 4, 4, sz, 2, r.B, false, part, dw, false, false, r.s);
   ws->release(part);
-  if (db) bias_grad(r, dy, c, dout.vox(), db);
+  if (db) bias_grad(r, dy_full, c, dout_full.vox(), db);
+  if (folded) ws->release(folded);
 }
 
 // CondUnet.forward after init_conv / embeddings (models.py:713-748). Takes ownership of h (a workspace block).

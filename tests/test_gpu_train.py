@@ -19,15 +19,15 @@ def _model(name):
     return CaloDiffusion(cfg, n_steps=cfg["NSTEPS"], loss_type=cfg["LOSS_TYPE"]), cfg
 
 
-def _oracle_grads(cfg, sd, data, E, noise, layers, rnd):
+def _oracle_grads(cfg, sd, data, E, noise, layers, rnd, tsteps):
     sd = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
     om = O.OracleModel(cfg, sd)
-    loss = om.hybrid_l2_loss(data, E, noise, layers, rnd_normal=rnd)
+    loss = om.hybrid_l2_loss(data, E, noise, layers, rnd_normal=rnd, time=tsteps)
     loss.backward()
     return float(loss), {k: v.grad for k, v in om.sd.items()}
 
 
-@pytest.mark.parametrize("name,B", [("tiny", 3), ("dataset2", 2)])
+@pytest.mark.parametrize("name,B", [("tiny", 3), ("dataset2", 2), ("dataset3", 1)])
 def test_parameter_gradients_match_autograd(name, B):
     m, cfg = _model(name)
     gen = torch.Generator().manual_seed(77)
@@ -35,13 +35,16 @@ def test_parameter_gradients_match_autograd(name, B):
     data = torch.randn(shape, generator=gen)
     noise = torch.randn(shape, generator=gen)
     E = torch.rand((B, 3 if cfg.get("HGCAL") else 1), generator=gen)
-    layers = torch.randn((B, 1 + cfg["SHAPE_FINAL"][2]), generator=gen)
+    layers = torch.randn((B, 1 + cfg["SHAPE_FINAL"][2]), generator=gen) if "layer" in cfg["SHOWERMAP"] else None
     rnd = torch.randn((B,), generator=gen)
+    tsteps = torch.randint(0, cfg["NSTEPS"], (B,), generator=gen)  # Dataset-3 (cosine schedule) draws sigma from the table
     sd_cpu = {k[6:]: v.detach().cpu() for k, v in m.state_dict().items()}
-    want_loss, want = _oracle_grads(cfg, sd_cpu, data, E, noise, layers, rnd)
+    want_loss, want = _oracle_grads(cfg, sd_cpu, data, E, noise, layers, rnd, tsteps)
 
     m.zero_grad()
-    loss = m.compute_loss(data.cuda(), E.cuda(), noise=noise.cuda(), layers=layers.cuda(), rnd_normal=rnd.cuda())
+    sigma = m.loss_function.draw_sigma(data.cuda(), time=tsteps.cuda(), rnd_normal=rnd.cuda())
+    loss = m.loss_function.loss_function(m, data.cuda(), E.cuda(), sigma=sigma, noise=noise.cuda(),
+                                         layers=None if layers is None else layers.cuda())
     assert loss.requires_grad and loss.dim() == 0
     assert abs(float(loss) - want_loss) <= 1e-5 * abs(want_loss)
     loss.backward()
