@@ -75,13 +75,29 @@ struct ConvFusion {
   int act = 0;
   float* ch_part = nullptr;
   int* units = nullptr;
-  const void* wpk_bf16x3 = nullptr;  // 3x3x3 stride-1 only: split-bf16 packed weights (launch_pack_weights_bf16x3)
+  // 16-bit split images of the weights (launch_pack_weights_split16): the bf16x3 image, followed at
+  // packed_bf16x3_bytes() by the f16x2 image
+  const void* wpk_bf16x3 = nullptr;
+  int* status = nullptr;  // device word; bit 0 is set when a value staged for an f16x2 conv exceeds the fp16 range
 };
 inline size_t packed_bf16x3_bytes(int cin, int cout, int taps) {
   return (size_t)(cin / 16) * taps * ((cout + 31) / 32) * 3 * 64 * 16;
 }
+inline size_t packed_f16x2_bytes(int cin, int cout, int taps) {
+  return (size_t)(cin / 16) * taps * ((cout + 31) / 32) * 2 * 64 * 16;
+}
+inline size_t packed_split16_bytes(int cin, int cout, int taps) {
+  return packed_bf16x3_bytes(cin, cout, taps) + packed_f16x2_bytes(cin, cout, taps);
+}
 void launch_pack_weights_bf16x3(const float* w_torch, void* wpk, int cout, int cin, int taps, hipStream_t s,
                                 bool transposed = false, bool flip = false);
+void launch_pack_weights_f16x2(const float* w_torch, void* wpk, int cout, int cin, int taps, hipStream_t s,
+                               bool transposed = false, bool flip = false);
+inline void launch_pack_weights_split16(const float* w_torch, void* wpk, int cout, int cin, int taps, hipStream_t s,
+                                        bool transposed = false, bool flip = false) {
+  launch_pack_weights_bf16x3(w_torch, wpk, cout, cin, taps, s, transposed, flip);
+  launch_pack_weights_f16x2(w_torch, (char*)wpk + packed_bf16x3_bytes(cin, cout, taps), cout, cin, taps, s, transposed, flip);
+}
 
 // packed image Wp[co'][ci'][tap'] (see above) of torch weights: transposed = stored [ci'][co'][tap] (ConvTranspose3d, or the
 // input gradient of a Conv3d, whose roles of in/out channels swap); flip = tap' <- taps-1-tap' (input gradient, stride 1)
@@ -91,6 +107,9 @@ void launch_pack_init_weights(const float* w_torch, float* wpk, int cout, int ci
 
 void launch_conv_mfma(const float* in0, int c0, const float* in1, int c1, const float* wpk, const float* bias, float* out,
                       int batch, int cout, const ConvGeom& g, hipStream_t s, const ConvFusion& fu = ConvFusion());
+// z-slide f16x2 kernel for the full-resolution 3x3x3 convs (kernels_conv_zs.hip); false = geometry not eligible
+bool try_launch_conv_zslide(const float* in0, int c0, const float* in1, int c1, const void* wpk_f16x2, const float* bias, float* out,
+                            int batch, int cout, const ConvGeom& g, hipStream_t s, const ConvFusion& fu);
 void launch_conv_transpose_mfma(const float* in, int cin, const float* wpk, const float* bias, float* out, int batch,
                                 int cout, Dims3 din, Dims3 dout, int kz, int sz, hipStream_t s);
 

@@ -1540,6 +1540,11 @@ void launch_conv_mfma(const float* in0, int c0, const float* in1, int c1, const 
                     4.0 * batch * ((double)g.in.vox() * (c0 + c1) + (double)g.out.vox() * cout));
   {
     static const bool want_f32 = getenv("CD_CONV_PRECISION") && !strcmp(getenv("CD_CONV_PRECISION"), "f32");
+    static const bool want_bf16x3 = getenv("CD_CONV_PRECISION") && !strcmp(getenv("CD_CONV_PRECISION"), "bf16x3");
+    if (fu.wpk_bf16x3 && !want_f32 && !want_bf16x3 &&
+        try_launch_conv_zslide(in0, c0, in1, c1, (const char*)fu.wpk_bf16x3 + packed_bf16x3_bytes(c0 + c1, cout, g.kd * g.kh * g.kw),
+                               bias, out, batch, cout, g, s, fu))
+      return;
     if (fu.wpk_bf16x3 && !want_f32 && try_launch_conv3_flat(in0, c0, in1, c1, fu.wpk_bf16x3, bias, out, batch, cout, g, s, fu, true))
       return;
     if (try_launch_conv3_flat(in0, c0, in1, c1, wpk, bias, out, batch, cout, g, s, fu, false)) return;

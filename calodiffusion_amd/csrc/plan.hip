@@ -322,7 +322,7 @@ void build_plan(CdPlan* p) {
   for (auto& w : p->weights) {
     w.raw_off = bump((size_t)w.numel);
     if (w.pack == PK_CONV || w.pack == PK_CONVT) w.pk_off = bump(packed_weight_floats(w.cin, w.cout, w.taps));
-    if (w.pack == PK_CONV && (w.taps == 27 || w.taps == 48)) w.pk3_off = bump(packed_bf16x3_bytes(w.cin, w.cout, w.taps) / 4);
+    if (w.pack == PK_CONV && (w.taps == 27 || w.taps == 48)) w.pk3_off = bump(packed_split16_bytes(w.cin, w.cout, w.taps) / 4);
     else if (w.pack == PK_INIT) w.pk_off = bump((size_t)w.numel);
   }
   p->arena_floats = off;
@@ -566,10 +566,10 @@ void conv_backward(Run& r, const float* x0, int c0, const float* x1, int c1, con
     } else if (g.sz == 1 && g.sh == 1 && g.sw == 1) {
       // dx = conv(dy, W^T flipped): the forward kernels with re-packed weights
       float* wp = ws->get<float>(packed_weight_floats(cout, cin, T));
-      float* wp3 = ws->get<float>(packed_bf16x3_bytes(cout, cin, T) / 4);
+      float* wp3 = ws->get<float>(packed_split16_bytes(cout, cin, T) / 4);
       if (!r.dry()) {
         launch_pack_weights(w_raw, wp, cin, cout, T, true, r.s, true);
-        launch_pack_weights_bf16x3(w_raw, wp3, cin, cout, T, r.s, true, true);
+        launch_pack_weights_split16(w_raw, wp3, cin, cout, T, r.s, true, true);
         ConvGeom gd{g.out, g.in, g.kd, g.kh, g.kw, 1, 1, 1};
         ConvFusion fu;
         fu.wpk_bf16x3 = wp3;
@@ -618,10 +618,10 @@ void conv_transpose_backward(Run& r, const float* x, const float* w_raw, const f
   if (dx) {
     // dx[i][ci] = sum_k dy[s*i + k - 1][co] w[ci][co][k]: a strided conv of dy with w viewed as (co' = ci, ci' = co)
     float* wp = ws->get<float>(packed_weight_floats(c, c, T));
-    float* wp3 = ws->get<float>(packed_bf16x3_bytes(c, c, T) / 4);
+    float* wp3 = ws->get<float>(packed_split16_bytes(c, c, T) / 4);
     if (!r.dry()) {
       launch_pack_weights(w_raw, wp, c, c, T, false, r.s);
-      launch_pack_weights_bf16x3(w_raw, wp3, c, c, T, r.s, false, false);
+      launch_pack_weights_split16(w_raw, wp3, c, c, T, r.s, false, false);
       ConvGeom gd{dout, din, kz, 4, 4, sz, 2, 2};
       ConvFusion fu;
       fu.wpk_bf16x3 = wp3;
@@ -882,7 +882,7 @@ int cd_plan_set_weight(CdPlan* plan, const char* name, const float* dev_ptr, int
     hipStream_t s = (hipStream_t)stream;
     CD_HIP(hipMemcpyAsync(plan->arena + w.raw_off, dev_ptr, sizeof(float) * (size_t)numel, hipMemcpyDeviceToDevice, s));
     if (w.pack == PK_CONV) launch_pack_weights(plan->arena + w.raw_off, plan->arena + w.pk_off, w.cout, w.cin, w.taps, false, s);
-    if (w.pk3_off) launch_pack_weights_bf16x3(plan->arena + w.raw_off, plan->arena + w.pk3_off, w.cout, w.cin, w.taps, s);
+    if (w.pk3_off) launch_pack_weights_split16(plan->arena + w.raw_off, plan->arena + w.pk3_off, w.cout, w.cin, w.taps, s);
     else if (w.pack == PK_CONVT) launch_pack_weights(plan->arena + w.raw_off, plan->arena + w.pk_off, w.cout, w.cin, w.taps, true, s);
     else if (w.pack == PK_INIT) launch_pack_init_weights(plan->arena + w.raw_off, plan->arena + w.pk_off, w.cout, w.cin, s);
     w.set = true;
@@ -1094,7 +1094,7 @@ int cd_loss_hybrid_l2(CdPlan* plan, int batch, const float* data, const float* n
 // ---- primitives -----------------------------------------------------------------------------------------------
 size_t cd_op_scratch_bytes(int batch, int max_channels, int64_t max_voxels) {
   // packed weights of the largest supported conv (256 x 256 x 64 taps) + norm partials + one activation
-  return (size_t)256 * 256 * 64 * 4 * 3 + (size_t)batch * 64 * 64 * 16 + (size_t)batch * max_channels * max_voxels * 4 + (1 << 20);
+  return (size_t)256 * 256 * 64 * 4 * 4 + (size_t)batch * 64 * 64 * 16 + (size_t)batch * max_channels * max_voxels * 4 + (1 << 20);
 }
 
 int cd_op_to_channels_last(const float* ncdhw, float* ndhwc, int batch, int channels, int64_t voxels, void* stream) {
@@ -1128,7 +1128,7 @@ int cd_op_cyl_conv(const float* x0, int c0, const float* x1, int c1, const float
       ConvFusion fu;
       if (taps == 27 || taps == 48) {
         float* w3 = wpk + packed_weight_floats(c0 + c1, cout, taps);
-        launch_pack_weights_bf16x3(w, w3, cout, c0 + c1, taps, s);
+        launch_pack_weights_split16(w, w3, cout, c0 + c1, taps, s);
         fu.wpk_bf16x3 = w3;
       }
       launch_conv_mfma(x0, c0, x1, c1, wpk, bias, y, batch, cout, g, s, fu);
@@ -1193,10 +1193,10 @@ int cd_op_resnet_block(const float* x0, int c0, const float* x1, int c1, const f
     float* p2 = ws.get<float>(packed_weight_floats(cout, cout, 27));
     launch_pack_weights(w[0], p1, cout, cin, 27, false, s);
     launch_pack_weights(w[4], p2, cout, cout, 27, false, s);
-    float* q1 = ws.get<float>(packed_bf16x3_bytes(cin, cout, 27) / 4);
-    float* q2 = ws.get<float>(packed_bf16x3_bytes(cout, cout, 27) / 4);
-    launch_pack_weights_bf16x3(w[0], q1, cout, cin, 27, s);
-    launch_pack_weights_bf16x3(w[4], q2, cout, cout, 27, s);
+    float* q1 = ws.get<float>(packed_split16_bytes(cin, cout, 27) / 4);
+    float* q2 = ws.get<float>(packed_split16_bytes(cout, cout, 27) / 4);
+    launch_pack_weights_split16(w[0], q1, cout, cin, 27, s);
+    launch_pack_weights_split16(w[4], q2, cout, cout, 27, s);
     ResP r;
     r.cin = cin; r.cout = cout; r.has_res = w[10] != nullptr;
     r.c1w3 = q1; r.c2w3 = q2;
