@@ -8,6 +8,7 @@
 // Reference semantics: CylindricalConv / CylindricalConvTrans / Downsample / Upsample,
 // calodiffusion/models/models.py:25-96, 335-369: circular padding along phi (H), zero padding along z (D) and r (W).
 #include "cd_common.h"
+#include "split16.h"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -605,8 +606,6 @@ struct FlatTile {
 // ------------------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
   const bf16x2 v = {(__bf16)lo, (__bf16)hi};  // v_cvt_pk_bf16_f32, round to nearest even
@@ -668,11 +667,15 @@ void launch_pack_weights_bf16x3(const float* w_torch, void* wpk, int cout, int c
 
 // Geometry is a template parameter: (KD,KH,KW) taps, z stride SZ, phi/r stride SXY; padding is always (1, circular 1, 1).
 // Instantiated for the 3x3x3 stride-1 conv and the (3,4,4) down-sampling conv with z stride 2 or 1.
-template <int VT, int CT, int KD, int KH, int KW, int SZ, int SXY>
-__global__ void __launch_bounds__(512, (VT * CT <= 2 ? 3 : 2)) conv3_flat_bf16x3_kernel(ConvFlatArgs a) {
+// NTERM = 3: bf16x3 (96 B per voxel per sub-chunk); NTERM = 2: f16x2 (split16.h; 64 B + 16 B pad = 80 B, an odd number of
+// 16-B slots => conflict-free ds_read_b128), two accumulators per tile folded after the K loop.
+template <int VT, int CT, int KD, int KH, int KW, int SZ, int SXY, int NTERM>
+__global__ void __launch_bounds__(512, (VT * CT * (NTERM == 2 ? 2 : 1) <= 2 ? 3 : 2)) conv3_flat_bf16x3_kernel(ConvFlatArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   char* ldsb = (char*)lds;
   constexpr int T = KD * KH * KW;
+  constexpr int VB = NTERM == 3 ? 96 : 80;   // bytes per staged voxel
+  constexpr int WS = 64 * NTERM;             // u32x4 per (tap, ct) in the packed weights
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
   const int b = blockIdx.y;
   const int ct0 = blockIdx.z * CT;
@@ -687,7 +690,7 @@ __global__ void __launch_bounds__(512, (VT * CT <= 2 ? 3 : 2)) conv3_flat_bf16x3
   const int nstage = (zB - zA + 1) * HW;
   const int NZ = a.P * HW;  // all-zero voxel
   const int half = lane >> 5, col = lane & 31;
-  if (tid < 24) ((float*)(ldsb + (size_t)NZ * 96))[tid] = 0.f;
+  if (tid < VB / 4) ((float*)(ldsb + (size_t)NZ * VB))[tid] = 0.f;
 
   // per-lane geometry of its output voxel in each of the wave's VT row tiles: LDS index of the (kz=0, kh=1, kw=1) tap,
   // phi-row offsets with wrap-around for each kh, r-validity bit for each kw
@@ -723,13 +726,16 @@ __global__ void __launch_bounds__(512, (VT * CT <= 2 ? 3 : 2)) conv3_flat_bf16x3
   }
   const bool wave_active = __any(any_valid);
 
-  f32x16 acc[VT][CT];
+  f32x16 acc[VT][CT], accB[NTERM == 2 ? VT : 1][NTERM == 2 ? CT : 1];
 #pragma unroll
   for (int vt = 0; vt < VT; ++vt)
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[vt][ct][r] = 0.f;
+      for (int r = 0; r < 16; ++r) {
+        acc[vt][ct][r] = 0.f;
+        if (NTERM == 2) accB[vt][ct][r] = 0.f;
+      }
 
   const int nsub = (a.c0 + a.c1) >> 4;
   const int gbase = zA * HW;
@@ -780,12 +786,19 @@ __global__ void __launch_bounds__(512, (VT * CT <= 2 ? 3 : 2)) conv3_flat_bf16x3
       for (int k = 0; k < 4; ++k) {
         const int sidx = s0 + k * nthreads;
         if (sidx < nslots) {
-          u32x2 t1, t2, t3;
-          split3(val[k], t1, t2, t3);
-          char* d = ldsb + (size_t)(sidx >> 2) * 96 + pq * 8;
-          *(u32x2*)d = t1;
-          *(u32x2*)(d + 32) = t2;
-          *(u32x2*)(d + 64) = t3;
+          char* d = ldsb + (size_t)(sidx >> 2) * VB + pq * 8;
+          if (NTERM == 3) {
+            u32x2 t1, t2, t3;
+            split3(val[k], t1, t2, t3);
+            *(u32x2*)d = t1;
+            *(u32x2*)(d + 32) = t2;
+            *(u32x2*)(d + 64) = t3;
+          } else {
+            u32x2 t1, t2;
+            split2(val[k], t1, t2);
+            *(u32x2*)d = t1;
+            *(u32x2*)(d + 32) = t2;
+          }
         }
       }
     }
@@ -795,22 +808,22 @@ __global__ void __launch_bounds__(512, (VT * CT <= 2 ? 3 : 2)) conv3_flat_bf16x3
 #pragma unroll
     for (int vt = 0; vt < VT; ++vt) asm volatile("" : "+v"(nb[vt]));
 
-    const u32x4* wq = (const u32x4*)a.wpk + ((size_t)sc * T * a.CTtot + ct0) * 192 + lane;
+    const u32x4* wq = (const u32x4*)a.wpk + ((size_t)sc * T * a.CTtot + ct0) * WS + lane;
     // Register rings: weight fragments (L1/L2) are requested WD taps ahead, LDS fragments AD taps ahead.
     constexpr int WD = 1, AD = 1;  // deeper rings were measured: they cost occupancy (VGPRs) and gain nothing
-    u32x4 bw[WD + 1][CT][3], av[AD + 1][VT][3];
+    u32x4 bw[WD + 1][CT][NTERM], av[AD + 1][VT][NTERM];
     auto load_w = [&](int tap) {
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-        for (int t = 0; t < 3; ++t) bw[tap % (WD + 1)][ct][t] = wq[((size_t)tap * a.CTtot + ct) * 192 + t * 64];
+        for (int t = 0; t < NTERM; ++t) bw[tap % (WD + 1)][ct][t] = wq[((size_t)tap * a.CTtot + ct) * WS + t * 64];
     };
     auto load_a = [&](int tap) {
 #pragma unroll
       for (int vt = 0; vt < VT; ++vt) {
-        const char* p = ldsb + (size_t)tap_voxel(vt, tap) * 96 + half * 16;
+        const char* p = ldsb + (size_t)tap_voxel(vt, tap) * VB + half * 16;
 #pragma unroll
-        for (int t = 0; t < 3; ++t) av[tap % (AD + 1)][vt][t] = *(const u32x4*)(p + t * 32);
+        for (int t = 0; t < NTERM; ++t) av[tap % (AD + 1)][vt][t] = *(const u32x4*)(p + t * 32);
       }
     };
 #pragma unroll
@@ -827,18 +840,32 @@ __global__ void __launch_bounds__(512, (VT * CT <= 2 ? 3 : 2)) conv3_flat_bf16x3
       for (int vt = 0; vt < VT; ++vt)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
-          f32x16 c = acc[vt][ct];
-          c = MFMA_BF16(av[ac][vt][2], bw[wc][ct][0], c);  // x3*w1
-          c = MFMA_BF16(av[ac][vt][1], bw[wc][ct][1], c);  // x2*w2
-          c = MFMA_BF16(av[ac][vt][0], bw[wc][ct][2], c);  // x1*w3
-          c = MFMA_BF16(av[ac][vt][1], bw[wc][ct][0], c);  // x2*w1
-          c = MFMA_BF16(av[ac][vt][0], bw[wc][ct][1], c);  // x1*w2
-          c = MFMA_BF16(av[ac][vt][0], bw[wc][ct][0], c);  // x1*w1
-          acc[vt][ct] = c;
+          if (NTERM == 3) {
+            f32x16 c = acc[vt][ct];
+            c = MFMA_BF16(av[ac][vt][NTERM - 1], bw[wc][ct][0], c);  // x3*w1
+            c = MFMA_BF16(av[ac][vt][1], bw[wc][ct][1], c);          // x2*w2
+            c = MFMA_BF16(av[ac][vt][0], bw[wc][ct][NTERM - 1], c);  // x1*w3
+            c = MFMA_BF16(av[ac][vt][1], bw[wc][ct][0], c);          // x2*w1
+            c = MFMA_BF16(av[ac][vt][0], bw[wc][ct][1], c);          // x1*w2
+            c = MFMA_BF16(av[ac][vt][0], bw[wc][ct][0], c);          // x1*w1
+            acc[vt][ct] = c;
+          } else {
+            acc[vt][ct] = MFMA_F16(av[ac][vt][0], bw[wc][ct][0], acc[vt][ct]);    // x1*w1
+            accB[vt][ct] = MFMA_F16(av[ac][vt][0], bw[wc][ct][1], accB[vt][ct]);  // x1*w2'
+            accB[vt][ct] = MFMA_F16(av[ac][vt][1], bw[wc][ct][0], accB[vt][ct]);  // x2'*w1
+          }
         }
     }
   }
 
+  if (NTERM == 2) {
+#pragma unroll
+    for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[vt][ct][r] += accB[vt][ct][r] * (1.f / 2048.f);
+  }
   float* outb = a.out + (size_t)b * voxo * a.cout;
   float bv[CT];
 #pragma unroll
@@ -1170,24 +1197,24 @@ void launch_ws_inst(const ConvFlatArgs& a, dim3 grid, int threads, size_t lds, i
 }  // namespace
 
 namespace {
-template <int VT, int CT, int KD, int KH, int KW, int SZ, int SXY>
+template <int VT, int CT, int KD, int KH, int KW, int SZ, int SXY, int NTERM>
 void launch_flat3_geo(const ConvFlatArgs& a, dim3 grid, int threads, size_t lds, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    CD_HIP(hipFuncSetAttribute((const void*)conv3_flat_bf16x3_kernel<VT, CT, KD, KH, KW, SZ, SXY>,
+    CD_HIP(hipFuncSetAttribute((const void*)conv3_flat_bf16x3_kernel<VT, CT, KD, KH, KW, SZ, SXY, NTERM>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv3_flat_bf16x3_kernel<VT, CT, KD, KH, KW, SZ, SXY>), grid, dim3(threads), lds, s, a);
+  hipLaunchKernelGGL((conv3_flat_bf16x3_kernel<VT, CT, KD, KH, KW, SZ, SXY, NTERM>), grid, dim3(threads), lds, s, a);
   CD_HIP(hipGetLastError());
 }
 // geo: 0 = 3x3x3 stride 1, 1 = (3,4,4) stride (2,2,2), 2 = (3,4,4) stride (1,2,2), 3 = (4,4,4) stride (2,2,2)
-template <int VT, int CT>
+template <int VT, int CT, int NTERM>
 void launch_flat3_inst(const ConvFlatArgs& a, dim3 grid, int threads, size_t lds, hipStream_t s, int geo = 0) {
-  if (geo == 0) launch_flat3_geo<VT, CT, 3, 3, 3, 1, 1>(a, grid, threads, lds, s);
-  else if (geo == 1) launch_flat3_geo<VT, CT, 3, 4, 4, 2, 2>(a, grid, threads, lds, s);
-  else if (geo == 2) launch_flat3_geo<VT, CT, 3, 4, 4, 1, 2>(a, grid, threads, lds, s);
-  else launch_flat3_geo<VT, CT, 4, 4, 4, 2, 2>(a, grid, threads, lds, s);
+  if (geo == 0) launch_flat3_geo<VT, CT, 3, 3, 3, 1, 1, NTERM>(a, grid, threads, lds, s);
+  else if (geo == 1) launch_flat3_geo<VT, CT, 3, 4, 4, 2, 2, NTERM>(a, grid, threads, lds, s);
+  else if (geo == 2) launch_flat3_geo<VT, CT, 3, 4, 4, 1, 2, NTERM>(a, grid, threads, lds, s);
+  else launch_flat3_geo<VT, CT, 4, 4, 4, 2, 2, NTERM>(a, grid, threads, lds, s);
 }
 }  // namespace
 
@@ -1417,7 +1444,8 @@ void launch_tiled3_inst(const ConvTiled3Args& a, dim3 grid, int threads, size_t 
 // (stride-1 3x3x3 only).
 static bool try_launch_conv3_flat(const float* in0, int c0, const float* in1, int c1, const void* wpk, const float* bias,
                                   float* out, int batch, int cout, const ConvGeom& g, hipStream_t s, const ConvFusion& fu,
-                                  bool bf16x3) {
+                                  int prec /* 0 = f32 MFMA, 3 = bf16x3, 2 = f16x2 */) {
+  const bool bf16x3 = prec != 0;  // any 16-bit split kernel
   if (getenv("CD_NO_FLAT")) return false;
   int geo = -1;
   if (g.kd == 3 && g.kh == 3 && g.kw == 3 && g.sz == 1 && g.sh == 1 && g.sw == 1) geo = 0;
@@ -1429,7 +1457,7 @@ static bool try_launch_conv3_flat(const float* in0, int c0, const float* in1, in
   const int CTmax = CTtot <= 3 ? CTtot : 2;
   if (CTtot % CTmax) return false;
   const int HW = d.h * d.w, HWo = g.out.h * g.out.w;
-  const size_t vox_bytes = bf16x3 ? 96 : 64;
+  const size_t vox_bytes = prec == 3 ? 96 : (prec == 2 ? 80 : 64);
   auto planes = [&](int NT) { return ((32 * NT - 1) / HWo + 1) * g.sz + g.kd; };
   // CT = output-channel tiles per workgroup: CTmax shares one staged input tile between them; 1 spreads them over
   // gridDim.z (shorter MFMA chains: wins on the deep, latency-bound levels)
@@ -1470,8 +1498,11 @@ static bool try_launch_conv3_flat(const float* in0, int c0, const float* in1, in
     const int threads = (NT / VT) * 64;
 #define CD_FLAT_CASE(V, C)                                                   \
   if (VT == V && CT == C) {                                                  \
-    if (bf16x3) launch_flat3_inst<V, C>(a, grid, threads, lds, s, geo);      \
-    else launch_flat_inst<V, C>(a, grid, threads, lds, s);                   \
+    if (prec == 3) launch_flat3_inst<V, C, 3>(a, grid, threads, lds, s, geo); \
+    else if (prec == 2) {                                                    \
+      if constexpr (V * C <= 4) launch_flat3_inst<V, C, 2>(a, grid, threads, lds, s, geo); \
+      else return false;                                                     \
+    } else launch_flat_inst<V, C>(a, grid, threads, lds, s);                 \
     return true;                                                             \
   }
     CD_FLAT_CASE(1, 1) CD_FLAT_CASE(2, 1) CD_FLAT_CASE(3, 1) CD_FLAT_CASE(4, 1)
@@ -1483,7 +1514,7 @@ static bool try_launch_conv3_flat(const float* in0, int c0, const float* in1, in
   if (const char* ov = getenv("CD_FLAT_TILE")) {
     int nt, vt;
     if (sscanf(ov, "%d,%d", &nt, &vt) == 2 && nt % vt == 0 && nt / vt <= 8 && vt * CTmax <= 8 &&
-        ((size_t)planes(nt) * HW + 1) * vox_bytes <= 160 * 1024)
+        ((size_t)planes(nt) * HW + 1) * vox_bytes <= 160 * 1024 && (prec != 2 || vt * CTmax <= 4))
       return launch(nt, vt, CTmax);
   }
   // candidate tilings: (tiles per workgroup, tiles per wave)
@@ -1497,13 +1528,14 @@ static bool try_launch_conv3_flat(const float* in0, int c0, const float* in1, in
     for (auto& c : kCand) {
       const int NT = c[0], VT = c[1];
       if (VT * CT > 8 || (CT == 3 && VT > 2)) continue;
+      if (prec == 2 && VT * CT > 4) continue;
       if ((int64_t)32 * (NT - 1) >= g.out.vox()) continue;
       if (((size_t)planes(NT) * HW + 1) * vox_bytes > 150 * 1024) continue;
       if (pass == 1 && NT > 4) continue;
       cand.push_back({NT, VT, CT});
     }
   }
-  if (bf16x3 && !getenv("CD_NO_WS")) {
+  if (prec == 3 && !getenv("CD_NO_WS")) {
     // warp-specialised persistent variants: (matrix waves, -loader waves); two LDS buffers + statistics scratch
     static const int kWs[][2] = {{8, 4}, {8, 2}, {4, 2}, {4, 4}, {8, 3}, {6, 2}, {2, 2}, {3, 1}, {1, 1}, {2, 1}};
     for (auto& c : kWs) {
@@ -1516,8 +1548,8 @@ static bool try_launch_conv3_flat(const float* in0, int c0, const float* in1, in
   }
   if (cand.empty()) return false;
   char key[192];
-  std::snprintf(key, sizeof key, "flat%s g%d %dx%dx%d c%d+%d->%d b%d", bf16x3 ? "_bf16x3" : "_f32", geo, d.d, d.h, d.w, c0, c1,
-                cout, batch);
+  std::snprintf(key, sizeof key, "flat%s g%d %dx%dx%d c%d+%d->%d b%d", prec == 3 ? "_bf16x3" : (prec == 2 ? "_f16x2" : "_f32"), geo,
+                d.d, d.h, d.w, c0, c1, cout, batch);
   const int pick = autotune(key, (int)cand.size(), [&](int i) { launch(cand[i].nt, cand[i].vt, cand[i].ct); }, s);
   const Cand& c = cand[pick < 0 ? 0 : pick];
   return launch(c.nt, c.vt, c.ct);
@@ -1545,9 +1577,13 @@ void launch_conv_mfma(const float* in0, int c0, const float* in1, int c1, const 
         try_launch_conv_zslide(in0, c0, in1, c1, (const char*)fu.wpk_bf16x3 + packed_bf16x3_bytes(c0 + c1, cout, g.kd * g.kh * g.kw),
                                bias, out, batch, cout, g, s, fu))
       return;
-    if (fu.wpk_bf16x3 && !want_f32 && try_launch_conv3_flat(in0, c0, in1, c1, fu.wpk_bf16x3, bias, out, batch, cout, g, s, fu, true))
+    if (fu.wpk_bf16x3 && !want_f32 && !want_bf16x3 &&
+        try_launch_conv3_flat(in0, c0, in1, c1, (const char*)fu.wpk_bf16x3 + packed_bf16x3_bytes(c0 + c1, cout, g.kd * g.kh * g.kw), bias,
+                              out, batch, cout, g, s, fu, 2))
       return;
-    if (try_launch_conv3_flat(in0, c0, in1, c1, wpk, bias, out, batch, cout, g, s, fu, false)) return;
+    if (fu.wpk_bf16x3 && !want_f32 && try_launch_conv3_flat(in0, c0, in1, c1, fu.wpk_bf16x3, bias, out, batch, cout, g, s, fu, 3))
+      return;
+    if (try_launch_conv3_flat(in0, c0, in1, c1, wpk, bias, out, batch, cout, g, s, fu, 0)) return;
   }
   {
     static const bool want_f32 = getenv("CD_CONV_PRECISION") && !strcmp(getenv("CD_CONV_PRECISION"), "f32");

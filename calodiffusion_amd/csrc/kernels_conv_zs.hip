@@ -20,34 +20,13 @@
 //    are exchanged through LDS (48 KiB) and wave t sums, adds bias, stores and accumulates the channel statistics of
 //    tile t.  Fixed summation order => deterministic.
 #include "cd_common.h"
+#include "split16.h"
 
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
 namespace cd {
-
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-#define MFMA_F16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, (a)), __builtin_bit_cast(f16x8, (b)), (c), 0, 0, 0)
-
-__device__ __forceinline__ unsigned pack_h2(_Float16 lo, _Float16 hi) {
-  return (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
-}
-// two-term split of 4 floats: t1 = f16(x), t2 = f16((x - t1) * 2^11)   (round to nearest even)
-__device__ __forceinline__ void split2(const f32x4 x, u32x2& t1, u32x2& t2) {
-  _Float16 h[4], l[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    h[e] = (_Float16)x[e];
-    l[e] = (_Float16)((x[e] - (float)h[e]) * 2048.f);
-  }
-  t1 = u32x2{pack_h2(h[0], h[1]), pack_h2(h[2], h[3])};
-  t2 = u32x2{pack_h2(l[0], l[1]), pack_h2(l[2], l[3])};
-}
 
 // packed f16x2 weights: [k-step = ci/16][tap][ct = co/32][term][lane = h*32+j][8 fp16] = W_term[co = ct*32+j][ci = ks*16+8h+0..7]
 __global__ void pack_weights_f16x2_kernel(const float* __restrict__ w, u32x4* __restrict__ wpk, int cout, int cin, int taps,
@@ -109,6 +88,7 @@ struct ConvZsArgs {
   int D, H, W;
   int nchunk, CV;    // voxels per chunk (multiple of 128)
   int* status;       // bit 0: a staged value exceeded the fp16 range
+  int dbg;           // timing experiments (CD_ZS_DBG): 1 = no conversion, 2 = no MFMA loop, 4 = no reduce/store
 };
 
 template <int WV, bool ACC>
@@ -168,7 +148,7 @@ __device__ __forceinline__ void zs_wave(const ConvZsArgs& a, char* lds) {
       const int p = p0 + 32 * k;
       if (p < PV) {
         u32x2 t1 = {0u, 0u}, t2 = {0u, 0u};
-        if (!zero) {
+        if (!zero && !(a.dbg & 1)) {
           f32x4 v = ld[k];
           if (a.coef) {
 #pragma unroll
@@ -270,10 +250,11 @@ __device__ __forceinline__ void zs_wave(const ConvZsArgs& a, char* lds) {
     };
     load_frag(0);
     load_frag(1);
+    if (!(a.dbg & 2))
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int t = i / NP, j = i % NP;
-      if (i + 2 < NI) load_frag(i + 2);
+      if (i + 2 < NI && !(a.dbg & 8)) load_frag(i + 2);
       __builtin_amdgcn_sched_barrier(0);
       if (j == 0) {
 #pragma unroll
@@ -288,7 +269,7 @@ __device__ __forceinline__ void zs_wave(const ConvZsArgs& a, char* lds) {
         for (int r = 0; r < 16; ++r) pt[r] = accA[r] + accB[r] * (1.f / 2048.f);
         if (t == WV) {
           own = pt;
-        } else {
+        } else if (!(a.dbg & 16)) {
           const int slot = WV < t ? WV : WV - 1;
           char* d = part + ((t * 3 + slot) * 4) * 1024 + lane * 16;
 #pragma unroll
@@ -304,7 +285,7 @@ __device__ __forceinline__ void zs_wave(const ConvZsArgs& a, char* lds) {
     __syncthreads();
 
     // ---- tile WV: sum the four K-slices in wave order, bias, store, statistics --------------------------------
-    {
+    if (!(a.dbg & 4)) {
       f32x16 sum;
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
@@ -427,6 +408,7 @@ bool try_launch_conv_zslide(const float* in0, int c0, const float* in1, int c1, 
     a.D = g.in.d; a.H = g.in.h; a.W = g.in.w;
     a.nchunk = nchunk; a.CV = CV;
     a.status = fu.status;
+    a.dbg = getenv("CD_ZS_DBG") ? atoi(getenv("CD_ZS_DBG")) : 0;
     const dim3 grid((unsigned)nchunk, (unsigned)batch, (unsigned)CTtot);
     if (kb == 0) hipLaunchKernelGGL(conv_zslide_f16x2_kernel<false>, grid, dim3(256), lds, s, a);
     else hipLaunchKernelGGL(conv_zslide_f16x2_kernel<true>, grid, dim3(256), lds, s, a);

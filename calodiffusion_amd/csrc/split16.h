@@ -1,0 +1,32 @@
+// 16-bit operand splits shared by the MFMA conv kernels (internal).
+//   bf16x3: x = x1 + x2 + x3 exactly (24 bits), 6 bf16 MFMAs per product block;
+//   f16x2 : x = x1 + 2^-11 x2' (22 bits, x2' = f16((x - x1) * 2^11) stays clear of the fp16 subnormals), 3 fp16 MFMAs into two
+//           accumulators A += x1*w1, B += x1*w2' + x2'*w1, result A + 2^-11 B.  fp16 range only (|x| <= 65504).
+#pragma once
+#include "cd_common.h"
+
+namespace cd {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#define MFMA_F16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, (a)), __builtin_bit_cast(f16x8, (b)), (c), 0, 0, 0)
+
+__device__ __forceinline__ unsigned pack_h2(_Float16 lo, _Float16 hi) {
+  return (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
+}
+// two-term split of 4 floats: t1 = f16(x), t2 = f16((x - t1) * 2^11)   (round to nearest even)
+// (written per element: a packed-conversion formulation was miscompiled by ROCm 7.2's clang)
+__device__ __forceinline__ void split2(const f32x4 x, u32x2& t1, u32x2& t2) {
+  _Float16 h[4], l[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    h[e] = (_Float16)x[e];
+    l[e] = (_Float16)((x[e] - (float)h[e]) * 2048.f);
+  }
+  t1 = u32x2{pack_h2(h[0], h[1]), pack_h2(h[2], h[3])};
+  t2 = u32x2{pack_h2(l[0], l[1]), pack_h2(l[2], l[3])};
+}
+
+}  // namespace cd
