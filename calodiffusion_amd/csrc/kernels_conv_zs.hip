@@ -69,10 +69,13 @@ void launch_pack_weights_f16x2(const float* w_torch, void* wpk, int cout, int ci
 
 namespace {
 
-constexpr int ZS_VB = 144;     // bytes per voxel record in the ring
-constexpr int ZS_RING = 5;     // planes in the ring
-constexpr int ZS_NSL = 5;      // staging slots per thread per plane (plane <= 160 voxels)
-constexpr int ZS_PART = 3 * 4 * 4096;  // partial-tile exchange: 4 tiles x 3 foreign waves x 4 KiB
+constexpr int ZS_VB = 144;     // bytes per voxel record: 2 k-steps x 2 terms x 16 fp16 + 16 B pad (odd number of 16-B slots
+                               // => conflict-free ds_read_b128 over consecutive records)
+constexpr int ZS_RING = 4;     // planes in the ring: the 3-4 planes a 64-voxel step reads + the one being staged for the next
+constexpr int ZS_NSL = 5;      // staging slots per helper thread per plane (plane <= 160 voxels)
+constexpr int ZS_TILES = 2;    // 32-voxel row tiles per step
+constexpr int ZS_STEP = 32 * ZS_TILES;
+constexpr int ZS_PART = 2 * ZS_TILES * 4 * 4096;  // partial-tile exchange, double buffered: 2 x tiles x 4 K-slices x 4 KiB
 
 struct ConvZsArgs {
   const float* in;   // (B, vox, ldc) channels-last, already offset to the first of the 32 input channels
@@ -86,37 +89,165 @@ struct ConvZsArgs {
   int cout;
   float* ch_part;    // [B][nchunk*4][cout][2] or null
   int D, H, W;
-  int nchunk, CV;    // voxels per chunk (multiple of 128)
+  int nchunk, CV;    // voxels per chunk (multiple of ZS_STEP)
   int* status;       // bit 0: a staged value exceeded the fp16 range
-  int dbg;           // timing experiments (CD_ZS_DBG): 1 = no conversion, 2 = no MFMA loop, 4 = no reduce/store
+  int dbg;           // timing experiments (CD_ZS_DBG): 1 = no conversion, 4 = no reduce/store, 32/64 = no LDS writes / no split
 };
 
-template <int WV, bool ACC>
-__device__ __forceinline__ void zs_wave(const ConvZsArgs& a, char* lds) {
-  constexpr int KSTEP = WV >> 1, TB = (WV & 1) * 14, NP = (WV & 1) ? 13 : 14;
-  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, col = lane & 31;
-  const int chunk = blockIdx.x, b = blockIdx.y, ct = blockIdx.z;
-  const int H = a.H, W = a.W, PV = H * W, vox = a.D * PV;
-  const int PVB = PV * ZS_VB;
-  const int ZADDR = ZS_RING * PVB;                                  // all-zero voxel record
-  char* const part = lds + ((ZADDR + ZS_VB + 255) & ~255);
+// LDS image: [zero record][ring: ZS_RING planes][partials].  A plane is H rows of W + 1 records: the extra record of every row
+// is zero, so the r - 1 neighbour of column 0 (the previous row's pad, or the record in front of the plane) and the r + 1
+// neighbour of column W - 1 read zeros without any per-tap validity select.  Tap addresses are then
+// (row base of (kz, kh)) + constant: the matrix waves spend ~1 VALU instruction per MFMA triple on addressing.  That matters:
+// one vector issue port per SIMD serves the matrix wave's MFMAs (8 of every 32 cycles) AND every VALU instruction of both
+// resident waves; address arithmetic and staging beyond the remaining slots lengthens the step.
+struct ZsGeo {
+  int PV, vox, pitch, PLB, RB, ZPART;
+  int v0, cend, nsteps, zfirst;
+};
+__device__ __forceinline__ ZsGeo zs_geo(const ConvZsArgs& a) {
+  ZsGeo g;
+  g.PV = a.H * a.W;
+  g.vox = a.D * g.PV;
+  g.pitch = a.W + 1;
+  g.PLB = a.H * g.pitch * ZS_VB;
+  g.RB = ZS_VB;  // ring starts after one zero record
+  g.ZPART = (g.RB + ZS_RING * g.PLB + 255) & ~255;
+  g.v0 = blockIdx.x * a.CV;
+  g.cend = min(g.v0 + a.CV, g.vox);
+  g.nsteps = (g.cend - g.v0 + ZS_STEP - 1) / ZS_STEP;
+  g.zfirst = g.v0 / g.PV;
+  return g;
+}
 
-  // ---- this wave's weight fragments: registers for the whole chunk -------------------------------------------
-  u32x4 w1[NP], w2[NP];
+// Workgroup barriers that wait for this wave's LDS traffic only.  __syncthreads() also drains vmcnt, which would tie the
+// helper waves' global loads (issued a step ahead) and output stores to every barrier.
+__device__ __forceinline__ void zs_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void zs_barrier_bare() { asm volatile("s_barrier" ::: "memory"); }
+// SiLU on the transcendental unit: t * rcp(1 + exp2(-t * log2 e)), ~3 ulp
+__device__ __forceinline__ float zs_silu(float t) {
+  return t * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(t * -1.4426950408889634f));
+}
+
+// ---- matrix waves 0..3: K-slice WV of every tile ------------------------------------------------------------
+// K split: wave WV owns k-step WV >> 1; its two waves share the 27 taps, [0, Ne) and [Ne, 27) with Ne = 14 on even tiles and
+// 13 on odd tiles, so that every wave runs 27 (tap, k-step) pairs per two-tile step (both hold tap 13's fragments).
+template <int WV>
+__device__ __forceinline__ void zs_matrix_wave(const ConvZsArgs& a, char* lds) {
+  constexpr int KSTEP = WV >> 1, ODD = WV & 1, T0 = ODD ? 13 : 0;  // weights held: taps T0 .. T0+13
+  static_assert(ZS_TILES == 2, "the tap split alternates over the two tiles of a step");
+  const int lane = threadIdx.x & 63, half = lane >> 5, col = lane & 31;
+  const int ct = blockIdx.z;
+  const ZsGeo G = zs_geo(a);
+  const int H = a.H, W = a.W;
+  char* const part = lds + G.ZPART;
+
+  u32x4 w1[14], w2[14];
   {
-    const u32x4* wq = a.wpk + ((size_t)(KSTEP * 27 + TB) * a.CTtot + ct) * 128 + lane;
+    const u32x4* wq = a.wpk + ((size_t)(KSTEP * 27 + T0) * a.CTtot + ct) * 128 + lane;
 #pragma unroll
-    for (int j = 0; j < NP; ++j) {
+    for (int j = 0; j < 14; ++j) {
       w1[j] = wq[(size_t)j * a.CTtot * 128];
       w2[j] = wq[(size_t)j * a.CTtot * 128 + 64];
     }
   }
 
-  const int v0 = chunk * a.CV;
-  const int cend = min(v0 + a.CV, vox);
-  const int nsteps = (cend - v0 + 127) >> 7;
+  // per-lane geometry of its row (voxel) in the current tile, advanced by 32 voxels per tile
+  int gh, gw, grs;  // phi row, r column, ring slot of plane z-1
+  {
+    const int v = G.v0 + col;
+    const int gz = v / G.PV;
+    const int p = v - gz * G.PV;
+    gh = p / W;
+    gw = p - gh * W;
+    grs = (gz + ZS_RING - 1) % ZS_RING;
+  }
+  const int adv_h = 32 / W, adv_w = 32 - adv_h * W;
+  const int RWB = G.pitch * ZS_VB;  // bytes per row of records
+  // constant part of every fragment address: ring base, this wave's k-step, this lane's channel half, and the -1 record of
+  // the kw = 0 tap (so that the per-tap constants kw * ZS_VB are non-negative immediates)
+  const int kconst = G.RB + KSTEP * 64 + half * 16 - ZS_VB;
 
-  // ---- staging role: thread = (channel quad q, voxel p0 + 32k) --------------------------------------------------
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // weights have landed: no vmcnt wait inside the loop
+  zs_barrier_lds();                    // P: prologue planes staged by the helper waves
+
+  // pair i of a step: tile and tap (27 pairs: tile 0 then tile 1)
+  constexpr int N0 = ODD ? 13 : 14;  // pairs of tile 0 (even tile): even wave [0,14), odd wave [14,27)
+  constexpr int NI = 27;
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  for (int s = 0; s < G.nsteps; ++s) {
+    int rb[ZS_TILES][3][3];  // address of the kw = 0 tap's fragment for every (kz, kh)
+#pragma unroll
+    for (int t = 0; t < ZS_TILES; ++t) {
+      const int pb = (gh * G.pitch + gw) * ZS_VB + kconst;
+      const int ro0 = gh > 0 ? -RWB : (H - 1) * RWB;
+      const int ro2 = gh < H - 1 ? RWB : -(H - 1) * RWB;
+#pragma unroll
+      for (int kz = 0; kz < 3; ++kz) {
+        int sl = grs + kz;
+        sl = sl >= ZS_RING ? sl - ZS_RING : sl;
+        const int bz = sl * G.PLB + pb;
+        rb[t][kz][0] = bz + ro0;
+        rb[t][kz][1] = bz;
+        rb[t][kz][2] = bz + ro2;
+      }
+      gw += adv_w;
+      gh += adv_h;
+      if (gw >= W) { gw -= W; gh += 1; }
+      if (gh >= H) { gh -= H; grs = grs == ZS_RING - 1 ? 0 : grs + 1; }
+    }
+    constexpr int PD = 3;  // fragments are requested PD pairs ahead of their MFMAs
+    u32x4 fa[PD + 1][2];
+    auto pair_tile = [](int i) { return i < N0 ? 0 : 1; };
+    auto pair_tap = [](int i) {  // absolute tap of pair i
+      if (i < N0) return ODD ? 14 + i : i;            // tile 0: even wave 0..13, odd wave 14..26
+      const int j = i - N0;
+      return ODD ? 13 + j : j;                        // tile 1: even wave 0..12, odd wave 13..26
+    };
+    auto load_frag = [&](int i) {
+      const int t = pair_tile(i), tap = pair_tap(i);
+      const int kz = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+      const char* p = lds + rb[t][kz][kh] + kw * ZS_VB;
+      fa[i % (PD + 1)][0] = *(const u32x4*)p;
+      fa[i % (PD + 1)][1] = *(const u32x4*)(p + 32);
+    };
+    auto write_partial = [&](int t, const f32x16& A, const f32x16& B) {
+      f32x16 pt;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pt[r] = A[r] + B[r] * (1.f / 2048.f);
+      char* d = part + (((s & 1) * ZS_TILES * 4 + t * 4 + WV) * 4) * 1024 + lane * 16;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) *(f32x4*)(d + g * 1024) = f32x4{pt[4 * g], pt[4 * g + 1], pt[4 * g + 2], pt[4 * g + 3]};
+    };
+    f32x16 accA[2], accB[2];  // one accumulator pair per tile: tile 0's is folded and written under tile 1's MFMAs
+#pragma unroll
+    for (int i = 0; i < PD; ++i) load_frag(i);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int t = pair_tile(i), j = pair_tap(i) - T0;
+      const bool first = i == 0 || i == N0;
+      if (i + PD < NI) load_frag(i + PD);
+      __builtin_amdgcn_sched_barrier(0);
+      accA[t] = MFMA_F16(fa[i % (PD + 1)][0], w1[j], first ? zero16 : accA[t]);
+      accB[t] = MFMA_F16(fa[i % (PD + 1)][0], w2[j], first ? zero16 : accB[t]);
+      accB[t] = MFMA_F16(fa[i % (PD + 1)][1], w1[j], accB[t]);
+      if (i == N0 + 3) write_partial(0, accA[0], accB[0]);
+    }
+    write_partial(1, accA[1], accB[1]);
+    zs_barrier_lds();  // A: this step's partials are complete (buffer s & 1); the next step's planes are staged
+  }
+}
+
+// ---- helper waves 4..7: stage incoming planes; sum / store half a tile of the previous step ----------------------------
+template <bool ACC>
+__device__ __forceinline__ void zs_helper_wave(const ConvZsArgs& a, char* lds, const int h) {
+  const int tid = threadIdx.x - 256, lane = tid & 63, half = lane >> 5, col = lane & 31;
+  const int chunk = blockIdx.x, b = blockIdx.y, ct = blockIdx.z;
+  const ZsGeo G = zs_geo(a);
+  const int PV = G.PV;
+  char* const part = lds + G.ZPART;
+
+  // staging role: thread = (channel quad q, voxel p0 + 32k)
   const int q = tid & 7, p0 = tid >> 3;
   f32x4 cf[4];
   if (a.coef) {
@@ -124,13 +255,18 @@ __device__ __forceinline__ void zs_wave(const ConvZsArgs& a, char* lds) {
     for (int e = 0; e < 4; ++e) cf[e] = *(const f32x4*)(a.coef + ((size_t)b * a.coef_c + q * 4 + e) * 4);
   }
   const float bv = a.bias ? a.bias[ct * 32 + col] : 0.f;
-  const float* src_b = a.in + (size_t)b * vox * a.ldc + q * 4;
-  const int st_off = (q >> 2) * 64 + (q & 3) * 8;
+  const float* src_b = a.in + (size_t)b * G.vox * a.ldc + q * 4;
+  int rec[ZS_NSL];  // byte offset of this thread's record k inside a plane (+ its quad's place in the record)
+#pragma unroll
+  for (int k = 0; k < ZS_NSL; ++k) {
+    const int p = min(p0 + 32 * k, PV - 1);
+    const int ph = p / a.W;
+    rec[k] = G.RB + (ph * G.pitch + (p - ph * a.W)) * ZS_VB + (q >> 2) * 64 + (q & 3) * 8;
+  }
   float amax = 0.f;
   f32x4 ld[ZS_NSL];
-  auto ring_slot = [&](int z) { return (z + ZS_RING) % ZS_RING; };  // z >= -1
   // Loads are unconditional (plane and voxel indices clamped into range; an out-of-range plane is zero-filled by
-  // convert()): a predicated load would be sunk by the compiler into convert()'s matching branch, behind the MFMAs.
+  // convert()): a predicated load would be sunk by the compiler into convert()'s matching branch.
   auto issue = [&](int z) {
     const int zc = min(max(z, 0), a.D - 1);
     const float* src = src_b + (size_t)zc * PV * a.ldc;
@@ -140,13 +276,14 @@ __device__ __forceinline__ void zs_wave(const ConvZsArgs& a, char* lds) {
       ld[k] = *(const f32x4*)(src + (size_t)p * a.ldc);
     }
   };
-  auto convert = [&](int z) {
-    char* dst = lds + ring_slot(z) * PVB + st_off;
+  auto convert = [&](int z, int k0, int k1) {  // slots [k0, k1) of plane z
+    const int slot = (z + ZS_RING) % ZS_RING;  // z >= -1
     const bool zero = z < 0 || z >= a.D;
+    char* dst = lds + slot * G.PLB;
 #pragma unroll
     for (int k = 0; k < ZS_NSL; ++k) {
-      const int p = p0 + 32 * k;
-      if (p < PV) {
+      if (k < k0 || k >= k1) continue;
+      if (p0 + 32 * k < PV) {
         u32x2 t1 = {0u, 0u}, t2 = {0u, 0u};
         if (!zero && !(a.dbg & 1)) {
           f32x4 v = ld[k];
@@ -154,188 +291,107 @@ __device__ __forceinline__ void zs_wave(const ConvZsArgs& a, char* lds) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               float t = cf[e][0] * v[e] + cf[e][1];
-              if (a.act) t = t / (1.f + expf(-t));
+              if (a.act) t = zs_silu(t);
               v[e] = t + cf[e][2];
             }
           }
           amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
           split2(v, t1, t2);
         }
-        *(u32x2*)(dst + p * ZS_VB) = t1;
-        *(u32x2*)(dst + p * ZS_VB + 32) = t2;
+        *(u32x2*)(dst + rec[k]) = t1;
+        *(u32x2*)(dst + rec[k] + 32) = t2;
       }
     }
   };
 
-  // ---- prologue: zero record, planes needed by step 0 -----------------------------------------------------------
-  if (tid < ZS_VB / 4) ((float*)(lds + ZADDR))[tid] = 0.f;
-  const int zfirst = v0 / PV;
-  int zstaged = (min(v0 + 127, cend - 1)) / PV + 1;
-  for (int z = zfirst - 1; z <= zstaged; ++z) {
+  // prologue: leading zero record, the zero pad record of every row of every ring plane, planes needed by steps 0..2
+  if (tid < ZS_VB / 4) ((float*)lds)[tid] = 0.f;
+  for (int i = tid; i < ZS_RING * a.H * (ZS_VB / 4); i += 256) {
+    const int row = i / (ZS_VB / 4), wd = i - row * (ZS_VB / 4);
+    ((float*)(lds + G.RB + (row * G.pitch + a.W) * ZS_VB))[wd] = 0.f;
+  }
+  auto need = [&](int k) {  // highest plane that step k reads
+    k = min(k, G.nsteps - 1);
+    return min(G.v0 + k * ZS_STEP + ZS_STEP - 1, G.cend - 1) / PV + 1;
+  };
+  int zstaged = need(0);
+  for (int z = G.zfirst - 1; z <= zstaged; ++z) {
     issue(z);
-    convert(z);
+    convert(z, 0, ZS_NSL);
   }
-
-  // ---- per-lane geometry of its row (voxel) in the current tile, advanced by 32 voxels per tile -------------------
-  int gz, gh, gw, grs;  // plane, phi row, r column, ring slot of plane gz-1
-  {
-    const int v = v0 + col;
-    gz = v / PV;
-    const int p = v - gz * PV;
-    gh = p / W;
-    gw = p - gh * W;
-    grs = (gz + ZS_RING - 1) % ZS_RING;
-  }
-  const int adv_h = 32 / W, adv_w = 32 - adv_h * W;
-  const int WB = W * ZS_VB;
-  const int kconst = KSTEP * 64 + half * 16;
   float s1 = 0.f, s2 = 0.f;
-  float* const out_b = a.out + (size_t)b * vox * a.cout + ct * 32 + col;
-
-  // every pre-loop load (weights, coefficients, bias) has landed: no vmcnt wait may be needed inside the step loop
-  // other than the one on the incoming plane (a conservative vmcnt(0) there would serialise the output stores)
+  float* const out_b = a.out + (size_t)b * G.vox * a.cout + ct * 32 + col;
+  // Incoming planes (at most one per step: a plane is >= 64 voxels): converted while the matrix waves run the step BEFORE
+  // the one that first reads the plane -- only then is its ring slot (plane - 4) free -- from loads issued a step earlier.
+  int zpend = zstaged < need(1) ? zstaged + 1 : -2;
+  issue(zpend);
   __builtin_amdgcn_s_waitcnt(0x0F70);
-  __syncthreads();
+  zs_barrier_lds();  // P
 
-  for (int s = 0; s < nsteps; ++s) {
-    const int vs = v0 + s * 128;
-    int zin = -2;
-    if (s + 1 < nsteps) {
-      const int need = min(vs + 255, cend - 1) / PV + 1;
-      if (zstaged < need) zin = zstaged + 1;
+  const int th = h >> 1, rh = h & 1;  // this wave sums rows 16*rh .. 16*rh+15 (accumulator registers 8*rh .. 8*rh+7) of tile th
+  float sum[8];
+  auto read_partials = [&](int s) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const char* d = part + (((s & 1) * ZS_TILES * 4 + th * 4 + w) * 4 + 2 * rh) * 1024 + lane * 16;
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const f32x4 x = *(const f32x4*)(d + g * 1024);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sum[4 * g + e] = w == 0 ? x[e] : sum[4 * g + e] + x[e];
+      }
     }
-    issue(zin);
+  };
+  auto epilogue = [&](int s) {  // bias, store, statistics of this wave's 16 rows of step s
+    if (a.dbg & 4) return;
+    const int vt = G.v0 + s * ZS_STEP + th * 32;
+    float* o = out_b + (size_t)vt * a.cout;
+    if (ACC) {  // continuation launch of a wider-K conv: add to what the previous launch stored
+      float prev[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int row = (r & 3) + 8 * ((r >> 2) + 2 * rh) + 4 * half;
+        prev[r] = vt + row < G.cend ? o[(size_t)row * a.cout] : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) sum[r] += prev[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int row = (r & 3) + 8 * ((r >> 2) + 2 * rh) + 4 * half;
+      if (vt + row < G.cend) {
+        const float v = sum[r] + bv;
+        o[(size_t)row * a.cout] = v;
+        s1 += v;
+        s2 += v * v;
+      }
+    }
+  };
+
+  // interval s = the time the matrix waves spend in step s (between barriers A(s-1) and A(s))
+  for (int s = 0; s < G.nsteps; ++s) {
+    // conversion first: its loads are then the OLDEST outstanding vector-memory operations (vmcnt retires in order, so
+    // waiting for a load that was issued before a batch of output stores would wait for those stores as well)
+    if (zpend != -2) {
+      convert(zpend, 0, ZS_NSL);  // read first by step s+1
+      zstaged = zpend;
+    }
+    zpend = (s + 2 < G.nsteps && zstaged < need(s + 2)) ? zstaged + 1 : -2;
+    issue(zpend);
     __builtin_amdgcn_sched_barrier(0);
-
-    // geometry of the 4 tiles of this step
-    int base[4][3], ro0[4], ro2[4];
-    bool okl[4], okr[4], okv[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int pb = (gh * W + gw) * ZS_VB + kconst;
-#pragma unroll
-      for (int kz = 0; kz < 3; ++kz) {
-        int sl = grs + kz;
-        sl = sl >= ZS_RING ? sl - ZS_RING : sl;
-        base[t][kz] = sl * PVB + pb;
-      }
-      ro0[t] = gh > 0 ? -WB : (H - 1) * WB;
-      ro2[t] = gh < H - 1 ? WB : -(H - 1) * WB;
-      okv[t] = vs + t * 32 + col < cend;
-      okl[t] = okv[t] && gw > 0;
-      okr[t] = okv[t] && gw < W - 1;
-      // advance to the next tile
-      gw += adv_w;
-      gh += adv_h;
-      if (gw >= W) { gw -= W; gh += 1; }
-      if (gh >= H) { gh -= H; gz += 1; grs = grs == ZS_RING - 1 ? 0 : grs + 1; }
+    if (s > 0) {
+      read_partials(s - 1);
+      epilogue(s - 1);
     }
-    auto frag_addr = [&](int t, int j) -> int {
-      const int tap = TB + j;
-      const int kz = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-      const int n = base[t][kz] + (kh == 0 ? ro0[t] : (kh == 2 ? ro2[t] : 0)) + (kw - 1) * ZS_VB;
-      const bool ok = kw == 0 ? okl[t] : (kw == 2 ? okr[t] : okv[t]);
-      return ok ? n : ZADDR + kconst;
-    };
-
-    f32x16 own;
-    f32x16 accA, accB;
-    u32x4 fa[3][2];
-    constexpr int NI = 4 * NP;
-    auto load_frag = [&](int i) {
-      const int t = i / NP, j = i % NP;
-      const char* p = lds + frag_addr(t, j);
-      fa[i % 3][0] = *(const u32x4*)p;
-      fa[i % 3][1] = *(const u32x4*)(p + 32);
-    };
-    load_frag(0);
-    load_frag(1);
-    if (!(a.dbg & 2))
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int t = i / NP, j = i % NP;
-      if (i + 2 < NI && !(a.dbg & 8)) load_frag(i + 2);
-      __builtin_amdgcn_sched_barrier(0);
-      if (j == 0) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) accA[r] = accB[r] = 0.f;
-      }
-      accA = MFMA_F16(fa[i % 3][0], w1[j], accA);
-      accB = MFMA_F16(fa[i % 3][0], w2[j], accB);
-      accB = MFMA_F16(fa[i % 3][1], w1[j], accB);
-      if (j == NP - 1) {
-        f32x16 pt;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) pt[r] = accA[r] + accB[r] * (1.f / 2048.f);
-        if (t == WV) {
-          own = pt;
-        } else if (!(a.dbg & 16)) {
-          const int slot = WV < t ? WV : WV - 1;
-          char* d = part + ((t * 3 + slot) * 4) * 1024 + lane * 16;
-#pragma unroll
-          for (int g = 0; g < 4; ++g) *(f32x4*)(d + g * 1024) = f32x4{pt[4 * g], pt[4 * g + 1], pt[4 * g + 2], pt[4 * g + 3]};
-        }
-      }
-    }
-
-    if (zin != -2) {
-      convert(zin);
-      zstaged = zin;
-    }
-    __syncthreads();
-
-    // ---- tile WV: sum the four K-slices in wave order, bias, store, statistics --------------------------------
-    if (!(a.dbg & 4)) {
-      f32x16 sum;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        f32x16 v;
-        if (w == WV) {
-          v = own;
-        } else {
-          const int slot = w < WV ? w : w - 1;
-          const char* d = part + ((WV * 3 + slot) * 4) * 1024 + lane * 16;
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const f32x4 x = *(const f32x4*)(d + g * 1024);
-            v[4 * g] = x[0]; v[4 * g + 1] = x[1]; v[4 * g + 2] = x[2]; v[4 * g + 3] = x[3];
-          }
-        }
-        if (w == 0) sum = v;
-        else
-#pragma unroll
-          for (int r = 0; r < 16; ++r) sum[r] += v[r];
-      }
-      const int vt = vs + WV * 32;
-      float* o = out_b + (size_t)vt * a.cout;
-      if (ACC) {  // continuation launch of a wider-K conv: add to what the previous launch stored
-        f32x16 prev;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-          prev[r] = vt + row < cend ? o[(size_t)row * a.cout] : 0.f;
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sum[r] += prev[r];
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (vt + row < cend) {
-          const float v = sum[r] + bv;
-          o[(size_t)row * a.cout] = v;
-          s1 += v;
-          s2 += v * v;
-        }
-      }
-    }
-    __syncthreads();
+    zs_barrier_lds();  // A(s)
   }
+  read_partials(G.nsteps - 1);
+  epilogue(G.nsteps - 1);
 
   if (a.ch_part) {
     const float t1 = s1 + __shfl_xor(s1, 32, 64), t2 = s2 + __shfl_xor(s2, 32, 64);
     if (half == 0) {
-      float* dst = a.ch_part + ((((size_t)b * a.nchunk + chunk) * 4 + WV) * a.cout + ct * 32 + col) * 2;
+      float* dst = a.ch_part + ((((size_t)b * a.nchunk + chunk) * 4 + h) * a.cout + ct * 32 + col) * 2;
       dst[0] = t1;
       dst[1] = t2;
     }
@@ -344,19 +400,20 @@ __device__ __forceinline__ void zs_wave(const ConvZsArgs& a, char* lds) {
 }
 
 template <bool ACC>
-__global__ void __launch_bounds__(256, 1) conv_zslide_f16x2_kernel(ConvZsArgs a) {
+__global__ void __launch_bounds__(512, 1) conv_zslide_f16x2_kernel(ConvZsArgs a) {
   extern __shared__ __attribute__((aligned(16))) char zs_lds[];
   switch (threadIdx.x >> 6) {
-    case 0: zs_wave<0, ACC>(a, zs_lds); break;
-    case 1: zs_wave<1, ACC>(a, zs_lds); break;
-    case 2: zs_wave<2, ACC>(a, zs_lds); break;
-    default: zs_wave<3, ACC>(a, zs_lds); break;
+    case 0: zs_matrix_wave<0>(a, zs_lds); break;
+    case 1: zs_matrix_wave<1>(a, zs_lds); break;
+    case 2: zs_matrix_wave<2>(a, zs_lds); break;
+    case 3: zs_matrix_wave<3>(a, zs_lds); break;
+    default: zs_helper_wave<ACC>(a, zs_lds, (int)(threadIdx.x >> 6) - 4); break;
   }
 }
 
 }  // namespace
 
-// Eligible: 3x3x3 stride 1, planes of 128..158 voxels (Dataset-2's 16x9), 32-channel input blocks.  Returns false otherwise.
+// Eligible: 3x3x3 stride 1, planes of 128..160 voxels (Dataset-2's 16x9), 32-channel input blocks.  Returns false otherwise.
 bool try_launch_conv_zslide(const float* in0, int c0, const float* in1, int c1, const void* wpk_f16x2, const float* bias, float* out,
                             int batch, int cout, const ConvGeom& g, hipStream_t s, const ConvFusion& fu) {
   if (getenv("CD_NO_ZSLIDE")) return false;
@@ -364,7 +421,7 @@ bool try_launch_conv_zslide(const float* in0, int c0, const float* in1, int c1, 
   const int PV = g.in.h * g.in.w;
   const int64_t vox = g.in.vox();
   if (PV < 128 || PV * 8 > ZS_NSL * 256) return false;
-  const size_t lds = (((size_t)ZS_RING * PV * ZS_VB + ZS_VB + 255) & ~(size_t)255) + ZS_PART;
+  const size_t lds = (((size_t)ZS_VB + (size_t)ZS_RING * g.in.h * (g.in.w + 1) * ZS_VB + 255) & ~(size_t)255) + ZS_PART;
   if (lds > 160 * 1024) return false;
   if (vox < 256 || cout % 32 || c0 % 32 || c1 % 32) return false;
   const int CTtot = cout / 32;
@@ -410,8 +467,8 @@ bool try_launch_conv_zslide(const float* in0, int c0, const float* in1, int c1, 
     a.status = fu.status;
     a.dbg = getenv("CD_ZS_DBG") ? atoi(getenv("CD_ZS_DBG")) : 0;
     const dim3 grid((unsigned)nchunk, (unsigned)batch, (unsigned)CTtot);
-    if (kb == 0) hipLaunchKernelGGL(conv_zslide_f16x2_kernel<false>, grid, dim3(256), lds, s, a);
-    else hipLaunchKernelGGL(conv_zslide_f16x2_kernel<true>, grid, dim3(256), lds, s, a);
+    if (kb == 0) hipLaunchKernelGGL(conv_zslide_f16x2_kernel<false>, grid, dim3(512), lds, s, a);
+    else hipLaunchKernelGGL(conv_zslide_f16x2_kernel<true>, grid, dim3(512), lds, s, a);
     CD_HIP(hipGetLastError());
   }
   if (fu.units) *fu.units = nchunk * 4;

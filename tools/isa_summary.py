@@ -31,6 +31,8 @@ for l in body:
         seq.append("|B|")
     elif op.startswith("ds_write"):
         seq.append("W")
+    elif op.startswith("global_store"):
+        seq.append("S")
     elif op.startswith(("s_cbranch", "s_branch")):
         seq.append("~")
 print(len(body), "lines")
