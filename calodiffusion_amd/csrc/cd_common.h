@@ -205,7 +205,15 @@ size_t attn_partial_floats(int batch, int nsplit);
 void launch_attn_context(const float* qkv, float* partials, int batch, int64_t vox, int nsplit, hipStream_t s);
 void launch_attn_combine(const float* partials, int nsplit, const float* w_out /*torch (C,32)*/, int cout, float* wpk_b,
                          int batch, float scale, hipStream_t s, float* ctx_out = nullptr /* [B][32][32] unscaled context */,
-                         float* kstat_out = nullptr /* [B][32][2] = {max, 1/sum} of the k softmax */);
+                         float* kstat_out = nullptr /* [B][32][2] = {max, 1/sum} of the k softmax */,
+                         bool layout_T = false /* wpk_b in the K order of launch_attn_out instead of the pointwise one */);
+
+// fused linear attention of the sampling path (kernels_attn.hip): qkv is never materialised
+int attn_fused_nsplit_for(int64_t vox, int batch);
+void launch_attn_kv_context(const float* x, int C, const float* coef, const float* wqkv_packed, float* partials, int batch,
+                            int64_t vox, int nsplit, hipStream_t s);
+void launch_attn_out(const float* x, int C, const float* coef, const float* wqkv_packed, const float* wT_b, const float* bias,
+                     float* y, float* ch_part /* [B][nsplit][C][2] */, int batch, int64_t vox, int nsplit, hipStream_t s);
 
 struct EmbedLayer {
   const float* w;  // (cout, 128) torch layout

@@ -1,0 +1,331 @@
+// Fused linear attention for the sampling path (LinearAttention, calodiffusion/models/models.py:281-329, heads = 1,
+// dim_head = 32, wrapped in PreNorm(GroupNorm(1)) :111-117): the (B, n, 96) qkv tensor is never written.
+//
+//   pass 1  attn_kv_context_kernel   x -> xn = GroupNorm(1) affine (folded coefficients) -> k, v = W_k xn, W_v xn on the matrix
+//                                    cores -> exp(k - max) and the un-normalised context  ctx[d][e] = sum_n e^{k[n][d]-m[d]} v[n][e]
+//                                    straight from the accumulator registers (the projection's C layout IS the A/B layout of
+//                                    the context MFMA); per-workgroup {max, sum, ctx} partials, merged log-sum-exp style by
+//                                    attn_combine_kernel (kernels_norm_attn.hip), which also folds W_out into per-sample weights
+//   pass 2  attn_out_kernel          x -> xn -> q^T = W_q xn^T (channels in registers => the 32-way softmax over channels is
+//                                    lane-local) -> y = softmax(q) W'^T + b with the q^T registers as the A operand -> y and its
+//                                    channel statistics (for the GroupNorm(1) that follows)
+//
+// HBM traffic per attention block: x twice + y once (3 x B n C floats) instead of x + 2 x qkv + q + y (= 10 x for C = 32).
+// All arithmetic is fp32 (v_mfma_f32_32x32x2_f32); the kernels are memory / latency bound.
+#include "cd_common.h"
+
+#include <cstdio>
+
+namespace cd {
+
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+namespace {
+
+struct AttnArgs {
+  const float* x;     // (B, vox, C) channels-last
+  const float* coef;  // [B][C][4] = {scale, shift, -, -} of the PreNorm
+  const float* wqkv;  // packed MFMA image of to_qkv (96 output channels: ct 0 = q, 1 = k, 2 = v)
+  int C;
+  int64_t vox;
+  int tiles_per_wg;   // 32-voxel tiles per workgroup (multiple of 8)
+  // pass 1
+  float* partials;    // [B][nsplit][64 + 1024]
+  int nsplit;
+  // pass 2
+  const float* wT;    // [B][CT][4][64][4]: per-sample folded output weights, transposed-K layout (attn_combine, layout_T)
+  const float* bias;  // (C)
+  float* y;           // (B, vox, C)
+  float* ch_part;     // [B][units][C][2]
+};
+
+// A fragments of one 32-voxel tile: lane (voxel n0 + col, half) holds channels chunk*32 + half*16 + 0..15, normalised
+template <int NCH>
+__device__ __forceinline__ void load_xn(const AttnArgs& a, int b, int64_t n0, int col, int half, const f32x4 (&cf)[NCH][8],
+                                        f32x4 (&av)[NCH][4]) {
+  const int64_t n = n0 + col;
+  const bool valid = n < a.vox;
+  const float* src = a.x + ((size_t)b * a.vox + (valid ? n : 0)) * a.C + half * 16;
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) av[ch][q] = *(const f32x4*)(src + ch * 32 + q * 4);
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        // cf[ch][2*q + (e>>1)] = {scale, shift} of channels (q*4+e) & ~1 .. |1 : {s0, h0, s1, h1}
+        const f32x4 c2 = cf[ch][2 * q + (e >> 1)];
+        av[ch][q][e] = valid ? c2[(e & 1) * 2] * av[ch][q][e] + c2[(e & 1) * 2 + 1] : 0.f;
+      }
+}
+template <int NCH>
+__device__ __forceinline__ void load_coef(const AttnArgs& a, int b, int half, f32x4 (&cf)[NCH][8]) {
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float* p = a.coef + ((size_t)b * a.C + ch * 32 + half * 16 + 2 * i) * 4;
+      cf[ch][i] = f32x4{p[0], p[1], p[4], p[5]};
+    }
+}
+
+template <int NCH>
+__global__ void __launch_bounds__(512) attn_kv_context_kernel(AttnArgs a) {
+  __shared__ float sMax[8][32];
+  __shared__ float sSum[16][32];
+  __shared__ float sCtx[8][1024];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, col = lane & 31;
+  const int split = blockIdx.x, b = blockIdx.y;
+  const int64_t T = (a.vox + 31) / 32;
+  const int64_t t0 = (int64_t)split * a.tiles_per_wg;
+  const int64_t t1 = (t0 + a.tiles_per_wg < T) ? t0 + a.tiles_per_wg : T;
+
+  f32x4 cf[NCH][8];
+  load_coef<NCH>(a, b, half, cf);
+  f32x4 wk[NCH][4], wv[NCH][4];
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      wk[ch][q] = ((const f32x4*)a.wqkv)[((size_t)(ch * 3 + 1) * 4 + q) * 64 + lane];
+      wv[ch][q] = ((const f32x4*)a.wqkv)[((size_t)(ch * 3 + 2) * 4 + q) * 64 + lane];
+    }
+
+  // sweep 1: per-channel max of k over this workgroup's voxels
+  float m = -3.0e38f;
+  for (int64_t t = t0 + wave; t < t1; t += 8) {
+    f32x4 av[NCH][4];
+    load_xn<NCH>(a, b, t * 32, col, half, cf, av);
+    f32x16 k;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) k[r] = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) k = MFMA32(av[ch][q][e], wk[ch][q][e], k);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (t * 32 + row < a.vox) m = fmaxf(m, k[r]);
+    }
+  }
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  if (half == 0) sMax[wave][col] = m;
+  __syncthreads();
+  m = sMax[0][col];
+#pragma unroll
+  for (int w = 1; w < 8; ++w) m = fmaxf(m, sMax[w][col]);
+
+  // sweep 2: e = exp(k - m) (rows = voxels, column = channel d), ctx[d][e'] += e^T v on the matrix cores: the k / v
+  // accumulator registers are the A / B operands of the context MFMA (k-slot = the lane's half)
+  f32x16 ctx;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) ctx[r] = 0.f;
+  float ssum = 0.f;
+  for (int64_t t = t0 + wave; t < t1; t += 8) {
+    f32x4 av[NCH][4];
+    load_xn<NCH>(a, b, t * 32, col, half, cf, av);
+    f32x16 k, v;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) k[r] = v[r] = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          k = MFMA32(av[ch][q][e], wk[ch][q][e], k);
+          v = MFMA32(av[ch][q][e], wv[ch][q][e], v);
+        }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+      const float ex = (t * 32 + row < a.vox) ? expf(k[r] - m) : 0.f;
+      ssum += ex;
+      ctx = MFMA32(ex, v[r], ctx);
+    }
+  }
+  sSum[wave * 2 + half][col] = ssum;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int d = (r & 3) + 8 * (r >> 2) + 4 * half;  // row = channel d; column = e
+    sCtx[wave][d * 32 + col] = ctx[r];
+  }
+  __syncthreads();
+  float* out = a.partials + ((size_t)b * a.nsplit + split) * (64 + 1024);
+  if (tid < 32) {
+    out[tid] = m;
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += sSum[i][tid];
+    out[32 + tid] = t;
+  }
+  for (int i = tid; i < 1024; i += 512) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) t += sCtx[w][i];
+    out[64 + i] = t;
+  }
+}
+
+template <int NCH>
+__global__ void __launch_bounds__(512) attn_out_kernel(AttnArgs a) {
+  __shared__ float sRed[8][NCH * 32][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, col = lane & 31;
+  const int unit = blockIdx.x, b = blockIdx.y;
+  const int64_t T = (a.vox + 31) / 32;
+  const int64_t t0 = (int64_t)unit * a.tiles_per_wg;
+  const int64_t t1 = (t0 + a.tiles_per_wg < T) ? t0 + a.tiles_per_wg : T;
+
+  f32x4 cf[NCH][8];
+  load_coef<NCH>(a, b, half, cf);
+  f32x4 wq[NCH][4], wt[NCH][4];
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      wq[ch][q] = ((const f32x4*)a.wqkv)[((size_t)(ch * 3 + 0) * 4 + q) * 64 + lane];
+      wt[ch][q] = ((const f32x4*)a.wT)[(((size_t)b * NCH + ch) * 4 + q) * 64 + lane];  // ch = output channel tile here
+    }
+  float bv[NCH], s1[NCH], s2[NCH];
+#pragma unroll
+  for (int ct = 0; ct < NCH; ++ct) {
+    bv[ct] = a.bias ? a.bias[ct * 32 + col] : 0.f;
+    s1[ct] = s2[ct] = 0.f;
+  }
+  float* const yb = a.y + (size_t)b * a.vox * a.C;
+
+  for (int64_t t = t0 + wave; t < t1; t += 8) {
+    f32x4 av[NCH][4];
+    load_xn<NCH>(a, b, t * 32, col, half, cf, av);
+    // q^T[d][n]: A = W_q (row d), B = xn^T (column n); the registers of a lane are 16 channels d of its voxel n = col
+    f32x16 q;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) q[r] = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q = MFMA32(wq[ch][qq][e], av[ch][qq][e], q);
+    float mx = q[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, q[r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float ss = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      q[r] = expf(q[r] - mx);
+      ss += q[r];
+    }
+    ss += __shfl_xor(ss, 32, 64);
+    const float inv = 1.f / ss;
+    // y[n][co] = sum_d softmax(q)[n][d] W'[co][d]: A = q^T registers (row n = col, k-slot = half <-> d = row(r, half))
+#pragma unroll
+    for (int ct = 0; ct < NCH; ++ct) {
+      f32x16 o;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o = MFMA32(q[r] * inv, wt[ct][r >> 2][r & 3], o);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t n = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (n < a.vox) {
+          const float v = o[r] + bv[ct];
+          yb[(size_t)n * a.C + ct * 32 + col] = v;
+          s1[ct] += v;
+          s2[ct] += v * v;
+        }
+      }
+    }
+  }
+  if (a.ch_part) {
+#pragma unroll
+    for (int ct = 0; ct < NCH; ++ct) {
+      const float t1s = s1[ct] + __shfl_xor(s1[ct], 32, 64), t2s = s2[ct] + __shfl_xor(s2[ct], 32, 64);
+      if (half == 0) {
+        sRed[wave][ct * 32 + col][0] = t1s;
+        sRed[wave][ct * 32 + col][1] = t2s;
+      }
+    }
+    __syncthreads();
+    if (tid < NCH * 32) {
+      float r1 = 0.f, r2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) {
+        r1 += sRed[w][tid][0];
+        r2 += sRed[w][tid][1];
+      }
+      float* dst = a.ch_part + (((size_t)b * gridDim.x + unit) * a.C + tid) * 2;
+      dst[0] = r1;
+      dst[1] = r2;
+    }
+  }
+}
+
+int tiles_per_wg_for(int64_t vox, int nsplit) {
+  const int64_t T = (vox + 31) / 32;
+  int64_t per = (T + nsplit - 1) / nsplit;
+  per = (per + 7) / 8 * 8;
+  return (int)per;
+}
+
+}  // namespace
+
+// workgroups per sample for both passes: enough to fill the chip twice, at least 8 tiles (one per wave) each
+int attn_fused_nsplit_for(int64_t vox, int batch) {
+  const int64_t T = (vox + 31) / 32;
+  int64_t want = (512 + batch - 1) / batch;
+  const int64_t cap = (T + 15) / 16;
+  int64_t n = want < cap ? want : cap;
+  if (n < 1) n = 1;
+  if (n > 128) n = 128;
+  // tiles_per_wg is rounded up to a multiple of 8: drop workgroups that would start past the end
+  const int per = tiles_per_wg_for(vox, (int)n);
+  n = (T + per - 1) / per;
+  return (int)n;
+}
+
+void launch_attn_kv_context(const float* x, int C, const float* coef, const float* wqkv_packed, float* partials, int batch,
+                            int64_t vox, int nsplit, hipStream_t s) {
+  CD_REQUIRE(C == 32 || C == 64 || C == 96 || C == 128, "fused attention: 32..128 input channels");
+  AttnArgs a{};
+  a.x = x; a.coef = coef; a.wqkv = wqkv_packed; a.C = C; a.vox = vox; a.tiles_per_wg = tiles_per_wg_for(vox, nsplit);
+  a.partials = partials; a.nsplit = nsplit;
+  prof::Scope scope("attn_kv_context", s, 2.0 * (2.0 * C + 32) * 32 * (double)vox * batch, 4.0 * batch * (double)vox * C);
+  const dim3 grid((unsigned)nsplit, (unsigned)batch);
+  switch (C / 32) {
+    case 1: hipLaunchKernelGGL(attn_kv_context_kernel<1>, grid, dim3(512), 0, s, a); break;
+    case 2: hipLaunchKernelGGL(attn_kv_context_kernel<2>, grid, dim3(512), 0, s, a); break;
+    case 3: hipLaunchKernelGGL(attn_kv_context_kernel<3>, grid, dim3(512), 0, s, a); break;
+    default: hipLaunchKernelGGL(attn_kv_context_kernel<4>, grid, dim3(512), 0, s, a); break;
+  }
+  CD_HIP(hipGetLastError());
+}
+
+void launch_attn_out(const float* x, int C, const float* coef, const float* wqkv_packed, const float* wT_b, const float* bias,
+                     float* y, float* ch_part, int batch, int64_t vox, int nsplit, hipStream_t s) {
+  CD_REQUIRE(C == 32 || C == 64 || C == 96 || C == 128, "fused attention: 32..128 channels");
+  AttnArgs a{};
+  a.x = x; a.coef = coef; a.wqkv = wqkv_packed; a.C = C; a.vox = vox; a.tiles_per_wg = tiles_per_wg_for(vox, nsplit);
+  a.wT = wT_b; a.bias = bias; a.y = y; a.ch_part = ch_part;
+  prof::Scope scope("attn_out", s, 2.0 * (2.0 * C) * 32 * (double)vox * batch, 4.0 * batch * (double)vox * C * 2);
+  const dim3 grid((unsigned)nsplit, (unsigned)batch);
+  switch (C / 32) {
+    case 1: hipLaunchKernelGGL(attn_out_kernel<1>, grid, dim3(512), 0, s, a); break;
+    case 2: hipLaunchKernelGGL(attn_out_kernel<2>, grid, dim3(512), 0, s, a); break;
+    case 3: hipLaunchKernelGGL(attn_out_kernel<3>, grid, dim3(512), 0, s, a); break;
+    default: hipLaunchKernelGGL(attn_out_kernel<4>, grid, dim3(512), 0, s, a); break;
+  }
+  CD_HIP(hipGetLastError());
+}
+
+}  // namespace cd

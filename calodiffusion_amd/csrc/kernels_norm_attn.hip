@@ -311,7 +311,7 @@ void launch_attn_context(const float* qkv, float* partials, int batch, int64_t v
 __global__ void __launch_bounds__(256) attn_combine_kernel(const float* __restrict__ partials, int nsplit,
                                                            const float* __restrict__ w_out, int cout,
                                                            float* __restrict__ wpk_b, float scale, float* __restrict__ ctx_out,
-                                                           float* __restrict__ kstat_out) {
+                                                           float* __restrict__ kstat_out, int layout_T) {
   __shared__ float sM[32], sInv[32];
   __shared__ float sCtx[1024];
   const int tid = threadIdx.x, b = blockIdx.x;
@@ -342,7 +342,9 @@ __global__ void __launch_bounds__(256) attn_combine_kernel(const float* __restri
   float* wo = wpk_b + (size_t)b * CT * 1024;
   for (int i = tid; i < CT * 1024; i += 256) {
     const int e4 = i & 3, lane = (i >> 2) & 63, q = (i >> 8) & 3, ct = i >> 10;
-    const int c = ct * 32 + (lane & 31), d = (lane >> 5) * 16 + q * 4 + e4;
+    // layout_T (attn_out_kernel): the k-slot order of an accumulator-register operand, d = row(r = 4q + e4, half)
+    const int c = ct * 32 + (lane & 31);
+    const int d = layout_T ? (e4 + 8 * q + 4 * (lane >> 5)) : (lane >> 5) * 16 + q * 4 + e4;
     float acc = 0.f;
     if (c < cout)
       for (int e = 0; e < 32; ++e) acc = fmaf(w_out[c * 32 + e], sCtx[d * 32 + e], acc);
@@ -351,10 +353,10 @@ __global__ void __launch_bounds__(256) attn_combine_kernel(const float* __restri
 }
 
 void launch_attn_combine(const float* partials, int nsplit, const float* w_out, int cout, float* wpk_b, int batch,
-                         float scale, hipStream_t s, float* ctx_out, float* kstat_out) {
+                         float scale, hipStream_t s, float* ctx_out, float* kstat_out, bool layout_T) {
   prof::Scope scope("attn_combine", s, 0, 0);
   hipLaunchKernelGGL(attn_combine_kernel, dim3(batch), dim3(256), 0, s, partials, nsplit, w_out, cout, wpk_b, scale, ctx_out,
-                     kstat_out);
+                     kstat_out, layout_T ? 1 : 0);
   CD_HIP(hipGetLastError());
 }
 

@@ -497,34 +497,56 @@ float* attn_block(Run& r, const AttnP& w, const float* x, Dims3 dims, float* xpa
   float* coefn = ws->get<float>((size_t)r.B * C * 4);
   if (!r.dry()) launch_gn_finalize(xpart, xunits, w.ng, w.nb, nullptr, 0, coefn, r.B, C, 1, vox, r.s);
   if (own) ws->release(own);
-  float* qkv = ws->get<float>((size_t)r.B * vox * 96);
-  if (!r.dry()) {
-    PointwiseArgs a;
-    a.in0 = x; a.ld0 = C; a.c0 = C; a.wpk = w.qkv; a.out = qkv; a.batch = r.B; a.cout = 96; a.vox = vox;
-    a.prologue = A_AFFINE; a.coef = coefn;
-    launch_pointwise(a, r.s);
-  }
-  ws->release(coefn);
-  const int nsp = attn_nsplit_for(vox, r.B);
-  float* part = ws->get<float>(attn_partial_floats(r.B, nsp));
+  static const bool no_fused = getenv("CD_NO_FUSED_ATTN") != nullptr;
   const int CT = (C + 31) / 32;
-  float* wpb = ws->get<float>((size_t)r.B * CT * 1024);
-  if (!r.dry()) {
-    launch_attn_context(qkv, part, r.B, vox, nsp, r.s);
-    launch_attn_combine(part, nsp, w.ow, C, wpb, r.B, 0.17677669529663689f /* 32^-1/2 */, r.s);
-  }
-  float* y = ws->get<float>((size_t)r.B * vox * C);
-  const int yu = pointwise_units(vox);
-  float* ypart = ws->get<float>((size_t)r.B * yu * C * 2);
-  if (!r.dry()) {
-    PointwiseArgs a;
-    a.in0 = qkv; a.ld0 = 96; a.off0 = 0; a.c0 = 32; a.wpk = wpb; a.w_batch_stride = (int64_t)CT * 1024; a.bias = w.ob;
-    a.out = y; a.batch = r.B; a.cout = C; a.vox = vox; a.prologue = A_SOFTMAX32; a.ch_part = ypart;
-    launch_pointwise(a, r.s);
-  }
-  ws->release(part);
-  ws->release(wpb);
-  ws->release(qkv);
+  float* y = nullptr;
+  float* ypart = nullptr;
+  int yu = 0;
+  if (!no_fused) {
+    // fused path (kernels_attn.hip): x -> {max, sum, context} partials -> per-sample folded W_out -> y; qkv never exists
+    const int nsp = attn_fused_nsplit_for(vox, r.B);
+    float* part = ws->get<float>(attn_partial_floats(r.B, nsp));
+    float* wpb = ws->get<float>((size_t)r.B * CT * 1024);
+    y = ws->get<float>((size_t)r.B * vox * C);
+    yu = nsp;
+    ypart = ws->get<float>((size_t)r.B * yu * C * 2);
+    if (!r.dry()) {
+      launch_attn_kv_context(x, C, coefn, w.qkv, part, r.B, vox, nsp, r.s);
+      launch_attn_combine(part, nsp, w.ow, C, wpb, r.B, 0.17677669529663689f /* 32^-1/2 */, r.s, nullptr, nullptr, true);
+      launch_attn_out(x, C, coefn, w.qkv, wpb, w.ob, y, ypart, r.B, vox, nsp, r.s);
+    }
+    ws->release(coefn);
+    ws->release(part);
+    ws->release(wpb);
+  } else {
+    float* qkv = ws->get<float>((size_t)r.B * vox * 96);
+    if (!r.dry()) {
+      PointwiseArgs a;
+      a.in0 = x; a.ld0 = C; a.c0 = C; a.wpk = w.qkv; a.out = qkv; a.batch = r.B; a.cout = 96; a.vox = vox;
+      a.prologue = A_AFFINE; a.coef = coefn;
+      launch_pointwise(a, r.s);
+    }
+    ws->release(coefn);
+    const int nsp = attn_nsplit_for(vox, r.B);
+    float* part = ws->get<float>(attn_partial_floats(r.B, nsp));
+    float* wpb = ws->get<float>((size_t)r.B * CT * 1024);
+    if (!r.dry()) {
+      launch_attn_context(qkv, part, r.B, vox, nsp, r.s);
+      launch_attn_combine(part, nsp, w.ow, C, wpb, r.B, 0.17677669529663689f /* 32^-1/2 */, r.s);
+    }
+    y = ws->get<float>((size_t)r.B * vox * C);
+    yu = pointwise_units(vox);
+    ypart = ws->get<float>((size_t)r.B * yu * C * 2);
+    if (!r.dry()) {
+      PointwiseArgs a;
+      a.in0 = qkv; a.ld0 = 96; a.off0 = 0; a.c0 = 32; a.wpk = wpb; a.w_batch_stride = (int64_t)CT * 1024; a.bias = w.ob;
+      a.out = y; a.batch = r.B; a.cout = C; a.vox = vox; a.prologue = A_SOFTMAX32; a.ch_part = ypart;
+      launch_pointwise(a, r.s);
+    }
+    ws->release(part);
+    ws->release(wpb);
+    ws->release(qkv);
+}
   float* coefg = ws->get<float>((size_t)r.B * C * 4);
   if (!r.dry()) {
     launch_gn_finalize(ypart, yu, w.gg, w.gb, nullptr, 0, coefg, r.B, C, 1, vox, r.s);
