@@ -118,15 +118,18 @@ def roofline_leg(model, cfg, batch, E, layers):
                      "tflops": round(v["flops"] / (v["ms"] / v["launches"] * 1e-3) / 1e12, 2) if v["flops"] else None,
                      "gbs": round(v["bytes"] / (v["ms"] / v["launches"] * 1e-3) / 1e9, 1) if v["bytes"] else None}
                  for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
-    # The convs compute fp32-grade results on the bf16 matrix pipe (exact 3-way bf16 split, 6 bf16 MFMAs per fp32 MAC):
-    # the roof of that algorithm is bf16-dense / 6.  CD_CONV_PRECISION=f32 selects the f32-input MFMA kernels instead,
-    # whose roof is the fp32 matrix peak.
-    f32_mode = os.environ.get("CD_CONV_PRECISION", "") == "f32"
-    peak = PEAK_FP32_MFMA_TFLOPS if f32_mode else PEAK_BF16_MFMA_TFLOPS / BF16X3_TERMS
+    # The convs compute fp32-grade results on the 16-bit matrix pipe.  Default (f16x2): every fp32 operand is split into two
+    # fp16 terms and a MAC block takes 3 fp16 MFMAs, so the roof of the algorithm that runs is fp16-dense / 3.
+    # CD_CONV_PRECISION=bf16x3 selects the exact 3-term bf16 split (6 MFMAs, roof bf16-dense / 6), =f32 the f32-input MFMA
+    # kernels (roof = the fp32 matrix peak).
+    mode = os.environ.get("CD_CONV_PRECISION", "f16x2")
+    peak = {"f32": PEAK_FP32_MFMA_TFLOPS, "bf16x3": PEAK_BF16_MFMA_TFLOPS / BF16X3_TERMS}.get(mode, PEAK_BF16_MFMA_TFLOPS / 3)
+    pipe = {"f32": "f32 MFMA (157.3 TFLOP/s)",
+            "bf16x3": "bf16 MFMA, fp32 operands split exactly into 3 bf16 terms, 6 MFMAs per MAC (2500/6 TFLOP/s)"}.get(
+        mode, "fp16 MFMA, fp32 operands split into 2 fp16 terms (22 bits), 3 MFMAs per MAC block (2500/3 TFLOP/s)")
     roof = {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 3), "peak": round(peak, 1),
             "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
-            "pipe": "f32 MFMA (157.3 TFLOP/s)" if f32_mode else
-                    "bf16 MFMA, fp32 operands split exactly into 3 bf16 terms, 6 MFMAs per MAC (2500/6 TFLOP/s)",
+            "pipe": pipe,
             "frac_of_fp32_mfma_peak": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
             "avg_launch_us": round(avg_ms * 1e3, 2), "alg_flops_per_launch": dom["flops"],
             "alg_bytes_per_launch": dom["bytes"],
@@ -247,7 +250,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32 (convs: fp32 operands as exact 3-term bf16 splits on the bf16 MFMA pipe, fp32 accumulate)",
+        "dtype": "f32 (convs: fp32 operands as 2-term fp16 splits on the fp16 MFMA pipe, fp32 accumulate; attention/norms fp32)",
         "data": "synthetic",
         "config": {"workload": f"{args.config}: {'x'.join(str(v) for v in cfg['SHAPE_PAD'][2:])} voxels, "
                                f"{args.sample_steps}-step DDIM, batch {B} per GPU, random-init weights (seed 1234)",

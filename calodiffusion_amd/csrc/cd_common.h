@@ -141,6 +141,8 @@ struct InitConvArgs {
   int cin = 0;                    // logical input channels of the conv (cx + synthesised coordinate channels)
   const float* scale_b = nullptr; // per-sample multiplier of channel 0 (c_in) or null: scale_b[b * scale_stride]
   int scale_stride = 1;
+  const float* sigma_b = nullptr; // alternative to scale_b: channel 0 is scaled by c_in = 1/sqrt(sigma_b[b]^2 + sigma_data^2)
+  float sigma_data = 1.f;         // (get_scaling, loss.py:29-41) so that the conv does not wait for the embedding kernel
   const float* r_w = nullptr;     // coordinate profiles, used when cin > cx
   const float* z_d = nullptr;
   const float* phi_h = nullptr;

@@ -2024,7 +2024,11 @@ __global__ void __launch_bounds__(256) init_conv_kernel(InitConvArgs a) {
   const int D = a.dims.d, H = a.dims.h, W = a.dims.w;
   const int nn = valid ? (int)n : 0;
   const int w = nn % W, h = (nn / W) % H, z = nn / (W * H);
-  const float sc = a.scale_b ? a.scale_b[(size_t)b * a.scale_stride] : 1.f;
+  float sc = a.scale_b ? a.scale_b[(size_t)b * a.scale_stride] : 1.f;
+  if (a.sigma_b) {  // same expression as embed_kernel's c_in
+    const float tv = a.sigma_b[b], sd = a.sigma_data;
+    sc = 1.f / sqrtf(tv * tv + sd * sd);
+  }
 
   float acc[32];
   const float* __restrict__ bias = a.bias;

@@ -2,6 +2,7 @@
 // Reference semantics: nn.GroupNorm(eps=1e-5, biased variance) as used by Block / PreNorm / LinearAttention.to_out
 // (calodiffusion/models/models.py:155,293,325) and LinearAttention.forward (models.py:301-318).
 #include "cd_common.h"
+#include <cstdlib>
 
 namespace cd {
 
