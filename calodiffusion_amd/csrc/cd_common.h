@@ -110,6 +110,9 @@ void launch_conv_mfma(const float* in0, int c0, const float* in1, int c1, const 
 // z-slide f16x2 kernel for the full-resolution 3x3x3 convs (kernels_conv_zs.hip); false = geometry not eligible
 bool try_launch_conv_zslide(const float* in0, int c0, const float* in1, int c1, const void* wpk_f16x2, const float* bias, float* out,
                             int batch, int cout, const ConvGeom& g, hipStream_t s, const ConvFusion& fu);
+// whole-sample-in-LDS f16x2 kernel for the deepest levels (kernels_conv_small.hip); false = geometry not eligible
+bool try_launch_conv_small(const float* in0, int c0, const float* in1, int c1, const void* wpk_f16x2, const float* bias, float* out,
+                           int batch, int cout, const ConvGeom& g, hipStream_t s, const ConvFusion& fu);
 void launch_conv_transpose_mfma(const float* in, int cin, const float* wpk, const float* bias, float* out, int batch,
                                 int cout, Dims3 din, Dims3 dout, int kz, int sz, hipStream_t s);
 

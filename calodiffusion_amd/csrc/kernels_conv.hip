@@ -356,6 +356,7 @@ struct ConvFlatArgs {
   const float* coef;
   int act;
   float* ch_part;
+  int* status = nullptr;  // f16x2 only: bit 0 <- a staged value exceeded the fp16 range
 };
 
 template <int VT, int CT>
@@ -737,6 +738,7 @@ __global__ void __launch_bounds__(512, (VT * CT * (NTERM == 2 ? 2 : 1) <= 2 ? 3 
         if (NTERM == 2) accB[vt][ct][r] = 0.f;
       }
 
+  float amax = 0.f;
   const int nsub = (a.c0 + a.c1) >> 4;
   const int gbase = zA * HW;
   const int nslots = nstage * 4;  // one slot = 4 channels of one voxel
@@ -794,6 +796,7 @@ __global__ void __launch_bounds__(512, (VT * CT * (NTERM == 2 ? 2 : 1) <= 2 ? 3 
             *(u32x2*)(d + 32) = t2;
             *(u32x2*)(d + 64) = t3;
           } else {
+            amax = fmaxf(amax, fmaxf(fmaxf(fabsf(val[k][0]), fabsf(val[k][1])), fmaxf(fabsf(val[k][2]), fabsf(val[k][3]))));
             u32x2 t1, t2;
             split2(val[k], t1, t2);
             *(u32x2*)d = t1;
@@ -866,6 +869,7 @@ __global__ void __launch_bounds__(512, (VT * CT * (NTERM == 2 ? 2 : 1) <= 2 ? 3 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[vt][ct][r] += accB[vt][ct][r] * (1.f / 2048.f);
   }
+  if (NTERM == 2 && a.status && amax > 65504.f) atomicOr(a.status, 1);
   float* outb = a.out + (size_t)b * voxo * a.cout;
   float bv[CT];
 #pragma unroll
@@ -1489,7 +1493,7 @@ static bool try_launch_conv3_flat(const float* in0, int c0, const float* in1, in
     a.D = d.d; a.H = d.h; a.W = d.w; a.Do = g.out.d; a.Ho = g.out.h; a.Wo = g.out.w;
     a.R = 32 * NT; a.P = planes(NT); a.cout = cout; a.CTtot = CTtot;
     a.dbg = getenv("CD_FLAT_DBG") ? atoi(getenv("CD_FLAT_DBG")) : 0;
-    a.coef = fu.coef; a.act = fu.act; a.ch_part = fu.ch_part;
+    a.coef = fu.coef; a.act = fu.act; a.ch_part = fu.ch_part; a.status = fu.status;
     size_t lds = ((size_t)a.P * HW + 1) * vox_bytes;
     const size_t red = (size_t)(NT / VT) * CT * 32 * 2 * 4;  // cross-wave reduction scratch of the stats epilogue
     if (lds < red) lds = red;
@@ -1576,6 +1580,10 @@ void launch_conv_mfma(const float* in0, int c0, const float* in1, int c1, const 
     if (fu.wpk_bf16x3 && !want_f32 && !want_bf16x3 &&
         try_launch_conv_zslide(in0, c0, in1, c1, (const char*)fu.wpk_bf16x3 + packed_bf16x3_bytes(c0 + c1, cout, g.kd * g.kh * g.kw),
                                bias, out, batch, cout, g, s, fu))
+      return;
+    if (fu.wpk_bf16x3 && !want_f32 && !want_bf16x3 &&
+        try_launch_conv_small(in0, c0, in1, c1, (const char*)fu.wpk_bf16x3 + packed_bf16x3_bytes(c0 + c1, cout, g.kd * g.kh * g.kw),
+                              bias, out, batch, cout, g, s, fu))
       return;
     if (fu.wpk_bf16x3 && !want_f32 && !want_bf16x3 &&
         try_launch_conv3_flat(in0, c0, in1, c1, (const char*)fu.wpk_bf16x3 + packed_bf16x3_bytes(c0 + c1, cout, g.kd * g.kh * g.kw), bias,

@@ -1,0 +1,270 @@
+// 3x3x3 stride-1 phi-periodic convolution for the deepest U-Net levels, where a whole sample is at most 128 voxels
+// (Dataset-2 level 2: 12 x 4 x 2 = 96).  At that size the general flat kernel is pure latency: tens of tiny workgroups, each
+// looping over sub-chunks and taps with a barrier and an L2 round trip per step (17-28 us per launch for ~2 us of MFMA work).
+//
+// Here one workgroup (4 waves) owns one (sample, 32-output-channel tile):
+//  * the sample's input -- up to 64 channels at a time, optionally normalised on the fly (fused GroupNorm + SiLU + embedding) --
+//    is split to f16x2 (split16.h) and laid out in LDS as a (D+2) x (H+2) x (W+1) block of voxel records: zero planes in
+//    front and behind, the phi rows -1 and H holding copies of rows H-1 and 0, one zero record closing every r row.  Every
+//    tap of every voxel is then "record + constant": no wrap or validity logic in the loop;
+//  * the 27 x (cin/16) (tap, k-step) pairs are dealt round-robin to the 4 waves; a wave streams its weight fragments from L2
+//    through a 6-deep register ring and applies each to all (<= 4) row tiles of the sample: 3 MFMAs per tile and pair;
+//  * the four K-slices of every tile are exchanged through LDS, wave t sums tile t, adds the bias, stores and accumulates the
+//    channel statistics; the workgroup has seen the whole sample, so it emits ONE partial per (sample, channel).
+#include "cd_common.h"
+#include "split16.h"
+
+#include <cstdio>
+#include <cstdlib>
+
+namespace cd {
+
+namespace {
+
+struct ConvSmallArgs {
+  const float* in0;
+  const float* in1;
+  int c0, c1;
+  const float* coef;  // [B][c0+c1][4] or null
+  int act;
+  const u32x4* wpk;   // f16x2 image [ks][tap][ct][term][lane]
+  int CTtot;
+  const float* bias;
+  float* out;         // (B, vox, cout)
+  int cout;
+  float* ch_part;     // [B][1][cout][2] or null
+  int D, H, W;
+  int VB;             // bytes per voxel record = min(cin, 64) * 4 + 16
+  int* status;        // bit 0: a staged value exceeded the fp16 range
+};
+
+constexpr int CS_PD = 6;  // weight fragments requested this many pairs ahead
+
+template <int NT>  // row tiles (32 voxels each) of the sample: ceil(vox / 32) <= 4
+__global__ void __launch_bounds__(256, 1) conv_small_f16x2_kernel(ConvSmallArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char cs_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
+  const int b = blockIdx.x, ct = blockIdx.y;
+  const int D = a.D, H = a.H, W = a.W, PV = H * W, vox = D * PV;
+  const int pitch = W + 1, prow = (H + 2) * pitch;  // records per row / per plane
+  const int nrec = (D + 2) * prow;
+  const int cin = a.c0 + a.c1;
+  const int VB = a.VB;
+  char* const part = cs_lds;  // the partial exchange re-uses the image after the last MFMA
+
+  // record (z, h, w) of the lane's voxel in each tile: address of its (kz = kh = 1, kw = 1) tap
+  int rec[NT];
+  bool okv[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int v = t * 32 + col;
+    okv[t] = v < vox;
+    const int vv = okv[t] ? v : 0;
+    const int z = vv / PV, p = vv - z * PV, h = p / W, w = p - h * W;
+    rec[t] = (((z + 1) * (H + 2) + (h + 1)) * pitch + w) * VB + half * 16;
+  }
+
+  f32x16 accA[NT], accB[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accA[t][r] = accB[t][r] = 0.f;
+  float amax = 0.f;
+
+  for (int cb = 0; cb < cin; cb += 64) {  // input channels in blocks of <= 64
+    const int cn = min(64, cin - cb);     // channels in this block (multiple of 16)
+    const int nq = cn >> 2;               // channel quads per voxel
+    __syncthreads();                      // previous block's MFMAs have finished reading the image
+    // ---- zero the image, then stage the sample (interior records; phi halo rows are copies) ----------------------
+    for (int i = tid; i < nrec * VB / 16; i += 256) ((u32x4*)cs_lds)[i] = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+    for (int i = tid; i < vox * nq; i += 256) {
+      const int v = i / nq, q = i - v * nq;
+      const int c = cb + q * 4;
+      const float* src = c < a.c0 ? a.in0 + ((size_t)b * vox + v) * a.c0 + c : a.in1 + ((size_t)b * vox + v) * a.c1 + (c - a.c0);
+      f32x4 x = *(const f32x4*)src;
+      if (a.coef) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const f32x4 cf = *(const f32x4*)(a.coef + ((size_t)b * cin + c + e) * 4);
+          float t = cf[0] * x[e] + cf[1];
+          if (a.act) t = t / (1.f + expf(-t));
+          x[e] = t + cf[2];
+        }
+      }
+      amax = fmaxf(amax, fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3]))));
+      u32x2 t1, t2;
+      split2(x, t1, t2);
+      const int z = v / PV, p = v - z * PV, h = p / W, w = p - h * W;
+      // record layout: [k-step][term][16 ch] => quad q sits at (q >> 2) * 64 + term * 32 + (q & 3) * 8
+      const int off = (q >> 2) * 64 + (q & 3) * 8;
+      char* d = cs_lds + (((z + 1) * (H + 2) + (h + 1)) * pitch + w) * VB + off;
+      *(u32x2*)d = t1;
+      *(u32x2*)(d + 32) = t2;
+      if (h == 0) {  // copy into the phi halo row H
+        char* d2 = d + H * pitch * VB;
+        *(u32x2*)d2 = t1;
+        *(u32x2*)(d2 + 32) = t2;
+      }
+      if (h == H - 1) {  // copy into the phi halo row -1
+        char* d2 = d - H * pitch * VB;
+        *(u32x2*)d2 = t1;
+        *(u32x2*)(d2 + 32) = t2;
+      }
+    }
+    __syncthreads();
+
+    // ---- this wave's (tap, k-step) pairs of the block: p = wave, wave + 4, ... ---------------------------------------
+    const int npairs = 27 * (cn >> 4);
+    const int mine = (npairs - wave + 3) >> 2;
+    const u32x4* wbase = a.wpk + lane;
+    auto wptr = [&](int i) {  // pair index i of this wave -> weight fragment pointer, tap, k-step
+      const int p = wave + 4 * i;
+      const int ks = p / 27, tap = p - ks * 27;
+      return wbase + ((size_t)(((cb >> 4) + ks) * 27 + tap) * a.CTtot + ct) * 128;
+    };
+    u32x4 wr[CS_PD][2];
+#pragma unroll
+    for (int i = 0; i < CS_PD; ++i)
+      if (i < mine) {
+        const u32x4* wp = wptr(i);
+        wr[i][0] = wp[0];
+        wr[i][1] = wp[64];
+      }
+    for (int i0 = 0; i0 < mine; i0 += CS_PD) {
+#pragma unroll
+      for (int k = 0; k < CS_PD; ++k) {
+        const int i = i0 + k;
+        if (i < mine) {
+          const int p = wave + 4 * i;
+          const int ks = p / 27, tap = p - ks * 27;
+          const int kz = tap / 9, kh = (tap - kz * 9) / 3, kw = tap - kz * 9 - kh * 3;
+          const int toff = ((kz - 1) * prow + (kh - 1) * pitch + (kw - 1)) * VB + ks * 64;
+          const u32x4 w1 = wr[k][0], w2 = wr[k][1];
+          if (i + CS_PD < mine) {  // refill this ring slot for pair i + CS_PD
+            const u32x4* wp = wptr(i + CS_PD);
+            wr[k][0] = wp[0];
+            wr[k][1] = wp[64];
+          }
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const char* ap = cs_lds + rec[t] + toff;
+            const u32x4 a1 = *(const u32x4*)ap, a2 = *(const u32x4*)(ap + 32);
+            accA[t] = MFMA_F16(a1, w1, accA[t]);
+            accB[t] = MFMA_F16(a1, w2, accB[t]);
+            accB[t] = MFMA_F16(a2, w1, accB[t]);
+          }
+        }
+      }
+    }
+  }
+
+  if (a.status && amax > 65504.f) atomicOr(a.status, 1);
+  // ---- exchange the K-slices: wave t sums tile t -----------------------------------------------------------------
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    char* d = part + ((t * 4 + wave) * 4) * 1024 + lane * 16;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *(f32x4*)(d + g * 1024) = f32x4{accA[t][4 * g] + accB[t][4 * g] * (1.f / 2048.f), accA[t][4 * g + 1] + accB[t][4 * g + 1] * (1.f / 2048.f),
+                                      accA[t][4 * g + 2] + accB[t][4 * g + 2] * (1.f / 2048.f),
+                                      accA[t][4 * g + 3] + accB[t][4 * g + 3] * (1.f / 2048.f)};
+  }
+  __syncthreads();
+  float s1 = 0.f, s2 = 0.f;
+  if (wave < NT) {
+    const float bv = a.bias ? a.bias[ct * 32 + col] : 0.f;
+    f32x16 sum;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const char* d = part + ((wave * 4 + w) * 4) * 1024 + lane * 16;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 x = *(const f32x4*)(d + g * 1024);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sum[4 * g + e] = w == 0 ? x[e] : sum[4 * g + e] + x[e];
+      }
+    }
+    float* o = a.out + ((size_t)b * vox + wave * 32) * a.cout + ct * 32 + col;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (wave * 32 + row < vox) {
+        const float v = sum[r] + bv;
+        o[(size_t)row * a.cout] = v;
+        s1 += v;
+        s2 += v * v;
+      }
+    }
+  }
+  if (a.ch_part) {
+    __syncthreads();  // partial reads done: re-use the head of the LDS block for the statistics
+    float* red = (float*)cs_lds;
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    if (half == 0) {
+      red[(wave * 32 + col) * 2] = s1;
+      red[(wave * 32 + col) * 2 + 1] = s2;
+    }
+    __syncthreads();
+    if (tid < 32) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        t1 += red[(w * 32 + tid) * 2];
+        t2 += red[(w * 32 + tid) * 2 + 1];
+      }
+      float* dst = a.ch_part + ((size_t)b * a.cout + ct * 32 + tid) * 2;
+      dst[0] = t1;
+      dst[1] = t2;
+    }
+  }
+}
+
+template <int NT>
+void launch_small_inst(const ConvSmallArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    CD_HIP(hipFuncSetAttribute((const void*)conv_small_f16x2_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(conv_small_f16x2_kernel<NT>, grid, dim3(256), lds, s, a);
+  CD_HIP(hipGetLastError());
+}
+
+}  // namespace
+
+// Eligible: 3x3x3 stride 1, whole sample <= 128 voxels.  Returns false otherwise.
+bool try_launch_conv_small(const float* in0, int c0, const float* in1, int c1, const void* wpk_f16x2, const float* bias, float* out,
+                           int batch, int cout, const ConvGeom& g, hipStream_t s, const ConvFusion& fu) {
+  if (getenv("CD_NO_CONV_SMALL")) return false;
+  if (!(g.kd == 3 && g.kh == 3 && g.kw == 3 && g.sz == 1 && g.sh == 1 && g.sw == 1)) return false;
+  const int64_t vox = g.in.vox();
+  if (vox > 128 || vox < 1) return false;
+  const int cin = c0 + c1;
+  if (cin % 16 || cout % 32 || c0 % 4 || c1 % 4) return false;
+  // a 64-channel block must not straddle the two sources unless the split is at a multiple of 4 (quads never straddle)
+  const int VB = (cin < 64 ? cin : 64) * 4 + 16;
+  const int NT = (int)((vox + 31) / 32);
+  const size_t image = (size_t)(g.in.d + 2) * (g.in.h + 2) * (g.in.w + 1) * VB;
+  const size_t partial = (size_t)NT * 4 * 4096;
+  size_t lds = image > partial ? image : partial;
+  lds = (lds + 255) & ~(size_t)255;
+  if (lds > 160 * 1024) return false;
+  ConvSmallArgs a;
+  a.in0 = in0; a.in1 = in1; a.c0 = c0; a.c1 = c1; a.coef = fu.coef; a.act = fu.act;
+  a.wpk = (const u32x4*)wpk_f16x2; a.CTtot = cout / 32; a.bias = bias; a.out = out; a.cout = cout; a.ch_part = fu.ch_part;
+  a.D = g.in.d; a.H = g.in.h; a.W = g.in.w; a.VB = VB; a.status = fu.status;
+  const dim3 grid((unsigned)batch, (unsigned)(cout / 32));
+  switch (NT) {
+    case 1: launch_small_inst<1>(a, grid, lds, s); break;
+    case 2: launch_small_inst<2>(a, grid, lds, s); break;
+    case 3: launch_small_inst<3>(a, grid, lds, s); break;
+    default: launch_small_inst<4>(a, grid, lds, s); break;
+  }
+  if (fu.units) *fu.units = fu.ch_part ? 1 : 0;
+  return true;
+}
+
+}  // namespace cd

@@ -354,7 +354,8 @@ void build_plan(CdPlan* p) {
 
   CD_HIP(hipMalloc((void**)&p->d_coords, sizeof(float) * (size_t)(d.grid[0] + d.grid[1] + d.grid[2] + 4)));
   CD_HIP(hipMalloc((void**)&p->d_table, sizeof(float) * 4 * CdPlan::kMaxSteps));
-  CD_HIP(hipMalloc((void**)&p->d_counter, sizeof(int) * 4));
+  CD_HIP(hipMalloc((void**)&p->d_counter, sizeof(int) * 4));  // [0] sampler step counter, [2] range flags
+  CD_HIP(hipMemset(p->d_counter, 0, sizeof(int) * 4));
   CD_HIP(hipMalloc((void**)&p->d_stepvals, sizeof(float) * 8));
 }
 
@@ -366,6 +367,7 @@ struct Run {
   hipStream_t s;
   int B;
   int groups;
+  int* status = nullptr;  // device word for sticky range flags (cd_plan_status), or null
   bool dry() const { return ws->dry(); }
 };
 
@@ -423,7 +425,7 @@ float* conv3_with_stats(Run& r, const float* x0, int c0, const float* x1, int c1
   if (!r.dry()) {
     ConvGeom g{dims, dims, 3, 3, 3, 1, 1, 1};
     ConvFusion fu;
-    fu.coef = coef_in; fu.act = 1; fu.ch_part = part; fu.units = &u; fu.wpk_bf16x3 = wpk3;
+    fu.coef = coef_in; fu.act = 1; fu.ch_part = part; fu.units = &u; fu.wpk_bf16x3 = wpk3; fu.status = r.status;
     launch_conv_mfma(x0, c0, x1, c1, wpk, bias, out, r.B, cout, g, r.s, fu);
     if (u == 0) {  // kernel without a stats epilogue: separate pass, same buffer (nsplit <= cap)
       u = gn_nsplit_for(vox, r.B);
@@ -776,6 +778,7 @@ void forward_impl(CdPlan* p, int B, const float* x, const float* cond, const flo
   const CdUnetDesc& d = p->desc;
   const Dims3 dims = p->shapes[0];
   Run r{&p->ws, s, B, d.groups};
+  r.status = p->d_counter + 2;
   float* emb = p->ws.get<float>((size_t)B * p->emb_ld);
   float* scal = p->ws.get<float>((size_t)B * 4);
   float* h = p->ws.get<float>((size_t)B * dims.vox() * d.layer_sizes[0]);
@@ -1058,6 +1061,16 @@ int cd_ddim_sample(CdPlan* plan, int batch, const float* start, const float* con
         one_step(s, i, step_noise ? step_noise + (size_t)i * n : nullptr, xs ? xs + (size_t)i * n : nullptr,
                  x0s ? x0s + (size_t)i * n : nullptr);
     }
+  });
+}
+
+int cd_plan_status(CdPlan* plan, int* flags, void* stream) {
+  return guarded([&] {
+    CD_REQUIRE(plan && flags, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    CD_HIP(hipMemcpyAsync(flags, plan->d_counter + 2, sizeof(int), hipMemcpyDeviceToHost, s));
+    CD_HIP(hipMemsetAsync(plan->d_counter + 2, 0, sizeof(int), s));
+    CD_HIP(hipStreamSynchronize(s));
   });
 }
 

@@ -63,6 +63,7 @@ _SIGNATURES = {
     "cd_randn": (C.c_int, [_P, C.c_int64, C.c_uint64, C.c_uint64, _P]),
     "cd_plan_grad_layout": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "cd_plan_train_workspace_bytes": (C.c_int, [_P, C.c_int, C.POINTER(C.c_size_t)]),
+    "cd_plan_status": (C.c_int, [_P, C.POINTER(C.c_int), _P]),
     "cd_train_step": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "cd_profile_begin": (C.c_int, []),
     "cd_profile_end": (C.c_int, [C.c_char_p, C.c_int]),
@@ -289,7 +290,16 @@ class UnetEngine:
                                        steps.ctypes.data_as(C.POINTER(CdStep)), n_steps, _ptr(step_noise), int(seed),
                                        int(offset), x_out.data_ptr(), _ptr(xs), _ptr(x0s), int(bool(use_graph)),
                                        ws.data_ptr(), ws.numel(), _stream()))
+        self.check_status()
         return x_out, xs, x0s
+
+    def check_status(self):
+        """Raise if a compute call since the last check left the fp16 range of the f16x2 convolution path (synchronises)."""
+        flags = C.c_int(0)
+        _check(self.lib.cd_plan_status(self.plan, C.byref(flags), _stream()))
+        if flags.value & 1:
+            raise FloatingPointError("calodiff: an activation exceeded the fp16 range of the f16x2 convolution kernels "
+                                     "(outputs contain inf/NaN); set CD_CONV_PRECISION=bf16x3 for the full fp32 range")
 
     # ------------------------------------------------------------------ training
     def grad_layout(self):

@@ -132,6 +132,11 @@ int cd_loss_hybrid_l2(CdPlan* plan, int batch, const float* data, const float* n
  * until the backward has consumed them). */
 int cd_plan_grad_layout(const CdPlan* plan, int idx, int64_t* offset, int64_t* total_floats);
 int cd_plan_train_workspace_bytes(CdPlan* plan, int batch, size_t* bytes);
+
+/* Sticky range flags of the compute calls issued on this plan since the last query (synchronises `stream`, then clears):
+ *   bit 0: an activation fed to an f16x2 convolution exceeded the fp16 range (|x| > 65504): the outputs of that call
+ *          contain inf/NaN.  The reference computes in fp32 throughout; rerun with CD_CONV_PRECISION=bf16x3 (full fp32 range). */
+int cd_plan_status(CdPlan* plan, int* flags, void* stream);
 int cd_train_step(CdPlan* plan, int batch, const float* data, const float* noise, const float* sigma, const float* cond,
                   double* loss_out, float* grads, void* workspace, size_t workspace_bytes, void* stream);
 

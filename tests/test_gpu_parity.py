@@ -4,6 +4,8 @@ Tolerances: north_star asks for <= 1e-4 relative L2 of the reference CPU path.  
 held to 1e-5 (the fp32 reorder floor of the reference itself is 5.5e-7 per denoise call); multi-step
 trajectories to 1e-4.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -109,6 +111,81 @@ def test_concat_conv_equals_conv_of_concat(ops):
     want = O.cyl_conv3d(torch.cat([a, b], 1), w1, bias).numpy()
     y = back(ops, ops.cyl_conv(cl(ops, a.numpy()), w1.cuda(), bias.cuda(), x1_cl=cl(ops, b.numpy())))
     assert rel_l2(y, want) < TOL_OP
+
+
+def _conv_case(ops, gen, B, c0, c1, cout, shape, nb=3):
+    from oracle import torch_oracle as O
+    cin = c0 + c1
+    x = torch.randn((B, cin) + shape, generator=gen)
+    w, bias = torch.randn((cout, cin, 3, 3, 3), generator=gen) * 0.05, torch.randn(cout, generator=gen)
+    nb = min(B, nb)
+    want = O.cyl_conv3d(x[:nb], w, bias, padding=(1, 1, 1)).numpy()
+    if c1:
+        y = ops.cyl_conv(cl(ops, x[:, :c0].contiguous().numpy()), w.cuda(), bias.cuda(), x1_cl=cl(ops, x[:, c0:].contiguous().numpy()))
+    else:
+        y = ops.cyl_conv(cl(ops, x.numpy()), w.cuda(), bias.cuda())
+    return rel_l2(back(ops, y)[:nb], want)
+
+
+def test_full_resolution_conv_kernel(ops):
+    """The z-slide f16x2 kernel (kernels_conv_zs.hip) takes 3x3x3 convs on grids whose planes hold 128..160 voxels: Dataset-2's
+    level 0 (16x9) in every channel configuration the U-Net uses there, ragged chunk ends, one and many samples."""
+    gen = torch.Generator().manual_seed(11)
+    for B, c0, c1, cout, shape in ((1, 32, 0, 32, (45, 16, 9)), (3, 32, 0, 32, (45, 16, 9)), (2, 32, 32, 32, (10, 16, 9)),
+                                   (2, 32, 0, 64, (7, 16, 8)), (5, 64, 0, 32, (3, 16, 9)), (64, 32, 0, 32, (45, 16, 9))):
+        err = _conv_case(ops, gen, B, c0, c1, cout, shape)
+        assert err < 2e-6, (B, c0, c1, cout, shape, err)
+
+
+def test_whole_sample_conv_kernel(ops):
+    """Grids of at most 128 voxels per sample (Dataset-2's level 2: 12x4x2) take the whole-sample-in-LDS kernel
+    (kernels_conv_small.hip): single-row / single-column grids, >64 input channels (two staging passes), concatenated inputs."""
+    gen = torch.Generator().manual_seed(12)
+    for B, c0, c1, cout, shape in ((2, 32, 0, 32, (12, 4, 2)), (3, 64, 0, 64, (12, 4, 2)), (2, 32, 32, 32, (12, 4, 2)),
+                                   (1, 128, 0, 64, (5, 5, 5)), (2, 96, 0, 32, (3, 1, 4)), (2, 32, 0, 32, (1, 2, 3)),
+                                   (2, 64, 64, 96, (4, 4, 8))):
+        err = _conv_case(ops, gen, B, c0, c1, cout, shape)
+        assert err < 2e-6, (B, c0, c1, cout, shape, err)
+
+
+def test_conv_precision_modes_agree(ops, monkeypatch):
+    """CD_CONV_PRECISION selects the arithmetic of the MFMA convs: f16x2 (default), bf16x3, f32.  All are fp32-grade."""
+    gen = torch.Generator().manual_seed(13)
+    errs = {}
+    for mode in ("bf16x3", "f32"):
+        monkeypatch.setenv("CD_CONV_PRECISION", mode)
+        # the mode is latched at the first conv launch of a process: run the comparison in a child interpreter
+        import subprocess, sys, json
+        code = ("import sys, json, torch; sys.path.insert(0, %r); sys.path.insert(0, %r);"
+                "from test_gpu_parity import _conv_case; from calodiffusion_amd.engine import Ops;"
+                "g = torch.Generator().manual_seed(13);"
+                "print(json.dumps([_conv_case(Ops(), g, 2, 32, 0, 32, (9, 16, 9)), _conv_case(Ops(), g, 2, 64, 0, 64, (6, 4, 2))]))"
+                % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))))
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        errs[mode] = json.loads(out.stdout.strip().splitlines()[-1])
+        assert max(errs[mode]) < 3e-6, (mode, errs[mode])
+
+
+def test_fp16_range_flag():
+    """f16x2 convs need |activation| <= 65504; leaving that range poisons the output with inf/NaN AND raises the plan's sticky
+    flag, which the sampler turns into an exception (the reference would have produced finite fp32 numbers)."""
+    m = _model("dataset2")
+    cfg = m.config
+    B = 1
+    shape = [B] + list(cfg["SHAPE_PAD"][1:])
+    x = torch.randn(shape, device="cuda")
+    E = torch.rand((B, 1), device="cuda")
+    layers = torch.randn((B, cfg["SHAPE_PAD"][2] + 1), device="cuda")
+    sig = torch.full((B,), 1.0, device="cuda")
+    m.denoise(x, E=E, sigma=sig, layers=layers)
+    m.engine().check_status()  # in range: no exception
+    with torch.no_grad():
+        m.model.init_conv.conv.bias.fill_(1.0e6)  # drives the first block's conv input out of range
+    m.denoise(x, E=E, sigma=sig, layers=layers)
+    with pytest.raises(FloatingPointError):
+        m.engine().check_status()
+    m.engine().check_status()  # the flag was cleared by the query
 
 
 def test_group_norm(ops):
