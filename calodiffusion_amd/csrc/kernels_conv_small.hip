@@ -78,47 +78,11 @@ __global__ void __launch_bounds__(256, 1) conv_small_f16x2_kernel(ConvSmallArgs 
     // ---- zero the image, then stage the sample (interior records; phi halo rows are copies) ----------------------
     for (int i = tid; i < nrec * VB / 16; i += 256) ((u32x4*)cs_lds)[i] = u32x4{0u, 0u, 0u, 0u};
     __syncthreads();
-    for (int i = tid; i < vox * nq; i += 256) {
-      const int v = i / nq, q = i - v * nq;
-      const int c = cb + q * 4;
-      const float* src = c < a.c0 ? a.in0 + ((size_t)b * vox + v) * a.c0 + c : a.in1 + ((size_t)b * vox + v) * a.c1 + (c - a.c0);
-      f32x4 x = *(const f32x4*)src;
-      if (a.coef) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const f32x4 cf = *(const f32x4*)(a.coef + ((size_t)b * cin + c + e) * 4);
-          float t = cf[0] * x[e] + cf[1];
-          if (a.act) t = t / (1.f + expf(-t));
-          x[e] = t + cf[2];
-        }
-      }
-      amax = fmaxf(amax, fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3]))));
-      u32x2 t1, t2;
-      split2(x, t1, t2);
-      const int z = v / PV, p = v - z * PV, h = p / W, w = p - h * W;
-      // record layout: [k-step][term][16 ch] => quad q sits at (q >> 2) * 64 + term * 32 + (q & 3) * 8
-      const int off = (q >> 2) * 64 + (q & 3) * 8;
-      char* d = cs_lds + (((z + 1) * (H + 2) + (h + 1)) * pitch + w) * VB + off;
-      *(u32x2*)d = t1;
-      *(u32x2*)(d + 32) = t2;
-      if (h == 0) {  // copy into the phi halo row H
-        char* d2 = d + H * pitch * VB;
-        *(u32x2*)d2 = t1;
-        *(u32x2*)(d2 + 32) = t2;
-      }
-      if (h == H - 1) {  // copy into the phi halo row -1
-        char* d2 = d - H * pitch * VB;
-        *(u32x2*)d2 = t1;
-        *(u32x2*)(d2 + 32) = t2;
-      }
-    }
-    __syncthreads();
-
-    // ---- this wave's (tap, k-step) pairs of the block: p = wave, wave + 4, ... ---------------------------------------
+    // this wave's first weight fragments are requested now: their L2 latency hides behind the staging
     const int npairs = 27 * (cn >> 4);
     const int mine = (npairs - wave + 3) >> 2;
     const u32x4* wbase = a.wpk + lane;
-    auto wptr = [&](int i) {  // pair index i of this wave -> weight fragment pointer, tap, k-step
+    auto wptr = [&](int i) {  // pair index i of this wave -> weight fragment pointer
       const int p = wave + 4 * i;
       const int ks = p / 27, tap = p - ks * 27;
       return wbase + ((size_t)(((cb >> 4) + ks) * 27 + tap) * a.CTtot + ct) * 128;
@@ -131,6 +95,57 @@ __global__ void __launch_bounds__(256, 1) conv_small_f16x2_kernel(ConvSmallArgs 
         wr[i][0] = wp[0];
         wr[i][1] = wp[64];
       }
+    // staging: all of a thread's global loads are issued before the first conversion (4 items per batch)
+    for (int i0 = tid; i0 < vox * nq; i0 += 4 * 256) {
+      f32x4 xs[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = min(i0 + k * 256, vox * nq - 1);
+        const int v = i / nq, q = i - v * nq;
+        const int c = cb + q * 4;
+        const float* src = c < a.c0 ? a.in0 + ((size_t)b * vox + v) * a.c0 + c : a.in1 + ((size_t)b * vox + v) * a.c1 + (c - a.c0);
+        xs[k] = *(const f32x4*)src;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = i0 + k * 256;
+        if (i >= vox * nq) break;
+        const int v = i / nq, q = i - v * nq;
+        const int c = cb + q * 4;
+        f32x4 x = xs[k];
+        if (a.coef) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const f32x4 cf = *(const f32x4*)(a.coef + ((size_t)b * cin + c + e) * 4);
+            float t = cf[0] * x[e] + cf[1];
+            if (a.act) t = t / (1.f + expf(-t));
+            x[e] = t + cf[2];
+          }
+        }
+        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3]))));
+        u32x2 t1, t2;
+        split2(x, t1, t2);
+        const int z = v / PV, p = v - z * PV, h = p / W, w = p - h * W;
+        // record layout: [k-step][term][16 ch] => quad q sits at (q >> 2) * 64 + term * 32 + (q & 3) * 8
+        const int off = (q >> 2) * 64 + (q & 3) * 8;
+        char* d = cs_lds + (((z + 1) * (H + 2) + (h + 1)) * pitch + w) * VB + off;
+        *(u32x2*)d = t1;
+        *(u32x2*)(d + 32) = t2;
+        if (h == 0) {  // copy into the phi halo row H
+          char* d2 = d + H * pitch * VB;
+          *(u32x2*)d2 = t1;
+          *(u32x2*)(d2 + 32) = t2;
+        }
+        if (h == H - 1) {  // copy into the phi halo row -1
+          char* d2 = d - H * pitch * VB;
+          *(u32x2*)d2 = t1;
+          *(u32x2*)(d2 + 32) = t2;
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- this wave's (tap, k-step) pairs of the block: p = wave, wave + 4, ... ---------------------------------------
     for (int i0 = 0; i0 < mine; i0 += CS_PD) {
 #pragma unroll
       for (int k = 0; k < CS_PD; ++k) {
