@@ -70,6 +70,19 @@ struct ConvGeom {
 //   ch_part  [B][units][Cout][2] = per-workgroup {sum, sum of squares} of the conv output, units <= ceil(vox/32);
 //            *units is set to the number of workgroups per sample that wrote partials, or 0 if the chosen kernel
 //            cannot (the caller then runs launch_ch_stats on the output).
+// Deferred GroupNorm coefficients (gn_defer.h): instead of a coefficient table the consumer gets the producer's channel
+// partials and the affine parameters and folds them in its prologue.  part == nullptr: not deferred.
+struct GnDefer {
+  const float* part = nullptr;  // [B][units][C][2]
+  int units = 0;
+  const float* gamma = nullptr;
+  const float* beta = nullptr;
+  const float* add = nullptr;   // [B][add_ld] added after the activation, or null
+  int add_ld = 0;
+  int C = 0, groups = 0;
+  int64_t vox = 0;
+};
+
 struct ConvFusion {
   const float* coef = nullptr;
   int act = 0;
@@ -79,6 +92,10 @@ struct ConvFusion {
   // packed_bf16x3_bytes() by the f16x2 image
   const void* wpk_bf16x3 = nullptr;
   int* status = nullptr;  // device word; bit 0 is set when a value staged for an f16x2 conv exceeds the fp16 range
+  // alternative to `coef`: fold the input normalisation from `defer` in the kernel's prologue.  Kernels without that
+  // prologue get the table materialised into `coef_buf` ([B][Cin][4]) by a gn_finalize launch first.
+  GnDefer defer;
+  float* coef_buf = nullptr;
 };
 inline size_t packed_bf16x3_bytes(int cin, int cout, int taps) {
   return (size_t)(cin / 16) * taps * ((cout + 31) / 32) * 3 * 64 * 16;
@@ -202,8 +219,10 @@ void launch_gn_backward(const float* dy, const float* h, const float* coef, cons
 int gn_apply_blocks_per_sample(int batch, int channels, int64_t vox);
 // y = act(scale*x + shift) + add (+ residual; residual1/res_c0: shortcut read from a two-source channel concat);
 // part_out (optional): channel partials of y, [B][gn_apply_blocks_per_sample][C][2]
+// defer (optional): fold the coefficients in the kernel's prologue instead of reading `coef`
 void launch_gn_apply(const float* x, float* y, const float* coef, int batch, int channels, int64_t vox, int silu,
-                     const float* residual, const float* residual1, int res_c0, float* part_out, hipStream_t s);
+                     const float* residual, const float* residual1, int res_c0, float* part_out, hipStream_t s,
+                     const GnDefer* defer = nullptr);
 
 int attn_nsplit_for(int64_t vox, int batch);
 size_t attn_partial_floats(int batch, int nsplit);
@@ -216,9 +235,10 @@ void launch_attn_combine(const float* partials, int nsplit, const float* w_out /
 // fused linear attention of the sampling path (kernels_attn.hip): qkv is never materialised
 int attn_fused_nsplit_for(int64_t vox, int batch);
 void launch_attn_kv_context(const float* x, int C, const float* coef, const float* wqkv_packed, float* partials, int batch,
-                            int64_t vox, int nsplit, hipStream_t s);
+                            int64_t vox, int nsplit, hipStream_t s, const GnDefer* defer = nullptr);
 void launch_attn_out(const float* x, int C, const float* coef, const float* wqkv_packed, const float* wT_b, const float* bias,
-                     float* y, float* ch_part /* [B][nsplit][C][2] */, int batch, int64_t vox, int nsplit, hipStream_t s);
+                     float* y, float* ch_part /* [B][nsplit][C][2] */, int batch, int64_t vox, int nsplit, hipStream_t s,
+                     const GnDefer* defer = nullptr);
 
 struct EmbedLayer {
   const float* w;  // (cout, 128) torch layout

@@ -13,6 +13,7 @@
 // HBM traffic per attention block: x twice + y once (3 x B n C floats) instead of x + 2 x qkv + q + y (= 10 x for C = 32).
 // All arithmetic is fp32 (v_mfma_f32_32x32x2_f32); the kernels are memory / latency bound.
 #include "cd_common.h"
+#include "gn_defer.h"
 
 #include <cstdio>
 
@@ -37,6 +38,7 @@ struct AttnArgs {
   const float* bias;  // (C)
   float* y;           // (B, vox, C)
   float* ch_part;     // [B][units][C][2]
+  GnDefer defer;      // PreNorm coefficients folded in the prologue instead of read from `coef`
 };
 
 // A fragments of one 32-voxel tile: lane (voxel n0 + col, half) holds channels chunk*32 + half*16 + 0..15, normalised
@@ -61,13 +63,21 @@ __device__ __forceinline__ void load_xn(const AttnArgs& a, int b, int64_t n0, in
         av[ch][q][e] = valid ? c2[(e & 1) * 2] * av[ch][q][e] + c2[(e & 1) * 2 + 1] : 0.f;
       }
 }
+// must be called by every thread of the workgroup (the deferred form contains barriers)
 template <int NCH>
 __device__ __forceinline__ void load_coef(const AttnArgs& a, int b, int half, f32x4 (&cf)[NCH][8]) {
+  __shared__ __attribute__((aligned(16))) float sCoef[NCH * 32 * 4];
+  __shared__ __attribute__((aligned(16))) char sDefer[NCH * 32 * 16 + 64 * 8];
+  const float* base = a.defer.part ? nullptr : a.coef + (size_t)b * a.C * 4;
+  if (a.defer.part) {
+    gn_defer_to_lds(a.defer, b, sCoef, sDefer);
+    base = sCoef;
+  }
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const float* p = a.coef + ((size_t)b * a.C + ch * 32 + half * 16 + 2 * i) * 4;
+      const float* p = base + (ch * 32 + half * 16 + 2 * i) * 4;
       cf[ch][i] = f32x4{p[0], p[1], p[4], p[5]};
     }
 }
@@ -295,11 +305,12 @@ int attn_fused_nsplit_for(int64_t vox, int batch) {
 }
 
 void launch_attn_kv_context(const float* x, int C, const float* coef, const float* wqkv_packed, float* partials, int batch,
-                            int64_t vox, int nsplit, hipStream_t s) {
+                            int64_t vox, int nsplit, hipStream_t s, const GnDefer* defer) {
   CD_REQUIRE(C == 32 || C == 64 || C == 96 || C == 128, "fused attention: 32..128 input channels");
   AttnArgs a{};
   a.x = x; a.coef = coef; a.wqkv = wqkv_packed; a.C = C; a.vox = vox; a.tiles_per_wg = tiles_per_wg_for(vox, nsplit);
   a.partials = partials; a.nsplit = nsplit;
+  if (defer) a.defer = *defer;
   prof::Scope scope("attn_kv_context", s, 2.0 * (2.0 * C + 32) * 32 * (double)vox * batch, 4.0 * batch * (double)vox * C);
   const dim3 grid((unsigned)nsplit, (unsigned)batch);
   switch (C / 32) {
@@ -312,11 +323,12 @@ void launch_attn_kv_context(const float* x, int C, const float* coef, const floa
 }
 
 void launch_attn_out(const float* x, int C, const float* coef, const float* wqkv_packed, const float* wT_b, const float* bias,
-                     float* y, float* ch_part, int batch, int64_t vox, int nsplit, hipStream_t s) {
+                     float* y, float* ch_part, int batch, int64_t vox, int nsplit, hipStream_t s, const GnDefer* defer) {
   CD_REQUIRE(C == 32 || C == 64 || C == 96 || C == 128, "fused attention: 32..128 channels");
   AttnArgs a{};
   a.x = x; a.coef = coef; a.wqkv = wqkv_packed; a.C = C; a.vox = vox; a.tiles_per_wg = tiles_per_wg_for(vox, nsplit);
   a.wT = wT_b; a.bias = bias; a.y = y; a.ch_part = ch_part;
+  if (defer) a.defer = *defer;
   prof::Scope scope("attn_out", s, 2.0 * (2.0 * C) * 32 * (double)vox * batch, 4.0 * batch * (double)vox * C * 2);
   const dim3 grid((unsigned)nsplit, (unsigned)batch);
   switch (C / 32) {

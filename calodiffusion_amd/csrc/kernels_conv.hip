@@ -9,6 +9,7 @@
 // calodiffusion/models/models.py:25-96, 335-369: circular padding along phi (H), zero padding along z (D) and r (W).
 #include "cd_common.h"
 #include "split16.h"
+#include "gn_defer.h"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -357,6 +358,8 @@ struct ConvFlatArgs {
   int act;
   float* ch_part;
   int* status = nullptr;  // f16x2 only: bit 0 <- a staged value exceeded the fp16 range
+  GnDefer defer;          // split-16 kernels: fold the input normalisation in the prologue (table at lds + coef_lds_off)
+  int coef_lds_off = 0;
 };
 
 template <int VT, int CT>
@@ -691,6 +694,8 @@ __global__ void __launch_bounds__(512, (VT * CT * (NTERM == 2 ? 2 : 1) <= 2 ? 3 
   const int nstage = (zB - zA + 1) * HW;
   const int NZ = a.P * HW;  // all-zero voxel
   const int half = lane >> 5, col = lane & 31;
+  if (a.defer.part) gn_defer_to_lds(a.defer, b, (float*)(ldsb + a.coef_lds_off), ldsb + a.coef_lds_off + a.defer.C * 16);
+  const bool normed = a.coef || a.defer.part;
   if (tid < VB / 4) ((float*)(ldsb + (size_t)NZ * VB))[tid] = 0.f;
 
   // per-lane geometry of its output voxel in each of the wave's VT row tiles: LDS index of the (kz=0, kh=1, kw=1) tap,
@@ -760,7 +765,10 @@ __global__ void __launch_bounds__(512, (VT * CT * (NTERM == 2 ? 2 : 1) <= 2 ? 3 
     const int pq = tid & 3;  // this thread always stages channel quad pq of a voxel
     src += (size_t)b * vox * ldc + coff + pq * 4;
     f32x4 cf[4];
-    if (a.coef) {
+    if (a.defer.part) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) cf[e] = *(const f32x4*)(ldsb + a.coef_lds_off + (sc * 16 + pq * 4 + e) * 16);
+    } else if (a.coef) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) cf[e] = *(const f32x4*)(a.coef + ((size_t)b * (a.c0 + a.c1) + sc * 16 + pq * 4 + e) * 4);
     }
@@ -774,7 +782,7 @@ __global__ void __launch_bounds__(512, (VT * CT * (NTERM == 2 ? 2 : 1) <= 2 ? 3 
         val[k] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (sidx < nslots && g >= 0 && g < vox) {
           val[k] = *(const f32x4*)(src + (size_t)g * ldc);
-          if (a.coef) {
+          if (normed) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               float t = cf[e][0] * val[k][e] + cf[e][1];
@@ -1497,6 +1505,13 @@ static bool try_launch_conv3_flat(const float* in0, int c0, const float* in1, in
     size_t lds = ((size_t)a.P * HW + 1) * vox_bytes;
     const size_t red = (size_t)(NT / VT) * CT * 32 * 2 * 4;  // cross-wave reduction scratch of the stats epilogue
     if (lds < red) lds = red;
+    if (fu.defer.part) {  // (only reached with prec != 0: launch_conv_mfma materialises the table for the f32 kernels)
+      lds = (lds + 15) & ~(size_t)15;
+      a.defer = fu.defer;
+      a.coef_lds_off = (int)lds;
+      lds += (size_t)fu.defer.C * 16 + gn_defer_scratch_bytes(fu.defer.C);
+      if (lds > 160 * 1024) return false;
+    }
     dim3 grid((unsigned)((g.out.vox() + a.R - 1) / a.R), (unsigned)batch, (unsigned)(CTtot / CT));
     if (fu.units) *fu.units = (int)grid.x;
     const int threads = (NT / VT) * 64;
@@ -1560,9 +1575,9 @@ static bool try_launch_conv3_flat(const float* in0, int c0, const float* in1, in
 }
 
 void launch_conv_mfma(const float* in0, int c0, const float* in1, int c1, const float* wpk, const float* bias, float* out,
-                      int batch, int cout, const ConvGeom& g, hipStream_t s, const ConvFusion& fu) {
-  CD_REQUIRE(!fu.coef || c1 == 0, "conv: a fused input normalisation needs a single (non-concatenated) source");
-  if (fu.units) *fu.units = 0;  // set by kernels that produce the output statistics themselves
+                      int batch, int cout, const ConvGeom& g, hipStream_t s, const ConvFusion& fu_in) {
+  CD_REQUIRE((!fu_in.coef && !fu_in.defer.part) || c1 == 0, "conv: a fused input normalisation needs a single (non-concatenated) source");
+  if (fu_in.units) *fu_in.units = 0;  // set by kernels that produce the output statistics themselves
   CD_REQUIRE(c0 % 32 == 0 && c1 % 32 == 0 && c0 > 0, "conv: channel counts must be multiples of 32");
   CD_REQUIRE(cout % 32 == 0, "conv: output channels must be a multiple of 32");
   CD_REQUIRE(g.kw <= 4, "conv: r kernel extent > 4 unsupported");
@@ -1574,6 +1589,17 @@ void launch_conv_mfma(const float* in0, int c0, const float* in1, int c1, const 
   const double taps = (double)g.kd * g.kh * g.kw;
   prof::Scope scope(cat, s, 2.0 * taps * (c0 + c1) * cout * (double)g.out.vox() * batch,
                     4.0 * batch * ((double)g.in.vox() * (c0 + c1) + (double)g.out.vox() * cout));
+  // deferred input normalisation: the split-16 kernels fold it in their prologue; for every other kernel the coefficient
+  // table is materialised first by a gn_finalize launch
+  ConvFusion fu = fu_in;
+  auto materialise = [&]() {
+    if (!fu.defer.part) return;
+    CD_REQUIRE(fu.coef_buf, "conv: deferred normalisation needs a coefficient buffer for kernels without the prologue");
+    launch_gn_finalize(fu.defer.part, fu.defer.units, fu.defer.gamma, fu.defer.beta, fu.defer.add, fu.defer.add_ld, fu.coef_buf, batch,
+                       fu.defer.C, fu.defer.groups, fu.defer.vox, s);
+    fu.coef = fu.coef_buf;
+    fu.defer = GnDefer();
+  };
   {
     static const bool want_f32 = getenv("CD_CONV_PRECISION") && !strcmp(getenv("CD_CONV_PRECISION"), "f32");
     static const bool want_bf16x3 = getenv("CD_CONV_PRECISION") && !strcmp(getenv("CD_CONV_PRECISION"), "bf16x3");
@@ -1589,6 +1615,7 @@ void launch_conv_mfma(const float* in0, int c0, const float* in1, int c1, const 
         try_launch_conv3_flat(in0, c0, in1, c1, (const char*)fu.wpk_bf16x3 + packed_bf16x3_bytes(c0 + c1, cout, g.kd * g.kh * g.kw), bias,
                               out, batch, cout, g, s, fu, 2))
       return;
+    materialise();
     if (fu.wpk_bf16x3 && !want_f32 && try_launch_conv3_flat(in0, c0, in1, c1, fu.wpk_bf16x3, bias, out, batch, cout, g, s, fu, 3))
       return;
     if (try_launch_conv3_flat(in0, c0, in1, c1, wpk, bias, out, batch, cout, g, s, fu, 0)) return;

@@ -13,6 +13,7 @@
 //    channel statistics; the workgroup has seen the whole sample, so it emits ONE partial per (sample, channel).
 #include "cd_common.h"
 #include "split16.h"
+#include "gn_defer.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -36,6 +37,8 @@ struct ConvSmallArgs {
   int D, H, W;
   int VB;             // bytes per voxel record = min(cin, 64) * 4 + 16
   int* status;        // bit 0: a staged value exceeded the fp16 range
+  GnDefer defer;      // input normalisation folded in the prologue (table at cs_lds + coef_lds_off) instead of `coef`
+  int coef_lds_off;
 };
 
 constexpr int CS_PD = 6;  // weight fragments requested this many pairs ahead
@@ -70,6 +73,8 @@ __global__ void __launch_bounds__(256, 1) conv_small_f16x2_kernel(ConvSmallArgs 
 #pragma unroll
     for (int r = 0; r < 16; ++r) accA[t][r] = accB[t][r] = 0.f;
   float amax = 0.f;
+  if (a.defer.part) gn_defer_to_lds(a.defer, b, (float*)(cs_lds + a.coef_lds_off), cs_lds + a.coef_lds_off + a.defer.C * 16);
+  const bool normed = a.coef || a.defer.part;
 
   for (int cb = 0; cb < cin; cb += 64) {  // input channels in blocks of <= 64
     const int cn = min(64, cin - cb);     // channels in this block (multiple of 16)
@@ -113,10 +118,11 @@ __global__ void __launch_bounds__(256, 1) conv_small_f16x2_kernel(ConvSmallArgs 
         const int v = i / nq, q = i - v * nq;
         const int c = cb + q * 4;
         f32x4 x = xs[k];
-        if (a.coef) {
+        if (normed) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const f32x4 cf = *(const f32x4*)(a.coef + ((size_t)b * cin + c + e) * 4);
+            const f32x4 cf = a.defer.part ? *(const f32x4*)(cs_lds + a.coef_lds_off + (c + e) * 16)
+                                          : *(const f32x4*)(a.coef + ((size_t)b * cin + c + e) * 4);
             float t = cf[0] * x[e] + cf[1];
             if (a.act) t = t / (1.f + expf(-t));
             x[e] = t + cf[2];
@@ -266,11 +272,14 @@ bool try_launch_conv_small(const float* in0, int c0, const float* in1, int c1, c
   const size_t partial = (size_t)NT * 4 * 4096;
   size_t lds = image > partial ? image : partial;
   lds = (lds + 255) & ~(size_t)255;
+  const size_t coef_off = lds;
+  if (fu.defer.part) lds += (size_t)fu.defer.C * 16 + gn_defer_scratch_bytes(fu.defer.C);
   if (lds > 160 * 1024) return false;
   ConvSmallArgs a;
   a.in0 = in0; a.in1 = in1; a.c0 = c0; a.c1 = c1; a.coef = fu.coef; a.act = fu.act;
   a.wpk = (const u32x4*)wpk_f16x2; a.CTtot = cout / 32; a.bias = bias; a.out = out; a.cout = cout; a.ch_part = fu.ch_part;
   a.D = g.in.d; a.H = g.in.h; a.W = g.in.w; a.VB = VB; a.status = fu.status;
+  a.defer = fu.defer; a.coef_lds_off = (int)coef_off;
   const dim3 grid((unsigned)batch, (unsigned)(cout / 32));
   switch (NT) {
     case 1: launch_small_inst<1>(a, grid, lds, s); break;

@@ -21,6 +21,7 @@
 //    tile t.  Fixed summation order => deterministic.
 #include "cd_common.h"
 #include "split16.h"
+#include "gn_defer.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -91,6 +92,8 @@ struct ConvZsArgs {
   int D, H, W;
   int nchunk, CV;    // voxels per chunk (multiple of ZS_STEP)
   int* status;       // bit 0: a staged value exceeded the fp16 range
+  GnDefer defer;     // input normalisation folded in the prologue (table of all defer.C channels in LDS) instead of `coef`
+  int choff;         // first of this launch's 32 input channels in that table
   int dbg;           // timing experiments (CD_ZS_DBG): 1 = no conversion, 4 = no reduce/store, 32/64 = no LDS writes / no split
 };
 
@@ -250,7 +253,11 @@ __device__ __forceinline__ void zs_helper_wave(const ConvZsArgs& a, char* lds, c
   // staging role: thread = (channel quad q, voxel p0 + 32k)
   const int q = tid & 7, p0 = tid >> 3;
   f32x4 cf[4];
-  if (a.coef) {
+  const bool normed = a.coef || a.defer.part;
+  if (a.defer.part) {  // table built by the whole workgroup in the (still unused) partial-exchange region
+#pragma unroll
+    for (int e = 0; e < 4; ++e) cf[e] = *(const f32x4*)(part + (a.choff + q * 4 + e) * 16);
+  } else if (a.coef) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) cf[e] = *(const f32x4*)(a.coef + ((size_t)b * a.coef_c + q * 4 + e) * 4);
   }
@@ -287,7 +294,7 @@ __device__ __forceinline__ void zs_helper_wave(const ConvZsArgs& a, char* lds, c
         u32x2 t1 = {0u, 0u}, t2 = {0u, 0u};
         if (!zero && !(a.dbg & 1)) {
           f32x4 v = ld[k];
-          if (a.coef) {
+          if (normed) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               float t = cf[e][0] * v[e] + cf[e][1];
@@ -402,6 +409,10 @@ __device__ __forceinline__ void zs_helper_wave(const ConvZsArgs& a, char* lds, c
 template <bool ACC>
 __global__ void __launch_bounds__(512, 1) conv_zslide_f16x2_kernel(ConvZsArgs a) {
   extern __shared__ __attribute__((aligned(16))) char zs_lds[];
+  if (a.defer.part) {
+    const ZsGeo G = zs_geo(a);
+    gn_defer_to_lds(a.defer, blockIdx.y, (float*)(zs_lds + G.ZPART), zs_lds + G.ZPART + a.defer.C * 16);
+  }
   switch (threadIdx.x >> 6) {
     case 0: zs_matrix_wave<0>(a, zs_lds); break;
     case 1: zs_matrix_wave<1>(a, zs_lds); break;
@@ -455,6 +466,8 @@ bool try_launch_conv_zslide(const float* in0, int c0, const float* in1, int c1, 
     else { a.in = in1 + (ch - c0); a.ldc = c1; }
     a.coef = fu.coef ? fu.coef + (size_t)ch * 4 : nullptr;
     a.coef_c = c0 + c1;
+    a.defer = fu.defer;
+    a.choff = ch;
     a.act = fu.act;
     a.wpk = (const u32x4*)wpk_f16x2 + (size_t)(kb * 2) * 27 * CTtot * 128;
     a.CTtot = CTtot;

@@ -2,6 +2,7 @@
 // Reference semantics: nn.GroupNorm(eps=1e-5, biased variance) as used by Block / PreNorm / LinearAttention.to_out
 // (calodiffusion/models/models.py:155,293,325) and LinearAttention.forward (models.py:301-318).
 #include "cd_common.h"
+#include "gn_defer.h"
 #include <cstdlib>
 
 namespace cd {
@@ -153,8 +154,11 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ coef, int channels, int64_t vox, int silu,
                                                        const float* __restrict__ residual,
                                                        const float* __restrict__ residual1, int res_c0,
-                                                       int blocks_per_sample, float* __restrict__ part_out) {
+                                                       int blocks_per_sample, float* __restrict__ part_out, GnDefer defer) {
   __shared__ double sP[256][2];
+  __shared__ __attribute__((aligned(16))) float sCoef[256 * 4];
+  __shared__ __attribute__((aligned(16))) char sDefer[256 * 16 + 64 * 8];
+  if (defer.part) gn_defer_to_lds(defer, blockIdx.x / blocks_per_sample, sCoef, sDefer);
   const int tid = threadIdx.x;
   const int b = blockIdx.x / blocks_per_sample, blk = blockIdx.x % blocks_per_sample;
   const int cols = channels >> 2;
@@ -168,7 +172,8 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
   if (row < rows) {
     f32x4 cf[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) cf[e] = *(const f32x4*)(coef + ((size_t)b * channels + c + e) * 4);
+    for (int e = 0; e < 4; ++e)
+      cf[e] = defer.part ? *(const f32x4*)(sCoef + (c + e) * 4) : *(const f32x4*)(coef + ((size_t)b * channels + c + e) * 4);
     const size_t sbase = (size_t)b * vox * channels;
     const int res_c1 = channels - res_c0;
     for (int64_t v = v0 + row; v < v1; v += rows) {
@@ -221,12 +226,14 @@ int gn_apply_blocks_per_sample(int batch, int channels, int64_t vox) {
 }
 
 void launch_gn_apply(const float* x, float* y, const float* coef, int batch, int channels, int64_t vox, int silu,
-                     const float* residual, const float* residual1, int res_c0, float* part_out, hipStream_t s) {
+                     const float* residual, const float* residual1, int res_c0, float* part_out, hipStream_t s,
+                     const GnDefer* defer) {
   CD_REQUIRE(channels % 4 == 0 && channels <= 256, "group norm: channels must be a multiple of 4 and <= 256");
+  CD_REQUIRE(!defer || !defer->part || (defer->C == channels && defer->groups <= 64), "gn_apply: bad deferred normalisation");
   const int bps = gn_apply_blocks_per_sample(batch, channels, vox);
   prof::Scope scope("gn_apply", s, 0, 4.0 * batch * (double)vox * channels * (2 + (residual ? 1 : 0)));
   hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)(batch * bps)), dim3(256), 0, s, x, y, coef, channels, vox, silu, residual,
-                     residual1, res_c0, bps, part_out);
+                     residual1, res_c0, bps, part_out, defer ? *defer : GnDefer());
   CD_HIP(hipGetLastError());
 }
 

@@ -416,8 +416,11 @@ float* stats_pass(Run& r, const float* x, int C, int64_t vox, int* units) {
 
 // conv + channel partials of its output (fused epilogue when the kernel supports it); input optionally normalised
 // on the fly by `coef_in` (+SiLU).  Returns the partial buffer (caller releases) and sets *units.
+// defer_in (optional, instead of coef_in): the input normalisation as partials + affine parameters, folded by the conv
+// kernel itself; coef_buf is the [B][Cin][4] table a kernel without that prologue gets materialised.
 float* conv3_with_stats(Run& r, const float* x0, int c0, const float* x1, int c1, const float* wpk, const void* wpk3,
-                        const float* bias, float* out, int cout, Dims3 dims, const float* coef_in, int* units) {
+                        const float* bias, float* out, int cout, Dims3 dims, const float* coef_in, int* units,
+                        const GnDefer* defer_in = nullptr, float* coef_buf = nullptr) {
   const int64_t vox = dims.vox();
   const int cap = (int)((vox + 31) / 32);
   float* part = r.ws->get<float>((size_t)r.B * cap * cout * 2);
@@ -426,6 +429,7 @@ float* conv3_with_stats(Run& r, const float* x0, int c0, const float* x1, int c1
     ConvGeom g{dims, dims, 3, 3, 3, 1, 1, 1};
     ConvFusion fu;
     fu.coef = coef_in; fu.act = 1; fu.ch_part = part; fu.units = &u; fu.wpk_bf16x3 = wpk3; fu.status = r.status;
+    if (defer_in) { fu.defer = *defer_in; fu.coef_buf = coef_buf; fu.coef = nullptr; }
     launch_conv_mfma(x0, c0, x1, c1, wpk, bias, out, r.B, cout, g, r.s, fu);
     if (u == 0) {  // kernel without a stats epilogue: separate pass, same buffer (nsplit <= cap)
       u = gn_nsplit_for(vox, r.B);
@@ -448,18 +452,25 @@ float* res_block(Run& r, const ResP& w, const float* x0, int c0, const float* x1
   const int64_t vox = dims.vox();
   const int G = r.groups;
   int u1 = 0, u2 = 0;
+  static const bool defer_gn = getenv("CD_NO_GNDEFER") == nullptr;  // consumers fold the GroupNorm coefficients (gn_defer.h)
   float* h1 = ws->get<float>((size_t)r.B * vox * w.cout);
   float* p1 = conv3_with_stats(r, x0, c0, x1, c1, w.c1w, w.c1w3, w.c1b, h1, w.cout, dims, nullptr, &u1);
   float* coef1 = ws->get<float>((size_t)r.B * w.cout * 4);
-  if (!r.dry()) launch_gn_finalize(p1, u1, w.n1g, w.n1b, w.emb, w.emb_ld, coef1, r.B, w.cout, G, vox, r.s);
-  ws->release(p1);
+  GnDefer d1;
+  d1.part = p1; d1.units = u1; d1.gamma = w.n1g; d1.beta = w.n1b; d1.add = w.emb; d1.add_ld = w.emb_ld; d1.C = w.cout; d1.groups = G;
+  d1.vox = vox;
+  if (!r.dry() && !defer_gn) launch_gn_finalize(p1, u1, w.n1g, w.n1b, w.emb, w.emb_ld, coef1, r.B, w.cout, G, vox, r.s);
   float* h2 = ws->get<float>((size_t)r.B * vox * w.cout);
-  float* p2 = conv3_with_stats(r, h1, w.cout, nullptr, 0, w.c2w, w.c2w3, w.c2b, h2, w.cout, dims, coef1, &u2);
+  float* p2 = conv3_with_stats(r, h1, w.cout, nullptr, 0, w.c2w, w.c2w3, w.c2b, h2, w.cout, dims, coef1, &u2, defer_gn ? &d1 : nullptr,
+                               coef1);
+  ws->release(p1);
   ws->release(h1);
   ws->release(coef1);
   float* coef2 = ws->get<float>((size_t)r.B * w.cout * 4);
-  if (!r.dry()) launch_gn_finalize(p2, u2, w.n2g, w.n2b, nullptr, 0, coef2, r.B, w.cout, G, vox, r.s);
-  ws->release(p2);
+  GnDefer d2;
+  d2.part = p2; d2.units = u2; d2.gamma = w.n2g; d2.beta = w.n2b; d2.C = w.cout; d2.groups = G; d2.vox = vox;
+  if (!r.dry() && !defer_gn) launch_gn_finalize(p2, u2, w.n2g, w.n2b, nullptr, 0, coef2, r.B, w.cout, G, vox, r.s);
+  const GnDefer* dp2 = defer_gn ? &d2 : nullptr;
   float* po = nullptr;
   if (part_out) {
     const int bps = gn_apply_blocks_per_sample(r.B, w.cout, vox);
@@ -474,13 +485,14 @@ float* res_block(Run& r, const ResP& w, const float* x0, int c0, const float* x1
       a.in0 = x0; a.ld0 = c0; a.off0 = 0; a.c0 = c0; a.in1 = x1; a.ld1 = c1; a.c1 = c1;
       a.wpk = w.rw; a.bias = w.rb; a.out = res; a.batch = r.B; a.cout = w.cout; a.vox = vox;
       launch_pointwise(a, r.s);
-      launch_gn_apply(h2, h2, coef2, r.B, w.cout, vox, 1, res, nullptr, 0, po, r.s);
+      launch_gn_apply(h2, h2, coef2, r.B, w.cout, vox, 1, res, nullptr, 0, po, r.s, dp2);
     }
     ws->release(res);
   } else {
     // identity shortcut; for a concatenated input it is read from the two sources (models.py:200,741)
-    if (!r.dry()) launch_gn_apply(h2, h2, coef2, r.B, w.cout, vox, 1, x0, c1 ? x1 : nullptr, c0, po, r.s);
+    if (!r.dry()) launch_gn_apply(h2, h2, coef2, r.B, w.cout, vox, 1, x0, c1 ? x1 : nullptr, c0, po, r.s, dp2);
   }
+  ws->release(p2);
   ws->release(coef2);
   return h2;
 }
@@ -496,10 +508,13 @@ float* attn_block(Run& r, const AttnP& w, const float* x, Dims3 dims, float* xpa
     own = stats_pass(r, x, C, vox, &xunits);
     xpart = own;
   }
-  float* coefn = ws->get<float>((size_t)r.B * C * 4);
-  if (!r.dry()) launch_gn_finalize(xpart, xunits, w.ng, w.nb, nullptr, 0, coefn, r.B, C, 1, vox, r.s);
-  if (own) ws->release(own);
   static const bool no_fused = getenv("CD_NO_FUSED_ATTN") != nullptr;
+  static const bool defer_gn = getenv("CD_NO_GNDEFER") == nullptr && !no_fused;  // consumers fold the coefficients (gn_defer.h)
+  float* coefn = ws->get<float>((size_t)r.B * C * 4);
+  GnDefer dn;
+  dn.part = xpart; dn.units = xunits; dn.gamma = w.ng; dn.beta = w.nb; dn.C = C; dn.groups = 1; dn.vox = vox;
+  const GnDefer* dnp = defer_gn ? &dn : nullptr;
+  if (!r.dry() && !defer_gn) launch_gn_finalize(xpart, xunits, w.ng, w.nb, nullptr, 0, coefn, r.B, C, 1, vox, r.s);
   const int CT = (C + 31) / 32;
   float* y = nullptr;
   float* ypart = nullptr;
@@ -513,10 +528,12 @@ float* attn_block(Run& r, const AttnP& w, const float* x, Dims3 dims, float* xpa
     yu = nsp;
     ypart = ws->get<float>((size_t)r.B * yu * C * 2);
     if (!r.dry()) {
-      launch_attn_kv_context(x, C, coefn, w.qkv, part, r.B, vox, nsp, r.s);
+      launch_attn_kv_context(x, C, coefn, w.qkv, part, r.B, vox, nsp, r.s, dnp);
       launch_attn_combine(part, nsp, w.ow, C, wpb, r.B, 0.17677669529663689f /* 32^-1/2 */, r.s, nullptr, nullptr, true);
-      launch_attn_out(x, C, coefn, w.qkv, wpb, w.ob, y, ypart, r.B, vox, nsp, r.s);
+      launch_attn_out(x, C, coefn, w.qkv, wpb, w.ob, y, ypart, r.B, vox, nsp, r.s, dnp);
     }
+    if (own) ws->release(own);
+    own = nullptr;
     ws->release(coefn);
     ws->release(part);
     ws->release(wpb);
@@ -549,10 +566,13 @@ float* attn_block(Run& r, const AttnP& w, const float* x, Dims3 dims, float* xpa
     ws->release(wpb);
     ws->release(qkv);
 }
+  if (own) ws->release(own);
   float* coefg = ws->get<float>((size_t)r.B * C * 4);
   if (!r.dry()) {
-    launch_gn_finalize(ypart, yu, w.gg, w.gb, nullptr, 0, coefg, r.B, C, 1, vox, r.s);
-    launch_gn_apply(y, y, coefg, r.B, C, vox, 0, x, nullptr, 0, nullptr, r.s);
+    GnDefer dg;
+    dg.part = ypart; dg.units = yu; dg.gamma = w.gg; dg.beta = w.gb; dg.C = C; dg.groups = 1; dg.vox = vox;
+    if (!defer_gn) launch_gn_finalize(ypart, yu, w.gg, w.gb, nullptr, 0, coefg, r.B, C, 1, vox, r.s);
+    launch_gn_apply(y, y, coefg, r.B, C, vox, 0, x, nullptr, 0, nullptr, r.s, defer_gn ? &dg : nullptr);
   }
   ws->release(ypart);
   ws->release(coefg);
