@@ -72,7 +72,9 @@ namespace {
 
 constexpr int ZS_VB = 144;     // bytes per voxel record: 2 k-steps x 2 terms x 16 fp16 + 16 B pad (odd number of 16-B slots
                                // => conflict-free ds_read_b128 over consecutive records)
-constexpr int ZS_RING = 4;     // planes in the ring: the 3-4 planes a 64-voxel step reads + the one being staged for the next
+// planes in the LDS ring (ConvZsArgs::NR): a 64-voxel step reads 3-4 planes and one more is staged for the next step.
+// With planes of >= 128 voxels two consecutive steps cross at most one plane boundary and 4 slots suffice; smaller
+// (strip-)planes need 5.
 constexpr int ZS_NSL = 5;      // staging slots per helper thread per plane (plane <= 160 voxels)
 constexpr int ZS_TILES = 2;    // 32-voxel row tiles per step
 constexpr int ZS_STEP = 32 * ZS_TILES;
@@ -90,7 +92,9 @@ struct ConvZsArgs {
   int cout;
   float* ch_part;    // [B][nchunk*4][cout][2] or null
   int D, H, W;
-  int nchunk, CV;    // voxels per chunk (multiple of ZS_STEP)
+  int NR;            // planes in the LDS ring (4 or 5, see above)
+  int HS;            // phi rows per strip: H (whole planes, phi wrap by address select) or a divisor of H (strips with halo rows)
+  int nchunk, CV;    // chunks per strip; voxels per chunk (multiple of ZS_STEP)
   int* status;       // bit 0: a staged value exceeded the fp16 range
   GnDefer defer;     // input normalisation folded in the prologue (table of all defer.C channels in LDS) instead of `coef`
   int choff;         // first of this launch's 32 input channels in that table
@@ -104,21 +108,31 @@ struct ConvZsArgs {
 // one vector issue port per SIMD serves the matrix wave's MFMAs (8 of every 32 cycles) AND every VALU instruction of both
 // resident waves; address arithmetic and staging beyond the remaining slots lengthens the step.
 struct ZsGeo {
-  int PV, vox, pitch, PLB, RB, ZPART;
-  int v0, cend, nsteps, zfirst;
+  int PV, vox;            // plane / sample size in voxels
+  int SPV, halo, rows;    // strip-plane voxels (HS * W); strips carry one phi halo row on either side; image rows per plane
+  int h0;                 // first phi row of this workgroup's strip
+  int pitch, PLB, RB, ZPART;
+  int chunk, strip;
+  int v0, cend, nsteps, zfirst;  // chunk = voxels [v0, cend) of the strip's own flattened (z, phi-in-strip, r) index space
 };
 __device__ __forceinline__ ZsGeo zs_geo(const ConvZsArgs& a) {
   ZsGeo g;
   g.PV = a.H * a.W;
   g.vox = a.D * g.PV;
+  g.SPV = a.HS * a.W;
+  g.halo = a.HS < a.H;
+  g.rows = a.HS + 2 * g.halo;
+  g.strip = blockIdx.x / a.nchunk;
+  g.chunk = blockIdx.x - g.strip * a.nchunk;
+  g.h0 = g.strip * a.HS;
   g.pitch = a.W + 1;
-  g.PLB = a.H * g.pitch * ZS_VB;
+  g.PLB = g.rows * g.pitch * ZS_VB;
   g.RB = ZS_VB;  // ring starts after one zero record
-  g.ZPART = (g.RB + ZS_RING * g.PLB + 255) & ~255;
-  g.v0 = blockIdx.x * a.CV;
-  g.cend = min(g.v0 + a.CV, g.vox);
+  g.ZPART = (g.RB + a.NR * g.PLB + 255) & ~255;
+  g.v0 = g.chunk * a.CV;
+  g.cend = min(g.v0 + a.CV, a.D * g.SPV);
   g.nsteps = (g.cend - g.v0 + ZS_STEP - 1) / ZS_STEP;
-  g.zfirst = g.v0 / g.PV;
+  g.zfirst = g.v0 / g.SPV;
   return g;
 }
 
@@ -141,7 +155,7 @@ __device__ __forceinline__ void zs_matrix_wave(const ConvZsArgs& a, char* lds) {
   const int lane = threadIdx.x & 63, half = lane >> 5, col = lane & 31;
   const int ct = blockIdx.z;
   const ZsGeo G = zs_geo(a);
-  const int H = a.H, W = a.W;
+  const int H = a.HS, W = a.W;  // rows of the strip-plane
   char* const part = lds + G.ZPART;
 
   u32x4 w1[14], w2[14];
@@ -158,11 +172,11 @@ __device__ __forceinline__ void zs_matrix_wave(const ConvZsArgs& a, char* lds) {
   int gh, gw, grs;  // phi row, r column, ring slot of plane z-1
   {
     const int v = G.v0 + col;
-    const int gz = v / G.PV;
-    const int p = v - gz * G.PV;
+    const int gz = v / G.SPV;
+    const int p = v - gz * G.SPV;
     gh = p / W;
     gw = p - gh * W;
-    grs = (gz + ZS_RING - 1) % ZS_RING;
+    grs = (gz + a.NR - 1) % a.NR;
   }
   const int adv_h = 32 / W, adv_w = 32 - adv_h * W;
   const int RWB = G.pitch * ZS_VB;  // bytes per row of records
@@ -182,13 +196,14 @@ __device__ __forceinline__ void zs_matrix_wave(const ConvZsArgs& a, char* lds) {
     int rb[ZS_TILES][3][3];  // address of the kw = 0 tap's fragment for every (kz, kh)
 #pragma unroll
     for (int t = 0; t < ZS_TILES; ++t) {
-      const int pb = (gh * G.pitch + gw) * ZS_VB + kconst;
-      const int ro0 = gh > 0 ? -RWB : (H - 1) * RWB;
-      const int ro2 = gh < H - 1 ? RWB : -(H - 1) * RWB;
+      const int pb = ((gh + G.halo) * G.pitch + gw) * ZS_VB + kconst;
+      // phi neighbours: strips carry halo rows; whole planes wrap around
+      const int ro0 = (G.halo || gh > 0) ? -RWB : (H - 1) * RWB;
+      const int ro2 = (G.halo || gh < H - 1) ? RWB : -(H - 1) * RWB;
 #pragma unroll
       for (int kz = 0; kz < 3; ++kz) {
         int sl = grs + kz;
-        sl = sl >= ZS_RING ? sl - ZS_RING : sl;
+        sl = sl >= a.NR ? sl - a.NR : sl;
         const int bz = sl * G.PLB + pb;
         rb[t][kz][0] = bz + ro0;
         rb[t][kz][1] = bz;
@@ -197,7 +212,7 @@ __device__ __forceinline__ void zs_matrix_wave(const ConvZsArgs& a, char* lds) {
       gw += adv_w;
       gh += adv_h;
       if (gw >= W) { gw -= W; gh += 1; }
-      if (gh >= H) { gh -= H; grs = grs == ZS_RING - 1 ? 0 : grs + 1; }
+      if (gh >= H) { gh -= H; grs = grs == a.NR - 1 ? 0 : grs + 1; }
     }
     constexpr int PD = 3;  // fragments are requested PD pairs ahead of their MFMAs
     u32x4 fa[PD + 1][2];
@@ -245,12 +260,14 @@ __device__ __forceinline__ void zs_matrix_wave(const ConvZsArgs& a, char* lds) {
 template <bool ACC>
 __device__ __forceinline__ void zs_helper_wave(const ConvZsArgs& a, char* lds, const int h) {
   const int tid = threadIdx.x - 256, lane = tid & 63, half = lane >> 5, col = lane & 31;
-  const int chunk = blockIdx.x, b = blockIdx.y, ct = blockIdx.z;
+  const int b = blockIdx.y, ct = blockIdx.z;
   const ZsGeo G = zs_geo(a);
-  const int PV = G.PV;
+  const int PV = G.PV, SPV = G.SPV;
+  const int NIMG = G.rows * a.W;  // voxels staged per plane: the strip's rows and, for strips, one halo row on either side
+  const int chunk = G.chunk + G.strip * a.nchunk;
   char* const part = lds + G.ZPART;
 
-  // staging role: thread = (channel quad q, voxel p0 + 32k)
+  // staging role: thread = (channel quad q, image voxel p0 + 32k)
   const int q = tid & 7, p0 = tid >> 3;
   f32x4 cf[4];
   const bool normed = a.coef || a.defer.part;
@@ -263,12 +280,16 @@ __device__ __forceinline__ void zs_helper_wave(const ConvZsArgs& a, char* lds, c
   }
   const float bv = a.bias ? a.bias[ct * 32 + col] : 0.f;
   const float* src_b = a.in + (size_t)b * G.vox * a.ldc + q * 4;
-  int rec[ZS_NSL];  // byte offset of this thread's record k inside a plane (+ its quad's place in the record)
+  int rec[ZS_NSL];   // byte offset of this thread's record k inside a plane image (+ its quad's place in the record)
+  int srcv[ZS_NSL];  // ... and the voxel of the global plane it is filled from (phi halo rows wrap around)
 #pragma unroll
   for (int k = 0; k < ZS_NSL; ++k) {
-    const int p = min(p0 + 32 * k, PV - 1);
-    const int ph = p / a.W;
-    rec[k] = G.RB + (ph * G.pitch + (p - ph * a.W)) * ZS_VB + (q >> 2) * 64 + (q & 3) * 8;
+    const int p = min(p0 + 32 * k, NIMG - 1);
+    const int ph = p / a.W, pw = p - ph * a.W;
+    rec[k] = G.RB + (ph * G.pitch + pw) * ZS_VB + (q >> 2) * 64 + (q & 3) * 8;
+    int sh = G.h0 + ph - G.halo;
+    sh = sh < 0 ? sh + a.H : (sh >= a.H ? sh - a.H : sh);
+    srcv[k] = sh * a.W + pw;
   }
   float amax = 0.f;
   f32x4 ld[ZS_NSL];
@@ -278,19 +299,16 @@ __device__ __forceinline__ void zs_helper_wave(const ConvZsArgs& a, char* lds, c
     const int zc = min(max(z, 0), a.D - 1);
     const float* src = src_b + (size_t)zc * PV * a.ldc;
 #pragma unroll
-    for (int k = 0; k < ZS_NSL; ++k) {
-      const int p = min(p0 + 32 * k, PV - 1);
-      ld[k] = *(const f32x4*)(src + (size_t)p * a.ldc);
-    }
+    for (int k = 0; k < ZS_NSL; ++k) ld[k] = *(const f32x4*)(src + (size_t)srcv[k] * a.ldc);
   };
   auto convert = [&](int z, int k0, int k1) {  // slots [k0, k1) of plane z
-    const int slot = (z + ZS_RING) % ZS_RING;  // z >= -1
+    const int slot = (z + a.NR) % a.NR;  // z >= -1
     const bool zero = z < 0 || z >= a.D;
     char* dst = lds + slot * G.PLB;
 #pragma unroll
     for (int k = 0; k < ZS_NSL; ++k) {
       if (k < k0 || k >= k1) continue;
-      if (p0 + 32 * k < PV) {
+      if (p0 + 32 * k < NIMG) {
         u32x2 t1 = {0u, 0u}, t2 = {0u, 0u};
         if (!zero && !(a.dbg & 1)) {
           f32x4 v = ld[k];
@@ -313,13 +331,13 @@ __device__ __forceinline__ void zs_helper_wave(const ConvZsArgs& a, char* lds, c
 
   // prologue: leading zero record, the zero pad record of every row of every ring plane, planes needed by steps 0..2
   if (tid < ZS_VB / 4) ((float*)lds)[tid] = 0.f;
-  for (int i = tid; i < ZS_RING * a.H * (ZS_VB / 4); i += 256) {
+  for (int i = tid; i < a.NR * G.rows * (ZS_VB / 4); i += 256) {
     const int row = i / (ZS_VB / 4), wd = i - row * (ZS_VB / 4);
     ((float*)(lds + G.RB + (row * G.pitch + a.W) * ZS_VB))[wd] = 0.f;
   }
   auto need = [&](int k) {  // highest plane that step k reads
     k = min(k, G.nsteps - 1);
-    return min(G.v0 + k * ZS_STEP + ZS_STEP - 1, G.cend - 1) / PV + 1;
+    return min(G.v0 + k * ZS_STEP + ZS_STEP - 1, G.cend - 1) / SPV + 1;
   };
   int zstaged = need(0);
   for (int z = G.zfirst - 1; z <= zstaged; ++z) {
@@ -327,7 +345,13 @@ __device__ __forceinline__ void zs_helper_wave(const ConvZsArgs& a, char* lds, c
     convert(z, 0, ZS_NSL);
   }
   float s1 = 0.f, s2 = 0.f;
-  float* const out_b = a.out + (size_t)b * G.vox * a.cout + ct * 32 + col;
+  // a strip-space voxel v = z * SPV + p lives at global voxel z * PV + h0 * W + p
+  float* const out_b = a.out + ((size_t)b * G.vox + (size_t)G.h0 * a.W) * a.cout + ct * 32 + col;
+  const float inv_spv = 1.f / (float)SPV;
+  auto gvox = [&](int v) {  // exact: (v + 0.5) / SPV is never within float error of an integer
+    const int z = (int)(((float)v + 0.5f) * inv_spv);
+    return z * PV + (v - z * SPV);
+  };
   // Incoming planes (at most one per step: a plane is >= 64 voxels): converted while the matrix waves run the step BEFORE
   // the one that first reads the plane -- only then is its ring slot (plane - 4) free -- from loads issued a step earlier.
   int zpend = zstaged < need(1) ? zstaged + 1 : -2;
@@ -352,23 +376,24 @@ __device__ __forceinline__ void zs_helper_wave(const ConvZsArgs& a, char* lds, c
   auto epilogue = [&](int s) {  // bias, store, statistics of this wave's 16 rows of step s
     if (a.dbg & 4) return;
     const int vt = G.v0 + s * ZS_STEP + th * 32;
-    float* o = out_b + (size_t)vt * a.cout;
+    int go[8];  // element offsets of this lane's 8 rows
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int row = (r & 3) + 8 * ((r >> 2) + 2 * rh) + 4 * half;
+      go[r] = vt + row < G.cend ? gvox(vt + row) * a.cout : -1;
+    }
     if (ACC) {  // continuation launch of a wider-K conv: add to what the previous launch stored
       float prev[8];
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const int row = (r & 3) + 8 * ((r >> 2) + 2 * rh) + 4 * half;
-        prev[r] = vt + row < G.cend ? o[(size_t)row * a.cout] : 0.f;
-      }
+      for (int r = 0; r < 8; ++r) prev[r] = go[r] >= 0 ? out_b[go[r]] : 0.f;
 #pragma unroll
       for (int r = 0; r < 8; ++r) sum[r] += prev[r];
     }
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-      const int row = (r & 3) + 8 * ((r >> 2) + 2 * rh) + 4 * half;
-      if (vt + row < G.cend) {
+      if (go[r] >= 0) {
         const float v = sum[r] + bv;
-        o[(size_t)row * a.cout] = v;
+        out_b[go[r]] = v;
         s1 += v;
         s2 += v * v;
       }
@@ -398,7 +423,7 @@ __device__ __forceinline__ void zs_helper_wave(const ConvZsArgs& a, char* lds, c
   if (a.ch_part) {
     const float t1 = s1 + __shfl_xor(s1, 32, 64), t2 = s2 + __shfl_xor(s2, 32, 64);
     if (half == 0) {
-      float* dst = a.ch_part + ((((size_t)b * a.nchunk + chunk) * 4 + h) * a.cout + ct * 32 + col) * 2;
+      float* dst = a.ch_part + ((((size_t)b * gridDim.x + chunk) * 4 + h) * a.cout + ct * 32 + col) * 2;
       dst[0] = t1;
       dst[1] = t2;
     }
@@ -424,34 +449,56 @@ __global__ void __launch_bounds__(512, 1) conv_zslide_f16x2_kernel(ConvZsArgs a)
 
 }  // namespace
 
-// Eligible: 3x3x3 stride 1, planes of 128..160 voxels (Dataset-2's 16x9), 32-channel input blocks.  Returns false otherwise.
+// Eligible: 3x3x3 stride 1 on grids whose planes -- or phi strips of them (HS rows, HS | H, with one halo row either side) --
+// hold 64..160 voxels and fit the LDS ring: Dataset-2's 16x9 planes whole, Dataset-3's 50x18 in 10 strips of 5 rows, HGCal's
+// 12x21 in 3 strips of 4.  Returns false otherwise.
 bool try_launch_conv_zslide(const float* in0, int c0, const float* in1, int c1, const void* wpk_f16x2, const float* bias, float* out,
                             int batch, int cout, const ConvGeom& g, hipStream_t s, const ConvFusion& fu) {
   if (getenv("CD_NO_ZSLIDE")) return false;
   if (!(g.kd == 3 && g.kh == 3 && g.kw == 3 && g.sz == 1 && g.sh == 1 && g.sw == 1)) return false;
-  const int PV = g.in.h * g.in.w;
-  const int64_t vox = g.in.vox();
-  if (PV < 128 || PV * 8 > ZS_NSL * 256) return false;
-  const size_t lds = (((size_t)ZS_VB + (size_t)ZS_RING * g.in.h * (g.in.w + 1) * ZS_VB + 255) & ~(size_t)255) + ZS_PART;
-  if (lds > 160 * 1024) return false;
-  if (vox < 256 || cout % 32 || c0 % 32 || c1 % 32) return false;
+  if (cout % 32 || c0 % 32 || c1 % 32) return false;
+  const int H = g.in.h, W = g.in.w;
+  auto ring_for = [&](int hs) { return hs * W >= 2 * ZS_STEP ? 4 : 5; };
+  auto lds_for = [&](int hs) {
+    const int rows = hs + (hs < H ? 2 : 0);
+    return (((size_t)ZS_VB + (size_t)ring_for(hs) * rows * (W + 1) * ZS_VB + 255) & ~(size_t)255) + ZS_PART;
+  };
+  int HS = 0;
+  for (int hs = H; hs >= 1; --hs) {  // the largest strip that fits: least halo restaging
+    if (H % hs) continue;
+    const int rows = hs + (hs < H ? 2 : 0);
+    if (hs * W < ZS_STEP || rows * W > ZS_NSL * 32 || lds_for(hs) > 160 * 1024) continue;
+    HS = hs;
+    break;
+  }
+  if (!HS) return false;
+  if (getenv("CD_ZS_STRIP")) {  // testing: force a strip height
+    const int hs = atoi(getenv("CD_ZS_STRIP"));
+    const int rows = hs + (hs < H ? 2 : 0);
+    if (hs >= 1 && H % hs == 0 && hs * W >= ZS_STEP && rows * W <= ZS_NSL * 32 && lds_for(hs) <= 160 * 1024) HS = hs;
+  }
+  const int nstrip = H / HS;
+  const int SPV = HS * W;
+  const int64_t svox = (int64_t)g.in.d * SPV;  // voxels per strip
+  if (svox < 2 * ZS_STEP) return false;
+  const size_t lds = lds_for(HS);
   const int CTtot = cout / 32;
-  // chunks per sample: fill the 256 CUs (one workgroup each) with as few rounds and as little halo restaging as possible
+  // chunks per strip: fill the 256 CUs (one workgroup each) with as few rounds and as little halo restaging as possible
   int best = 1;
   double best_eff = 0.0;
-  const int max_chunks = (int)(vox / 256);
+  const int max_chunks = (int)(svox / (2 * ZS_STEP));
   for (int n = 1; n <= max_chunks && n <= 64; ++n) {
-    const int64_t cv = ((vox + n - 1) / n + 127) / 128 * 128;
-    const int nc = (int)((vox + cv - 1) / cv);
+    const int64_t cv = ((svox + n - 1) / n + ZS_STEP - 1) / ZS_STEP * ZS_STEP;
+    const int nc = (int)((svox + cv - 1) / cv);
     if (nc != n) continue;
-    const int64_t total = (int64_t)batch * nc * CTtot;
+    const int64_t total = (int64_t)batch * nstrip * nc * CTtot;
     const int64_t rounds = (total + 255) / 256;
-    const double planes = (double)cv / PV;
+    const double planes = (double)cv / SPV;
     const double eff = (double)total / (rounds * 256.0) * planes / (planes + 2.5);  // halo planes + prologue
     if (eff > best_eff * 1.0001) { best_eff = eff; best = n; }
   }
   const int nchunk = best;
-  const int CV = (int)(((vox + nchunk - 1) / nchunk + 127) / 128 * 128);
+  const int CV = (int)(((svox + nchunk - 1) / nchunk + ZS_STEP - 1) / ZS_STEP * ZS_STEP);
   static bool attr_set = false;
   if (!attr_set) {
     CD_HIP(hipFuncSetAttribute((const void*)conv_zslide_f16x2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -475,16 +522,16 @@ bool try_launch_conv_zslide(const float* in0, int c0, const float* in1, int c1, 
     a.out = out;
     a.cout = cout;
     a.ch_part = kb == nblk - 1 ? fu.ch_part : nullptr;
-    a.D = g.in.d; a.H = g.in.h; a.W = g.in.w;
+    a.D = g.in.d; a.H = g.in.h; a.W = g.in.w; a.HS = HS; a.NR = ring_for(HS);
     a.nchunk = nchunk; a.CV = CV;
     a.status = fu.status;
     a.dbg = getenv("CD_ZS_DBG") ? atoi(getenv("CD_ZS_DBG")) : 0;
-    const dim3 grid((unsigned)nchunk, (unsigned)batch, (unsigned)CTtot);
+    const dim3 grid((unsigned)(nstrip * nchunk), (unsigned)batch, (unsigned)CTtot);
     if (kb == 0) hipLaunchKernelGGL(conv_zslide_f16x2_kernel<false>, grid, dim3(512), lds, s, a);
     else hipLaunchKernelGGL(conv_zslide_f16x2_kernel<true>, grid, dim3(512), lds, s, a);
     CD_HIP(hipGetLastError());
   }
-  if (fu.units) *fu.units = nchunk * 4;
+  if (fu.units) *fu.units = nstrip * nchunk * 4;
   return true;
 }
 

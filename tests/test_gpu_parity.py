@@ -135,6 +135,12 @@ def test_full_resolution_conv_kernel(ops):
                                    (2, 32, 0, 64, (7, 16, 8)), (5, 64, 0, 32, (3, 16, 9)), (64, 32, 0, 32, (45, 16, 9))):
         err = _conv_case(ops, gen, B, c0, c1, cout, shape)
         assert err < 2e-6, (B, c0, c1, cout, shape, err)
+    # wider planes run as phi strips with halo rows and a 5-plane ring: Dataset-3 (50x18 -> 10 strips of 5 rows), HGCal
+    # (12x21 -> 3 strips of 4 rows), a two-strip grid with a concatenated input
+    for B, c0, c1, cout, shape in ((1, 32, 0, 32, (6, 50, 18)), (2, 32, 0, 32, (9, 12, 21)), (1, 32, 0, 32, (45, 50, 18)),
+                                   (2, 32, 32, 32, (5, 10, 18))):
+        err = _conv_case(ops, gen, B, c0, c1, cout, shape)
+        assert err < 2e-6, (B, c0, c1, cout, shape, err)
 
 
 def test_whole_sample_conv_kernel(ops):

@@ -24,3 +24,18 @@ for B, cin, cout, shape in ((1, 32, 32, (45, 16, 9)), (3, 32, 32, (45, 16, 9)), 
         print("  err by h", d.sum(dim=(0, 2)).numpy().round(1))
         print("  err by w", d.sum(dim=(0, 1)).numpy().round(1))
         print("  err by c", (got - want).abs().sum(dim=(0, 2, 3, 4)).numpy().round(1))
+# phi strips: Dataset-3 (50x18 planes, strips of 5 rows) and HGCal (12x21, strips of 4) grids
+for B, cin, cout, shape in ((1, 32, 32, (6, 50, 18)), (2, 32, 32, (9, 12, 21)), (1, 32, 32, (45, 50, 18)), (2, 64, 32, (5, 10, 18))):
+    x = torch.randn((B, cin) + shape, generator=gen)
+    w = torch.randn((cout, cin, 3, 3, 3), generator=gen) * 0.05
+    bias = torch.randn(cout, generator=gen)
+    want = O.cyl_conv3d(x, w, bias, padding=(1, 1, 1))
+    y = ops.cyl_conv(ops.to_channels_last(x.cuda()), w.cuda(), bias.cuda())
+    got = ops.to_ncdhw(y).cpu()
+    err = (got - want).norm() / want.norm()
+    print(B, cin, cout, shape, "rel err", float(err))
+    if err > 1e-5:
+        d = (got - want).abs().sum(dim=(0, 1))
+        print("  err by z", d.sum(dim=(1, 2)).numpy().round(1))
+        print("  err by h", d.sum(dim=(0, 2)).numpy().round(1))
+        print("  err by w", d.sum(dim=(0, 1)).numpy().round(1))
