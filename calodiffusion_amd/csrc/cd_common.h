@@ -189,6 +189,10 @@ size_t wgrad_partial_floats(int64_t out_vox, int batch, bool per_sample, int A, 
 void launch_wgrad(const float* g, int A, Dims3 dg, const float* x, int Bc, int xld, int xoff, Dims3 dx, int kd, int kh, int kw,
                   int sz, int sxy, int batch, bool per_sample, float* partial, float* dw, bool accumulate, bool transposed_out,
                   hipStream_t s, int b_total = 0, int b_off = 0);
+// stride-1 3x3x3 weight gradient on the fp16 matrix pipe (kernels_wgrad16.hip); false = geometry not eligible
+bool wgrad_f16x2_eligible(Dims3 d);
+bool try_launch_wgrad_f16x2(const float* g, int A, const float* x, int Bc, int xld, int xoff, Dims3 d, int batch, float* partial,
+                            unsigned* gmax_word, int* nblk_out, hipStream_t s);
 void launch_strided_dgrad_naive(const float* dy, const float* w, float* dx, int batch, int cin, int cout, Dims3 din, Dims3 dout,
                                 int kd, int sz, hipStream_t s);
 void launch_softmax32(const float* qkv, float* qs, int64_t rows, hipStream_t s);

@@ -305,6 +305,23 @@ void launch_wgrad(const float* g, int A, Dims3 dg, const float* x, int Bc, int x
   a.Dg = dg.d; a.Hg = dg.h; a.Wg = dg.w; a.Dx = dx.d; a.Hx = dx.h; a.Wx = dx.w;
   a.KD = kd; a.KH = kh; a.KW = kw; a.SZ = sz; a.S = sxy; a.batch = batch; a.per_sample = per_sample ? 1 : 0;
   const int Tt = kd * kh * kw;
+  if (Tt == 27 && sz == 1 && sxy == 1 && !per_sample && dg.vox() == dx.vox()) {
+    // fp16 matrix pipe (f16x2), transposing LDS loads: kernels_wgrad16.hip
+    static unsigned* gmax_word = nullptr;
+    if (!gmax_word) CD_HIP(hipMalloc((void**)&gmax_word, 64));
+    int nblk16 = 0;
+    if (wgrad_f16x2_eligible(dg)) {
+      char cat16[96];
+      std::snprintf(cat16, sizeof cat16, "wgrad T27 C%dx%d n%ld", A, Bc, (long)dg.vox());
+      prof::Scope scope16(cat16, s, 2.0 * 27 * A * Bc * (double)dg.vox() * batch, 4.0 * batch * (double)dg.vox() * (A + Bc));
+      CD_REQUIRE(try_launch_wgrad_f16x2(g, A, x, Bc, xld, xoff, dg, batch, partial, gmax_word, &nblk16, s), "internal: wgrad f16x2");
+      const size_t total = (size_t)A * Bc * 27;
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256), 1), dim3(256), 0, s, partial, dw, A, Bc, 27, nblk16,
+                         accumulate ? 1 : 0, transposed_out ? 1 : 0, (size_t)nblk16 * total, total, b_total, b_off);
+      CD_HIP(hipGetLastError());
+      return;
+    }
+  }
   if (Tt == 27 && sz == 1 && sxy == 1 && !per_sample && dg.vox() == dx.vox() && !getenv("CD_NO_WGRAD_FLAT")) {
     // LDS-staged persistent kernel
     const int HW = dg.h * dg.w;

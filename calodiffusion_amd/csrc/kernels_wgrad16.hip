@@ -1,0 +1,289 @@
+// Weight gradient of the stride-1 3x3x3 phi-periodic conv on the fp16 matrix pipe (f16x2 split, split16.h):
+//     dW[co][ci][tap] = sum_{b, n} dy[b][n][co] * x[b][n + tap][ci]
+// a contraction over VOXELS.  v_mfma_f32_32x32x16_f16 wants 8 consecutive K (= voxel) values of one channel per lane, the
+// transpose of the channels-last tensors: both operands are read from [voxel][channel] LDS images with the gfx950
+// transposing load ds_read_b64_tr_b16 (4 voxels x 16 channels per 16-lane group, delivered channel-major), so no transposed
+// copy is ever built and the tap shift is a per-lane record address.
+//
+// A persistent workgroup (8 waves) loops over units = (sample, NZ consecutive z-planes):
+//  * dy rows of the unit and the x planes they touch (+1 halo plane each side; phi halo rows; a zero record closing every r
+//    row: every tap is "record + constant") are staged as f16x2 records.  dy is scaled by 2^s first, s from the tensor's
+//    max |dy| (a one-word atomic-max pre-pass): gradients of O(1e-6) would sit in the fp16 subnormals otherwise;
+//  * the 27 taps are dealt to the 8 waves (4,4,4,3,3,3,3,3: 7,7,7,6 per SIMD); a wave keeps its taps' 32x32 accumulator
+//    pairs in registers across ALL its units; per 16-voxel K step it reads the dy fragments once (4 transposed loads) and
+//    per tap the shifted x fragments (4 loads) for 3 MFMAs;
+//  * one partial [27][32][32] per workgroup, summed in a fixed order by wgrad_reduce_kernel (deterministic).
+#include "cd_common.h"
+#include "split16.h"
+
+#include <cstdio>
+#include <cstdlib>
+
+namespace cd {
+
+typedef __fp16 fh4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef __fp16 fh8 __attribute__((__vector_size__(8 * sizeof(__fp16))));
+
+__global__ void absmax_bits_kernel(const float* __restrict__ x, size_t n4, unsigned* __restrict__ out) {
+  float m = 0.f;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const f32x4 v = ((const f32x4*)x)[i];
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));  // non-negative floats order like their bit patterns
+}
+
+namespace {
+
+constexpr int WG_VB = 144;  // record: [k-step (16 channels)][term][16 fp16] + 16 B pad
+constexpr int WG_NZ = 2;    // z-planes per unit
+
+struct Wgrad16Args {
+  const float* g;   // dy (B, vox, A), channel tile ta
+  const float* x;   // (B, vox, xld) read at channel offset xoff, channel tile tb
+  int A, xld, xoff;
+  int D, H, W;
+  int units_per_sample, total_units;
+  float* partial;   // [gridDim.x][tilesA][tilesB][27][32][32]
+  int tilesB;
+  const unsigned* gmax_bits;  // max |dy| of the whole tensor (bit pattern)
+};
+
+__device__ __forceinline__ fh8 cat8(fh4 a, fh4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
+
+__global__ void __launch_bounds__(512, 1) wgrad_f16x2_kernel(Wgrad16Args a) {
+  extern __shared__ __attribute__((aligned(16))) char wl[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, col = lane & 31;
+  const int ta = blockIdx.y / a.tilesB, tb = blockIdx.y % a.tilesB;
+  const int H = a.H, W = a.W, PV = H * W, vox = a.D * PV;
+  const int pitch = W + 1, prow = (H + 2) * pitch;
+  const int R = WG_NZ * PV;                 // voxels per unit
+  const int RP = (R + 15) & ~15;            // padded to whole 16-voxel K steps (extra dy records are zero)
+  char* const gL = wl;                      // dy image: [RP][WG_VB]
+  char* const xL = wl + (size_t)(RP + 1) * WG_VB;  // x image: one zero record (the r-1 neighbour of the first column of the
+                                                   // first row), then [(NZ+2)][H+2][W+1] records
+  const int nxrec = (WG_NZ + 2) * prow;
+
+  // dy scale 2^s: bring the tensor's max |dy| to ~2^10 (exact power of two; undone when the partial is written)
+  const unsigned mb = *a.gmax_bits;
+  const int e = (int)((mb >> 23) & 0xff) - 127;            // floor(log2(max)) for normal numbers
+  const int sexp = mb == 0u ? 0 : max(-100, min(100, 10 - e));
+  const float gscale = __uint_as_float((unsigned)(127 + sexp) << 23);
+  const float ginv = __uint_as_float((unsigned)(127 - sexp) << 23);
+
+  // zero both images once: pad records, out-of-range planes and tail rows are never written afterwards (or rewritten as 0)
+  for (int i = tid; i < ((RP + 1) * WG_VB + nxrec * WG_VB) / 16; i += 512) ((u32x4*)wl)[i] = u32x4{0u, 0u, 0u, 0u};
+
+  // this wave's taps: wave, wave + 8, wave + 16, wave + 24
+  const int ntap = wave < 3 ? 4 : 3;
+  int toff[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int tap = min(wave + 8 * t, 26);
+    const int kz = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+    toff[t] = ((kz - 1) * prow + (kh - 1) * pitch + (kw - 1)) * WG_VB;
+  }
+  f32x16 accA[4], accB[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accA[t][r] = accB[t][r] = 0.f;
+
+  // transposing-load roles: 16-lane group g = lane >> 4 reads voxel rows 8*(g>>1) + 4j + q (q = (lane&15)>>2), channel block
+  // g & 1 (= k-step of the record), 8 bytes p = lane & 3 of that block's 32-byte term row
+  const int g4 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+  const int chan_off = (g4 & 1) * 64 + p4 * 8;
+  const int vrow0 = 8 * (g4 >> 1) + q4;  // + 4j + 16 * chunk
+  const int adv_h = 16 / W, adv_w = 16 - adv_h * W;
+  // exact small-integer division by reciprocal: (v + 0.5) / d is never within float error of an integer for v < 2^20
+  const float inv_pv = 1.f / (float)PV, inv_w = 1.f / (float)W;
+  auto div_pv = [&](int v) { return (int)(((float)v + 0.5f) * inv_pv); };
+  auto div_w = [&](int v) { return (int)(((float)v + 0.5f) * inv_w); };
+
+  for (int u = blockIdx.x; u < a.total_units; u += gridDim.x) {
+    const int n = u / a.units_per_sample, uz = u - n * a.units_per_sample;
+    const int z0 = uz * WG_NZ;
+    __syncthreads();  // previous unit fully consumed
+    // ---- stage dy rows (scaled) ---------------------------------------------------------------------------------
+    {
+      const float* gs = a.g + ((size_t)n * vox + (size_t)z0 * PV) * a.A + ta * 32;
+      const int nvalid = min(R, vox - z0 * PV);
+      for (int i0 = tid; i0 < R * 8; i0 += 4 * 512) {
+        f32x4 val[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int i = i0 + k * 512;
+          val[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (i < R * 8 && (i >> 3) < nvalid) val[k] = *(const f32x4*)(gs + (size_t)(i >> 3) * a.A + (i & 7) * 4);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int i = i0 + k * 512;
+          if (i < R * 8) {
+            const int v = i >> 3, qd = i & 7;
+            u32x2 t1, t2;
+            split2(val[k] * gscale, t1, t2);
+            char* d = gL + v * WG_VB + (qd >> 2) * 64 + (qd & 3) * 8;
+            *(u32x2*)d = t1;
+            *(u32x2*)(d + 32) = t2;
+          }
+        }
+      }
+      // ---- stage x planes z0-1 .. z0+NZ (zero outside the sample), interior rows + phi halo copies ------------------
+      const float* xs = a.x + (size_t)n * vox * a.xld + a.xoff + tb * 32;
+      const int nst = (WG_NZ + 2) * PV * 8;
+      for (int i0 = tid; i0 < nst; i0 += 4 * 512) {
+        f32x4 val[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int i = i0 + k * 512;
+          const int v = i >> 3;
+          const int zl = div_pv(v), z = z0 - 1 + zl;
+          val[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (i < nst && z >= 0 && z < a.D) val[k] = *(const f32x4*)(xs + ((size_t)z * PV + (v - zl * PV)) * a.xld + (i & 7) * 4);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int i = i0 + k * 512;
+          if (i < nst) {
+            const int v = i >> 3, qd = i & 7;
+            const int zl = div_pv(v), p = v - zl * PV, h = div_w(p), w = p - h * W;
+            u32x2 t1, t2;
+            split2(val[k], t1, t2);
+            char* d = xL + ((zl * (H + 2) + (h + 1)) * pitch + w) * WG_VB + (qd >> 2) * 64 + (qd & 3) * 8;
+            *(u32x2*)d = t1;
+            *(u32x2*)(d + 32) = t2;
+            if (h == 0) {
+              char* d2 = d + H * pitch * WG_VB;
+              *(u32x2*)d2 = t1;
+              *(u32x2*)(d2 + 32) = t2;
+            }
+            if (h == H - 1) {
+              char* d2 = d - H * pitch * WG_VB;
+              *(u32x2*)d2 = t1;
+              *(u32x2*)(d2 + 32) = t2;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- K loop: 16 voxels per step -------------------------------------------------------------------------------
+    // per-lane voxel of its two transposing loads (j = 0, 1): unit-local index and (plane, phi row, r column), advanced by 16
+    // voxels per K step without divisions
+    int vloc[2], vz[2], vh[2], vw[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int v = vrow0 + 4 * j;
+      vloc[j] = v;
+      const int vv = min(v, R - 1);
+      vz[j] = vv / PV;
+      const int p = vv - vz[j] * PV;
+      vh[j] = p / W;
+      vw[j] = p - vh[j] * W;
+    }
+    for (int c = 0; c < RP / 16; ++c) {
+      int xr[2];  // byte offset of the x record of (plane + 1, row + 1, column); past the unit: any valid record (dy is 0 there)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const bool in = vloc[j] < R;
+        xr[j] = (((in ? vz[j] + 1 : 1) * (H + 2) + (in ? vh[j] + 1 : 1)) * pitch + (in ? vw[j] : 0)) * WG_VB;
+      }
+      // dy fragments (A operand: M = co): term 0 / term 1
+      fh4 g0[2], g1[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const char* gp = gL + (size_t)min(vloc[j], RP - 1) * WG_VB + chan_off;
+        g0[j] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fh4*)(gp));
+        g1[j] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fh4*)(gp + 32));
+      }
+      const fh8 G0 = cat8(g0[0], g0[1]), G1 = cat8(g1[0], g1[1]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (t < ntap) {
+          fh4 x0[2], x1[2];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const char* xp = xL + xr[j] + toff[t] + chan_off;
+            x0[j] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fh4*)(xp));
+            x1[j] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fh4*)(xp + 32));
+          }
+          const fh8 X0 = cat8(x0[0], x0[1]), X1 = cat8(x1[0], x1[1]);
+          accA[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(G0, X0, accA[t], 0, 0, 0);
+          accB[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(G0, X1, accB[t], 0, 0, 0);
+          accB[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(G1, X0, accB[t], 0, 0, 0);
+        }
+      }
+      // advance both voxels by 16
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        vloc[j] += 16;
+        vw[j] += adv_w;
+        vh[j] += adv_h;
+        if (vw[j] >= W) { vw[j] -= W; vh[j] += 1; }
+        while (vh[j] >= H) { vh[j] -= H; vz[j] += 1; }
+      }
+    }
+  }
+
+  float* pbase = a.partial + (((size_t)blockIdx.x * (a.A / 32) + ta) * a.tilesB + tb) * (size_t)27 * 1024;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    if (t < ntap) {
+      const int tap = wave + 8 * t;
+      float* pp = pbase + (size_t)tap * 1024;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        pp[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + col] = (accA[t][r] + accB[t][r] * (1.f / 2048.f)) * ginv;
+    }
+  }
+}
+
+}  // namespace
+
+// returns false when the geometry does not fit (caller falls back to the fp32 kernels).  gmax_word: a device word the
+// caller owns (zeroed here); `partial` sized by wgrad_partial_floats.
+static size_t wgrad16_lds(Dims3 d) {
+  const int PV = d.h * d.w;
+  const int RP = (WG_NZ * PV + 15) & ~15;
+  return (size_t)(RP + 1) * WG_VB + (size_t)(WG_NZ + 2) * (d.h + 2) * (d.w + 1) * WG_VB;
+}
+bool wgrad_f16x2_eligible(Dims3 d) {
+  if (getenv("CD_NO_WGRAD16")) return false;
+  // tiny planes: a unit's few 16-voxel K steps do not amortise its staging; the fp32 kernels win there
+  return d.d >= 1 && d.h * d.w >= 64 && wgrad16_lds(d) <= 160 * 1024;
+}
+bool try_launch_wgrad_f16x2(const float* g, int A, const float* x, int Bc, int xld, int xoff, Dims3 d, int batch, float* partial,
+                            unsigned* gmax_word, int* nblk_out, hipStream_t s) {
+  if (!wgrad_f16x2_eligible(d)) return false;
+  const size_t lds = wgrad16_lds(d);
+  Wgrad16Args f;
+  f.g = g; f.x = x; f.A = A; f.xld = xld; f.xoff = xoff; f.D = d.d; f.H = d.h; f.W = d.w;
+  f.units_per_sample = (d.d + WG_NZ - 1) / WG_NZ;
+  f.total_units = f.units_per_sample * batch;
+  f.partial = partial; f.tilesB = Bc / 32;
+  f.gmax_bits = gmax_word;
+  const int tiles = (A / 32) * (Bc / 32);
+  int nblk = 256 / tiles;
+  if (nblk < 32) nblk = 32;
+  if (nblk > f.total_units) nblk = f.total_units;
+  CD_HIP(hipMemsetAsync(gmax_word, 0, sizeof(unsigned), s));
+  const size_t n4 = (size_t)batch * d.vox() * A / 4;
+  hipLaunchKernelGGL(absmax_bits_kernel, dim3(1024), dim3(256), 0, s, g, n4, gmax_word);
+  CD_HIP(hipGetLastError());
+  static bool attr_set = false;
+  if (!attr_set) {
+    CD_HIP(hipFuncSetAttribute((const void*)wgrad_f16x2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(wgrad_f16x2_kernel, dim3(nblk, tiles), dim3(512), lds, s, f);
+  CD_HIP(hipGetLastError());
+  *nblk_out = nblk;
+  return true;
+}
+
+}  // namespace cd
