@@ -96,7 +96,24 @@ struct ConvFusion {
   // prologue get the table materialised into `coef_buf` ([B][Cin][4]) by a gn_finalize launch first.
   GnDefer defer;
   float* coef_buf = nullptr;
+  // max |input| as a float bit pattern in a device word (launch_absmax_bits), or null.  Given, the f16x2 kernels multiply the
+  // staged input by 2^s (bringing that maximum to ~2^10) and their output by 2^-s: the input gradients of a conv are
+  // O(1e-6), deep in the fp16 subnormals, and the conv is linear.  Needs bias == null and no input normalisation.
+  const unsigned* in_absmax = nullptr;
 };
+// device word holding max |x| (bit pattern) of the tensor last passed to launch_absmax_bits; valid in stream order
+const unsigned* launch_absmax_bits(const float* x, size_t n, hipStream_t s);
+// 2^s and 2^-s for a tensor whose max |x| has bit pattern mb: s = 10 - floor(log2 max)
+__host__ __device__ inline void pow2_scale_for(unsigned mb, float* scale, float* inv) {
+  const int e = (int)((mb >> 23) & 0xff) - 127;
+  int sexp = mb == 0u ? 0 : 10 - e;
+  sexp = sexp < -100 ? -100 : (sexp > 100 ? 100 : sexp);
+  union { unsigned u; float f; } a, b;
+  a.u = (unsigned)(127 + sexp) << 23;
+  b.u = (unsigned)(127 - sexp) << 23;
+  *scale = a.f;
+  *inv = b.f;
+}
 inline size_t packed_bf16x3_bytes(int cin, int cout, int taps) {
   return (size_t)(cin / 16) * taps * ((cout + 31) / 32) * 3 * 64 * 16;
 }

@@ -360,6 +360,7 @@ struct ConvFlatArgs {
   int* status = nullptr;  // f16x2 only: bit 0 <- a staged value exceeded the fp16 range
   GnDefer defer;          // split-16 kernels: fold the input normalisation in the prologue (table at lds + coef_lds_off)
   int coef_lds_off = 0;
+  const unsigned* in_absmax = nullptr;  // f16x2: power-of-two input rescaling (ConvFusion::in_absmax)
 };
 
 template <int VT, int CT>
@@ -744,6 +745,8 @@ __global__ void __launch_bounds__(512, (VT * CT * (NTERM == 2 ? 2 : 1) <= 2 ? 3 
       }
 
   float amax = 0.f;
+  float gscale = 1.f, ginv = 1.f;
+  if (NTERM == 2 && a.in_absmax) pow2_scale_for(*a.in_absmax, &gscale, &ginv);
   const int nsub = (a.c0 + a.c1) >> 4;
   const int gbase = zA * HW;
   const int nslots = nstage * 4;  // one slot = 4 channels of one voxel
@@ -804,9 +807,10 @@ __global__ void __launch_bounds__(512, (VT * CT * (NTERM == 2 ? 2 : 1) <= 2 ? 3 
             *(u32x2*)(d + 32) = t2;
             *(u32x2*)(d + 64) = t3;
           } else {
-            amax = fmaxf(amax, fmaxf(fmaxf(fabsf(val[k][0]), fabsf(val[k][1])), fmaxf(fabsf(val[k][2]), fabsf(val[k][3]))));
+            const f32x4 vs = val[k] * gscale;
+            amax = fmaxf(amax, fmaxf(fmaxf(fabsf(vs[0]), fabsf(vs[1])), fmaxf(fabsf(vs[2]), fabsf(vs[3]))));
             u32x2 t1, t2;
-            split2(val[k], t1, t2);
+            split2(vs, t1, t2);
             *(u32x2*)d = t1;
             *(u32x2*)(d + 32) = t2;
           }
@@ -875,7 +879,7 @@ __global__ void __launch_bounds__(512, (VT * CT * (NTERM == 2 ? 2 : 1) <= 2 ? 3 
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[vt][ct][r] += accB[vt][ct][r] * (1.f / 2048.f);
+        for (int r = 0; r < 16; ++r) acc[vt][ct][r] = (acc[vt][ct][r] + accB[vt][ct][r] * (1.f / 2048.f)) * ginv;
   }
   if (NTERM == 2 && a.status && amax > 65504.f) atomicOr(a.status, 1);
   float* outb = a.out + (size_t)b * voxo * a.cout;
@@ -1501,7 +1505,7 @@ static bool try_launch_conv3_flat(const float* in0, int c0, const float* in1, in
     a.D = d.d; a.H = d.h; a.W = d.w; a.Do = g.out.d; a.Ho = g.out.h; a.Wo = g.out.w;
     a.R = 32 * NT; a.P = planes(NT); a.cout = cout; a.CTtot = CTtot;
     a.dbg = getenv("CD_FLAT_DBG") ? atoi(getenv("CD_FLAT_DBG")) : 0;
-    a.coef = fu.coef; a.act = fu.act; a.ch_part = fu.ch_part; a.status = fu.status;
+    a.coef = fu.coef; a.act = fu.act; a.ch_part = fu.ch_part; a.status = fu.status; a.in_absmax = fu.in_absmax;
     size_t lds = ((size_t)a.P * HW + 1) * vox_bytes;
     const size_t red = (size_t)(NT / VT) * CT * 32 * 2 * 4;  // cross-wave reduction scratch of the stats epilogue
     if (lds < red) lds = red;

@@ -39,6 +39,7 @@ struct ConvSmallArgs {
   int* status;        // bit 0: a staged value exceeded the fp16 range
   GnDefer defer;      // input normalisation folded in the prologue (table at cs_lds + coef_lds_off) instead of `coef`
   int coef_lds_off;
+  const unsigned* in_absmax;  // power-of-two input rescaling (ConvFusion::in_absmax) or null
 };
 
 constexpr int CS_PD = 6;  // weight fragments requested this many pairs ahead
@@ -73,6 +74,8 @@ __global__ void __launch_bounds__(256, 1) conv_small_f16x2_kernel(ConvSmallArgs 
 #pragma unroll
     for (int r = 0; r < 16; ++r) accA[t][r] = accB[t][r] = 0.f;
   float amax = 0.f;
+  float gscale = 1.f, ginv = 1.f;
+  if (a.in_absmax) pow2_scale_for(*a.in_absmax, &gscale, &ginv);
   if (a.defer.part) gn_defer_to_lds(a.defer, b, (float*)(cs_lds + a.coef_lds_off), cs_lds + a.coef_lds_off + a.defer.C * 16);
   const bool normed = a.coef || a.defer.part;
 
@@ -117,7 +120,7 @@ __global__ void __launch_bounds__(256, 1) conv_small_f16x2_kernel(ConvSmallArgs 
         if (i >= vox * nq) break;
         const int v = i / nq, q = i - v * nq;
         const int c = cb + q * 4;
-        f32x4 x = xs[k];
+        f32x4 x = xs[k] * gscale;
         if (normed) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -212,7 +215,7 @@ __global__ void __launch_bounds__(256, 1) conv_small_f16x2_kernel(ConvSmallArgs 
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
       if (wave * 32 + row < vox) {
-        const float v = sum[r] + bv;
+        const float v = sum[r] * ginv + bv;
         o[(size_t)row * a.cout] = v;
         s1 += v;
         s2 += v * v;
@@ -279,7 +282,7 @@ bool try_launch_conv_small(const float* in0, int c0, const float* in1, int c1, c
   a.in0 = in0; a.in1 = in1; a.c0 = c0; a.c1 = c1; a.coef = fu.coef; a.act = fu.act;
   a.wpk = (const u32x4*)wpk_f16x2; a.CTtot = cout / 32; a.bias = bias; a.out = out; a.cout = cout; a.ch_part = fu.ch_part;
   a.D = g.in.d; a.H = g.in.h; a.W = g.in.w; a.VB = VB; a.status = fu.status;
-  a.defer = fu.defer; a.coef_lds_off = (int)coef_off;
+  a.defer = fu.defer; a.coef_lds_off = (int)coef_off; a.in_absmax = fu.in_absmax;
   const dim3 grid((unsigned)batch, (unsigned)(cout / 32));
   switch (NT) {
     case 1: launch_small_inst<1>(a, grid, lds, s); break;

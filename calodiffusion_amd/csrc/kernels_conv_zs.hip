@@ -98,6 +98,7 @@ struct ConvZsArgs {
   int* status;       // bit 0: a staged value exceeded the fp16 range
   GnDefer defer;     // input normalisation folded in the prologue (table of all defer.C channels in LDS) instead of `coef`
   int choff;         // first of this launch's 32 input channels in that table
+  const unsigned* in_absmax;  // input rescaling by a power of two (ConvFusion::in_absmax) or null
   int dbg;           // timing experiments (CD_ZS_DBG): 1 = no conversion, 4 = no reduce/store, 32/64 = no LDS writes / no split
 };
 
@@ -292,6 +293,8 @@ __device__ __forceinline__ void zs_helper_wave(const ConvZsArgs& a, char* lds, c
     srcv[k] = sh * a.W + pw;
   }
   float amax = 0.f;
+  float gscale = 1.f, ginv = 1.f;
+  if (a.in_absmax) pow2_scale_for(*a.in_absmax, &gscale, &ginv);
   f32x4 ld[ZS_NSL];
   // Loads are unconditional (plane and voxel indices clamped into range; an out-of-range plane is zero-filled by
   // convert()): a predicated load would be sunk by the compiler into convert()'s matching branch.
@@ -311,7 +314,7 @@ __device__ __forceinline__ void zs_helper_wave(const ConvZsArgs& a, char* lds, c
       if (p0 + 32 * k < NIMG) {
         u32x2 t1 = {0u, 0u}, t2 = {0u, 0u};
         if (!zero && !(a.dbg & 1)) {
-          f32x4 v = ld[k];
+          f32x4 v = ld[k] * gscale;
           if (normed) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -387,7 +390,10 @@ __device__ __forceinline__ void zs_helper_wave(const ConvZsArgs& a, char* lds, c
 #pragma unroll
       for (int r = 0; r < 8; ++r) prev[r] = go[r] >= 0 ? out_b[go[r]] : 0.f;
 #pragma unroll
-      for (int r = 0; r < 8; ++r) sum[r] += prev[r];
+      for (int r = 0; r < 8; ++r) sum[r] = sum[r] * ginv + prev[r];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) sum[r] *= ginv;
     }
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
@@ -515,6 +521,7 @@ bool try_launch_conv_zslide(const float* in0, int c0, const float* in1, int c1, 
     a.coef_c = c0 + c1;
     a.defer = fu.defer;
     a.choff = ch;
+    a.in_absmax = fu.in_absmax;
     a.act = fu.act;
     a.wpk = (const u32x4*)wpk_f16x2 + (size_t)(kb * 2) * 27 * CTtot * 128;
     a.CTtot = CTtot;

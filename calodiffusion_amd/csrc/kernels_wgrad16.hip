@@ -68,11 +68,8 @@ __global__ void __launch_bounds__(512, 1) wgrad_f16x2_kernel(Wgrad16Args a) {
   const int nxrec = (WG_NZ + 2) * prow;
 
   // dy scale 2^s: bring the tensor's max |dy| to ~2^10 (exact power of two; undone when the partial is written)
-  const unsigned mb = *a.gmax_bits;
-  const int e = (int)((mb >> 23) & 0xff) - 127;            // floor(log2(max)) for normal numbers
-  const int sexp = mb == 0u ? 0 : max(-100, min(100, 10 - e));
-  const float gscale = __uint_as_float((unsigned)(127 + sexp) << 23);
-  const float ginv = __uint_as_float((unsigned)(127 - sexp) << 23);
+  float gscale, ginv;
+  pow2_scale_for(*a.gmax_bits, &gscale, &ginv);
 
   // zero both images once: pad records, out-of-range planes and tail rows are never written afterwards (or rewritten as 0)
   for (int i = tid; i < ((RP + 1) * WG_VB + nxrec * WG_VB) / 16; i += 512) ((u32x4*)wl)[i] = u32x4{0u, 0u, 0u, 0u};
@@ -247,6 +244,20 @@ __global__ void __launch_bounds__(512, 1) wgrad_f16x2_kernel(Wgrad16Args a) {
 
 // returns false when the geometry does not fit (caller falls back to the fp32 kernels).  gmax_word: a device word the
 // caller owns (zeroed here); `partial` sized by wgrad_partial_floats.
+namespace {
+unsigned* g_absmax_word = nullptr;
+const float* g_absmax_of = nullptr;  // tensor the word currently describes (stream order)
+}  // namespace
+const unsigned* launch_absmax_bits(const float* x, size_t n, hipStream_t s) {
+  if (!g_absmax_word) CD_HIP(hipMalloc((void**)&g_absmax_word, 64));
+  CD_REQUIRE(n % 4 == 0, "absmax: element count must be a multiple of 4");
+  CD_HIP(hipMemsetAsync(g_absmax_word, 0, sizeof(unsigned), s));
+  hipLaunchKernelGGL(absmax_bits_kernel, dim3(1024), dim3(256), 0, s, x, n / 4, g_absmax_word);
+  CD_HIP(hipGetLastError());
+  g_absmax_of = x;
+  return g_absmax_word;
+}
+
 static size_t wgrad16_lds(Dims3 d) {
   const int PV = d.h * d.w;
   const int RP = (WG_NZ * PV + 15) & ~15;
@@ -266,15 +277,13 @@ bool try_launch_wgrad_f16x2(const float* g, int A, const float* x, int Bc, int x
   f.units_per_sample = (d.d + WG_NZ - 1) / WG_NZ;
   f.total_units = f.units_per_sample * batch;
   f.partial = partial; f.tilesB = Bc / 32;
-  f.gmax_bits = gmax_word;
+  // max |dy|: reuse the word if the caller (conv_backward) already computed it for this tensor
+  f.gmax_bits = (g_absmax_of == g && g_absmax_word) ? g_absmax_word : launch_absmax_bits(g, (size_t)batch * d.vox() * A, s);
+  (void)gmax_word;
   const int tiles = (A / 32) * (Bc / 32);
   int nblk = 256 / tiles;
   if (nblk < 32) nblk = 32;
   if (nblk > f.total_units) nblk = f.total_units;
-  CD_HIP(hipMemsetAsync(gmax_word, 0, sizeof(unsigned), s));
-  const size_t n4 = (size_t)batch * d.vox() * A / 4;
-  hipLaunchKernelGGL(absmax_bits_kernel, dim3(1024), dim3(256), 0, s, g, n4, gmax_word);
-  CD_HIP(hipGetLastError());
   static bool attr_set = false;
   if (!attr_set) {
     CD_HIP(hipFuncSetAttribute((const void*)wgrad_f16x2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -617,6 +617,7 @@ void conv_backward(Run& r, const float* x0, int c0, const float* x1, int c1, con
         ConvGeom gd{g.out, g.in, g.kd, g.kh, g.kw, 1, 1, 1};
         ConvFusion fu;
         fu.wpk_bf16x3 = wp3;
+        fu.in_absmax = launch_absmax_bits(dy, (size_t)r.B * g.out.vox() * cout, r.s);  // also serves the weight gradient below
         launch_conv_mfma(dy, cout, nullptr, 0, wp, nullptr, dx, r.B, cin, gd, r.s, fu);
       }
       ws->release(wp3);
@@ -669,6 +670,7 @@ void conv_transpose_backward(Run& r, const float* x, const float* w_raw, const f
       ConvGeom gd{dout, din, kz, 4, 4, sz, 2, 2};
       ConvFusion fu;
       fu.wpk_bf16x3 = wp3;
+      fu.in_absmax = launch_absmax_bits(dy, (size_t)r.B * dout.vox() * c, r.s);
       launch_conv_mfma(dy, c, nullptr, 0, wp, nullptr, dx, r.B, c, gd, r.s, fu);
     }
     ws->release(wp3);

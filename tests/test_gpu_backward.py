@@ -28,13 +28,13 @@ def back(ops, y_cl):
     return ops.to_ncdhw(y_cl).cpu().numpy()
 
 
-def _conv_case(ops, cin, cout, shape, k, stride, gen, split=None):
+def _conv_case(ops, cin, cout, shape, k, stride, gen, split=None, dy_scale=1.0):
     x = torch.randn((shape[0], cin) + shape[1:], generator=gen, requires_grad=True)
     w = (torch.randn((cout, cin) + k, generator=gen) * 0.1).requires_grad_()
     b = torch.randn(cout, generator=gen, requires_grad=True)
     pad = (0, 0, 0) if k == (1, 1, 1) else (1, 1, 1)
     y = O.cyl_conv3d(x, w, b, stride=stride, padding=pad)
-    dy = torch.randn(y.shape, generator=gen)
+    dy = torch.randn(y.shape, generator=gen) * dy_scale
     y.backward(dy)
     if split:
         x0, x1 = x[:, :split], x[:, split:]
@@ -57,6 +57,13 @@ def test_conv_backward(ops):
     _conv_case(ops, 32, 32, (1, 9, 8, 9), (3, 4, 4), (2, 2, 2), gen)             # Dataset-2-like down-sampling
     _conv_case(ops, 32, 32, (2, 5, 5, 7), (3, 4, 4), (2, 2, 2), gen)             # odd extents
     _conv_case(ops, 64, 64, (1, 4, 6, 4), (3, 4, 4), (1, 2, 2), gen)             # COMPRESS_Z false
+    # planes of >= 64 voxels: the weight gradient runs on the fp16 matrix pipe (kernels_wgrad16.hip); odd plane counts,
+    # concatenated input, and gradients far below the fp16 normal range (the kernel rescales them by a power of two)
+    _conv_case(ops, 32, 32, (2, 5, 16, 9), (3, 3, 3), (1, 1, 1), gen)
+    _conv_case(ops, 64, 32, (1, 3, 16, 9), (3, 3, 3), (1, 1, 1), gen, split=32)
+    _conv_case(ops, 32, 64, (1, 4, 8, 8), (3, 3, 3), (1, 1, 1), gen)
+    _conv_case(ops, 32, 32, (2, 7, 12, 7), (3, 3, 3), (1, 1, 1), gen, dy_scale=3e-7)
+    _conv_case(ops, 32, 32, (1, 2, 16, 9), (3, 3, 3), (1, 1, 1), gen, dy_scale=2e4)
 
 
 def test_conv_transpose_backward(ops):
