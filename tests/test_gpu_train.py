@@ -54,11 +54,13 @@ def test_parameter_gradients_match_autograd(name, B):
         err = rel_l2(p.grad.cpu().numpy(), want[kname].numpy())
         worst.append((err, kname))
     worst.sort(reverse=True)
-    assert worst[0][0] < 2e-4, worst[:8]
+    print(f"[{name}] worst per-tensor gradient errors: {[(round(e, 8), k) for e, k in worst[:3]]}")
+    assert worst[0][0] < 1e-4, worst[:8]
     # all gradients together
     got_all = np.concatenate([p.grad.cpu().numpy().ravel() for _, p in m.model.named_parameters()])
     want_all = np.concatenate([want[k].numpy().ravel() for k, _ in m.model.named_parameters()])
-    assert rel_l2(got_all, want_all) < 2e-5
+    print(f"[{name}] all gradients together: {rel_l2(got_all, want_all):.3e}")
+    assert rel_l2(got_all, want_all) < 5e-6
 
 
 def test_training_loop_protocol_one_adam_step():
