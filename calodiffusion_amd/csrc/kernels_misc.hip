@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(512) embed_kernel(EmbedArgs a) {
   float t_in = tv;
   if (a.time_kind == 0) t_in = 0.5f * logf(tv);
   else if (a.time_kind == 1) t_in = tv / sqrtf(1.f + tv * tv);
-  if (a.scal && tid == 0) {
+  if (a.scal && tid == 0 && blockIdx.y == 0) {
     const float sd = a.sigma_data;
     const float s2 = tv * tv + sd * sd;
     a.scal[b * 4 + 0] = 1.f / sqrtf(s2);           // c_in
@@ -68,8 +68,10 @@ __global__ void __launch_bounds__(512) embed_kernel(EmbedArgs a) {
   }
   __syncthreads();
   // all ResnetBlock projections: a wave owns 4 output rows at a time so that 4 independent weight-row loads are in flight
+  // gridDim.y workgroups per sample share the projection layers (each repeats the two small MLPs above: the projections'
+  // ~700 weight rows are the latency chain of this kernel)
   const int nin = 2 * half;
-  for (int l = 0; l < a.n_layers; ++l) {
+  for (int l = blockIdx.y; l < a.n_layers; l += gridDim.y) {
     const EmbedLayer L = a.layers[l];
     for (int j0 = wave * 4; j0 < L.cout; j0 += nw * 4) {
       float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -92,7 +94,8 @@ __global__ void __launch_bounds__(512) embed_kernel(EmbedArgs a) {
 void launch_embed(const EmbedArgs& a, hipStream_t s) {
   CD_REQUIRE(a.half * 2 <= 256 && a.cond_hidden <= 256 && a.cond_size <= 256, "embedding widths above 256 unsupported");
   prof::Scope scope("embed", s, 0, 0);
-  hipLaunchKernelGGL(embed_kernel, dim3(a.batch), dim3(512), 0, s, a);
+  const int groups = a.n_layers >= 4 ? 4 : 1;
+  hipLaunchKernelGGL(embed_kernel, dim3(a.batch, groups), dim3(512), 0, s, a);
   CD_HIP(hipGetLastError());
 }
 
