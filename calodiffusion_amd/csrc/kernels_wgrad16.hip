@@ -53,6 +53,30 @@ struct Wgrad16Args {
 
 __device__ __forceinline__ fh8 cat8(fh4 a, fh4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
 
+template <int NTAP>
+__device__ __forceinline__ void k_step(const char* xL, const int (&xr)[2], const int (&toff)[4], int chan_off, fh8 G0, fh8 G1,
+                                       f32x16 (&accA)[4], f32x16 (&accB)[4]) {
+  fh8 X0[NTAP], X1[NTAP];
+#pragma unroll
+  for (int t = 0; t < NTAP; ++t) {
+    fh4 x0[2], x1[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const char* xp = xL + xr[j] + toff[t] + chan_off;
+      x0[j] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fh4*)(xp));
+      x1[j] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fh4*)(xp + 32));
+    }
+    X0[t] = cat8(x0[0], x0[1]);
+    X1[t] = cat8(x1[0], x1[1]);
+  }
+#pragma unroll
+  for (int t = 0; t < NTAP; ++t) {
+    accA[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(G0, X0[t], accA[t], 0, 0, 0);
+    accB[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(G0, X1[t], accB[t], 0, 0, 0);
+    accB[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(G1, X0[t], accB[t], 0, 0, 0);
+  }
+}
+
 __global__ void __launch_bounds__(512, 1) wgrad_f16x2_kernel(Wgrad16Args a) {
   extern __shared__ __attribute__((aligned(16))) char wl[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -199,22 +223,9 @@ __global__ void __launch_bounds__(512, 1) wgrad_f16x2_kernel(Wgrad16Args a) {
         g1[j] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fh4*)(gp + 32));
       }
       const fh8 G0 = cat8(g0[0], g0[1]), G1 = cat8(g1[0], g1[1]);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        if (t < ntap) {
-          fh4 x0[2], x1[2];
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const char* xp = xL + xr[j] + toff[t] + chan_off;
-            x0[j] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fh4*)(xp));
-            x1[j] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fh4*)(xp + 32));
-          }
-          const fh8 X0 = cat8(x0[0], x0[1]), X1 = cat8(x1[0], x1[1]);
-          accA[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(G0, X0, accA[t], 0, 0, 0);
-          accB[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(G0, X1, accB[t], 0, 0, 0);
-          accB[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(G1, X0, accB[t], 0, 0, 0);
-        }
-      }
+      // all of the step's x fragments are requested before its first MFMA (one LDS round trip per step, not per tap)
+      if (ntap == 4) k_step<4>(xL, xr, toff, chan_off, G0, G1, accA, accB);
+      else k_step<3>(xL, xr, toff, chan_off, G0, G1, accA, accB);
       // advance both voxels by 16
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
