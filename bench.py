@@ -31,6 +31,10 @@ if ROOT not in sys.path:
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32-in MFMA = vector fp32 peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA
+# HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, profiles/r01f_zslide_traffic.txt):
+# PMC counters cannot be collected inside this process, so the figure of the committed profile is attached when the dominant
+# kernel and batch are the profiled ones (f16x2 default path only).
+MEASURED_TRAFFIC_BYTES = {("conv3x3x3_s1 C32->32 @45x16x9", 64): 121.7e6}
 BF16X3_TERMS = 6                # bf16 MFMAs per fp32 product in the split-bf16 convolution
 PEAK_HBM_GBS = 8000.0
 
@@ -128,7 +132,8 @@ def roofline_leg(model, cfg, batch, E, layers):
             "bf16x3": "bf16 MFMA, fp32 operands split exactly into 3 bf16 terms, 6 MFMAs per MAC (2500/6 TFLOP/s)"}.get(
         mode, "fp16 MFMA, fp32 operands split into 2 fp16 terms (22 bits), 3 MFMAs per MAC block (2500/3 TFLOP/s)")
     roof = {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 3), "peak": round(peak, 1),
-            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+            "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+            "traffic": MEASURED_TRAFFIC_BYTES.get((dom_name, batch)) if mode == "f16x2" else None,
             "pipe": pipe,
             "frac_of_fp32_mfma_peak": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
             "avg_launch_us": round(avg_ms * 1e3, 2), "alg_flops_per_launch": dom["flops"],
