@@ -255,9 +255,9 @@ void launch_attn_combine(const float* partials, int nsplit, const float* w_out /
 
 // fused linear attention of the sampling path (kernels_attn.hip): qkv is never materialised
 int attn_fused_nsplit_for(int64_t vox, int batch);
-void launch_attn_kv_context(const float* x, int C, const float* coef, const float* wqkv_packed, float* partials, int batch,
+void launch_attn_kv_context(const float* x, int C, const float* coef, const void* wqkv_f16x2, float* partials, int batch,
                             int64_t vox, int nsplit, hipStream_t s, const GnDefer* defer = nullptr);
-void launch_attn_out(const float* x, int C, const float* coef, const float* wqkv_packed, const float* wT_b, const float* bias,
+void launch_attn_out(const float* x, int C, const float* coef, const void* wqkv_f16x2, const float* wT_b, const float* bias,
                      float* y, float* ch_part /* [B][nsplit][C][2] */, int batch, int64_t vox, int nsplit, hipStream_t s,
                      const GnDefer* defer = nullptr);
 

@@ -11,9 +11,12 @@
 //                                    channel statistics (for the GroupNorm(1) that follows)
 //
 // HBM traffic per attention block: x twice + y once (3 x B n C floats) instead of x + 2 x qkv + q + y (= 10 x for C = 32).
-// All arithmetic is fp32 (v_mfma_f32_32x32x2_f32); the kernels are memory / latency bound.
+// The q / k / v projections run on the fp16 matrix pipe with the convs' f16x2 split (split16.h: fp32-grade rounding, 3 MFMAs
+// per 16 channels instead of 16 f32 MFMAs at half the rate); the context and output products take their operands from
+// accumulator registers and stay on v_mfma_f32_32x32x2_f32.
 #include "cd_common.h"
 #include "gn_defer.h"
+#include "split16.h"
 
 #include <cstdio>
 
@@ -26,7 +29,7 @@ namespace {
 struct AttnArgs {
   const float* x;     // (B, vox, C) channels-last
   const float* coef;  // [B][C][4] = {scale, shift, -, -} of the PreNorm
-  const float* wqkv;  // packed MFMA image of to_qkv (96 output channels: ct 0 = q, 1 = k, 2 = v)
+  const u32x4* wqkv;  // f16x2 image of to_qkv [k-step][ct (0 = q, 1 = k, 2 = v)][term][lane] (launch_pack_weights_f16x2, taps = 1)
   int C;
   int64_t vox;
   int tiles_per_wg;   // 32-voxel tiles per workgroup (multiple of 8)
@@ -41,27 +44,35 @@ struct AttnArgs {
   GnDefer defer;      // PreNorm coefficients folded in the prologue instead of read from `coef`
 };
 
-// A fragments of one 32-voxel tile: lane (voxel n0 + col, half) holds channels chunk*32 + half*16 + 0..15, normalised
+// A fragments of one 32-voxel tile for v_mfma_f32_32x32x16_f16: lane (voxel n0 + col, half) holds, per 16-channel k-step ks,
+// channels ks*16 + half*8 + 0..7 of the normalised input as two fp16 terms (f16x2).  NKS = C / 16 k-steps.
 template <int NCH>
 __device__ __forceinline__ void load_xn(const AttnArgs& a, int b, int64_t n0, int col, int half, const f32x4 (&cf)[NCH][8],
-                                        f32x4 (&av)[NCH][4]) {
+                                        u32x4 (&x1)[NCH * 2], u32x4 (&x2)[NCH * 2]) {
   const int64_t n = n0 + col;
   const bool valid = n < a.vox;
-  const float* src = a.x + ((size_t)b * a.vox + (valid ? n : 0)) * a.C + half * 16;
+  const float* src = a.x + ((size_t)b * a.vox + (valid ? n : 0)) * a.C + half * 8;
+  f32x4 v[NCH * 2][2];
 #pragma unroll
-  for (int ch = 0; ch < NCH; ++ch)
+  for (int ks = 0; ks < NCH * 2; ++ks)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) av[ch][q] = *(const f32x4*)(src + ch * 32 + q * 4);
+    for (int j = 0; j < 2; ++j) v[ks][j] = *(const f32x4*)(src + ks * 16 + j * 4);
 #pragma unroll
-  for (int ch = 0; ch < NCH; ++ch)
+  for (int ks = 0; ks < NCH * 2; ++ks) {
+    u32x2 t1[2], t2[2];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int j = 0; j < 2; ++j) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        // cf[ch][2*q + (e>>1)] = {scale, shift} of channels (q*4+e) & ~1 .. |1 : {s0, h0, s1, h1}
-        const f32x4 c2 = cf[ch][2 * q + (e >> 1)];
-        av[ch][q][e] = valid ? c2[(e & 1) * 2] * av[ch][q][e] + c2[(e & 1) * 2 + 1] : 0.f;
+        // cf[ks >> 1][(ks & 1) * 4 + j * 2 + (e >> 1)] = {scale, shift} pairs of channels ks*16 + half*8 + j*4 + (e & ~1), +1
+        const f32x4 c2 = cf[ks >> 1][(ks & 1) * 4 + j * 2 + (e >> 1)];
+        v[ks][j][e] = valid ? c2[(e & 1) * 2] * v[ks][j][e] + c2[(e & 1) * 2 + 1] : 0.f;
       }
+      split2(v[ks][j], t1[j], t2[j]);
+    }
+    x1[ks] = u32x4{t1[0][0], t1[0][1], t1[1][0], t1[1][1]};
+    x2[ks] = u32x4{t2[0][0], t2[0][1], t2[1][0], t2[1][1]};
+  }
 }
 // must be called by every thread of the workgroup (the deferred form contains barriers)
 template <int NCH>
@@ -77,7 +88,7 @@ __device__ __forceinline__ void load_coef(const AttnArgs& a, int b, int half, f3
   for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const float* p = base + (ch * 32 + half * 16 + 2 * i) * 4;
+      const float* p = base + (ch * 32 + (i >> 2) * 16 + half * 8 + 2 * (i & 3)) * 4;
       cf[ch][i] = f32x4{p[0], p[1], p[4], p[5]};
     }
 }
@@ -96,29 +107,36 @@ __global__ void __launch_bounds__(512) attn_kv_context_kernel(AttnArgs a) {
 
   f32x4 cf[NCH][8];
   load_coef<NCH>(a, b, half, cf);
-  f32x4 wk[NCH][4], wv[NCH][4];
+  constexpr int NKS = NCH * 2;
+  u32x4 wk1[NKS], wk2[NKS], wv1[NKS], wv2[NKS];
 #pragma unroll
-  for (int ch = 0; ch < NCH; ++ch)
+  for (int ks = 0; ks < NKS; ++ks) {
+    wk1[ks] = a.wqkv[(size_t)(ks * 3 + 1) * 128 + lane];
+    wk2[ks] = a.wqkv[(size_t)(ks * 3 + 1) * 128 + 64 + lane];
+    wv1[ks] = a.wqkv[(size_t)(ks * 3 + 2) * 128 + lane];
+    wv2[ks] = a.wqkv[(size_t)(ks * 3 + 2) * 128 + 64 + lane];
+  }
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  // y = x W^T on the fp16 pipe: A += x1 w1, B += x1 w2' + x2' w1, y = A + B / 2048
+  auto project = [&](const u32x4 (&x1)[NKS], const u32x4 (&x2)[NKS], const u32x4 (&w1)[NKS], const u32x4 (&w2)[NKS]) {
+    f32x16 pa = zero16, pb = zero16;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      wk[ch][q] = ((const f32x4*)a.wqkv)[((size_t)(ch * 3 + 1) * 4 + q) * 64 + lane];
-      wv[ch][q] = ((const f32x4*)a.wqkv)[((size_t)(ch * 3 + 2) * 4 + q) * 64 + lane];
+    for (int ks = 0; ks < NKS; ++ks) {
+      pa = MFMA_F16(x1[ks], w1[ks], pa);
+      pb = MFMA_F16(x1[ks], w2[ks], pb);
+      pb = MFMA_F16(x2[ks], w1[ks], pb);
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pa[r] += pb[r] * (1.f / 2048.f);
+    return pa;
+  };
 
   // sweep 1: per-channel max of k over this workgroup's voxels
   float m = -3.0e38f;
   for (int64_t t = t0 + wave; t < t1; t += 8) {
-    f32x4 av[NCH][4];
-    load_xn<NCH>(a, b, t * 32, col, half, cf, av);
-    f32x16 k;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) k[r] = 0.f;
-#pragma unroll
-    for (int ch = 0; ch < NCH; ++ch)
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) k = MFMA32(av[ch][q][e], wk[ch][q][e], k);
+    u32x4 x1[NKS], x2[NKS];
+    load_xn<NCH>(a, b, t * 32, col, half, cf, x1, x2);
+    const f32x16 k = project(x1, x2, wk1, wk2);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -139,20 +157,10 @@ __global__ void __launch_bounds__(512) attn_kv_context_kernel(AttnArgs a) {
   for (int r = 0; r < 16; ++r) ctx[r] = 0.f;
   float ssum = 0.f;
   for (int64_t t = t0 + wave; t < t1; t += 8) {
-    f32x4 av[NCH][4];
-    load_xn<NCH>(a, b, t * 32, col, half, cf, av);
-    f32x16 k, v;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) k[r] = v[r] = 0.f;
-#pragma unroll
-    for (int ch = 0; ch < NCH; ++ch)
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          k = MFMA32(av[ch][q][e], wk[ch][q][e], k);
-          v = MFMA32(av[ch][q][e], wv[ch][q][e], v);
-        }
+    u32x4 x1[NKS], x2[NKS];
+    load_xn<NCH>(a, b, t * 32, col, half, cf, x1, x2);
+    const f32x16 k = project(x1, x2, wk1, wk2);
+    const f32x16 v = project(x1, x2, wv1, wv2);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -196,14 +204,19 @@ __global__ void __launch_bounds__(512) attn_out_kernel(AttnArgs a) {
 
   f32x4 cf[NCH][8];
   load_coef<NCH>(a, b, half, cf);
-  f32x4 wq[NCH][4], wt[NCH][4];
+  constexpr int NKS = NCH * 2;
+  u32x4 wq1[NKS], wq2[NKS];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    wq1[ks] = a.wqkv[(size_t)(ks * 3 + 0) * 128 + lane];
+    wq2[ks] = a.wqkv[(size_t)(ks * 3 + 0) * 128 + 64 + lane];
+  }
+  f32x4 wt[NCH][4];
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      wq[ch][q] = ((const f32x4*)a.wqkv)[((size_t)(ch * 3 + 0) * 4 + q) * 64 + lane];
-      wt[ch][q] = ((const f32x4*)a.wT)[(((size_t)b * NCH + ch) * 4 + q) * 64 + lane];  // ch = output channel tile here
-    }
+    for (int q = 0; q < 4; ++q) wt[ch][q] = ((const f32x4*)a.wT)[(((size_t)b * NCH + ch) * 4 + q) * 64 + lane];  // output channel tile ch
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float bv[NCH], s1[NCH], s2[NCH];
 #pragma unroll
   for (int ct = 0; ct < NCH; ++ct) {
@@ -213,18 +226,18 @@ __global__ void __launch_bounds__(512) attn_out_kernel(AttnArgs a) {
   float* const yb = a.y + (size_t)b * a.vox * a.C;
 
   for (int64_t t = t0 + wave; t < t1; t += 8) {
-    f32x4 av[NCH][4];
-    load_xn<NCH>(a, b, t * 32, col, half, cf, av);
+    u32x4 x1[NKS], x2[NKS];
+    load_xn<NCH>(a, b, t * 32, col, half, cf, x1, x2);
     // q^T[d][n]: A = W_q (row d), B = xn^T (column n); the registers of a lane are 16 channels d of its voxel n = col
-    f32x16 q;
+    f32x16 q = zero16, qb = zero16;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) q[r] = 0.f;
+    for (int ks = 0; ks < NKS; ++ks) {
+      q = MFMA_F16(wq1[ks], x1[ks], q);
+      qb = MFMA_F16(wq2[ks], x1[ks], qb);
+      qb = MFMA_F16(wq1[ks], x2[ks], qb);
+    }
 #pragma unroll
-    for (int ch = 0; ch < NCH; ++ch)
-#pragma unroll
-      for (int qq = 0; qq < 4; ++qq)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) q = MFMA32(wq[ch][qq][e], av[ch][qq][e], q);
+    for (int r = 0; r < 16; ++r) q[r] += qb[r] * (1.f / 2048.f);
     float mx = q[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, q[r]);
@@ -304,11 +317,11 @@ int attn_fused_nsplit_for(int64_t vox, int batch) {
   return (int)n;
 }
 
-void launch_attn_kv_context(const float* x, int C, const float* coef, const float* wqkv_packed, float* partials, int batch,
+void launch_attn_kv_context(const float* x, int C, const float* coef, const void* wqkv_f16x2, float* partials, int batch,
                             int64_t vox, int nsplit, hipStream_t s, const GnDefer* defer) {
   CD_REQUIRE(C == 32 || C == 64 || C == 96 || C == 128, "fused attention: 32..128 input channels");
   AttnArgs a{};
-  a.x = x; a.coef = coef; a.wqkv = wqkv_packed; a.C = C; a.vox = vox; a.tiles_per_wg = tiles_per_wg_for(vox, nsplit);
+  a.x = x; a.coef = coef; a.wqkv = (const u32x4*)wqkv_f16x2; a.C = C; a.vox = vox; a.tiles_per_wg = tiles_per_wg_for(vox, nsplit);
   a.partials = partials; a.nsplit = nsplit;
   if (defer) a.defer = *defer;
   prof::Scope scope("attn_kv_context", s, 2.0 * (2.0 * C + 32) * 32 * (double)vox * batch, 4.0 * batch * (double)vox * C);
@@ -322,11 +335,11 @@ void launch_attn_kv_context(const float* x, int C, const float* coef, const floa
   CD_HIP(hipGetLastError());
 }
 
-void launch_attn_out(const float* x, int C, const float* coef, const float* wqkv_packed, const float* wT_b, const float* bias,
+void launch_attn_out(const float* x, int C, const float* coef, const void* wqkv_f16x2, const float* wT_b, const float* bias,
                      float* y, float* ch_part, int batch, int64_t vox, int nsplit, hipStream_t s, const GnDefer* defer) {
   CD_REQUIRE(C == 32 || C == 64 || C == 96 || C == 128, "fused attention: 32..128 channels");
   AttnArgs a{};
-  a.x = x; a.coef = coef; a.wqkv = wqkv_packed; a.C = C; a.vox = vox; a.tiles_per_wg = tiles_per_wg_for(vox, nsplit);
+  a.x = x; a.coef = coef; a.wqkv = (const u32x4*)wqkv_f16x2; a.C = C; a.vox = vox; a.tiles_per_wg = tiles_per_wg_for(vox, nsplit);
   a.wT = wT_b; a.bias = bias; a.y = y; a.ch_part = ch_part;
   if (defer) a.defer = *defer;
   prof::Scope scope("attn_out", s, 2.0 * (2.0 * C) * 32 * (double)vox * batch, 4.0 * batch * (double)vox * C * 2);

@@ -322,7 +322,9 @@ void build_plan(CdPlan* p) {
   for (auto& w : p->weights) {
     w.raw_off = bump((size_t)w.numel);
     if (w.pack == PK_CONV || w.pack == PK_CONVT) w.pk_off = bump(packed_weight_floats(w.cin, w.cout, w.taps));
-    if (w.pack == PK_CONV && (w.taps == 27 || w.taps == 48)) w.pk3_off = bump(packed_split16_bytes(w.cin, w.cout, w.taps) / 4);
+    // 16-bit split images: the 3x3x3 / strided convs and the attention's to_qkv (cout = 96)
+    if (w.pack == PK_CONV && (w.taps == 27 || w.taps == 48 || (w.taps == 1 && w.cout == 96)))
+      w.pk3_off = bump(packed_split16_bytes(w.cin, w.cout, w.taps) / 4);
     else if (w.pack == PK_INIT) w.pk_off = bump((size_t)w.numel);
   }
   p->arena_floats = off;
@@ -385,6 +387,7 @@ struct ResP {
 struct AttnP {
   int c = 0;
   const float *ng = nullptr, *nb = nullptr, *qkv = nullptr, *ow = nullptr, *ob = nullptr, *gg = nullptr, *gb = nullptr;
+  const void* qkv16 = nullptr;  // f16x2 image of to_qkv (fused attention kernels)
 };
 
 ResP resolve(const CdPlan* p, const ResW& w, const float* emb) {
@@ -401,6 +404,7 @@ AttnP resolve(const CdPlan* p, const AttnW& w) {
   AttnP a;
   a.c = w.c;
   a.ng = p->raw(w.ng); a.nb = p->raw(w.nb); a.qkv = p->packed(w.qkv); a.ow = p->raw(w.ow); a.ob = p->raw(w.ob);
+  a.qkv16 = (const char*)p->packed3(w.qkv) + packed_bf16x3_bytes(w.c, 96, 1);
   a.gg = p->raw(w.gg); a.gb = p->raw(w.gb);
   return a;
 }
@@ -528,9 +532,9 @@ float* attn_block(Run& r, const AttnP& w, const float* x, Dims3 dims, float* xpa
     yu = nsp;
     ypart = ws->get<float>((size_t)r.B * yu * C * 2);
     if (!r.dry()) {
-      launch_attn_kv_context(x, C, coefn, w.qkv, part, r.B, vox, nsp, r.s, dnp);
+      launch_attn_kv_context(x, C, coefn, w.qkv16, part, r.B, vox, nsp, r.s, dnp);
       launch_attn_combine(part, nsp, w.ow, C, wpb, r.B, 0.17677669529663689f /* 32^-1/2 */, r.s, nullptr, nullptr, true);
-      launch_attn_out(x, C, coefn, w.qkv, wpb, w.ob, y, ypart, r.B, vox, nsp, r.s, dnp);
+      launch_attn_out(x, C, coefn, w.qkv16, wpb, w.ob, y, ypart, r.B, vox, nsp, r.s, dnp);
     }
     if (own) ws->release(own);
     own = nullptr;
@@ -1285,8 +1289,11 @@ int cd_op_linear_attention(const float* x, const float* const* w, float* y, int 
     ws.reset((char*)workspace, workspace_bytes, false);
     float* pq = ws.get<float>(packed_weight_floats(channels, 96, 1));
     launch_pack_weights(w[2], pq, 96, channels, 1, false, s);
+    float* pq16 = ws.get<float>(packed_f16x2_bytes(channels, 96, 1) / 4);
+    launch_pack_weights_f16x2(w[2], pq16, 96, channels, 1, s);
     AttnP a;
     a.c = channels; a.ng = w[0]; a.nb = w[1]; a.qkv = pq; a.ow = w[3]; a.ob = w[4]; a.gg = w[5]; a.gb = w[6];
+    a.qkv16 = pq16;
     Run run{&ws, s, batch, 8};
     const Dims3 d{dims[0], dims[1], dims[2]};
     float* out = attn_block(run, a, x, d);
