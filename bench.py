@@ -152,7 +152,8 @@ def train_bench(args, model, cfg, E, layers, rank, world):
     data = torch.randn(shape, generator=g).cuda()
     noise = torch.randn(shape, generator=g).cuda()
     rnd = torch.randn((B,), generator=g).cuda()
-    opt = torch.optim.Adam(model.parameters(), lr=float(cfg["LR"]))
+    from calodiffusion_amd.optim import FusedAdam  # torch.optim.Adam semantics, one launch per 48 tensors (cd_adam_step)
+    opt = (torch.optim.Adam if os.environ.get("CD_TORCH_ADAM") else FusedAdam)(model.parameters(), lr=float(cfg["LR"]))
 
     def step():
         opt.zero_grad()

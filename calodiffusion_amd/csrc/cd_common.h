@@ -314,6 +314,17 @@ void launch_loss_final(const double* partial, const float* sigma_b, double* loss
 void launch_transpose_to_cl(const float* ncdhw, float* ndhwc, int batch, int channels, int64_t vox, hipStream_t s);
 void launch_transpose_to_planar(const float* ndhwc, float* ncdhw, int batch, int channels, int64_t vox, hipStream_t s);
 
+// fused Adam over up to 48 tensors per launch (kernel-argument table)
+struct AdamChunk {
+  float* p[48];
+  const float* g[48];
+  float* m[48];
+  float* v[48];
+  int64_t n[48];
+};
+void launch_adam(const AdamChunk& c, int ntensors, int64_t max_numel, double lr, double beta1, double beta2, float eps,
+                 float weight_decay, int step, hipStream_t s);
+
 size_t init_wgrad_partial_floats(int batch, int64_t vox, int cin, int cout);
 void launch_init_wgrad(const InitConvArgs& a, const float* g, float* part, float* dw, hipStream_t s);
 // per-sample record the embedding backward leaves for the Linear weight gradients

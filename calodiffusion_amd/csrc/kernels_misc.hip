@@ -2,6 +2,8 @@
 // loss reduction and layout transposes.
 #include "cd_common.h"
 
+#include <cmath>
+
 namespace cd {
 
 // ------------------------------------------------------------------------------------------------------------
@@ -357,6 +359,46 @@ void launch_transpose_to_planar(const float* ndhwc, float* ncdhw, int batch, int
   int64_t bx = (vox * channels + 255) / 256;
   if (bx > 1024) bx = 1024;
   hipLaunchKernelGGL(to_planar_kernel, dim3((unsigned)bx, batch), dim3(256), 0, s, ndhwc, ncdhw, channels, vox);
+  CD_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Adam step over many parameter tensors in one launch per 48 tensors (torch.optim.Adam as the reference's training loop
+// builds it, train/train.py:144: no amsgrad, optional L2 weight decay), same element-wise formulas and operation order as
+// torch's implementation:  m <- m + (1-b1)(g - m);  v <- b2 v + (1-b2) g g;  p <- p - (lr/bc1) m / (sqrt(v)/sqrt(bc2) + eps).
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) adam_kernel(AdamChunk c, float w1, float beta2, float w2, float eps, float weight_decay,
+                                                   float step_size, float bc2_sqrt) {
+  const int t = blockIdx.y;
+  float* __restrict__ p = c.p[t];
+  const float* __restrict__ g = c.g[t];
+  float* __restrict__ m = c.m[t];
+  float* __restrict__ v = c.v[t];
+  const int64_t n = c.n[t];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float gi = g[i];
+    const float pi = p[i];
+    if (weight_decay != 0.f) gi = gi + weight_decay * pi;
+    const float mi = m[i] + w1 * (gi - m[i]);
+    const float vi = v[i] * beta2 + w2 * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - step_size * (mi / denom);
+  }
+}
+
+void launch_adam(const AdamChunk& c, int ntensors, int64_t max_numel, double lr, double beta1, double beta2, float eps,
+                 float weight_decay, int step, hipStream_t s) {
+  const double bc1 = 1.0 - std::pow(beta1, step), bc2 = 1.0 - std::pow(beta2, step);
+  const float step_size = (float)(lr / bc1), bc2_sqrt = (float)std::sqrt(bc2);
+  int64_t bx = (max_numel + 256 * 4 - 1) / (256 * 4);
+  if (bx < 1) bx = 1;
+  if (bx > 1024) bx = 1024;
+  // 1 - beta in double like torch (python floats), then rounded once to fp32
+  const float w1 = (float)(1.0 - beta1), w2 = (float)(1.0 - beta2);
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)bx, (unsigned)ntensors), dim3(256), 0, s, c, w1, (float)beta2, w2, eps, weight_decay, step_size,
+                     bc2_sqrt);
   CD_HIP(hipGetLastError());
 }
 

@@ -990,6 +990,24 @@ int cd_denoise(CdPlan* plan, int batch, const float* x, const float* sigma, cons
   });
 }
 
+int cd_adam_step(int n, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                 const int64_t* numel, double lr, double beta1, double beta2, float eps, float weight_decay, int step, void* stream) {
+  return guarded([&] {
+    CD_REQUIRE(n >= 0 && (n == 0 || (params && grads && exp_avg && exp_avg_sq && numel)) && step >= 1, "bad argument");
+    for (int i0 = 0; i0 < n; i0 += 48) {
+      AdamChunk c{};
+      const int k = n - i0 < 48 ? n - i0 : 48;
+      int64_t mx = 0;
+      for (int j = 0; j < k; ++j) {
+        c.p[j] = params[i0 + j]; c.g[j] = grads[i0 + j]; c.m[j] = exp_avg[i0 + j]; c.v[j] = exp_avg_sq[i0 + j]; c.n[j] = numel[i0 + j];
+        CD_REQUIRE(c.p[j] && c.g[j] && c.m[j] && c.v[j] && c.n[j] >= 0, "adam: null tensor pointer");
+        if (c.n[j] > mx) mx = c.n[j];
+      }
+      launch_adam(c, k, mx, lr, beta1, beta2, eps, weight_decay, step, (hipStream_t)stream);
+    }
+  });
+}
+
 int cd_profile_begin(void) {
   return guarded([&] { prof::begin(); });
 }

@@ -140,6 +140,14 @@ int cd_plan_status(CdPlan* plan, int* flags, void* stream);
 int cd_train_step(CdPlan* plan, int batch, const float* data, const float* noise, const float* sigma, const float* cond,
                   double* loss_out, float* grads, void* workspace, size_t workspace_bytes, void* stream);
 
+/* torch.optim.Adam step (train/train.py:144: Adam(model.parameters(), lr); no amsgrad) over n tensors in ceil(n / 48)
+ * launches: params / grads / exp_avg / exp_avg_sq are HOST arrays of n DEVICE pointers, numel their lengths.  step is the
+ * 1-based step count after this update (torch's state['step']).  Same element-wise formulas as torch:
+ *   m += (1-beta1)(g - m);  v = beta2 v + (1-beta2) g^2;  p -= lr/(1-beta1^step) * m / (sqrt(v)/sqrt(1-beta2^step) + eps);
+ * lr and the betas are doubles (python floats): 1-beta and the bias corrections are formed in double, as torch does. */
+int cd_adam_step(int n, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                 const int64_t* numel, double lr, double beta1, double beta2, float eps, float weight_decay, int step, void* stream);
+
 /* ---- measurement ---------------------------------------------------------------------------------------------- */
 /* Per-launch timing with HIP events on the launch stream (eager mode; graphs are bypassed while active).
  * cd_profile_end synchronises the device and writes a JSON object

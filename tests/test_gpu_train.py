@@ -83,3 +83,34 @@ def test_training_loop_protocol_one_adam_step():
     with torch.no_grad():
         l_eval = m.compute_loss(data, E, noise=noise, layers=layers, rnd_normal=rnd)
     assert not l_eval.requires_grad and float(l_eval) < losses[0]
+
+
+def test_fused_adam_matches_torch_adam():
+    """cd_adam_step against torch.optim.Adam on the CPU (the optimizer of train/train.py:144): parameters, both moments and the
+    checkpointable state after several steps, odd sizes, a learning-rate change in between, weight decay."""
+    from calodiffusion_amd.optim import FusedAdam
+    gen = torch.Generator().manual_seed(5)
+    shapes = [(32, 32, 3, 3, 3), (96,), (7, 13), (1,), (64, 128)]
+    for wd in (0.0, 1e-2):
+        ref = [torch.randn(s, generator=gen).requires_grad_() for s in shapes]
+        dev = [p.detach().clone().cuda().requires_grad_() for p in ref]
+        o_ref = torch.optim.Adam(ref, lr=3e-3, weight_decay=wd)
+        o_dev = FusedAdam(dev, lr=3e-3, weight_decay=wd)
+        for it in range(6):
+            for p, q in zip(ref, dev):
+                g = torch.randn(p.shape, generator=gen) * (10.0 ** (it - 3))
+                p.grad = g.clone()
+                q.grad = g.clone().cuda()
+            if it == 3:
+                for o in (o_ref, o_dev):
+                    o.param_groups[0]["lr"] = 1e-3
+            o_ref.step()
+            o_dev.step()
+        for p, q in zip(ref, dev):
+            assert rel_l2(q.detach().cpu().numpy(), p.detach().numpy()) < 1e-6
+            assert rel_l2(o_dev.state[q]["exp_avg"].cpu().numpy(), o_ref.state[p]["exp_avg"].numpy()) < 1e-6
+            assert rel_l2(o_dev.state[q]["exp_avg_sq"].cpu().numpy(), o_ref.state[p]["exp_avg_sq"].numpy()) < 1e-6
+        # state_dict interchange with torch.optim.Adam
+        o_t = torch.optim.Adam(dev, lr=1e-3, weight_decay=wd)
+        o_t.load_state_dict(o_dev.state_dict())
+        assert int(o_t.state[dev[0]]["step"]) == 6
