@@ -50,3 +50,33 @@ class DDPM(DDim):
     def __init__(self, config):
         super().__init__(config)
         self.ddim_eta = 1.0
+
+
+class Euler(Sample):
+    """EDM first-order (Euler) sampler on the Karras noise schedule (reference models/sample.py:577-727, 771-789), deterministic
+    form: NOISY_SAMPLE off (S_churn = 0), which is the configuration default.  The update x + (t_next - t)(x - x0)/t equals
+    x0 + t_next (x - x0)/t, i.e. the device loop of DDim with the step table (t_i, t_{i+1}, 0, 1): the whole trajectory is one
+    C-ABI call with one captured step graph, like DDim.
+
+    SAMPLER_OPTIONS: RHO, SIGMA_MIN, SIGMA_MAX (defaults 7, 0.002, 80).  NOISY_SAMPLE / ORG_SCHEDULE are not provided."""
+
+    def __init__(self, config):
+        super().__init__(config)
+        if self.config.get("NOISY_SAMPLE", False):
+            raise NotImplementedError("Euler: the stochastic (NOISY_SAMPLE / S_churn > 0) variant is not provided")
+        if self.sample_config.get("ORG_SCHEDULE", False):
+            raise NotImplementedError("Euler: ORG_SCHEDULE (iDDPM time steps) is not provided")
+        self.sigma_min = self.sample_config.get("SIGMA_MIN", 0.002)
+        self.sigma_max = self.sample_config.get("SIGMA_MAX", 80.0)
+        self.rho = self.sample_config.get("RHO", 7)
+        self.use_graph = bool(self.sample_config.get("HIP_GRAPH", True))
+
+    @torch.no_grad()
+    def __call__(self, model, start, energy, layers, num_steps, sample_offset=0, debug=False) -> Any:
+        table = schedule.edm_euler_step_table(num_steps, sample_offset or 0, sigma_min=self.sigma_min, sigma_max=self.sigma_max,
+                                              rho=self.rho)
+        x, xs, x0s = model.engine().ddim_sample(start, model.cond_tensor(energy, layers), table, debug=debug,
+                                                use_graph=self.use_graph)
+        if debug:
+            return x, list(xs.unbind(0)), list(x0s.unbind(0))
+        return x, [], []

@@ -40,3 +40,22 @@ def ddim_step_table(num_steps: int, eta: float, sample_offset: int = 0) -> np.nd
     sigma_prev = (1.0 - alpha_prev - ddim_sigma ** 2).sqrt() / denom
     sigma_prev = (t > 0).to(torch.float32) * sigma_prev
     return torch.stack([sigma, sigma_prev, ddim_sigma * torch.ones_like(sigma), denom], dim=1).numpy().astype(np.float32)
+
+
+def edm_time_steps(num_steps: int, sample_offset: int = 0, sigma_min: float = 0.002, sigma_max: float = 80.0,
+                   rho: float = 7) -> torch.Tensor:
+    """EDM (Karras et al.) noise levels t_0 > ... > t_{N-1} > t_N = 0 in the reference's fp32 operation order
+    (EDMAbstract.setup, models/sample.py:688-702; the iDDPM 'ORG_SCHEDULE' variant is not provided)."""
+    step_indices = torch.arange(num_steps, dtype=torch.float32)
+    t_steps = (sigma_max ** (1 / rho) + step_indices / (num_steps - 1)
+               * (sigma_min ** (1 / rho) - sigma_max ** (1 / rho))) ** rho
+    t_steps = torch.cat([torch.as_tensor(t_steps), torch.zeros_like(t_steps[:1])])
+    return t_steps[sample_offset:]
+
+
+def edm_euler_step_table(num_steps: int, sample_offset: int = 0, **kw) -> np.ndarray:
+    """Rows (sigma, sigma_prev, 0, 1) that turn the device sampler loop (x <- x0 + sigma_prev * (x - x0) / sigma) into the
+    deterministic EDM Euler sampler x <- x + (t_next - t) * (x - x0) / t (models/sample.py:771-789 with S_churn = 0)."""
+    t = edm_time_steps(num_steps, sample_offset, **kw)
+    n = t.numel() - 1
+    return torch.stack([t[:-1], t[1:], torch.zeros(n), torch.ones(n)], dim=1).numpy().astype(np.float32)

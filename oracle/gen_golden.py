@@ -302,6 +302,25 @@ def gold_models():
     save("unet_d1grid", seed=np.array(SEED), ck_keys=keys, ck_vals=cks, x=npf(xx), cond=npf(cc), time=npf(tt), y=npf(yy))
 
 
+def gold_euler():
+    """EDM Euler trajectories on Dataset-2 from the reference's own Euler sampler (default options: deterministic)."""
+    cfg2 = my_configs.load_config("dataset2")
+    m2 = build_ref(cfg2)
+    x, E, layers = synth_inputs(cfg2, 2, SEED + 10)
+    out = {"start": npf(x), "E": npf(E), "layers": npf(layers)}
+    euler = ref_sample.Euler(cfg2)
+    for n in (5, 18):
+        xf, xs, x0s = euler(m2, x, E, layers, n, 0, False)
+        out[f"euler_{n}"] = npf(xf)
+        out[f"tsteps_{n}"] = npf(euler.setup(n, 0))
+        if n == 5:
+            out["euler_5_x0s"] = np.stack([npf(t) for t in x0s])
+        print("euler", n, float(xf.abs().mean()))
+    xf, _, _ = euler(m2, x, E, layers, 18, 2, False)
+    out["euler_18_off2"] = npf(xf)
+    save("euler_dataset2", **out)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     which = sys.argv[1:] or ["known", "prims", "sched", "models"]
@@ -313,3 +332,5 @@ if __name__ == "__main__":
         gold_schedules()
     if "models" in which:
         gold_models()
+    if "euler" in which:
+        gold_euler()

@@ -398,6 +398,26 @@ class OracleModel:
                 x0s.append(x0)
         return x, xs, x0s
 
+    def edm_euler_sample(self, start: Tensor, E: Tensor, layers: Optional[Tensor], num_steps: int, sample_offset: int = 0,
+                         sigma_min: float = 0.002, sigma_max: float = 80.0, rho: float = 7, keep: bool = False):
+        """EDMAbstract.setup / for_loop + Euler.in_loop_sampler with S_churn = 0 (models/sample.py:639-727, 771-789)."""
+        step_indices = torch.arange(num_steps, dtype=torch.float32)
+        t_steps = (sigma_max ** (1 / rho) + step_indices / (num_steps - 1)
+                   * (sigma_min ** (1 / rho) - sigma_max ** (1 / rho))) ** rho
+        t_steps = torch.cat([t_steps, torch.zeros_like(t_steps[:1])])[sample_offset:]
+        x_next = start.to(torch.float32) * t_steps[0]
+        xs, x0s = [], []
+        B = start.shape[0]
+        for t_cur, t_next in zip(t_steps[:-1], t_steps[1:]):
+            x_hat = x_next  # gamma = 0: t_hat = t_cur and the churn noise is multiplied by sqrt(0)
+            denoised = self.denoise(x_hat, E, t_cur.expand(B), layers)
+            d_cur = (x_hat - denoised) / t_cur
+            x_next = x_hat + (t_next - t_cur) * d_cur
+            if keep:
+                xs.append(x_hat)
+                x0s.append(denoised)
+        return x_next, xs, x0s
+
     def hybrid_l2_loss(self, data: Tensor, E: Tensor, noise: Tensor, layers: Optional[Tensor],
                        rnd_normal: Optional[Tensor] = None, time: Optional[Tensor] = None,
                        n_steps: int = 400) -> Tensor:

@@ -279,6 +279,26 @@ def test_ddim_trajectories_dataset2():
     assert rel_l2(m.sample(E, layers, num_steps=10, start=start, sample_offset=3), g["ddim_10_off3"]) < TOL_TRAJ
 
 
+def test_edm_euler_sampler_dataset2():
+    """The EDM Euler sampler rides the device sampler loop (one step table, one captured step graph); against the
+    reference's own Euler trajectories."""
+    from calodiffusion_amd import sample
+    g = gold("euler_dataset2")
+    m = _model("dataset2")
+    start, E, layers = t(g["start"]).cuda(), t(g["E"]).cuda(), t(g["layers"]).cuda()
+    eul = sample.Euler(m.config)
+    for n in (5, 18):
+        x, _, _ = eul(m, start, E, layers, n, 0, False)
+        assert rel_l2(x.cpu().numpy(), g[f"euler_{n}"]) < TOL_TRAJ, n
+    x, xs, x0s = eul(m, start, E, layers, 5, 0, True)
+    assert rel_l2(torch.stack(x0s).cpu().numpy(), g["euler_5_x0s"]) < TOL_TRAJ
+    x, _, _ = eul(m, start, E, layers, 18, 2, False)
+    assert rel_l2(x.cpu().numpy(), g["euler_18_off2"]) < TOL_TRAJ
+    # resolved by name like the reference's utils.load_attr("sampler", ...)
+    from calodiffusion_amd.utils import load_attr
+    assert load_attr("sampler", "Euler") is sample.Euler
+
+
 def test_graph_replay_equals_eager_bitwise():
     m = _model("tiny")
     g = gold("ddpm_tiny")

@@ -98,6 +98,26 @@ def test_unet_d1_grid():
     assert rel_l2(y.numpy(), g["y"]) < TOL
 
 
+def test_edm_euler_trajectories():
+    """EDM Euler sampler (reference models/sample.py:577-727, 771-789): the Karras time steps bit for bit, the oracle's loop
+    against the reference's trajectories, and the host step table that maps it onto the device sampler loop."""
+    from calodiffusion_amd import schedule
+    g = gold("euler_dataset2")
+    for n in (5, 18):
+        assert np.array_equal(schedule.edm_time_steps(n).numpy(), g[f"tsteps_{n}"])
+        tab = schedule.edm_euler_step_table(n)
+        assert tab.shape == (n, 4) and np.array_equal(tab[:, 0], g[f"tsteps_{n}"][:-1]) and np.array_equal(tab[:, 1], g[f"tsteps_{n}"][1:])
+        assert tab[-1, 1] == 0.0 and not tab[:, 2].any() and (tab[:, 3] == 1).all()
+    cfg = load_config("dataset2")
+    m = O.OracleModel(cfg, seeded_unet("dataset2").state_dict())
+    start, E, layers = t(g["start"]), t(g["E"]), t(g["layers"])
+    x, xs, x0s = m.edm_euler_sample(start, E, layers, 5, keep=True)
+    assert rel_l2(x.numpy(), g["euler_5"]) < 1e-5
+    assert rel_l2(torch.stack(x0s).numpy(), g["euler_5_x0s"]) < 1e-5
+    x, _, _ = m.edm_euler_sample(start, E, layers, 18, sample_offset=2)
+    assert rel_l2(x.numpy(), g["euler_18_off2"]) < 1e-5
+
+
 def test_ddim_trajectories():
     g = gold("ddim_dataset2")
     cfg = load_config("dataset2")
