@@ -314,6 +314,16 @@ void launch_loss_final(const double* partial, const float* sigma_b, double* loss
 void launch_transpose_to_cl(const float* ncdhw, float* ndhwc, int batch, int channels, int64_t vox, hipStream_t s);
 void launch_transpose_to_planar(const float* ndhwc, float* ncdhw, int batch, int channels, int64_t vox, hipStream_t s);
 
+struct ReverseNormArgs {
+  const float* voxels;  // (B, 1, D, H, W) normalised-space showers
+  const float* energy;  // (B) incident energies (physical units)
+  const float* layerE;  // (B, 1 + D) normalised {total, layers} or null
+  float* out;           // (B, D*H*W)
+  int batch, D, H, W, layer_mode;
+  float logit_mean, logit_std, totalE_mean, totalE_std, layers_mean, layers_std, max_deposit, ecut;
+};
+void launch_reverse_norm(const ReverseNormArgs& a, hipStream_t s);
+
 // fused Adam over up to 48 tensors per launch (kernel-argument table)
 struct AdamChunk {
   float* p[48];

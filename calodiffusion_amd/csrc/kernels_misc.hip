@@ -402,4 +402,75 @@ void launch_adam(const AdamChunk& c, int ntensors, int64_t max_numel, double lr,
   CD_HIP(hipGetLastError());
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Inverse pre-processing of generated showers (ReverseNormCaloChall, calodiffusion/utils/utils.py:446-573, for the regular
+// grids: dataset_num 2 / 3, showerMap 'layer-logit-norm' / 'logit-norm'): un-normalise, inverse logit, (layer mode) clamp
+// negatives and rescale every calorimeter layer to the layer energy given by the conditioning vector, scale to the incident
+// energy, apply the read-out threshold.  One workgroup per (sample, layer z): the layer sum is a workgroup reduction.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float rev_logit(float x) {  // utils.py:233-237
+  const float ex = expf(x);
+  const float o = ex / (1.f + ex);
+  return (o - 1e-6f) / (1.f - 2.f * 1e-6f);
+}
+
+__global__ void __launch_bounds__(256) reverse_norm_kernel(ReverseNormArgs a) {
+  __shared__ float red[256];
+  __shared__ float s_layer;
+  const int b = blockIdx.y, z = blockIdx.x, tid = threadIdx.x;
+  const int PV = a.H * a.W;
+  float layer_e = 0.f;
+  if (a.layer_mode) {
+    // this sample's layer energies: reverse transform, normalise to the total deposited energy (utils.py:519-528)
+    const float* le = a.layerE + (size_t)b * (a.D + 1);
+    float part = 0.f;
+    for (int i = tid; i < a.D; i += 256) part += rev_logit(le[1 + i] * a.layers_std + a.layers_mean);
+    red[tid] = part;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (tid < o) red[tid] += red[tid + o];
+      __syncthreads();
+    }
+    if (tid == 0) {
+      const float total = le[0] * a.totalE_std + a.totalE_mean;
+      s_layer = rev_logit(le[1 + z] * a.layers_std + a.layers_mean) / red[0] * total;
+    }
+    __syncthreads();
+    layer_e = s_layer;
+    __syncthreads();
+  }
+  const float* v = a.voxels + ((size_t)b * a.D + z) * PV;
+  float* out = a.out + ((size_t)b * a.D + z) * PV;
+  float part = 0.f;
+  for (int i = tid; i < PV; i += 256) {
+    float d = rev_logit(v[i] * a.logit_std + a.logit_mean);
+    if (a.layer_mode) d = d < 0.f ? 0.f : d;
+    out[i] = d;
+    part += d;
+  }
+  float fac = 1.f;
+  if (a.layer_mode) {
+    red[tid] = part;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (tid < o) red[tid] += red[tid + o];
+      __syncthreads();
+    }
+    const float prev = red[0];
+    fac = layer_e / (prev + 1e-10f);
+    if (layer_e < 1e-6f || prev < 1e-6f) fac = 1.f;
+  }
+  const float en = a.energy[b];
+  for (int i = tid; i < PV; i += 256) {
+    float d = out[i] * fac * a.max_deposit * en;
+    if (a.ecut > 0.f && d < a.ecut) d = 0.f;
+    out[i] = d;
+  }
+}
+
+void launch_reverse_norm(const ReverseNormArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(reverse_norm_kernel, dim3((unsigned)a.D, (unsigned)a.batch), dim3(256), 0, s, a);
+  CD_HIP(hipGetLastError());
+}
+
 }  // namespace cd

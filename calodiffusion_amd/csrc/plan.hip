@@ -1008,6 +1008,19 @@ int cd_adam_step(int n, float* const* params, const float* const* grads, float* 
   });
 }
 
+int cd_reverse_norm(const float* voxels, const float* energy, const float* layerE, float* out, int batch, const int32_t dims[3],
+                    const float consts[6], float max_deposit, float ecut, void* stream) {
+  return guarded([&] {
+    CD_REQUIRE(voxels && energy && out && dims && consts && batch > 0, "bad argument");
+    ReverseNormArgs a;
+    a.voxels = voxels; a.energy = energy; a.layerE = layerE; a.out = out; a.batch = batch;
+    a.D = dims[0]; a.H = dims[1]; a.W = dims[2]; a.layer_mode = layerE ? 1 : 0;
+    a.logit_mean = consts[0]; a.logit_std = consts[1]; a.totalE_mean = consts[2]; a.totalE_std = consts[3];
+    a.layers_mean = consts[4]; a.layers_std = consts[5]; a.max_deposit = max_deposit; a.ecut = ecut;
+    launch_reverse_norm(a, (hipStream_t)stream);
+  });
+}
+
 int cd_profile_begin(void) {
   return guarded([&] { prof::begin(); });
 }

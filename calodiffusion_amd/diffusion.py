@@ -80,9 +80,11 @@ class Diffusion(torch.nn.Module, ABC):
                  reverse_norm: Optional[Callable] = None):
         """Sampling loop over a loader of (E, layers, data) batches (diffusion.py:118-197).
 
-        The inverse pre-processing (``utils.ReverseNorm``, host numpy) is outside the hot path:
-        pass the reference's function as ``reverse_norm`` to get physical energies, otherwise the normalised-space
-        showers are returned.
+        The inverse pre-processing (``utils.ReverseNorm``, diffusion.py:171-195) runs on the device for the regular-grid
+        configs (``postprocess.ReverseNorm``: Dataset-2 / Dataset-3 shower maps; needs the EMAX / EMIN / logE / MAXDEP / ECUT
+        keys of the reference's configs).  ``reverse_norm`` = a callable (generated, energies, layers, config) overrides it
+        (e.g. the reference's own function for the geometry-converted datasets); ``reverse_norm=False`` returns the
+        normalised-space showers.
         """
         generated, energies, layers = [], [], []
         for E, layers_, d_batch in data_loader:
@@ -95,6 +97,15 @@ class Diffusion(torch.nn.Module, ABC):
                 layers.append(layers_.detach().cpu().numpy())
         generated, energies = np.concatenate(generated), np.concatenate(energies)
         layers = np.concatenate(layers) if layers else None
-        if reverse_norm is not None:
-            generated, energies = reverse_norm(generated, energies, layers, self.config)
+        cfg = self.config
+        if callable(reverse_norm):
+            generated, energies = reverse_norm(generated, energies, layers, cfg)
+        elif reverse_norm is None and not debug and all(k in cfg for k in ("EMAX", "EMIN", "logE", "MAXDEP", "ECUT")) \
+                and cfg.get("DATASET_NUM", 2) in (2, 3) and cfg["SHOWERMAP"] in ("layer-logit-norm", "logit-norm"):
+            from .postprocess import ReverseNorm
+            generated, energies = ReverseNorm(generated, energies, shape=cfg["SHAPE_FINAL"], config=cfg, emax=cfg["EMAX"],
+                                              emin=cfg["EMIN"], layerE=layers, logE=cfg["logE"], max_deposit=cfg["MAXDEP"],
+                                              showerMap=cfg["SHOWERMAP"], dataset_num=cfg.get("DATASET_NUM", 2),
+                                              ecut=float(cfg["ECUT"]))
+            generated = generated.reshape(cfg["SHAPE_ORIG"])
         return generated, np.reshape(energies, (energies.shape[0], -1))

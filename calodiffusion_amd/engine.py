@@ -64,6 +64,7 @@ _SIGNATURES = {
     "cd_plan_grad_layout": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "cd_plan_train_workspace_bytes": (C.c_int, [_P, C.c_int, C.POINTER(C.c_size_t)]),
     "cd_plan_status": (C.c_int, [_P, C.POINTER(C.c_int), _P]),
+    "cd_reverse_norm": (C.c_int, [_P, _P, _P, _P, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.c_float, C.c_float, _P]),
     "cd_adam_step": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                C.POINTER(C.c_int64), C.c_double, C.c_double, C.c_double, C.c_float, C.c_float, C.c_int, _P]),
     "cd_train_step": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),

@@ -148,6 +148,14 @@ int cd_train_step(CdPlan* plan, int batch, const float* data, const float* noise
 int cd_adam_step(int n, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                  const int64_t* numel, double lr, double beta1, double beta2, float eps, float weight_decay, int step, void* stream);
 
+/* Inverse pre-processing of generated showers on the device: utils.ReverseNormCaloChall (calodiffusion/utils/utils.py:446-573)
+ * for the regular grids (dataset_num 2 / 3; showerMap 'layer-logit-norm' when layerE != NULL, 'logit-norm' otherwise).
+ * voxels (B,1,D,H,W) normalised; energy (B) incident energies already in physical units (emin*(emax/emin)^e on the host);
+ * layerE (B, 1+D) normalised {total, layer} energies or NULL; out (B, D*H*W).  consts = {logit_mean, logit_std, totalE_mean,
+ * totalE_std, layers_mean, layers_std} (utils/consts.py:82-116). */
+int cd_reverse_norm(const float* voxels, const float* energy, const float* layerE, float* out, int batch, const int32_t dims[3],
+                    const float consts[6], float max_deposit, float ecut, void* stream);
+
 /* ---- measurement ---------------------------------------------------------------------------------------------- */
 /* Per-launch timing with HIP events on the launch stream (eager mode; graphs are bypassed while active).
  * cd_profile_end synchronises the device and writes a JSON object

@@ -321,6 +321,28 @@ def gold_euler():
     save("euler_dataset2", **out)
 
 
+def gold_reverse_norm():
+    """utils.ReverseNormCaloChall of the reference on synthetic normalised showers (Dataset-2 with layer energies, Dataset-3)."""
+    from calodiffusion.utils import utils as ref_utils
+    g = torch.Generator().manual_seed(SEED + 40)
+    out = {}
+    for tag, dims, dnum, smap in (("d2", (45, 16, 9), 2, "layer-logit-norm"), ("d3", (6, 50, 18), 3, "logit-norm")):
+        B = 3
+        vox = (torch.randn((B, 1) + dims, generator=g) * 1.3 + 0.2).numpy().astype(np.float32)
+        vox[0, 0, 3] = -30.0   # an (almost) empty layer: the rescale factor falls back to 1
+        e = torch.rand((B, 1), generator=g).numpy().astype(np.float32)
+        layerE = torch.randn((B, dims[0] + 1), generator=g).numpy().astype(np.float32) if "layer" in smap else None
+        data, energy = ref_utils.ReverseNormCaloChall(vox.copy(), e.copy(), emax=1000., emin=1., max_deposit=2, logE=True,
+                                                      layerE=None if layerE is None else layerE.copy(), showerMap=smap,
+                                                      dataset_num=dnum, orig_shape=False, ecut=0.0000151)
+        out[f"{tag}.vox"], out[f"{tag}.e"] = vox, e
+        if layerE is not None:
+            out[f"{tag}.layerE"] = layerE
+        out[f"{tag}.data"], out[f"{tag}.energy"] = np.asarray(data, dtype=np.float32), np.asarray(energy, dtype=np.float32)
+        print("reverse_norm", tag, float(np.abs(data).mean()))
+    save("reverse_norm", **out)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     which = sys.argv[1:] or ["known", "prims", "sched", "models"]
@@ -334,3 +356,5 @@ if __name__ == "__main__":
         gold_models()
     if "euler" in which:
         gold_euler()
+    if "renorm" in which:
+        gold_reverse_norm()

@@ -488,3 +488,38 @@ def algorithmic_work(spec: UnetSpec) -> Dict[str, float]:
     fl["total"] = sum(fl.values())
     by["total"] = sum(by.values()) + 3 * 4.0 * vox[0]
     return {"flops": fl, "bytes": by}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Inverse pre-processing (utils.ReverseNormCaloChall, calodiffusion/utils/utils.py:446-573) for the regular grids
+# ------------------------------------------------------------------------------------------------------------------
+def reverse_norm_calochall(voxels, e, layerE, consts, emax=1000.0, emin=1.0, max_deposit=2, logE=True, ecut=0.0):
+    """numpy restatement; ``consts`` = the dataset's normalisation constants (utils/consts.py:82-116);
+    layer mode ('layer-logit-norm') when layerE is given, 'logit-norm' otherwise.  Returns (data (B, -1), energy)."""
+    import numpy as np
+
+    def reverse_logit(x, alpha=1e-6):  # utils.py:233-237
+        ex = np.exp(x)
+        o = ex / (1 + ex)
+        return (o - alpha) / (1 - 2 * alpha)
+
+    energy = emin * (emax / emin) ** e if logE else emin + (emax - emin) * e
+    voxels = (voxels * consts["logit_std"]) + consts["logit_mean"]
+    data = reverse_logit(voxels)
+    if layerE is not None:
+        totalE, layers = layerE[:, :1], layerE[:, 1:]
+        totalE = (totalE * consts["totalE_std"]) + consts["totalE_mean"]
+        layers = reverse_logit((layers * consts["layers_std"]) + consts["layers_mean"])
+        layers = layers / np.sum(layers, axis=1, keepdims=True) * totalE
+        data = np.squeeze(data, axis=1).copy()
+        data[data < 0] = 0
+        prev = np.sum(data, (2, 3), keepdims=True)
+        layers = layers.reshape((-1, data.shape[1], 1, 1))
+        fac = layers / (prev + 1e-10)
+        fac[layers < 1e-6] = 1.0
+        fac[prev < 1e-6] = 1.0
+        data = data * fac
+    data = data.reshape(voxels.shape[0], -1) * max_deposit * energy.reshape(-1, 1)
+    if ecut > 0:
+        data[data < ecut] = 0
+    return data, energy

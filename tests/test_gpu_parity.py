@@ -279,6 +279,43 @@ def test_ddim_trajectories_dataset2():
     assert rel_l2(m.sample(E, layers, num_steps=10, start=start, sample_offset=3), g["ddim_10_off3"]) < TOL_TRAJ
 
 
+def test_reverse_norm_on_device():
+    """cd_reverse_norm (inverse logit-norm, per-layer rescale to the conditioning layer energies, energy scale, threshold)
+    against the reference's ReverseNormCaloChall; also through the reference-shaped entry point ReverseNorm(...)."""
+    from calodiffusion_amd.postprocess import ReverseNorm
+    g = gold("reverse_norm")
+    for tag, dnum, smap in (("d2", 2, "layer-logit-norm"), ("d3", 3, "logit-norm")):
+        layerE = g[f"{tag}.layerE"] if f"{tag}.layerE" in g.files else None
+        data, energy = ReverseNorm(g[f"{tag}.vox"], g[f"{tag}.e"], emax=1000., emin=1., max_deposit=2, logE=True, layerE=layerE,
+                                   showerMap=smap, dataset_num=dnum, ecut=0.0000151)
+        assert data.shape == g[f"{tag}.data"].shape and data.dtype == np.float32
+        assert np.array_equal(np.asarray(energy, dtype=np.float32), g[f"{tag}.energy"])
+        assert rel_l2(data, g[f"{tag}.data"]) < 1e-5, tag
+        assert ((data == 0) == (g[f"{tag}.data"] == 0)).mean() > 0.999
+    with pytest.raises(NotImplementedError):
+        ReverseNorm(g["d2.vox"], g["d2.e"], showerMap="log-norm", dataset_num=2)
+
+
+def test_generate_returns_physical_showers():
+    """Diffusion.generate (diffusion.py:118-197): sampling loop over a loader + inverse pre-processing on the device; the
+    output has the reference's shapes (SHAPE_ORIG, (N, 1)) and equals ReverseNorm applied to the normalised-space showers."""
+    from calodiffusion_amd.postprocess import ReverseNorm
+    m = _model("dataset2")
+    cfg = m.config
+    gen = torch.Generator().manual_seed(3)
+    loader = [(torch.rand((3, 1), generator=gen), torch.randn((3, 46), generator=gen), None) for _ in range(2)]
+    m.noise_offset = 0
+    raw, e_raw = m.generate(loader, sample_steps=4, reverse_norm=False)
+    m.noise_offset = 0
+    phys, e = m.generate(loader, sample_steps=4)
+    assert raw.shape == (6, 1, 45, 16, 9) and phys.shape == (6, 6480) and e.shape == (6, 1)
+    layers = np.concatenate([l.numpy() for _, l, _ in loader])
+    want, want_e = ReverseNorm(raw, e_raw, emax=cfg["EMAX"], emin=cfg["EMIN"], layerE=layers, logE=cfg["logE"],
+                               max_deposit=cfg["MAXDEP"], showerMap=cfg["SHOWERMAP"], dataset_num=2, ecut=float(cfg["ECUT"]))
+    assert np.array_equal(phys, want) and np.array_equal(e, np.reshape(want_e, (6, -1)))
+    assert np.isfinite(phys).all() and (phys >= 0).all()
+
+
 def test_edm_euler_sampler_dataset2():
     """The EDM Euler sampler rides the device sampler loop (one step table, one captured step graph); against the
     reference's own Euler trajectories."""

@@ -98,6 +98,18 @@ def test_unet_d1_grid():
     assert rel_l2(y.numpy(), g["y"]) < TOL
 
 
+def test_reverse_norm():
+    """Inverse pre-processing (utils.ReverseNormCaloChall): numpy restatement against the reference's outputs."""
+    from calodiffusion_amd.postprocess import DATASET_PARAMS
+    g = gold("reverse_norm")
+    for tag, dnum in (("d2", 2), ("d3", 3)):
+        layerE = g[f"{tag}.layerE"] if f"{tag}.layerE" in g.files else None
+        data, energy = O.reverse_norm_calochall(g[f"{tag}.vox"], g[f"{tag}.e"], layerE, DATASET_PARAMS[dnum], ecut=0.0000151)
+        assert np.array_equal(np.asarray(energy, dtype=np.float32), g[f"{tag}.energy"])
+        assert rel_l2(np.asarray(data, dtype=np.float32), g[f"{tag}.data"]) < 2e-6, tag
+        assert ((np.asarray(data) == 0) == (g[f"{tag}.data"] == 0)).mean() > 0.9999  # same voxels under the read-out threshold
+
+
 def test_edm_euler_trajectories():
     """EDM Euler sampler (reference models/sample.py:577-727, 771-789): the Karras time steps bit for bit, the oracle's loop
     against the reference's trajectories, and the host step table that maps it onto the device sampler loop."""
