@@ -324,6 +324,22 @@ struct ReverseNormArgs {
 };
 void launch_reverse_norm(const ReverseNormArgs& a, hipStream_t s);
 
+// LayerDiffusion's layer-energy MLP: raw forward (mode 0), EDM denoise (mode 1) or a whole sampler trajectory (mode 2)
+struct LayerMlpArgs {
+  const float* w[64];    // (weight, bias) per Linear in the reference ResNet's state_dict order
+  int dim_in, hidden, cond_emb, cond_size, n_res, time_kind, objective, mode, batch, n_steps;
+  float sigma_data;
+  const float* x;        // (B, dim_in): input / start noise
+  const float* cond;     // (B, cond_size)
+  const float* tsig;     // (B): time (mode 0) or sigma (mode 1)
+  const float* table;    // device (n_steps, 4) step table (mode 2)
+  const float* noise;    // (n_steps, B, dim_in) or null
+  float* out;            // (B, dim_in)
+  float* xs;             // (n_steps, B, dim_in) or null
+  float* x0s;
+};
+void launch_layer_mlp(const LayerMlpArgs& a, hipStream_t s);
+
 // fused Adam over up to 48 tensors per launch (kernel-argument table)
 struct AdamChunk {
   float* p[48];

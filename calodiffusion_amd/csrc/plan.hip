@@ -1021,6 +1021,49 @@ int cd_reverse_norm(const float* voxels, const float* energy, const float* layer
   });
 }
 
+static void layer_mlp_call(const CdLayerMlpDesc* d, const float* const* weights, int n_weights, int batch, int mode,
+                           const float* x, const float* cond, const float* tsig, const float* table, int n_steps,
+                           const float* noise, float* out, float* xs, float* x0s, void* stream) {
+  CD_REQUIRE(d && weights && x && cond && out && batch > 0, "bad argument");
+  CD_REQUIRE(d->n_res >= 0 && d->n_res <= 8 && n_weights == 2 * (8 + 3 * d->n_res),
+             "layer MLP: n_weights must be 2*(8 + 3*n_res) (time_mlp, cond_mlp, in_lay, blocks, out_lay)");
+  CD_REQUIRE(d->time_embed_kind >= 0 && d->time_embed_kind <= 2 && d->objective >= 0 && d->objective <= 2, "bad descriptor");
+  LayerMlpArgs a{};
+  for (int i = 0; i < n_weights; ++i) {
+    CD_REQUIRE(weights[i], "null weight pointer");
+    a.w[i] = weights[i];
+  }
+  a.dim_in = d->dim_in; a.hidden = d->hidden; a.cond_emb = d->cond_emb; a.cond_size = d->cond_size; a.n_res = d->n_res;
+  a.time_kind = d->time_embed_kind; a.objective = d->objective; a.mode = mode; a.batch = batch; a.n_steps = n_steps;
+  a.sigma_data = d->sigma_data;
+  a.x = x; a.cond = cond; a.tsig = tsig; a.table = table; a.noise = noise; a.out = out; a.xs = xs; a.x0s = x0s;
+  launch_layer_mlp(a, (hipStream_t)stream);
+}
+
+int cd_layer_forward(const CdLayerMlpDesc* desc, const float* const* weights, int n_weights, int batch, const float* x,
+                     const float* cond, const float* time, float* out, void* stream) {
+  return guarded([&] {
+    CD_REQUIRE(time, "bad argument");
+    layer_mlp_call(desc, weights, n_weights, batch, 0, x, cond, time, nullptr, 1, nullptr, out, nullptr, nullptr, stream);
+  });
+}
+int cd_layer_denoise(const CdLayerMlpDesc* desc, const float* const* weights, int n_weights, int batch, const float* x,
+                     const float* sigma, const float* cond, float* out, void* stream) {
+  return guarded([&] {
+    CD_REQUIRE(sigma, "bad argument");
+    layer_mlp_call(desc, weights, n_weights, batch, 1, x, cond, sigma, nullptr, 1, nullptr, out, nullptr, nullptr, stream);
+  });
+}
+int cd_layer_sample(const CdLayerMlpDesc* desc, const float* const* weights, int n_weights, int batch, const float* start,
+                    const float* cond, const CdStep* steps_dev, int n_steps, const float* step_noise, float* x_out, float* xs,
+                    float* x0s, void* stream) {
+  return guarded([&] {
+    CD_REQUIRE(steps_dev && n_steps > 0, "bad argument");
+    layer_mlp_call(desc, weights, n_weights, batch, 2, start, cond, nullptr, (const float*)steps_dev, n_steps, step_noise,
+                   x_out, xs, x0s, stream);
+  });
+}
+
 int cd_profile_begin(void) {
   return guarded([&] { prof::begin(); });
 }

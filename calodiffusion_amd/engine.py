@@ -40,6 +40,11 @@ class CdUnetDesc(C.Structure):
     ]
 
 
+class CdLayerMlpDesc(C.Structure):
+    _fields_ = [("dim_in", C.c_int32), ("hidden", C.c_int32), ("cond_emb", C.c_int32), ("cond_size", C.c_int32),
+                ("n_res", C.c_int32), ("time_embed_kind", C.c_int32), ("objective", C.c_int32), ("sigma_data", C.c_float)]
+
+
 class CdStep(C.Structure):
     _fields_ = [("sigma", C.c_float), ("sigma_prev_masked", C.c_float), ("ddim_sigma", C.c_float), ("denom", C.c_float)]
 
@@ -64,6 +69,9 @@ _SIGNATURES = {
     "cd_plan_grad_layout": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "cd_plan_train_workspace_bytes": (C.c_int, [_P, C.c_int, C.POINTER(C.c_size_t)]),
     "cd_plan_status": (C.c_int, [_P, C.POINTER(C.c_int), _P]),
+    "cd_layer_forward": (C.c_int, [_P, C.POINTER(C.c_void_p), C.c_int, C.c_int, _P, _P, _P, _P, _P]),
+    "cd_layer_denoise": (C.c_int, [_P, C.POINTER(C.c_void_p), C.c_int, C.c_int, _P, _P, _P, _P, _P]),
+    "cd_layer_sample": (C.c_int, [_P, C.POINTER(C.c_void_p), C.c_int, C.c_int, _P, _P, _P, C.c_int, _P, _P, _P, _P, _P]),
     "cd_reverse_norm": (C.c_int, [_P, _P, _P, _P, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.c_float, C.c_float, _P]),
     "cd_adam_step": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                C.POINTER(C.c_int64), C.c_double, C.c_double, C.c_double, C.c_float, C.c_float, C.c_int, _P]),
@@ -362,6 +370,87 @@ class UnetEngine:
         _check(self.lib.cd_loss_hybrid_l2(self.plan, B, data.data_ptr(), noise.data_ptr(), sigma.data_ptr(), cond.data_ptr(),
                                           out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
         return out
+
+
+class LayerMlpEngine:
+    """The layer-energy MLP of LayerDiffusion on the HIP library (cd_layer_forward / cd_layer_denoise / cd_layer_sample).
+    Stateless on the library side: the parameters are read in place from the torch storage."""
+
+    def __init__(self, resnet, time_kind="raw", objective="hybrid", sigma_data=1.0):
+        self.lib = load_library()
+        self.device_name = require_gpu()
+        self.net = resnet
+        d = CdLayerMlpDesc()
+        d.dim_in, d.hidden, d.cond_emb, d.cond_size = resnet.dim_in, resnet.hidden_dim, resnet.cond_emb_dim, resnet.cond_size
+        d.n_res = len(resnet.hidden_layers)
+        d.time_embed_kind, d.objective, d.sigma_data = TIME_KINDS[time_kind], OBJECTIVES[objective], float(sigma_data)
+        self.desc = d
+        self.dim = resnet.dim_in
+
+    def _weights(self):
+        ps = [_dev32(p.detach(), k) for k, p in self.net.state_dict().items()]
+        if len(ps) != 2 * (8 + 3 * self.desc.n_res):
+            raise RuntimeError("unexpected layer-model state_dict")
+        for p in ps:
+            if p.data_ptr() % 16:
+                raise RuntimeError("layer-model parameters must be 16-byte aligned")
+        self._keep = ps
+        return (C.c_void_p * len(ps))(*[p.data_ptr() for p in ps]), len(ps)
+
+    def _io(self, x, cond):
+        x, cond = _dev32(x, "x"), _dev32(cond, "cond")
+        B = x.shape[0]
+        if x.shape != (B, self.dim) or cond.shape != (B, self.desc.cond_size):
+            raise ValueError(f"layer model shapes: x {tuple(x.shape)} (expected (B, {self.dim})), cond {tuple(cond.shape)} "
+                             f"(expected (B, {self.desc.cond_size}))")
+        return x, cond, B
+
+    def forward(self, x, cond, time):
+        x, cond, B = self._io(x, cond)
+        time = _dev32(time, "time").reshape(-1)
+        if time.numel() != B:
+            raise ValueError("time must be (B,)")
+        w, n = self._weights()
+        out = torch.empty_like(x)
+        _check(self.lib.cd_layer_forward(C.byref(self.desc), w, n, B, x.data_ptr(), cond.data_ptr(), time.data_ptr(),
+                                         out.data_ptr(), _stream()))
+        return out
+
+    def denoise(self, x, sigma, cond):
+        x, cond, B = self._io(x, cond)
+        sigma = _dev32(sigma, "sigma").reshape(-1)
+        if sigma.numel() == 1 and B > 1:
+            sigma = sigma.expand(B).contiguous()
+        if sigma.numel() != B:
+            raise ValueError("sigma must be (B,)")
+        w, n = self._weights()
+        out = torch.empty_like(x)
+        _check(self.lib.cd_layer_denoise(C.byref(self.desc), w, n, B, x.data_ptr(), sigma.data_ptr(), cond.data_ptr(),
+                                         out.data_ptr(), _stream()))
+        return out
+
+    def ddim_sample(self, start, cond, steps: np.ndarray, step_noise=None, seed=0, offset=0, debug=False, use_graph=True,
+                    out=None):
+        """Same contract as UnetEngine.ddim_sample; the whole trajectory is one launch (use_graph is irrelevant)."""
+        start, cond, B = self._io(start, cond)
+        steps = np.ascontiguousarray(steps, dtype=np.float32)
+        n_steps = steps.shape[0]
+        assert steps.shape == (n_steps, 4)
+        table = torch.from_numpy(steps).to(start.device)
+        if step_noise is None and float(np.abs(steps[:, 2]).max()) > 0:
+            step_noise = randn((n_steps, B, self.dim), start.device, seed, offset)
+        if step_noise is not None:
+            step_noise = _dev32(step_noise, "step_noise")
+            assert step_noise.numel() == n_steps * start.numel()
+        x_out = torch.empty_like(start) if out is None else out
+        xs = x0s = None
+        if debug:
+            xs = torch.empty((n_steps,) + tuple(start.shape), dtype=torch.float32, device=start.device)
+            x0s = torch.empty_like(xs)
+        w, n = self._weights()
+        _check(self.lib.cd_layer_sample(C.byref(self.desc), w, n, B, start.data_ptr(), cond.data_ptr(), table.data_ptr(),
+                                        n_steps, _ptr(step_noise), x_out.data_ptr(), _ptr(xs), _ptr(x0s), _stream()))
+        return x_out, xs, x0s
 
 
 def profile_begin():

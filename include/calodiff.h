@@ -156,6 +156,36 @@ int cd_adam_step(int n, float* const* params, const float* const* grads, float* 
 int cd_reverse_norm(const float* voxels, const float* energy, const float* layerE, float* out, int batch, const int32_t dims[3],
                     const float consts[6], float max_deposit, float ecut, void* stream);
 
+/* ---- LayerDiffusion's layer-energy model --------------------------------------------------------------------------
+ * The conditional residual MLP `ResNet` (calodiffusion/models/models.py:391-457) that LayerDiffusion
+ * (calodiffusion/models/layerdiffusion.py:35-38, 114-132) samples the (B, D+1) {total, per-layer} energies with.
+ * Stateless: `weights` is a HOST array of n_weights = 2*(8 + 3*n_res) DEVICE pointers, (weight, bias) per nn.Linear in the
+ * module's state_dict order: time_mlp.{1,3,5}, cond_mlp.{0,2,4}, in_lay, hidden_layers.i.{embeder.1, dense1.0, dense2.0},
+ * out_lay; torch (out, in) row-major fp32. */
+typedef struct CdLayerMlpDesc {
+  int32_t dim_in;           /* SHAPE_FINAL[2] + 1 */
+  int32_t hidden;           /* 256 */
+  int32_t cond_emb;         /* 128: cat(cond_mlp, time_mlp) */
+  int32_t cond_size;        /* 1 (3 for HGCal) */
+  int32_t n_res;            /* num_layers - 1 ResDense blocks */
+  int32_t time_embed_kind;  /* CD_TIME_* (calodiffusion.py:144-152) */
+  int32_t objective;        /* CD_OBJ_* */
+  float sigma_data;
+} CdLayerMlpDesc;
+
+/* ResNet.forward(x, cond, time) (models.py:444-457): x (B, dim_in), cond (B, cond_size), time (B) -> out (B, dim_in). */
+int cd_layer_forward(const CdLayerMlpDesc* desc, const float* const* weights, int n_weights, int batch, const float* x,
+                     const float* cond, const float* time, float* out, void* stream);
+/* CaloDiffusion.denoise on the layer model (calodiffusion.py:154-169 with layerdiffusion.py:109-112): sigma (B). */
+int cd_layer_denoise(const CdLayerMlpDesc* desc, const float* const* weights, int n_weights, int batch, const float* x,
+                     const float* sigma, const float* cond, float* out, void* stream);
+/* LayerDiffusion.sample_layers' sampler loop (layerdiffusion.py:114-132 -> models/sample.py:40-110) in ONE launch.
+ * steps_dev: DEVICE (n_steps, 4) table of CdStep rows; step_noise (n_steps, B, dim_in) or NULL (deterministic);
+ * xs / x0s (n_steps, B, dim_in) or NULL. */
+int cd_layer_sample(const CdLayerMlpDesc* desc, const float* const* weights, int n_weights, int batch, const float* start,
+                    const float* cond, const CdStep* steps_dev, int n_steps, const float* step_noise, float* x_out, float* xs,
+                    float* x0s, void* stream);
+
 /* ---- measurement ---------------------------------------------------------------------------------------------- */
 /* Per-launch timing with HIP events on the launch stream (eager mode; graphs are bypassed while active).
  * cd_profile_end synchronises the device and writes a JSON object

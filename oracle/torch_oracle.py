@@ -434,6 +434,52 @@ class OracleModel:
 
 
 # --------------------------------------------------------------------------
+# LayerDiffusion's layer-energy model (models/models.py:373-457, models/layerdiffusion.py:109-132)
+# --------------------------------------------------------------------------
+def resnet_mlp_forward(sd: SD, x: Tensor, cond: Tensor, time: Tensor) -> Tensor:
+    """ResNet.forward (models/models.py:444-457) with ResDense.forward (models.py:385-391)."""
+    c = _mlp(sd, "cond_mlp", cond, (0, 2, 4))
+    t = _mlp(sd, "time_mlp", time.reshape(-1, 1), (1, 3, 5))
+    emb = torch.cat([c, t], dim=-1)
+    x = F.linear(x, sd["in_lay.weight"], sd["in_lay.bias"])
+    i = 0
+    while f"hidden_layers.{i}.dense1.0.weight" in sd:
+        p = f"hidden_layers.{i}"
+        h = F.gelu(F.linear(x, sd[p + ".dense1.0.weight"], sd[p + ".dense1.0.bias"]))
+        h = h + F.linear(F.gelu(emb), sd[p + ".embeder.1.weight"], sd[p + ".embeder.1.bias"])
+        h = F.gelu(F.linear(h, sd[p + ".dense2.0.weight"], sd[p + ".dense2.0.bias"]))
+        x = h + x
+        i += 1
+    return F.linear(x, sd["out_lay.weight"], sd["out_lay.bias"])
+
+
+class OracleLayerModel(OracleModel):
+    """The layer stage of reference LayerDiffusion (set_layer_state(True)): the denoiser and the sampler loops of OracleModel
+    on (B, D+1) vectors with the ResNet MLP as the network; `layers` is ignored (layerdiffusion.py:109-112)."""
+
+    def __init__(self, cfg: dict, sd: SD):
+        self.cfg = cfg
+        self.sd = {(k[12:] if k.startswith("layer_model.") else k): v for k, v in sd.items()}
+        self.sigma_data = sigma_data_of(cfg)
+        self.time_kind = cfg.get("TIME_EMBED", "sin")
+        self.objective = cfg.get("TRAINING_OBJ", "noise_pred")
+
+    def forward(self, x: Tensor, E: Tensor, t_emb: Tensor, layers: Optional[Tensor] = None) -> Tensor:
+        return resnet_mlp_forward(self.sd, x.float(), E.float(), t_emb.float())
+
+    def denoise(self, x: Tensor, E: Tensor, sigma: Tensor, layers: Optional[Tensor] = None) -> Tensor:
+        sigma = sigma.reshape(-1, 1)
+        t_emb = time_embed(sigma.reshape(-1), self.time_kind)
+        c_skip, c_out, c_in = edm_scalings(sigma, self.sigma_data)
+        pred = self.forward(x * c_in, E, t_emb)
+        if "noise_pred" in self.objective:
+            return x - sigma * pred
+        if "mean_pred" in self.objective:
+            return pred
+        return c_skip * x + c_out * pred
+
+
+# --------------------------------------------------------------------------
 # work accounting (SURVEY.md section 8d): algorithmic FLOPs / bytes per sample-step
 # --------------------------------------------------------------------------
 def algorithmic_work(spec: UnetSpec) -> Dict[str, float]:

@@ -36,3 +36,16 @@ def d1grid_kwargs():
 
 def t(a):
     return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def seeded_layer_models(cfg_name="dataset2", seed=SEED):
+    """(ResNet layer model, CondUnet) with the parameters the reference's LayerDiffusion gets for torch.manual_seed(seed):
+    the layer model is constructed first (layerdiffusion.py:35-40)."""
+    from calodiffusion_amd.resnet import ResNet
+    cfg = load_config(cfg_name)
+    state = torch.random.get_rng_state()
+    torch.manual_seed(seed)
+    layer = ResNet(dim_in=cfg["SHAPE_FINAL"][2] + 1, num_layers=5, cond_size=3 if cfg.get("HGCAL", False) else 1)
+    unet = CondUnet(**unet_kwargs_from_config(cfg))
+    torch.random.set_rng_state(state)
+    return layer, unet

@@ -176,3 +176,35 @@ def test_work_accounting_matches_survey():
     for name, want in (("dataset2", 5.44e9), ("dataset3", 30.3e9), ("hgcal", 6.47e9)):
         w = O.algorithmic_work(O.spec_from_config(load_config(name)))
         assert abs(w["flops"]["total"] - want) / want < 0.02, (name, w["flops"]["total"])
+
+
+def test_layer_model_against_reference():
+    """LayerDiffusion's layer stage (reference models/layerdiffusion.py:109-132, models/models.py:373-457): the oracle's ResNet
+    MLP, its EDM denoiser and the DDim / Euler trajectories over (B, D+1) vectors against the reference's outputs; the
+    parameter containers reproduce the reference's seeded initialisation (layer model first, then the U-Net)."""
+    from helpers import seeded_layer_models
+    g = gold("layer_dataset2")
+    layer, unet = seeded_layer_models("dataset2")
+    verify_checksums(layer.state_dict(), g)
+    verify_checksums(unet.state_dict(), {"ck_keys": g["unet_ck_keys"], "ck_vals": g["unet_ck_vals"]})
+    cfg = load_config("dataset2")
+    m = O.OracleLayerModel(cfg, layer.state_dict())
+    x, E, tm, start = t(g["x"]), t(g["E"]), t(g["time"]), t(g["start"])
+    with torch.no_grad():
+        assert rel_l2(O.resnet_mlp_forward(m.sd, x, E, tm).numpy(), g["forward"]) < TOL
+        for i in range(3):
+            s = float(g[f"sigma_{i}"])
+            y = m.denoise(x * float(np.sqrt(0.25 + s * s)), E, torch.full((3,), s), None)
+            assert rel_l2(y.numpy(), g[f"denoise_{i}"]) < TOL, i
+        for n in (12, 400):
+            y, _, _ = m.ddim_sample(start, E, None, n)
+            assert rel_l2(y.numpy(), g[f"layers_{n}"]) < 1e-5, n
+        y, _, _ = m.ddim_sample(start, E, None, 12, sample_offset=2)
+        assert rel_l2(y.numpy(), g["layers_12_off2"]) < 1e-5
+        y, _, _ = m.edm_euler_sample(start, E, None, 12)
+        assert rel_l2(y.numpy(), g["layers_euler_12"]) < 1e-5
+        # two-stage sample: the generated layer energies condition the U-Net sampler
+        assert rel_l2(m.ddim_sample(start, E, None, 12)[0].numpy(), g["sample_3_layers"]) < 1e-5
+        u = O.OracleModel(cfg, unet.state_dict())
+        xs, _, _ = u.ddim_sample(t(g["shower_start"]), E, t(g["sample_3_layers"]), 3)
+        assert rel_l2(xs.numpy(), g["sample_3_x"]) < 1e-5
