@@ -99,7 +99,8 @@ struct ConvZsArgs {
   GnDefer defer;     // input normalisation folded in the prologue (table of all defer.C channels in LDS) instead of `coef`
   int choff;         // first of this launch's 32 input channels in that table
   const unsigned* in_absmax;  // input rescaling by a power of two (ConvFusion::in_absmax) or null
-  int dbg;           // timing experiments (CD_ZS_DBG): 1 = no conversion, 4 = no reduce/store, 32/64 = no LDS writes / no split
+  int dbg;           // timing experiments (builds with -DCD_ZS_EXPERIMENTS, CD_ZS_DBG): 2 = no plane loads / conversion,
+                     // 4 = no reduce/store, 16 = no MFMAs or fragment reads, 32 = no fragment reads, 64 = no MFMAs
 };
 
 // LDS image: [zero record][ring: ZS_RING planes][partials].  A plane is H rows of W + 1 records: the extra record of every row
@@ -149,7 +150,7 @@ __device__ __forceinline__ float zs_silu(float t) {
 // ---- matrix waves 0..3: K-slice WV of every tile ------------------------------------------------------------
 // K split: wave WV owns k-step WV >> 1; its two waves share the 27 taps, [0, Ne) and [Ne, 27) with Ne = 14 on even tiles and
 // 13 on odd tiles, so that every wave runs 27 (tap, k-step) pairs per two-tile step (both hold tap 13's fragments).
-template <int WV>
+template <int WV, int DBG>
 __device__ __forceinline__ void zs_matrix_wave(const ConvZsArgs& a, char* lds) {
   constexpr int KSTEP = WV >> 1, ODD = WV & 1, T0 = ODD ? 13 : 0;  // weights held: taps T0 .. T0+13
   static_assert(ZS_TILES == 2, "the tap split alternates over the two tiles of a step");
@@ -224,6 +225,7 @@ __device__ __forceinline__ void zs_matrix_wave(const ConvZsArgs& a, char* lds) {
       return ODD ? 13 + j : j;                        // tile 1: even wave 0..12, odd wave 13..26
     };
     auto load_frag = [&](int i) {
+      if (DBG & 32) return;
       const int t = pair_tile(i), tap = pair_tap(i);
       const int kz = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
       const char* p = lds + rb[t][kz][kh] + kw * ZS_VB;
@@ -239,6 +241,10 @@ __device__ __forceinline__ void zs_matrix_wave(const ConvZsArgs& a, char* lds) {
       for (int g = 0; g < 4; ++g) *(f32x4*)(d + g * 1024) = f32x4{pt[4 * g], pt[4 * g + 1], pt[4 * g + 2], pt[4 * g + 3]};
     };
     f32x16 accA[2], accB[2];  // one accumulator pair per tile: tile 0's is folded and written under tile 1's MFMAs
+    if (DBG & 16) {  // timing experiment: no fragment reads, no MFMAs
+      zs_barrier_lds();
+      continue;
+    }
 #pragma unroll
     for (int i = 0; i < PD; ++i) load_frag(i);
 #pragma unroll
@@ -247,9 +253,14 @@ __device__ __forceinline__ void zs_matrix_wave(const ConvZsArgs& a, char* lds) {
       const bool first = i == 0 || i == N0;
       if (i + PD < NI) load_frag(i + PD);
       __builtin_amdgcn_sched_barrier(0);
-      accA[t] = MFMA_F16(fa[i % (PD + 1)][0], w1[j], first ? zero16 : accA[t]);
-      accB[t] = MFMA_F16(fa[i % (PD + 1)][0], w2[j], first ? zero16 : accB[t]);
-      accB[t] = MFMA_F16(fa[i % (PD + 1)][1], w1[j], accB[t]);
+      if (DBG & 64) {  // timing experiment: fragments are read but not multiplied
+        asm volatile("" ::"v"(fa[i % (PD + 1)][0]), "v"(fa[i % (PD + 1)][1]));
+        if (first) { accA[t] = zero16; accB[t] = zero16; }
+      } else {
+        accA[t] = MFMA_F16(fa[i % (PD + 1)][0], w1[j], first ? zero16 : accA[t]);
+        accB[t] = MFMA_F16(fa[i % (PD + 1)][0], w2[j], first ? zero16 : accB[t]);
+        accB[t] = MFMA_F16(fa[i % (PD + 1)][1], w1[j], accB[t]);
+      }
       if (i == N0 + 3) write_partial(0, accA[0], accB[0]);
     }
     write_partial(1, accA[1], accB[1]);
@@ -257,8 +268,14 @@ __device__ __forceinline__ void zs_matrix_wave(const ConvZsArgs& a, char* lds) {
   }
 }
 
+// Sink for the output rows a helper lane does not own (chunk tail, the dummy epilogues).  Every epilogue issues exactly 8
+// stores on every path, so the compiler can count the vector-memory operations between a plane's loads and their use
+// (s_waitcnt vmcnt(8 + k) instead of vmcnt(k): in-order retirement would otherwise make every conversion wait for the previous
+// step's output stores as well).
+__device__ float zs_sink[256];
+
 // ---- helper waves 4..7: stage incoming planes; sum / store half a tile of the previous step ----------------------------
-template <bool ACC>
+template <bool ACC, int DBG>
 __device__ __forceinline__ void zs_helper_wave(const ConvZsArgs& a, char* lds, const int h) {
   const int tid = threadIdx.x - 256, lane = tid & 63, half = lane >> 5, col = lane & 31;
   const int b = blockIdx.y, ct = blockIdx.z;
@@ -296,14 +313,27 @@ __device__ __forceinline__ void zs_helper_wave(const ConvZsArgs& a, char* lds, c
   float gscale = 1.f, ginv = 1.f;
   if (a.in_absmax) pow2_scale_for(*a.in_absmax, &gscale, &ginv);
   f32x4 ld[ZS_NSL];
-  // Loads are unconditional (plane and voxel indices clamped into range; an out-of-range plane is zero-filled by
-  // convert()): a predicated load would be sunk by the compiler into convert()'s matching branch.
+  static_assert(ZS_NSL == 5, "landed() names the five staging registers");
+  // Plane loads are issued and awaited by hand: vmcnt retires in order, and between a plane's loads (issued in interval s-1) and
+  // their conversion (start of interval s) the wave issues exactly NYOUNG vector-memory operations -- the 8 output stores of
+  // epilogue(s-2) (plus its 8 read-backs in a continuation launch) -- so `s_waitcnt vmcnt(NYOUNG)` waits for the loads and not
+  // for those stores.  (Left to the compiler the wait is vmcnt(4..0): conditional paths make it assume no younger operation,
+  // and every conversion then also waits a store round trip.)  Out-of-range planes are clamped and zero-filled by convert().
+  constexpr int NYOUNG = ACC ? 16 : 8;
   auto issue = [&](int z) {
     const int zc = min(max(z, 0), a.D - 1);
     const float* src = src_b + (size_t)zc * PV * a.ldc;
 #pragma unroll
-    for (int k = 0; k < ZS_NSL; ++k) ld[k] = *(const f32x4*)(src + (size_t)srcv[k] * a.ldc);
+    for (int k = 0; k < ZS_NSL; ++k) {
+      const float* p = src + (size_t)srcv[k] * a.ldc;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ld[k]) : "v"(p) : "memory");
+    }
   };
+#define ZS_LANDED(younger)                                                                                   \
+  asm volatile("s_waitcnt vmcnt(%5)"                                                                         \
+               : "+v"(ld[0]), "+v"(ld[1]), "+v"(ld[2]), "+v"(ld[3]), "+v"(ld[4])                             \
+               : "n"(younger)                                                                                \
+               : "memory")
   auto convert = [&](int z, int k0, int k1) {  // slots [k0, k1) of plane z
     const int slot = (z + a.NR) % a.NR;  // z >= -1
     const bool zero = z < 0 || z >= a.D;
@@ -313,7 +343,7 @@ __device__ __forceinline__ void zs_helper_wave(const ConvZsArgs& a, char* lds, c
       if (k < k0 || k >= k1) continue;
       if (p0 + 32 * k < NIMG) {
         u32x2 t1 = {0u, 0u}, t2 = {0u, 0u};
-        if (!zero && !(a.dbg & 1)) {
+        if (!zero && !(DBG & 1)) {
           f32x4 v = ld[k] * gscale;
           if (normed) {
 #pragma unroll
@@ -345,6 +375,7 @@ __device__ __forceinline__ void zs_helper_wave(const ConvZsArgs& a, char* lds, c
   int zstaged = need(0);
   for (int z = G.zfirst - 1; z <= zstaged; ++z) {
     issue(z);
+    ZS_LANDED(0);
     convert(z, 0, ZS_NSL);
   }
   float s1 = 0.f, s2 = 0.f;
@@ -358,8 +389,10 @@ __device__ __forceinline__ void zs_helper_wave(const ConvZsArgs& a, char* lds, c
   // Incoming planes (at most one per step: a plane is >= 64 voxels): converted while the matrix waves run the step BEFORE
   // the one that first reads the plane -- only then is its ring slot (plane - 4) free -- from loads issued a step earlier.
   int zpend = zstaged < need(1) ? zstaged + 1 : -2;
-  issue(zpend);
-  __builtin_amdgcn_s_waitcnt(0x0F70);
+  if (zpend != -2) {
+    issue(zpend);
+    ZS_LANDED(0);  // no stores follow these loads: the count of the loop's wait does not hold for them
+  }
   zs_barrier_lds();  // P
 
   const int th = h >> 1, rh = h & 1;  // this wave sums rows 16*rh .. 16*rh+15 (accumulator registers 8*rh .. 8*rh+7) of tile th
@@ -376,19 +409,21 @@ __device__ __forceinline__ void zs_helper_wave(const ConvZsArgs& a, char* lds, c
       }
     }
   };
-  auto epilogue = [&](int s) {  // bias, store, statistics of this wave's 16 rows of step s
-    if (a.dbg & 4) return;
+  float* const sink = zs_sink + (threadIdx.x & 255);
+  auto epilogue = [&](int s, bool live) {  // bias, store, statistics of this wave's 16 rows of step s
     const int vt = G.v0 + s * ZS_STEP + th * 32;
-    int go[8];  // element offsets of this lane's 8 rows
+    float* dst[8];  // this lane's 8 rows
+    bool ok[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       const int row = (r & 3) + 8 * ((r >> 2) + 2 * rh) + 4 * half;
-      go[r] = vt + row < G.cend ? gvox(vt + row) * a.cout : -1;
+      ok[r] = live && vt + row < G.cend;
+      dst[r] = ok[r] ? out_b + (size_t)gvox(vt + row) * a.cout : sink;
     }
     if (ACC) {  // continuation launch of a wider-K conv: add to what the previous launch stored
       float prev[8];
 #pragma unroll
-      for (int r = 0; r < 8; ++r) prev[r] = go[r] >= 0 ? out_b[go[r]] : 0.f;
+      for (int r = 0; r < 8; ++r) prev[r] = *dst[r];
 #pragma unroll
       for (int r = 0; r < 8; ++r) sum[r] = sum[r] * ginv + prev[r];
     } else {
@@ -397,34 +432,35 @@ __device__ __forceinline__ void zs_helper_wave(const ConvZsArgs& a, char* lds, c
     }
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-      if (go[r] >= 0) {
-        const float v = sum[r] + bv;
-        out_b[go[r]] = v;
-        s1 += v;
-        s2 += v * v;
-      }
+      const float v = sum[r] + bv;
+      *dst[r] = v;
+      const float m = ok[r] ? v : 0.f;
+      s1 += m;
+      s2 += m * m;
     }
   };
 
-  // interval s = the time the matrix waves spend in step s (between barriers A(s-1) and A(s))
+  // interval s = the time the matrix waves spend in step s (between barriers A(s-1) and A(s)): conversion of the pending plane,
+  // loads of the next one, then the 8 output stores of step s-1 (always 8: landed() counts them).
   for (int s = 0; s < G.nsteps; ++s) {
-    // conversion first: its loads are then the OLDEST outstanding vector-memory operations (vmcnt retires in order, so
-    // waiting for a load that was issued before a batch of output stores would wait for those stores as well)
     if (zpend != -2) {
-      convert(zpend, 0, ZS_NSL);  // read first by step s+1
+      if (!(DBG & 2)) {
+        ZS_LANDED(NYOUNG);
+        convert(zpend, 0, ZS_NSL);  // read first by step s+1
+      }
       zstaged = zpend;
     }
     zpend = (s + 2 < G.nsteps && zstaged < need(s + 2)) ? zstaged + 1 : -2;
-    issue(zpend);
+    if (zpend != -2 && !(DBG & 2)) issue(zpend);
     __builtin_amdgcn_sched_barrier(0);
-    if (s > 0) {
-      read_partials(s - 1);
-      epilogue(s - 1);
+    if (!(DBG & 4)) {
+      read_partials(s - 1);  // s = 0: nothing to sum yet, the stores go to the sink
+      epilogue(s - 1, s > 0);
     }
     zs_barrier_lds();  // A(s)
   }
   read_partials(G.nsteps - 1);
-  epilogue(G.nsteps - 1);
+  epilogue(G.nsteps - 1, true);
 
   if (a.ch_part) {
     const float t1 = s1 + __shfl_xor(s1, 32, 64), t2 = s2 + __shfl_xor(s2, 32, 64);
@@ -437,7 +473,7 @@ __device__ __forceinline__ void zs_helper_wave(const ConvZsArgs& a, char* lds, c
   if (a.status && amax > 65504.f) atomicOr(a.status, 1);
 }
 
-template <bool ACC>
+template <bool ACC, int DBG = 0>
 __global__ void __launch_bounds__(512, 1) conv_zslide_f16x2_kernel(ConvZsArgs a) {
   extern __shared__ __attribute__((aligned(16))) char zs_lds[];
   if (a.defer.part) {
@@ -445,11 +481,11 @@ __global__ void __launch_bounds__(512, 1) conv_zslide_f16x2_kernel(ConvZsArgs a)
     gn_defer_to_lds(a.defer, blockIdx.y, (float*)(zs_lds + G.ZPART), zs_lds + G.ZPART + a.defer.C * 16);
   }
   switch (threadIdx.x >> 6) {
-    case 0: zs_matrix_wave<0>(a, zs_lds); break;
-    case 1: zs_matrix_wave<1>(a, zs_lds); break;
-    case 2: zs_matrix_wave<2>(a, zs_lds); break;
-    case 3: zs_matrix_wave<3>(a, zs_lds); break;
-    default: zs_helper_wave<ACC>(a, zs_lds, (int)(threadIdx.x >> 6) - 4); break;
+    case 0: zs_matrix_wave<0, DBG>(a, zs_lds); break;
+    case 1: zs_matrix_wave<1, DBG>(a, zs_lds); break;
+    case 2: zs_matrix_wave<2, DBG>(a, zs_lds); break;
+    case 3: zs_matrix_wave<3, DBG>(a, zs_lds); break;
+    default: zs_helper_wave<ACC, DBG>(a, zs_lds, (int)(threadIdx.x >> 6) - 4); break;
   }
 }
 
@@ -534,6 +570,22 @@ bool try_launch_conv_zslide(const float* in0, int c0, const float* in1, int c1, 
     a.status = fu.status;
     a.dbg = getenv("CD_ZS_DBG") ? atoi(getenv("CD_ZS_DBG")) : 0;
     const dim3 grid((unsigned)(nstrip * nchunk), (unsigned)batch, (unsigned)CTtot);
+#ifdef CD_ZS_EXPERIMENTS
+#define ZS_DBG_CASE(D)                                                                                                     \
+  case D:                                                                                                                  \
+    CD_HIP(hipFuncSetAttribute((const void*)conv_zslide_f16x2_kernel<false, D>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                               160 * 1024));                                                                               \
+    hipLaunchKernelGGL((conv_zslide_f16x2_kernel<false, D>), grid, dim3(512), lds, s, a);                                   \
+    break;
+    if (kb == 0 && a.dbg) {
+      switch (a.dbg) {
+        ZS_DBG_CASE(2) ZS_DBG_CASE(4) ZS_DBG_CASE(6) ZS_DBG_CASE(22) ZS_DBG_CASE(38) ZS_DBG_CASE(70)
+        default: CD_REQUIRE(false, "CD_ZS_DBG: not an instantiated experiment");
+      }
+      CD_HIP(hipGetLastError());
+      continue;
+    }
+#endif
     if (kb == 0) hipLaunchKernelGGL(conv_zslide_f16x2_kernel<false>, grid, dim3(512), lds, s, a);
     else hipLaunchKernelGGL(conv_zslide_f16x2_kernel<true>, grid, dim3(512), lds, s, a);
     CD_HIP(hipGetLastError());

@@ -38,6 +38,13 @@ def main():
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.iters  # includes the (tiny) weight-pack kernel of the op entry point
     flops = 2.0 * 27 * a.cin * a.cout * D * H * W * a.batch
+    from calodiffusion_amd import engine
+    engine.profile_begin()
+    for _ in range(a.iters):
+        y = ops.cyl_conv(x, w, b)
+    prof = engine.profile_end()
+    kern = {k: round(v["ms"] / v["launches"] * 1e3, 1) for k, v in prof.items() if v["launches"]}
+    print("kernel us:", kern)
     print(f"tile={os.environ.get('CD_CONV_TILE','auto'):>12s}  {ms*1e3:8.1f} us  {flops/ms/1e9:7.2f} TFLOP/s  "
           f"({flops/ms/1e9/157.3*100:5.1f}% of fp32 MFMA peak)  checksum {float(y.double().sum()):.6e}")
 
