@@ -19,6 +19,7 @@
 #include "split16.h"
 
 #include <cstdio>
+#include <cstdlib>
 
 namespace cd {
 
@@ -47,33 +48,71 @@ struct AttnArgs {
 // A fragments of one 32-voxel tile for v_mfma_f32_32x32x16_f16: lane (voxel n0 + col, half) holds, per 16-channel k-step ks,
 // channels ks*16 + half*8 + 0..7 of the normalised input as two fp16 terms (f16x2).  NKS = C / 16 k-steps.
 template <int NCH>
-__device__ __forceinline__ void load_xn(const AttnArgs& a, int b, int64_t n0, int col, int half, const f32x4 (&cf)[NCH][8],
-                                        u32x4 (&x1)[NCH * 2], u32x4 (&x2)[NCH * 2]) {
-  const int64_t n = n0 + col;
-  const bool valid = n < a.vox;
-  const float* src = a.x + ((size_t)b * a.vox + (valid ? n : 0)) * a.C + half * 8;
+struct RawTile {
   f32x4 v[NCH * 2][2];
+};
+// global loads of one tile (issued ahead of their use; tiles past the end are clamped to the last one and never consumed)
+template <int NCH>
+__device__ __forceinline__ void load_raw(const AttnArgs& a, int b, int64_t t, int64_t tlast, int col, int half, RawTile<NCH>& raw) {
+  const int64_t tc = t < tlast ? t : tlast;
+  int64_t n = tc * 32 + col;
+  n = n < a.vox ? n : a.vox - 1;
+  const float* src = a.x + ((size_t)b * a.vox + n) * a.C + half * 8;
 #pragma unroll
   for (int ks = 0; ks < NCH * 2; ++ks)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) v[ks][j] = *(const f32x4*)(src + ks * 16 + j * 4);
+    for (int j = 0; j < 2; ++j) raw.v[ks][j] = *(const f32x4*)(src + ks * 16 + j * 4);
+}
+template <int NCH>
+__device__ __forceinline__ void norm_split(const AttnArgs& a, int64_t n0, int col, const f32x4 (&cf)[NCH][8], const RawTile<NCH>& raw,
+                                           u32x4 (&x1)[NCH * 2], u32x4 (&x2)[NCH * 2]) {
+  const bool valid = n0 + col < a.vox;
 #pragma unroll
   for (int ks = 0; ks < NCH * 2; ++ks) {
     u32x2 t1[2], t2[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
+      f32x4 v = raw.v[ks][j];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         // cf[ks >> 1][(ks & 1) * 4 + j * 2 + (e >> 1)] = {scale, shift} pairs of channels ks*16 + half*8 + j*4 + (e & ~1), +1
         const f32x4 c2 = cf[ks >> 1][(ks & 1) * 4 + j * 2 + (e >> 1)];
-        v[ks][j][e] = valid ? c2[(e & 1) * 2] * v[ks][j][e] + c2[(e & 1) * 2 + 1] : 0.f;
+        v[e] = valid ? c2[(e & 1) * 2] * v[e] + c2[(e & 1) * 2 + 1] : 0.f;
       }
-      split2(v[ks][j], t1[j], t2[j]);
+      split2(v, t1[j], t2[j]);
     }
     x1[ks] = u32x4{t1[0][0], t1[0][1], t1[1][0], t1[1][1]};
     x2[ks] = u32x4{t2[0][0], t2[0][1], t2[1][0], t2[1][1]};
   }
 }
+// Tiles whose loads are in flight ahead of their use, per wave (0 = load and consume in place).  Measured on MI355X with the
+// one-round grids below: depth 2-3 makes pass 1 slower (0.146 -> 0.155 ms per denoise step, register pressure) and leaves
+// pass 2 unchanged -- these kernels are bound by their VALU work (split, exp) and the f32 context MFMAs, not by load latency.
+#ifndef ATTN_KV_D1
+#define ATTN_KV_D1 0
+#endif
+#ifndef ATTN_OUT_D1
+#define ATTN_OUT_D1 0
+#endif
+template <int NCH>
+struct AttnDepthKV {
+  static constexpr int value = NCH == 1 ? ATTN_KV_D1 : 0;
+};
+template <int NCH>
+struct AttnDepthOut {
+  static constexpr int value = NCH == 1 ? ATTN_OUT_D1 : 0;
+};
+// e^x for x <= 0 on the transcendental unit: 2^(x log2 e) with the rounding error of the product carried into a first-order
+// correction (relative error ~1e-7, against ~|x| 6e-8 for the bare product; libm's expf costs ~25 VALU instructions and
+// these kernels are VALU-bound: 16 exponentials per lane and tile).
+__device__ __forceinline__ float attn_exp(float x) {
+  const float L2E = 1.4426950408889634f, L2E_LO = 1.925963033500519e-8f;  // log2 e = L2E + L2E_LO
+  const float t = x * L2E;
+  const float lo = __builtin_fmaf(x, L2E, -t) + x * L2E_LO;  // exact remainder of the product + low part of the constant
+  const float e = __builtin_amdgcn_exp2f(t);
+  return __builtin_fmaf(e, lo * 0.6931471805599453f, e);
+}
+__device__ __forceinline__ void attn_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // must be called by every thread of the workgroup (the deferred form contains barriers)
 template <int NCH>
 __device__ __forceinline__ void load_coef(const AttnArgs& a, int b, int half, f32x4 (&cf)[NCH][8]) {
@@ -131,21 +170,40 @@ __global__ void __launch_bounds__(512) attn_kv_context_kernel(AttnArgs a) {
     return pa;
   };
 
+  constexpr int PRE = AttnDepthKV<NCH>::value, DEPTH = PRE ? PRE : 1;
+  RawTile<NCH> raw[DEPTH];
+  const int64_t tlast = t1 - 1;
   // sweep 1: per-channel max of k over this workgroup's voxels
   float m = -3.0e38f;
-  for (int64_t t = t0 + wave; t < t1; t += 8) {
-    u32x4 x1[NKS], x2[NKS];
-    load_xn<NCH>(a, b, t * 32, col, half, cf, x1, x2);
-    const f32x16 k = project(x1, x2, wk1, wk2);
+  if (PRE) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (t * 32 + row < a.vox) m = fmaxf(m, k[r]);
+    for (int d = 0; d < DEPTH; ++d) load_raw<NCH>(a, b, t0 + wave + 8 * d, tlast, col, half, raw[d]);
+  }
+  for (int64_t t = t0 + wave; t < t1; t += 8 * DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      const int64_t tt = t + 8 * d;
+      if (tt >= t1) break;
+      u32x4 x1[NKS], x2[NKS];
+      if (!PRE) load_raw<NCH>(a, b, tt, tlast, col, half, raw[d]);
+      norm_split<NCH>(a, tt * 32, col, cf, raw[d], x1, x2);
+      if (PRE && tt + 8 * DEPTH < t1) load_raw<NCH>(a, b, tt + 8 * DEPTH, tlast, col, half, raw[d]);
+      const f32x16 k = project(x1, x2, wk1, wk2);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (tt * 32 + row < a.vox) m = fmaxf(m, k[r]);
+      }
     }
+  }
+  // the second sweep's first loads go out before the maxima are exchanged (LDS-only barrier: it does not wait for them)
+  if (PRE) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) load_raw<NCH>(a, b, t0 + wave + 8 * d, tlast, col, half, raw[d]);
   }
   m = fmaxf(m, __shfl_xor(m, 32, 64));
   if (half == 0) sMax[wave][col] = m;
-  __syncthreads();
+  attn_barrier_lds();
   m = sMax[0][col];
 #pragma unroll
   for (int w = 1; w < 8; ++w) m = fmaxf(m, sMax[w][col]);
@@ -156,17 +214,24 @@ __global__ void __launch_bounds__(512) attn_kv_context_kernel(AttnArgs a) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) ctx[r] = 0.f;
   float ssum = 0.f;
-  for (int64_t t = t0 + wave; t < t1; t += 8) {
-    u32x4 x1[NKS], x2[NKS];
-    load_xn<NCH>(a, b, t * 32, col, half, cf, x1, x2);
-    const f32x16 k = project(x1, x2, wk1, wk2);
-    const f32x16 v = project(x1, x2, wv1, wv2);
+  for (int64_t t = t0 + wave; t < t1; t += 8 * DEPTH) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-      const float ex = (t * 32 + row < a.vox) ? expf(k[r] - m) : 0.f;
-      ssum += ex;
-      ctx = MFMA32(ex, v[r], ctx);
+    for (int d = 0; d < DEPTH; ++d) {
+      const int64_t tt = t + 8 * d;
+      if (tt >= t1) break;
+      u32x4 x1[NKS], x2[NKS];
+      if (!PRE) load_raw<NCH>(a, b, tt, tlast, col, half, raw[d]);
+      norm_split<NCH>(a, tt * 32, col, cf, raw[d], x1, x2);
+      if (PRE && tt + 8 * DEPTH < t1) load_raw<NCH>(a, b, tt + 8 * DEPTH, tlast, col, half, raw[d]);
+      const f32x16 k = project(x1, x2, wk1, wk2);
+      const f32x16 v = project(x1, x2, wv1, wv2);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const float ex = (tt * 32 + row < a.vox) ? attn_exp(k[r] - m) : 0.f;
+        ssum += ex;
+        ctx = MFMA32(ex, v[r], ctx);
+      }
     }
   }
   sSum[wave * 2 + half][col] = ssum;
@@ -225,9 +290,22 @@ __global__ void __launch_bounds__(512) attn_out_kernel(AttnArgs a) {
   }
   float* const yb = a.y + (size_t)b * a.vox * a.C;
 
-  for (int64_t t = t0 + wave; t < t1; t += 8) {
+  constexpr int PRE = AttnDepthOut<NCH>::value, DEPTH = PRE ? PRE : 1;
+  RawTile<NCH> raw[DEPTH];
+  const int64_t tlast = t1 - 1;
+  if (PRE) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) load_raw<NCH>(a, b, t0 + wave + 8 * d, tlast, col, half, raw[d]);
+  }
+  for (int64_t tg = t0 + wave; tg < t1; tg += 8 * DEPTH) {
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) {
+    const int64_t t = tg + 8 * d;
+    if (t >= t1) break;
     u32x4 x1[NKS], x2[NKS];
-    load_xn<NCH>(a, b, t * 32, col, half, cf, x1, x2);
+    if (!PRE) load_raw<NCH>(a, b, t, tlast, col, half, raw[d]);
+    norm_split<NCH>(a, t * 32, col, cf, raw[d], x1, x2);
+    if (PRE && t + 8 * DEPTH < t1) load_raw<NCH>(a, b, t + 8 * DEPTH, tlast, col, half, raw[d]);
     // q^T[d][n]: A = W_q (row d), B = xn^T (column n); the registers of a lane are 16 channels d of its voxel n = col
     f32x16 q = zero16, qb = zero16;
 #pragma unroll
@@ -245,7 +323,7 @@ __global__ void __launch_bounds__(512) attn_out_kernel(AttnArgs a) {
     float ss = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      q[r] = expf(q[r] - mx);
+      q[r] = attn_exp(q[r] - mx);
       ss += q[r];
     }
     ss += __shfl_xor(ss, 32, 64);
@@ -269,6 +347,7 @@ __global__ void __launch_bounds__(512) attn_out_kernel(AttnArgs a) {
         }
       }
     }
+  }
   }
   if (a.ch_part) {
 #pragma unroll
@@ -303,10 +382,13 @@ int tiles_per_wg_for(int64_t vox, int nsplit) {
 
 }  // namespace
 
-// workgroups per sample for both passes: enough to fill the chip twice, at least 8 tiles (one per wave) each
+// workgroups per sample for both passes: one round of the 256 CUs (a 512-thread workgroup of these kernels owns a CU: 8 waves
+// x 256 VGPRs), at least 8 tiles (one per wave) each.  Two WGs per CU's worth (448 for Dataset-2's level 0 at batch 64) ran
+// as two rounds, each paying the prologue again: 66 -> 4x us per launch.
 int attn_fused_nsplit_for(int64_t vox, int batch) {
   const int64_t T = (vox + 31) / 32;
-  int64_t want = (512 + batch - 1) / batch;
+  static const int target = getenv("CD_ATTN_WGS") ? atoi(getenv("CD_ATTN_WGS")) : 256;
+  int64_t want = (target + batch - 1) / batch;
   const int64_t cap = (T + 15) / 16;
   int64_t n = want < cap ? want : cap;
   if (n < 1) n = 1;

@@ -1719,6 +1719,8 @@ struct ConvTArgs {
   int TZ, TH, nTZ, nTH;  // tile extents in class-index space: oz = SZ*a + pz, oh = 2*b + ph
   int Cw;                // ceil(Wo/2)
   int CS;                // LDS voxel stride in floats
+  const u32x4* wpk16;    // f16x2 image [k-step][tap][ct][term][lane] (conv_transpose_f16x2_kernel)
+  int* status;           // bit 0: a staged value exceeded the fp16 range
 };
 
 template <int CT>
@@ -1824,22 +1826,138 @@ __global__ void __launch_bounds__(256) conv_transpose_kernel(ConvTArgs a) {
   }
 }
 
+// The same gather on the fp16 matrix pipe (f16x2, see kernels_conv_zs.hip): the haloed input tile is split into two fp16
+// terms while it is staged (record = [k-step][term][16 fp16] + 16 B pad, the byte size of the fp32 record), every valid
+// (tap, 16-channel k-step) costs two ds_read_b128 and three MFMAs per 32 output channels instead of eight f32 MFMAs of twice
+// the duration.
+template <int CT>
+__global__ void __launch_bounds__(256) conv_transpose_f16x2_kernel(ConvTArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  int bid = blockIdx.x;
+  const int thi = bid % a.nTH;
+  bid /= a.nTH;
+  const int tzi = bid % a.nTZ;
+  const int b = bid / a.nTZ;
+  const int a0 = tzi * a.TZ, b0 = thi * a.TH;
+  const int PZ = a.TZ + 2, PH = a.TH + 2;
+  const int tileVox = PZ * PH * a.Win;
+  const int ZERO = tileVox * a.CS;
+  const int half = lane >> 5, col = lane & 31;
+  for (int i = tid; i < a.CS; i += blockDim.x) lds[ZERO + i] = 0.f;
+
+  {  // stage + split all input channels of the haloed tile
+    const int c4 = a.cin >> 2;
+    const int items = tileVox * c4;
+    const float* src = a.in + (size_t)b * a.Din * a.Hin * a.Win * a.cin;
+    float amax = 0.f;
+    for (int idx = tid; idx < items; idx += blockDim.x) {
+      const int q = idx % c4, vox = idx / c4;
+      const int iw = vox % a.Win;
+      const int r = vox / a.Win;
+      const int lh = r % PH, lz = r / PH;
+      const int gz = a0 - 1 + lz;
+      int gh = (b0 - 1 + lh) % a.Hin;
+      if (gh < 0) gh += a.Hin;
+      f32x4 val = {0.f, 0.f, 0.f, 0.f};
+      if (gz >= 0 && gz < a.Din) val = *(const f32x4*)(src + ((size_t)(gz * a.Hin + gh) * a.Win + iw) * a.cin + q * 4);
+      amax = fmaxf(amax, fmaxf(fmaxf(fabsf(val[0]), fabsf(val[1])), fmaxf(fabsf(val[2]), fabsf(val[3]))));
+      u32x2 t1, t2;
+      split2(val, t1, t2);
+      char* dst = (char*)(lds + vox * a.CS) + (q >> 2) * 64 + (q & 3) * 8;
+      *(u32x2*)dst = t1;
+      *(u32x2*)(dst + 32) = t2;
+    }
+    if (a.status && amax > 65504.f) atomicOr(a.status, 1);
+  }
+  __syncthreads();
+
+  const int ncls = a.SZ * 4;
+  const int njt = (a.TZ * a.TH * a.Cw + 31) / 32;
+  const int nks = a.cin >> 4;
+  const int T = a.KZ * 16;
+  float* outb = a.out + (size_t)b * a.Do * a.Ho * a.Wo * a.cout;
+
+  for (int job = wave; job < ncls * njt; job += nw) {
+    const int cls = job / njt, jt = job % njt;
+    const int pz = cls >> 2, ph = (cls >> 1) & 1, pw = cls & 1;
+    const int v = jt * 32 + col;
+    const int c = v % a.Cw;
+    const int t = v / a.Cw;
+    const int bb = t % a.TH, aa = t / a.TH;
+    const int oz = a.SZ * (a0 + aa) + pz, oh = 2 * (b0 + bb) + ph, ow = 2 * c + pw;
+    const bool valid = (aa < a.TZ) && (oz < a.Do) && (oh < a.Ho) && (ow < a.Wo);
+    if (!__any(valid)) continue;
+    const int ooff = valid ? ((oz * a.Ho + oh) * a.Wo + ow) * a.cout : -1;
+
+    f32x16 accA[CT], accB[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { accA[ct][r] = 0.f; accB[ct][r] = 0.f; }
+
+    for (int kz = (pz + 1) % a.SZ; kz < a.KZ; kz += a.SZ) {
+      const int lz = aa + (pz + 1 - kz) / a.SZ + 1;
+      for (int kh = (ph + 3) & 1; kh < 4; kh += 2) {
+        const int lh = bb + (ph + 3 - kh) / 2;  // (.. )/2 - 1 (circular halo) + 1 (tile halo)
+        for (int kw = (pw + 1) & 1; kw < 4; kw += 2) {
+          const int iw = c + (pw + 1 - kw) / 2;
+          const bool ok = valid && iw >= 0 && iw < a.Win;
+          const char* rec = (const char*)(lds + (ok ? ((lz * PH + lh) * a.Win + iw) * a.CS : ZERO)) + half * 16;
+          const int tap = (kz * 4 + kh) * 4 + kw;
+          for (int ks = 0; ks < nks; ++ks) {
+            const u32x4 x1 = *(const u32x4*)(rec + ks * 64);
+            const u32x4 x2 = *(const u32x4*)(rec + ks * 64 + 32);
+            const u32x4* wq = a.wpk16 + ((size_t)(ks * T + tap) * a.CTtot) * 128 + lane;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+              const u32x4 w1 = wq[ct * 128], w2 = wq[ct * 128 + 64];
+              accA[ct] = MFMA_F16(x1, w1, accA[ct]);
+              accB[ct] = MFMA_F16(x1, w2, accB[ct]);
+              accB[ct] = MFMA_F16(x2, w1, accB[ct]);
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int off = __shfl(ooff, row, 64);
+      if (off >= 0) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          const int co = ct * 32 + col;
+          outb[off + co] = accA[ct][r] + accB[ct][r] * (1.f / 2048.f) + (a.bias ? a.bias[co] : 0.f);
+        }
+      }
+    }
+  }
+}
+
 template <int CT>
 static void launch_convT_inst(const ConvTArgs& a, dim3 grid, size_t lds, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
     CD_HIP(hipFuncSetAttribute((const void*)conv_transpose_kernel<CT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CD_HIP(hipFuncSetAttribute((const void*)conv_transpose_f16x2_kernel<CT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_transpose_kernel<CT>), grid, dim3(256), lds, s, a);
+  if (a.wpk16) hipLaunchKernelGGL((conv_transpose_f16x2_kernel<CT>), grid, dim3(256), lds, s, a);
+  else hipLaunchKernelGGL((conv_transpose_kernel<CT>), grid, dim3(256), lds, s, a);
   CD_HIP(hipGetLastError());
 }
 
 void launch_conv_transpose_mfma(const float* in, int cin, const float* wpk, const float* bias, float* out, int batch,
-                                int cout, Dims3 din, Dims3 dout, int kz, int sz, hipStream_t s) {
+                                int cout, Dims3 din, Dims3 dout, int kz, int sz, hipStream_t s, const void* wpk_f16x2,
+                                int* status) {
   CD_REQUIRE(cin % 32 == 0 && cout % 32 == 0, "conv_transpose: channels must be multiples of 32");
   CD_REQUIRE(sz == 1 || sz == 2, "conv_transpose: z stride must be 1 or 2");
+  static const bool full_range = getenv("CD_CONV_PRECISION") && (!strcmp(getenv("CD_CONV_PRECISION"), "f32") ||
+                                                                  !strcmp(getenv("CD_CONV_PRECISION"), "bf16x3"));
   ConvTArgs a;
+  a.wpk16 = full_range ? nullptr : (const u32x4*)wpk_f16x2;
+  a.status = status;
   a.in = in; a.cin = cin; a.wpk = wpk; a.bias = bias; a.out = out;
   a.Din = din.d; a.Hin = din.h; a.Win = din.w; a.Do = dout.d; a.Ho = dout.h; a.Wo = dout.w;
   a.KZ = kz; a.SZ = sz; a.cout = cout; a.CTtot = cout / 32;
@@ -1884,7 +2002,7 @@ void launch_conv_transpose_mfma(const float* in, int cin, const float* wpk, cons
     }
   };
   char key[192];
-  std::snprintf(key, sizeof key, "%s k%d s%d b%d", cat, kz, sz, batch);
+  std::snprintf(key, sizeof key, "%s k%d s%d b%d%s", cat, kz, sz, batch, a.wpk16 ? " f16x2" : "");
   const int pick = autotune(key, (int)cand.size(), [&](int i) { launch(cand[i]); }, s);
   launch(cand[pick < 0 ? 0 : pick]);
 }

@@ -75,6 +75,7 @@ constexpr int ZS_VB = 144;     // bytes per voxel record: 2 k-steps x 2 terms x 
 // planes in the LDS ring (ConvZsArgs::NR): a 64-voxel step reads 3-4 planes and one more is staged for the next step.
 // With planes of >= 128 voxels two consecutive steps cross at most one plane boundary and 4 slots suffice; smaller
 // (strip-)planes need 5.
+constexpr int ZS_ZERO = 512;   // zero area in front of the ring (r - 1 / r + 1 neighbours of the edge columns read it)
 constexpr int ZS_NSL = 5;      // staging slots per helper thread per plane (plane <= 160 voxels)
 constexpr int ZS_TILES = 2;    // 32-voxel row tiles per step
 constexpr int ZS_STEP = 32 * ZS_TILES;
@@ -103,12 +104,15 @@ struct ConvZsArgs {
                      // 4 = no reduce/store, 16 = no MFMAs or fragment reads, 32 = no fragment reads, 64 = no MFMAs
 };
 
-// LDS image: [zero record][ring: ZS_RING planes][partials].  A plane is H rows of W + 1 records: the extra record of every row
-// is zero, so the r - 1 neighbour of column 0 (the previous row's pad, or the record in front of the plane) and the r + 1
-// neighbour of column W - 1 read zeros without any per-tap validity select.  Tap addresses are then
-// (row base of (kz, kh)) + constant: the matrix waves spend ~1 VALU instruction per MFMA triple on addressing.  That matters:
-// one vector issue port per SIMD serves the matrix wave's MFMAs (8 of every 32 cycles) AND every VALU instruction of both
-// resident waves; address arithmetic and staging beyond the remaining slots lengthens the step.
+// LDS image: [512 B of zeros][ring: NR planes][partials].  A plane is H rows of W records, planes 256-byte aligned: the
+// records of consecutive voxels are 144 B apart everywhere -- across row ends, across planes (the slot stride is a multiple of
+// 256 B) and across the phi wrap of a whole plane when H*W is a multiple of 16 -- so the 16 lanes of a ds_read_b128 phase always
+// hit 16 different bank quads.  (A zero pad record per row, as in the first version, shifts every row by 144 B mod 256 and
+// made two lanes of most phases collide.)  The r - 1 neighbour of column 0 and the r + 1 neighbour of column W - 1 are read
+// from the zero area instead, at the lane's own offset mod 256 so that the redirected lanes keep their bank quads.
+// Tap addresses are (row base of (kz, kh)) + constant: the matrix waves spend ~1-2 VALU instructions per MFMA triple on
+// addressing.  That matters: one vector issue port per SIMD serves the matrix wave's MFMAs (8 of every 32 cycles) AND every
+// VALU instruction of both resident waves.
 struct ZsGeo {
   int PV, vox;            // plane / sample size in voxels
   int SPV, halo, rows;    // strip-plane voxels (HS * W); strips carry one phi halo row on either side; image rows per plane
@@ -127,10 +131,10 @@ __device__ __forceinline__ ZsGeo zs_geo(const ConvZsArgs& a) {
   g.strip = blockIdx.x / a.nchunk;
   g.chunk = blockIdx.x - g.strip * a.nchunk;
   g.h0 = g.strip * a.HS;
-  g.pitch = a.W + 1;
-  g.PLB = g.rows * g.pitch * ZS_VB;
-  g.RB = ZS_VB;  // ring starts after one zero record
-  g.ZPART = (g.RB + a.NR * g.PLB + 255) & ~255;
+  g.pitch = a.W;
+  g.PLB = (g.rows * g.pitch * ZS_VB + 255) & ~255;
+  g.RB = ZS_ZERO;  // ring starts after the zero area
+  g.ZPART = g.RB + a.NR * g.PLB;
   g.v0 = g.chunk * a.CV;
   g.cend = min(g.v0 + a.CV, a.D * g.SPV);
   g.nsteps = (g.cend - g.v0 + ZS_STEP - 1) / ZS_STEP;
@@ -185,6 +189,7 @@ __device__ __forceinline__ void zs_matrix_wave(const ConvZsArgs& a, char* lds) {
   // constant part of every fragment address: ring base, this wave's k-step, this lane's channel half, and the -1 record of
   // the kw = 0 tap (so that the per-tap constants kw * ZS_VB are non-negative immediates)
   const int kconst = G.RB + KSTEP * 64 + half * 16 - ZS_VB;
+  const int W1 = W - 1;
 
   __builtin_amdgcn_s_waitcnt(0x0F70);  // weights have landed: no vmcnt wait inside the loop
   zs_barrier_lds();                    // P: prologue planes staged by the helper waves
@@ -196,8 +201,11 @@ __device__ __forceinline__ void zs_matrix_wave(const ConvZsArgs& a, char* lds) {
 
   for (int s = 0; s < G.nsteps; ++s) {
     int rb[ZS_TILES][3][3];  // address of the kw = 0 tap's fragment for every (kz, kh)
+    bool eL[ZS_TILES], eR[ZS_TILES];  // this lane's voxel is in the first / last column: its kw = 0 / kw = 2 taps read zeros
 #pragma unroll
     for (int t = 0; t < ZS_TILES; ++t) {
+      eL[t] = gw == 0;
+      eR[t] = gw == W1;
       const int pb = ((gh + G.halo) * G.pitch + gw) * ZS_VB + kconst;
       // phi neighbours: strips carry halo rows; whole planes wrap around
       const int ro0 = (G.halo || gh > 0) ? -RWB : (H - 1) * RWB;
@@ -228,7 +236,10 @@ __device__ __forceinline__ void zs_matrix_wave(const ConvZsArgs& a, char* lds) {
       if (DBG & 32) return;
       const int t = pair_tile(i), tap = pair_tap(i);
       const int kz = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-      const char* p = lds + rb[t][kz][kh] + kw * ZS_VB;
+      int base = rb[t][kz][kh] + kw * ZS_VB;
+      if (kw == 0) base = eL[t] ? (base & 255) : base;  // into the zero area, same bank quad
+      if (kw == 2) base = eR[t] ? (base & 255) : base;
+      const char* p = lds + base;
       fa[i % (PD + 1)][0] = *(const u32x4*)p;
       fa[i % (PD + 1)][1] = *(const u32x4*)(p + 32);
     };
@@ -362,12 +373,8 @@ __device__ __forceinline__ void zs_helper_wave(const ConvZsArgs& a, char* lds, c
     }
   };
 
-  // prologue: leading zero record, the zero pad record of every row of every ring plane, planes needed by steps 0..2
-  if (tid < ZS_VB / 4) ((float*)lds)[tid] = 0.f;
-  for (int i = tid; i < a.NR * G.rows * (ZS_VB / 4); i += 256) {
-    const int row = i / (ZS_VB / 4), wd = i - row * (ZS_VB / 4);
-    ((float*)(lds + G.RB + (row * G.pitch + a.W) * ZS_VB))[wd] = 0.f;
-  }
+  // prologue: the zero area, planes needed by steps 0..2
+  if (tid < ZS_ZERO / 4) ((float*)lds)[tid] = 0.f;
   auto need = [&](int k) {  // highest plane that step k reads
     k = min(k, G.nsteps - 1);
     return min(G.v0 + k * ZS_STEP + ZS_STEP - 1, G.cend - 1) / SPV + 1;
@@ -503,7 +510,7 @@ bool try_launch_conv_zslide(const float* in0, int c0, const float* in1, int c1, 
   auto ring_for = [&](int hs) { return hs * W >= 2 * ZS_STEP ? 4 : 5; };
   auto lds_for = [&](int hs) {
     const int rows = hs + (hs < H ? 2 : 0);
-    return (((size_t)ZS_VB + (size_t)ring_for(hs) * rows * (W + 1) * ZS_VB + 255) & ~(size_t)255) + ZS_PART;
+    return (size_t)ZS_ZERO + (size_t)ring_for(hs) * (((size_t)rows * W * ZS_VB + 255) & ~(size_t)255) + ZS_PART;
   };
   int HS = 0;
   for (int hs = H; hs >= 1; --hs) {  // the largest strip that fits: least halo restaging

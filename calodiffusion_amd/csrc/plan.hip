@@ -325,6 +325,7 @@ void build_plan(CdPlan* p) {
     // 16-bit split images: the 3x3x3 / strided convs and the attention's to_qkv (cout = 96)
     if (w.pack == PK_CONV && (w.taps == 27 || w.taps == 48 || (w.taps == 1 && w.cout == 96)))
       w.pk3_off = bump(packed_split16_bytes(w.cin, w.cout, w.taps) / 4);
+    else if (w.pack == PK_CONVT) w.pk3_off = bump(packed_f16x2_bytes(w.cin, w.cout, w.taps) / 4);  // f16x2 image only
     else if (w.pack == PK_INIT) w.pk_off = bump((size_t)w.numel);
   }
   p->arena_floats = off;
@@ -768,7 +769,8 @@ float* unet_body(CdPlan* p, Run& r, const float* emb, float* h) {
       const Dims3 od = p->up_out[i];
       float* y = r.ws->get<float>((size_t)r.B * od.vox() * cx);
       if (!r.dry())
-        launch_conv_transpose_mfma(x, cx, p->packed(p->ups[i].sw), p->raw(p->ups[i].sb), y, r.B, cx, dims, od, p->up_kz[i], zs, r.s);
+        launch_conv_transpose_mfma(x, cx, p->packed(p->ups[i].sw), p->raw(p->ups[i].sb), y, r.B, cx, dims, od, p->up_kz[i], zs, r.s,
+                                   p->packed3(p->ups[i].sw), r.status);
       r.ws->release(x);
       x = y;
     }
@@ -934,8 +936,12 @@ int cd_plan_set_weight(CdPlan* plan, const char* name, const float* dev_ptr, int
     hipStream_t s = (hipStream_t)stream;
     CD_HIP(hipMemcpyAsync(plan->arena + w.raw_off, dev_ptr, sizeof(float) * (size_t)numel, hipMemcpyDeviceToDevice, s));
     if (w.pack == PK_CONV) launch_pack_weights(plan->arena + w.raw_off, plan->arena + w.pk_off, w.cout, w.cin, w.taps, false, s);
-    if (w.pk3_off) launch_pack_weights_split16(plan->arena + w.raw_off, plan->arena + w.pk3_off, w.cout, w.cin, w.taps, s);
-    else if (w.pack == PK_CONVT) launch_pack_weights(plan->arena + w.raw_off, plan->arena + w.pk_off, w.cout, w.cin, w.taps, true, s);
+    if (w.pack == PK_CONVT) {
+      launch_pack_weights(plan->arena + w.raw_off, plan->arena + w.pk_off, w.cout, w.cin, w.taps, true, s);
+      launch_pack_weights_f16x2(plan->arena + w.raw_off, plan->arena + w.pk3_off, w.cout, w.cin, w.taps, s, true, false);
+    } else if (w.pk3_off) {
+      launch_pack_weights_split16(plan->arena + w.raw_off, plan->arena + w.pk3_off, w.cout, w.cin, w.taps, s);
+    }
     else if (w.pack == PK_INIT) launch_pack_init_weights(plan->arena + w.raw_off, plan->arena + w.pk_off, w.cout, w.cin, s);
     w.set = true;
   });
@@ -1281,9 +1287,11 @@ int cd_op_cyl_conv_transpose(const float* x, const float* w, const float* bias, 
     hipStream_t s = (hipStream_t)stream;
     float* wpk = (float*)scratch;
     launch_pack_weights(w, wpk, channels, channels, kernel_z * 16, true, s);
+    float* wpk16 = wpk + ((packed_weight_floats(channels, channels, kernel_z * 16) + 63) & ~(size_t)63);
+    launch_pack_weights_f16x2(w, wpk16, channels, channels, kernel_z * 16, s, true, false);
     const Dims3 din{dims_in[0], dims_in[1], dims_in[2]};
     const Dims3 dout{(din.d - 1) * stride_z - 2 + kernel_z, 2 * din.h + out_pad[1], 2 * din.w + out_pad[2]};
-    launch_conv_transpose_mfma(x, channels, wpk, bias, y, batch, channels, din, dout, kernel_z, stride_z, s);
+    launch_conv_transpose_mfma(x, channels, wpk, bias, y, batch, channels, din, dout, kernel_z, stride_z, s, wpk16, nullptr);
   });
 }
 

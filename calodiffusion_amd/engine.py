@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcalodiff_hip.so")
+LIB_PATH = os.environ.get("CALODIFF_LIB") or os.path.join(_HERE, "lib", "libcalodiff_hip.so")  # override: A/B builds
 
 CD_MAX_SIZES = 8
 TIME_KINDS = {"log": 0, "sigma": 1, "raw": 2}
