@@ -260,7 +260,9 @@ void launch_attn_kv_context(const float* x, int C, const float* coef, const void
                             int64_t vox, int nsplit, hipStream_t s, const GnDefer* defer = nullptr);
 void launch_attn_out(const float* x, int C, const float* coef, const void* wqkv_f16x2, const float* wT_b, const float* bias,
                      float* y, float* ch_part /* [B][nsplit][C][2] */, int batch, int64_t vox, int nsplit, hipStream_t s,
-                     const GnDefer* defer = nullptr);
+                     const GnDefer* defer = nullptr,
+                     // wT_b == null: every workgroup merges the pass-1 partials and folds W_out itself (no combine launch)
+                     const float* partials = nullptr, const float* w_out = nullptr, float scale = 0.f);
 
 struct EmbedLayer {
   const float* w;  // (cout, 128) torch layout

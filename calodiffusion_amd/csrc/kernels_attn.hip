@@ -38,7 +38,10 @@ struct AttnArgs {
   float* partials;    // [B][nsplit][64 + 1024]
   int nsplit;
   // pass 2
-  const float* wT;    // [B][CT][4][64][4]: per-sample folded output weights, transposed-K layout (attn_combine, layout_T)
+  const float* wT;    // [B][CT][4][64][4]: per-sample folded output weights, transposed-K layout (attn_combine, layout_T),
+                      // or null: every workgroup folds them itself from `partials` (fold_*)
+  const float* fold_wout;  // to_out weight, torch (C, 32)
+  float fold_scale;        // dim_head^-1/2
   const float* bias;  // (C)
   float* y;           // (B, vox, C)
   float* ch_part;     // [B][units][C][2]
@@ -257,6 +260,43 @@ __global__ void __launch_bounds__(512) attn_kv_context_kernel(AttnArgs a) {
   }
 }
 
+// Merge of the pass-1 partials and fold of the context into the output projection, by every workgroup of pass 2 for its own
+// sample (same arithmetic, in the same order, as attn_combine_kernel, kernels_norm_attn.hip: the separate launch was 11 us of
+// pure latency per attention block):  W'[c][d] = scale * sum_e W_out[c][e] ctx[d][e] / sum[d]  in the k-slot order of an
+// accumulator-register A operand, into sW[NCH][4][64][4].
+template <int NCH>
+__device__ __forceinline__ void attn_fold_weights(const AttnArgs& a, int b, float* sW) {
+  __shared__ float sM[32], sInv[32];
+  __shared__ float sCtx[1024];
+  const int tid = threadIdx.x;
+  const float* p = a.partials + (size_t)b * a.nsplit * (64 + 1024);
+  if (tid < 32) {
+    float M = -3.0e38f;
+    for (int i = 0; i < a.nsplit; ++i) M = fmaxf(M, p[(size_t)i * 1088 + tid]);
+    float S = 0.f;
+    for (int i = 0; i < a.nsplit; ++i) S += p[(size_t)i * 1088 + 32 + tid] * expf(p[(size_t)i * 1088 + tid] - M);
+    sM[tid] = M;
+    sInv[tid] = a.fold_scale / S;
+  }
+  __syncthreads();
+  for (int i = tid; i < 1024; i += 512) {
+    const int d = i >> 5;
+    float c = 0.f;
+    for (int k = 0; k < a.nsplit; ++k) c += p[(size_t)k * 1088 + 64 + i] * expf(p[(size_t)k * 1088 + d] - sM[d]);
+    sCtx[i] = c * sInv[d];
+  }
+  __syncthreads();
+  for (int i = tid; i < NCH * 1024; i += 512) {
+    const int e4 = i & 3, lane = (i >> 2) & 63, q = (i >> 8) & 3, ct = i >> 10;
+    const int c = ct * 32 + (lane & 31);
+    const int d = e4 + 8 * q + 4 * (lane >> 5);
+    float acc = 0.f;
+    for (int e = 0; e < 32; ++e) acc = fmaf(a.fold_wout[c * 32 + e], sCtx[d * 32 + e], acc);
+    sW[i] = acc;
+  }
+  __syncthreads();
+}
+
 template <int NCH>
 __global__ void __launch_bounds__(512) attn_out_kernel(AttnArgs a) {
   __shared__ float sRed[8][NCH * 32][2];
@@ -277,10 +317,19 @@ __global__ void __launch_bounds__(512) attn_out_kernel(AttnArgs a) {
     wq2[ks] = a.wqkv[(size_t)(ks * 3 + 0) * 128 + 64 + lane];
   }
   f32x4 wt[NCH][4];
+  if (a.wT) {
 #pragma unroll
-  for (int ch = 0; ch < NCH; ++ch)
+    for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) wt[ch][q] = ((const f32x4*)a.wT)[(((size_t)b * NCH + ch) * 4 + q) * 64 + lane];  // output channel tile ch
+      for (int q = 0; q < 4; ++q) wt[ch][q] = ((const f32x4*)a.wT)[(((size_t)b * NCH + ch) * 4 + q) * 64 + lane];  // output channel tile ch
+  } else {
+    __shared__ __attribute__((aligned(16))) float sW[NCH * 1024];
+    attn_fold_weights<NCH>(a, b, sW);
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) wt[ch][q] = ((const f32x4*)sW)[(ch * 4 + q) * 64 + lane];
+  }
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float bv[NCH], s1[NCH], s2[NCH];
 #pragma unroll
@@ -418,11 +467,14 @@ void launch_attn_kv_context(const float* x, int C, const float* coef, const void
 }
 
 void launch_attn_out(const float* x, int C, const float* coef, const void* wqkv_f16x2, const float* wT_b, const float* bias,
-                     float* y, float* ch_part, int batch, int64_t vox, int nsplit, hipStream_t s, const GnDefer* defer) {
+                     float* y, float* ch_part, int batch, int64_t vox, int nsplit, hipStream_t s, const GnDefer* defer,
+                     const float* partials, const float* w_out, float scale) {
   CD_REQUIRE(C == 32 || C == 64 || C == 96 || C == 128, "fused attention: 32..128 channels");
   AttnArgs a{};
   a.x = x; a.coef = coef; a.wqkv = (const u32x4*)wqkv_f16x2; a.C = C; a.vox = vox; a.tiles_per_wg = tiles_per_wg_for(vox, nsplit);
   a.wT = wT_b; a.bias = bias; a.y = y; a.ch_part = ch_part;
+  CD_REQUIRE(wT_b || (partials && w_out), "attn_out: folded weights or the pass-1 partials to fold them from");
+  a.partials = const_cast<float*>(partials); a.nsplit = nsplit; a.fold_wout = w_out; a.fold_scale = scale;
   if (defer) a.defer = *defer;
   prof::Scope scope("attn_out", s, 2.0 * (2.0 * C) * 32 * (double)vox * batch, 4.0 * batch * (double)vox * C * 2);
   const dim3 grid((unsigned)nsplit, (unsigned)batch);

@@ -534,8 +534,13 @@ float* attn_block(Run& r, const AttnP& w, const float* x, Dims3 dims, float* xpa
     ypart = ws->get<float>((size_t)r.B * yu * C * 2);
     if (!r.dry()) {
       launch_attn_kv_context(x, C, coefn, w.qkv16, part, r.B, vox, nsp, r.s, dnp);
-      launch_attn_combine(part, nsp, w.ow, C, wpb, r.B, 0.17677669529663689f /* 32^-1/2 */, r.s, nullptr, nullptr, true);
-      launch_attn_out(x, C, coefn, w.qkv16, wpb, w.ob, y, ypart, r.B, vox, nsp, r.s, dnp);
+      static const bool sep_combine = getenv("CD_ATTN_COMBINE_LAUNCH") != nullptr;  // A/B: the separate combine launch
+      if (sep_combine) {
+        launch_attn_combine(part, nsp, w.ow, C, wpb, r.B, 0.17677669529663689f /* 32^-1/2 */, r.s, nullptr, nullptr, true);
+        launch_attn_out(x, C, coefn, w.qkv16, wpb, w.ob, y, ypart, r.B, vox, nsp, r.s, dnp);
+      } else {
+        launch_attn_out(x, C, coefn, w.qkv16, nullptr, w.ob, y, ypart, r.B, vox, nsp, r.s, dnp, part, w.ow, 0.17677669529663689f);
+      }
     }
     if (own) ws->release(own);
     own = nullptr;
