@@ -190,8 +190,14 @@ struct InitConvArgs {
   float* out = nullptr;           // channels-last
   int batch = 0, cout = 0;
   Dims3 dims{};
+  float* coord_table = nullptr;   // optional (vox, cout) buffer: enables the matrix-core path (cx == 1), which splits the conv
+                                  // into the sample-independent coordinate-channel part (+ bias) and the x part
+  bool table_ready = false;       // coord_table already holds that part (launch_init_coord_table); else it is filled first
+  int* status = nullptr;          // bit 0: a staged value exceeded the fp16 range (matrix-core path)
 };
 void launch_init_conv(const InitConvArgs& a, hipStream_t s);
+// coordinate channels + bias of the init conv into a.coord_table (vox, cout): changes only with the weights / profiles
+void launch_init_coord_table(const InitConvArgs& a, hipStream_t s);
 
 int gn_nsplit_for(int64_t vox, int batch);
 // channel partials [B][nsplit][C][2] of a tensor whose producer has no stats epilogue

@@ -2181,8 +2181,8 @@ __global__ void __launch_bounds__(256) init_conv_kernel(InitConvArgs a) {
   const int D = a.dims.d, H = a.dims.h, W = a.dims.w;
   const int nn = valid ? (int)n : 0;
   const int w = nn % W, h = (nn / W) % H, z = nn / (W * H);
-  float sc = a.scale_b ? a.scale_b[(size_t)b * a.scale_stride] : 1.f;
-  if (a.sigma_b) {  // same expression as embed_kernel's c_in
+  float sc = (a.x && a.scale_b) ? a.scale_b[(size_t)b * a.scale_stride] : 1.f;
+  if (a.x && a.sigma_b) {  // same expression as embed_kernel's c_in
     const float tv = a.sigma_b[b], sd = a.sigma_data;
     sc = 1.f / sqrtf(tv * tv + sd * sd);
   }
@@ -2209,8 +2209,10 @@ __global__ void __launch_bounds__(256) init_conv_kernel(InitConvArgs a) {
           float v = 0.f;
           if (inb) {
             if (ci < a.cx) {
-              v = a.x[(((size_t)b * a.cx + ci) * D + zz) * H * W + (size_t)hh * W + ww];
-              if (ci == 0) v *= sc;
+              if (a.x) {  // null: only the synthesised channels contribute (coordinate table of the matrix-core path)
+                v = a.x[(((size_t)b * a.cx + ci) * D + zz) * H * W + (size_t)hh * W + ww];
+                if (ci == 0) v *= sc;
+              }
             } else {
               const int k = ci - a.cx;
               if (a.use_rz) v = (k == 0) ? a.r_w[ww] : (k == 1 ? a.z_d[zz] : a.phi_h[hh]);
@@ -2231,9 +2233,147 @@ __global__ void __launch_bounds__(256) init_conv_kernel(InitConvArgs a) {
   }
 }
 
+// The same conv on the matrix cores when x is the only data channel (the denoiser's case).  The conv is linear in its input
+// channels: the coordinate channels' contribution (+ bias) is the same for every sample and step -- `table` (vox, cout), filled
+// by one batch-1 launch of the kernel above with x = null -- and what remains is a 27-tap, one-channel conv of c_in * x:
+// K = 27 padded to 32 = two fp16 k-steps (f16x2: three MFMAs each) per 32 voxels instead of 27 * cin * 32 scalar FMAs per
+// voxel.  A workgroup owns TZ z-planes of one sample: c_in * x of those planes (+ halo: zero planes / columns outside the
+// grid, phi rows wrapped) sits in LDS as fp32, so every tap of every voxel is "base + constant".
+__global__ void __launch_bounds__(256) init_conv_f16x2_kernel(InitConvArgs a, const float* __restrict__ table, int TZ) {
+  extern __shared__ __attribute__((aligned(16))) float img[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
+  const int b = blockIdx.y;
+  const int D = a.dims.d, H = a.dims.h, W = a.dims.w, PV = H * W;
+  const int z0 = blockIdx.x * TZ, nz = min(TZ, D - z0);
+  const int HP = H + 2, WP = W + 2;
+  float sc = a.scale_b ? a.scale_b[(size_t)b * a.scale_stride] : 1.f;
+  if (a.sigma_b) {  // same expression as embed_kernel's c_in
+    const float tv = a.sigma_b[b], sd = a.sigma_data;
+    sc = 1.f / sqrtf(tv * tv + sd * sd);
+  }
+  {
+    const float* xb = a.x + (size_t)b * D * PV;
+    float amax = 0.f;
+    for (int i = tid; i < (nz + 2) * HP * WP; i += 256) {
+      const int lw = i % WP, r = i / WP, lh = r % HP, lz = r / HP;
+      const int gz = z0 - 1 + lz, gw = lw - 1;
+      int gh = lh - 1;
+      gh = gh < 0 ? gh + H : (gh >= H ? gh - H : gh);
+      gh = gh % H;  // H == 1 or 2
+      float v = 0.f;
+      if (gz >= 0 && gz < D && gw >= 0 && gw < W) v = xb[((size_t)gz * H + gh) * W + gw] * sc;
+      amax = fmaxf(amax, fabsf(v));
+      img[i] = v;
+    }
+    if (a.status && amax > 65504.f) atomicOr(a.status, 1);
+  }
+  // this lane's 16 im2col columns: k = ks*16 + half*8 + e = tap index (k >= 27: zero weight, any readable cell)
+  int toff[2][8];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = ks * 16 + half * 8 + e;
+      const int kz = k / 9, kh = (k / 3) % 3, kw = k % 3;
+      toff[ks][e] = k < 27 ? (kz * HP + kh) * WP + kw : 0;
+    }
+  __syncthreads();
+  const int nvox = nz * PV, ntiles = (nvox + 31) / 32;
+  const int64_t vox = a.dims.vox();
+  for (int ct = 0; ct < a.cout / 32; ++ct) {
+    u32x4 w1[2], w2[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      f32x4 wv[2];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = ks * 16 + half * 8 + e;
+        wv[e >> 2][e & 3] = k < 27 ? a.wpk[((size_t)k * a.cin) * a.cout + ct * 32 + col] : 0.f;
+      }
+      u32x2 a1, a2, b1, b2;
+      split2(wv[0], a1, a2);
+      split2(wv[1], b1, b2);
+      w1[ks] = u32x4{a1[0], a1[1], b1[0], b1[1]};
+      w2[ks] = u32x4{a2[0], a2[1], b2[0], b2[1]};
+    }
+    for (int tile = wave; tile < ntiles; tile += 4) {
+      const int v = min(tile * 32 + col, nvox - 1);
+      const int lz = v / PV, p = v - lz * PV, h = p / W, w = p - h * W;
+      const float* base = img + (lz * HP + h) * WP + w;
+      // the table rows of this tile are requested first, unconditionally (clamped), so that all 16 loads are in flight
+      // under the gather and the MFMAs instead of one load-store round trip per row
+      float tb[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int vr = min(tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, nvox - 1);
+        tb[r] = table[((size_t)z0 * PV + vr) * a.cout + ct * 32 + col];
+      }
+      f32x16 accA, accB;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accA[r] = accB[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        f32x4 xv[2];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xv[e >> 2][e & 3] = base[toff[ks][e]];
+        u32x2 a1, a2, b1, b2;
+        split2(xv[0], a1, a2);
+        split2(xv[1], b1, b2);
+        const u32x4 x1 = {a1[0], a1[1], b1[0], b1[1]}, x2 = {a2[0], a2[1], b2[0], b2[1]};
+        accA = MFMA_F16(x1, w1[ks], accA);
+        accB = MFMA_F16(x1, w2[ks], accB);
+        accB = MFMA_F16(x2, w1[ks], accB);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int vr = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (vr < nvox) {
+          const size_t g = (size_t)z0 * PV + vr;
+          a.out[((size_t)b * vox + g) * a.cout + ct * 32 + col] = accA[r] + accB[r] * (1.f / 2048.f) + tb[r];
+        }
+      }
+    }
+  }
+}
+
+void launch_init_coord_table(const InitConvArgs& a, hipStream_t s) {
+  CD_REQUIRE(a.coord_table && a.cout % 32 == 0 && a.cin >= 1 && a.cin <= 4, "init conv table: bad arguments");
+  // the scalar kernel at batch 1 without x
+  InitConvArgs t = a;
+  t.x = nullptr; t.cx = 1; t.batch = 1; t.out = a.coord_table; t.scale_b = nullptr; t.sigma_b = nullptr;
+  dim3 tgrid((unsigned)((a.dims.vox() + 255) / 256), 1u, (unsigned)(a.cout / 32));
+  switch (a.cin) {
+    case 1: hipLaunchKernelGGL(init_conv_kernel<1>, tgrid, dim3(256), 0, s, t); break;
+    case 2: hipLaunchKernelGGL(init_conv_kernel<2>, tgrid, dim3(256), 0, s, t); break;
+    case 3: hipLaunchKernelGGL(init_conv_kernel<3>, tgrid, dim3(256), 0, s, t); break;
+    case 4: hipLaunchKernelGGL(init_conv_kernel<4>, tgrid, dim3(256), 0, s, t); break;
+  }
+  CD_HIP(hipGetLastError());
+}
+
 void launch_init_conv(const InitConvArgs& a, hipStream_t s) {
   CD_REQUIRE(a.cout % 32 == 0, "init conv: output channels must be a multiple of 32");
   CD_REQUIRE(a.cin >= 1 && a.cin <= 4 && a.cx <= a.cin, "init conv: 1..4 input channels supported");
+  static const bool full_range = getenv("CD_CONV_PRECISION") && (!strcmp(getenv("CD_CONV_PRECISION"), "f32") ||
+                                                                  !strcmp(getenv("CD_CONV_PRECISION"), "bf16x3"));
+  static const bool no_mfma = getenv("CD_NO_INIT_MFMA") != nullptr;
+  if (a.coord_table && a.cx == 1 && a.x && !full_range && !no_mfma) {
+    prof::Scope scope("init_conv", s, 2.0 * 27 * a.cin * a.cout * (double)a.dims.vox() * a.batch,
+                      4.0 * a.batch * (double)a.dims.vox() * (a.cx + a.cout));
+    if (!a.table_ready) launch_init_coord_table(a, s);  // (~25 us of scalar-kernel latency: callers that can, keep the table)
+    // 2. the x part on the matrix cores: TZ planes per workgroup, about two rounds of workgroups
+    const int D = a.dims.d;
+    int slabs = (512 + a.batch - 1) / a.batch;
+    slabs = slabs < 1 ? 1 : (slabs > D ? D : slabs);
+    int TZ = (D + slabs - 1) / slabs;
+    while (TZ > 1 && (size_t)(TZ + 2) * (a.dims.h + 2) * (a.dims.w + 2) * 4 > 60 * 1024) --TZ;
+    const size_t lds = (size_t)(TZ + 2) * (a.dims.h + 2) * (a.dims.w + 2) * 4;
+    CD_REQUIRE(lds <= 64 * 1024, "init conv: plane too large for the LDS image");
+    dim3 grid((unsigned)((D + TZ - 1) / TZ), (unsigned)a.batch);
+    hipLaunchKernelGGL(init_conv_f16x2_kernel, grid, dim3(256), lds, s, a, (const float*)a.coord_table, TZ);
+    CD_HIP(hipGetLastError());
+    return;
+  }
   dim3 grid((unsigned)((a.dims.vox() + 255) / 256), (unsigned)a.batch, (unsigned)(a.cout / 32));
   prof::Scope scope("init_conv", s, 2.0 * 27 * a.cin * a.cout * (double)a.dims.vox() * a.batch,
                     4.0 * a.batch * (double)a.dims.vox() * (a.cx + a.cout));

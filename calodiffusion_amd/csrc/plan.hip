@@ -138,6 +138,7 @@ struct CdPlan {
   std::vector<std::pair<int, int>> embed_list;  // (weight idx of mlp w, emb offset) in ResW order
 
   float* d_coords = nullptr;  // r[W], z[D], phi[H]
+  float* d_init_table = nullptr;  // (vox, C0): coordinate-channel part + bias of the init conv (refresh_init_table)
   bool coords_set = false;
 
   // sampler state (device): step table, counter, stepvals
@@ -356,6 +357,8 @@ void build_plan(CdPlan* p) {
   if (p->emb_ld == 0) p->emb_ld = 4;
 
   CD_HIP(hipMalloc((void**)&p->d_coords, sizeof(float) * (size_t)(d.grid[0] + d.grid[1] + d.grid[2] + 4)));
+  CD_HIP(hipMemset(p->d_coords, 0, sizeof(float) * (size_t)(d.grid[0] + d.grid[1] + d.grid[2] + 4)));
+  CD_HIP(hipMalloc((void**)&p->d_init_table, sizeof(float) * (size_t)p->shapes[0].vox() * d.layer_sizes[0]));
   CD_HIP(hipMalloc((void**)&p->d_table, sizeof(float) * 4 * CdPlan::kMaxSteps));
   CD_HIP(hipMalloc((void**)&p->d_counter, sizeof(int) * 4));  // [0] sampler step counter, [2] range flags
   CD_HIP(hipMemset(p->d_counter, 0, sizeof(int) * 4));
@@ -806,6 +809,22 @@ EmbedArgs embed_args(CdPlan* p, int B, const float* cond, const float* t, int ki
   return e;
 }
 
+// The init conv's coordinate channels (R, Z, phi images) and bias contribute the same (vox, C0) tensor to every sample and
+// step: kept in the plan, recomputed whenever the init conv's parameters or the coordinate profiles are (re)set.
+static void init_conv_coord_args(CdPlan* p, InitConvArgs& a) {
+  const CdUnetDesc& d = p->desc;
+  a.cin = d.in_channels; a.wpk = p->packed(p->init_w); a.bias = p->raw(p->init_b); a.cout = d.layer_sizes[0]; a.dims = p->shapes[0];
+  a.cx = 1; a.use_rz = d.rz_input; a.use_phi = d.phi_input;
+  a.r_w = p->d_coords; a.z_d = p->d_coords + d.grid[2]; a.phi_h = p->d_coords + d.grid[2] + d.grid[0];
+  a.coord_table = p->d_init_table;
+}
+static void refresh_init_table(CdPlan* p, hipStream_t s) {
+  if (!p->weights[p->init_w].set || !p->weights[p->init_b].set) return;
+  InitConvArgs a;
+  init_conv_coord_args(p, a);
+  launch_init_coord_table(a, s);
+}
+
 // shared by cd_unet_forward (raw = true) and cd_denoise; workspace must have been reset by the caller
 void forward_impl(CdPlan* p, int B, const float* x, const float* cond, const float* t, float* out, bool raw, hipStream_t s) {
   const CdUnetDesc& d = p->desc;
@@ -826,6 +845,7 @@ void forward_impl(CdPlan* p, int B, const float* x, const float* cond, const flo
     } else {
       a.cx = 1; a.sigma_b = t; a.sigma_data = d.sigma_data; a.use_rz = d.rz_input; a.use_phi = d.phi_input;
       a.r_w = p->d_coords; a.z_d = p->d_coords + d.grid[2]; a.phi_h = p->d_coords + d.grid[2] + d.grid[0];
+      a.coord_table = p->d_init_table; a.table_ready = true; a.status = r.status;
     }
     launch_init_conv(a, s);
   }
@@ -907,6 +927,7 @@ int cd_plan_destroy(CdPlan* plan) {
     if (plan->arena) hipFree(plan->arena);
     if (plan->d_embed_layers) hipFree(plan->d_embed_layers);
     if (plan->d_coords) hipFree(plan->d_coords);
+    if (plan->d_init_table) hipFree(plan->d_init_table);
     if (plan->d_table) hipFree(plan->d_table);
     if (plan->d_counter) hipFree(plan->d_counter);
     if (plan->d_stepvals) hipFree(plan->d_stepvals);
@@ -949,6 +970,7 @@ int cd_plan_set_weight(CdPlan* plan, const char* name, const float* dev_ptr, int
     }
     else if (w.pack == PK_INIT) launch_pack_init_weights(plan->arena + w.raw_off, plan->arena + w.pk_off, w.cout, w.cin, s);
     w.set = true;
+    if (it->second == plan->init_w || it->second == plan->init_b) refresh_init_table(plan, s);
   });
 }
 
@@ -962,6 +984,7 @@ int cd_plan_set_coords(CdPlan* plan, const float* r_w, const float* z_d, const f
     CD_HIP(hipMemcpyAsync(plan->d_coords + d.grid[2] + d.grid[0], phi_h, sizeof(float) * d.grid[1], hipMemcpyHostToDevice, s));
     CD_HIP(hipStreamSynchronize(s));  // the host arrays may be temporaries
     plan->coords_set = true;
+    refresh_init_table(plan, s);
   });
 }
 
