@@ -191,6 +191,7 @@ __device__ __forceinline__ void zs_matrix_wave(const ConvZsArgs& a, char* lds) {
   const int kconst = G.RB + KSTEP * 64 + half * 16 - ZS_VB;
   const int W1 = W - 1;
 
+  if (a.defer.part) gn_defer_to_lds(a.defer, blockIdx.y, (float*)(lds + G.ZPART), lds + G.ZPART + a.defer.C * 16);
   __builtin_amdgcn_s_waitcnt(0x0F70);  // weights have landed: no vmcnt wait inside the loop
   zs_barrier_lds();                    // P: prologue planes staged by the helper waves
 
@@ -300,13 +301,6 @@ __device__ __forceinline__ void zs_helper_wave(const ConvZsArgs& a, char* lds, c
   const int q = tid & 7, p0 = tid >> 3;
   f32x4 cf[4];
   const bool normed = a.coef || a.defer.part;
-  if (a.defer.part) {  // table built by the whole workgroup in the (still unused) partial-exchange region
-#pragma unroll
-    for (int e = 0; e < 4; ++e) cf[e] = *(const f32x4*)(part + (a.choff + q * 4 + e) * 16);
-  } else if (a.coef) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) cf[e] = *(const f32x4*)(a.coef + ((size_t)b * a.coef_c + q * 4 + e) * 4);
-  }
   const float bv = a.bias ? a.bias[ct * 32 + col] : 0.f;
   const float* src_b = a.in + (size_t)b * G.vox * a.ldc + q * 4;
   int rec[ZS_NSL];   // byte offset of this thread's record k inside a plane image (+ its quad's place in the record)
@@ -331,21 +325,22 @@ __device__ __forceinline__ void zs_helper_wave(const ConvZsArgs& a, char* lds, c
   // for those stores.  (Left to the compiler the wait is vmcnt(4..0): conditional paths make it assume no younger operation,
   // and every conversion then also waits a store round trip.)  Out-of-range planes are clamped and zero-filled by convert().
   constexpr int NYOUNG = ACC ? 16 : 8;
-  auto issue = [&](int z) {
+  auto issue_to = [&](f32x4 (&dst)[ZS_NSL], int z) {
     const int zc = min(max(z, 0), a.D - 1);
     const float* src = src_b + (size_t)zc * PV * a.ldc;
 #pragma unroll
     for (int k = 0; k < ZS_NSL; ++k) {
       const float* p = src + (size_t)srcv[k] * a.ldc;
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ld[k]) : "v"(p) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[k]) : "v"(p) : "memory");
     }
   };
+  auto issue = [&](int z) { issue_to(ld, z); };
 #define ZS_LANDED(younger)                                                                                   \
   asm volatile("s_waitcnt vmcnt(%5)"                                                                         \
                : "+v"(ld[0]), "+v"(ld[1]), "+v"(ld[2]), "+v"(ld[3]), "+v"(ld[4])                             \
                : "n"(younger)                                                                                \
                : "memory")
-  auto convert = [&](int z, int k0, int k1) {  // slots [k0, k1) of plane z
+  auto convert_from = [&](const f32x4 (&src)[ZS_NSL], int z, int k0, int k1) {  // slots [k0, k1) of plane z
     const int slot = (z + a.NR) % a.NR;  // z >= -1
     const bool zero = z < 0 || z >= a.D;
     char* dst = lds + slot * G.PLB;
@@ -355,7 +350,7 @@ __device__ __forceinline__ void zs_helper_wave(const ConvZsArgs& a, char* lds, c
       if (p0 + 32 * k < NIMG) {
         u32x2 t1 = {0u, 0u}, t2 = {0u, 0u};
         if (!zero && !(DBG & 1)) {
-          f32x4 v = ld[k] * gscale;
+          f32x4 v = src[k] * gscale;
           if (normed) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -373,14 +368,39 @@ __device__ __forceinline__ void zs_helper_wave(const ConvZsArgs& a, char* lds, c
     }
   };
 
-  // prologue: the zero area, planes needed by steps 0..2
+  auto convert = [&](int z, int k0, int k1) { convert_from(ld, z, k0, k1); };
+
+  // prologue: the zero area, planes needed by step 0 (z-1 .. z+1 of its first voxel, one more if the step crosses a plane
+  // boundary: at most 4 since a plane holds at least one step).  Their loads all go out first, under the construction of the
+  // GroupNorm table, so the prologue pays one memory latency instead of one per plane.
   if (tid < ZS_ZERO / 4) ((float*)lds)[tid] = 0.f;
   auto need = [&](int k) {  // highest plane that step k reads
     k = min(k, G.nsteps - 1);
     return min(G.v0 + k * ZS_STEP + ZS_STEP - 1, G.cend - 1) / SPV + 1;
   };
   int zstaged = need(0);
-  for (int z = G.zfirst - 1; z <= zstaged; ++z) {
+  f32x4 ldp[4][ZS_NSL];
+  const int zp0 = G.zfirst - 1, npro = zstaged - zp0 + 1;  // 3 or 4
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (i < npro) issue_to(ldp[i], zp0 + i);
+  if (a.defer.part) {  // table built by the whole workgroup in the (still unused) partial-exchange region
+    gn_defer_to_lds(a.defer, b, (float*)part, part + a.defer.C * 16);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) cf[e] = *(const f32x4*)(part + (a.choff + q * 4 + e) * 16);
+  } else if (a.coef) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) cf[e] = *(const f32x4*)(a.coef + ((size_t)b * a.coef_c + q * 4 + e) * 4);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(ldp[i][0]), "+v"(ldp[i][1]), "+v"(ldp[i][2]), "+v"(ldp[i][3]), "+v"(ldp[i][4])
+                 :
+                 : "memory");
+    if (i < npro) convert_from(ldp[i], zp0 + i, 0, ZS_NSL);
+  }
+  for (int z = zp0 + 4; z <= zstaged; ++z) {  // (not reached for planes of >= 64 voxels)
     issue(z);
     ZS_LANDED(0);
     convert(z, 0, ZS_NSL);
@@ -483,10 +503,8 @@ __device__ __forceinline__ void zs_helper_wave(const ConvZsArgs& a, char* lds, c
 template <bool ACC, int DBG = 0>
 __global__ void __launch_bounds__(512, 1) conv_zslide_f16x2_kernel(ConvZsArgs a) {
   extern __shared__ __attribute__((aligned(16))) char zs_lds[];
-  if (a.defer.part) {
-    const ZsGeo G = zs_geo(a);
-    gn_defer_to_lds(a.defer, blockIdx.y, (float*)(zs_lds + G.ZPART), zs_lds + G.ZPART + a.defer.C * 16);
-  }
+  // (the GroupNorm coefficient table -- gn_defer_to_lds, a whole-workgroup call with barriers -- is built inside the two roles:
+  // the helper waves first put the loads of the chunk's first planes in flight)
   switch (threadIdx.x >> 6) {
     case 0: zs_matrix_wave<0, DBG>(a, zs_lds); break;
     case 1: zs_matrix_wave<1, DBG>(a, zs_lds); break;
