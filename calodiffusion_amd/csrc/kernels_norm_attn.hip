@@ -176,24 +176,48 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
       cf[e] = defer.part ? *(const f32x4*)(sCoef + (c + e) * 4) : *(const f32x4*)(coef + ((size_t)b * channels + c + e) * 4);
     const size_t sbase = (size_t)b * vox * channels;
     const int res_c1 = channels - res_c0;
-    for (int64_t v = v0 + row; v < v1; v += rows) {
-      f32x4 t = *(const f32x4*)(x + sbase + (size_t)v * channels + c);
+    // SiLU on the transcendental unit (v_exp / v_rcp, ~3 ulp: the conv kernels' fused form, zs_silu): libm's expf was ~25 VALU
+    // instructions per element on a kernel that should only wait for HBM
+    auto act = [&](f32x4 t) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float u = cf[e][0] * t[e] + cf[e][1];
-        if (silu) u = u / (1.f + expf(-u));
+        if (silu) u = u * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(u * -1.4426950408889634f));
         t[e] = u + cf[e][2];
       }
-      if (residual1) {
-        // identity shortcut of a block whose input is a (never materialised) channel concat of two tensors
-        t += c < res_c0 ? *(const f32x4*)(residual + ((size_t)b * vox + v) * res_c0 + c)
-                        : *(const f32x4*)(residual1 + ((size_t)b * vox + v) * res_c1 + (c - res_c0));
-      } else if (residual) {
-        t += *(const f32x4*)(residual + sbase + (size_t)v * channels + c);
+      return t;
+    };
+    auto res_at = [&](int64_t v) {
+      if (residual1)  // identity shortcut of a block whose input is a (never materialised) channel concat of two tensors
+        return c < res_c0 ? *(const f32x4*)(residual + ((size_t)b * vox + v) * res_c0 + c)
+                          : *(const f32x4*)(residual1 + ((size_t)b * vox + v) * res_c1 + (c - res_c0));
+      return *(const f32x4*)(residual + sbase + (size_t)v * channels + c);
+    };
+    int64_t v = v0 + row;
+    // four voxels per trip: all eight loads are in flight before the first result is needed
+    for (; v + 3 * rows < v1; v += 4 * rows) {
+      f32x4 t[4], r[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) t[u] = *(const f32x4*)(x + sbase + (size_t)(v + u * rows) * channels + c);
+      if (residual) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) r[u] = res_at(v + u * rows);
       }
-      *(f32x4*)(y + sbase + (size_t)v * channels + c) = t;
-      s1 += t;
-      s2 += t * t;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        f32x4 o = act(t[u]);
+        if (residual) o += r[u];
+        *(f32x4*)(y + sbase + (size_t)(v + u * rows) * channels + c) = o;
+        s1 += o;
+        s2 += o * o;
+      }
+    }
+    for (; v < v1; v += rows) {
+      f32x4 o = act(*(const f32x4*)(x + sbase + (size_t)v * channels + c));
+      if (residual) o += res_at(v);
+      *(f32x4*)(y + sbase + (size_t)v * channels + c) = o;
+      s1 += o;
+      s2 += o * o;
     }
   }
   if (part_out) {
