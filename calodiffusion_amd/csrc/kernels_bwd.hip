@@ -62,29 +62,70 @@ __global__ void __launch_bounds__(1024) wgrad_kernel(WgradArgs a) {
   const float* xb = a.x + (size_t)n * Ox * a.xld + a.xoff + tb * 32 + col;
   const int o0 = chunk * a.chunk_vox;
   const int o1 = min(o0 + a.chunk_vox, Og);
-  if (ntap > 0) {
-    for (int o = o0 + half; o < o0 + a.chunk_vox; o += 2) {
-      const bool ov = o < o1;
-      const int oo = ov ? o : o0;
-      const float gv = ov ? gb[(size_t)oo * a.A] : 0.f;
-      const int ow = oo % a.Wg;
-      const int t2 = oo / a.Wg;
-      const int oh = t2 % a.Hg, oz = t2 / a.Hg;
+  if (T == 1 && a.S == 1 && a.SZ == 1 && TPW == 1) {
+    // pointwise conv: in(o) = o.  Eight voxel pairs per trip: 16 loads in flight, no index arithmetic (the general loop below
+    // spent ~100 VALU instructions of div/mod per 64-cycle MFMA and one memory round trip per voxel pair)
+    constexpr int U = 8;
+    int ob = o0;  // wave-uniform pair base: both lane halves run the same MFMAs (EXEC does not mask an MFMA)
+    for (; ob + 2 * U <= o1; ob += 2 * U) {
+      const int o = ob + half;
+      float gv[U], xv[U];
 #pragma unroll
-      for (int t = 0; t < TPW; ++t) {
-        if (t < ntap) {
-          const int tap = tap0 + t;
-          const int kw = tap % a.KW, kh = (tap / a.KW) % a.KH, kz = tap / (a.KW * a.KH);
-          const int pz = a.KD == 1 ? 0 : 1, pw = a.KW == 1 ? 0 : 1, ph = a.KH == 1 ? 0 : 1;
-          const int iz = oz * a.SZ + kz - pz, iw = ow * a.S + kw - pw;
-          int ih = oh * a.S + kh - ph;
+      for (int u = 0; u < U; ++u) {
+        gv[u] = gb[(size_t)(o + 2 * u) * a.A];
+        xv[u] = xb[(size_t)(o + 2 * u) * a.xld];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc[0] = MFMA32(gv[u], xv[u], acc[0]);
+    }
+    for (; ob < o0 + a.chunk_vox; ob += 2) {
+      const int o = ob + half;
+      const bool ov = o < o1;
+      const float gv = ov ? gb[(size_t)o * a.A] : 0.f;
+      const float xv = ov ? xb[(size_t)o * a.xld] : 0.f;
+      acc[0] = MFMA32(gv, xv, acc[0]);
+    }
+  } else if (ntap > 0) {
+    // tap geometry of this wave, hoisted out of the voxel loop (div / mod by run-time kernel extents)
+    int dz[TPW], dh[TPW], dw[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      const int tap = min(tap0 + t, T - 1);
+      const int kw = tap % a.KW, kh = (tap / a.KW) % a.KH, kz = tap / (a.KW * a.KH);
+      dz[t] = kz - (a.KD == 1 ? 0 : 1);
+      dh[t] = kh - (a.KH == 1 ? 0 : 1);
+      dw[t] = kw - (a.KW == 1 ? 0 : 1);
+    }
+    // U voxel pairs per trip: their U * (1 + TPW) loads are all in flight before the first MFMA
+    constexpr int U = TPW >= 3 ? 3 : 4;
+    for (int ob = o0; ob < o0 + a.chunk_vox; ob += 2 * U) {
+      float gv[U], xv[U][TPW];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int o = ob + 2 * u + half;
+        const bool ov = o < o1;
+        const int oo = ov ? o : o0;
+        const float g0 = gb[(size_t)oo * a.A];
+        gv[u] = ov ? g0 : 0.f;
+        const int ow = oo % a.Wg;
+        const int t2 = oo / a.Wg;
+        const int oh = t2 % a.Hg, oz = t2 / a.Hg;
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+          const int iz = oz * a.SZ + dz[t], iw = ow * a.S + dw[t];
+          int ih = oh * a.S + dh[t];
           ih = ih < 0 ? ih + a.Hx : (ih >= a.Hx ? ih - a.Hx : ih);
           ih = ih >= a.Hx ? ih - a.Hx : ih;
-          float xv = 0.f;
-          if (ov && iz >= 0 && iz < a.Dx && iw >= 0 && iw < a.Wx) xv = xb[((size_t)(iz * a.Hx + ih) * a.Wx + iw) * a.xld];
-          acc[t] = MFMA32(gv, xv, acc[t]);
+          const bool ok = ov && iz >= 0 && iz < a.Dx && iw >= 0 && iw < a.Wx;
+          const float v = xb[ok ? ((size_t)(iz * a.Hx + ih) * a.Wx + iw) * a.xld : 0];
+          xv[u][t] = ok ? v : 0.f;
         }
       }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+          if (t < ntap) acc[t] = MFMA32(gv[u], xv[u][t], acc[t]);
     }
   }
   // C layout: col = lane&31 (b), row = (r&3) + 8*(r>>2) + 4*half (a)
@@ -245,8 +286,9 @@ __global__ void __launch_bounds__(64 * ((27 + TPW - 1) / TPW)) wgrad_flat_kernel
 //   transposed_out = 0: dW[a][b][tap] (Conv3d weight, a = out channel)   1: dW[b][a][tap]
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int A, int Bc, int T, int nslots,
                                     int accumulate, int transposed_out, size_t sample_stride_partial, size_t sample_stride_out,
-                                    int b_total, int b_off) {
+                                    int b_total, int b_off, int slot_step = 1) {
   const size_t total = (size_t)A * Bc * T;
+  const size_t sstride = total * (size_t)slot_step;  // the slots left by wgrad_prereduce_kernel are slot_step apart
   const size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (idx >= total) return;
   const int n = blockIdx.y;
@@ -264,17 +306,48 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __
   for (; k + 16 <= nslots; k += 16) {
     float v[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) v[j] = p[(size_t)(k + j) * total];
+    for (int j = 0; j < 16; ++j) v[j] = p[(size_t)(k + j) * sstride];
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc8[j & 7] += v[j];
   }
-  for (; k < nslots; ++k) acc8[k & 7] += p[(size_t)k * total];
+  for (; k < nslots; ++k) acc8[k & 7] += p[(size_t)k * sstride];
   const float s = ((acc8[0] + acc8[1]) + (acc8[2] + acc8[3])) + ((acc8[4] + acc8[5]) + (acc8[6] + acc8[7]));
   const int ga = ta * 32 + ra, gb2 = tb * 32 + cb;
   // b_total / b_off: the b columns are a slice of a wider weight (second source of a channel concat)
   const size_t o = (transposed_out ? ((size_t)(gb2 + b_off) * A + ga) : ((size_t)ga * b_total + b_off + gb2)) * T + tap;
   float* d = dw + (size_t)n * sample_stride_out + o;
   *d = accumulate ? *d + s : s;
+}
+
+// First level of the slot reduction when there are many slots (the 1x1 convs write 4096 four-KiB partials: a single-level
+// reduce is 1024 threads x 4096 serial loads = 75 us of a 100 us weight gradient).  Group g sums its `per` consecutive slots
+// in a fixed order into the group's first slot, in place; wgrad_reduce_kernel then sums the group heads (slot_step = per).
+__global__ void wgrad_prereduce_kernel(float* __restrict__ partial, size_t total, int nslots, int per) {
+  const size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int k0 = blockIdx.y * per, k1 = min(k0 + per, nslots);
+  float* p = partial + idx;
+  float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int k = k0;
+  for (; k + 16 <= k1; k += 16) {
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = p[(size_t)(k + j) * total];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc8[j & 7] += v[j];
+  }
+  for (; k < k1; ++k) acc8[(k - k0) & 7] += p[(size_t)k * total];
+  p[(size_t)k0 * total] = ((acc8[0] + acc8[1]) + (acc8[2] + acc8[3])) + ((acc8[4] + acc8[5]) + (acc8[6] + acc8[7]));
+}
+// returns the slot step for wgrad_reduce_kernel and updates *nslots to the number of group heads
+static int wgrad_prereduce(float* partial, size_t total, int* nslots, hipStream_t s) {
+  if (*nslots < 256) return 1;
+  const int per = 64, groups = (*nslots + per - 1) / per;
+  hipLaunchKernelGGL(wgrad_prereduce_kernel, dim3((unsigned)((total + 255) / 256), (unsigned)groups), dim3(256), 0, s, partial, total,
+                     *nslots, per);
+  CD_HIP(hipGetLastError());
+  *nslots = groups;
+  return per;
 }
 
 // chunks per sample: enough workgroups to fill the chip, chunks of >= 128 voxels, partial volume <= 32 MiB
@@ -377,10 +450,12 @@ void launch_wgrad(const float* g, int A, Dims3 dg, const float* x, int Bc, int x
   else hipLaunchKernelGGL(wgrad_kernel<4>, grid, dim3(64 * ((T + 3) / 4)), 0, s, a);
   CD_HIP(hipGetLastError());
   const size_t total = (size_t)A * Bc * T;
-  const int nslots = per_sample ? a.nchunks : a.nchunks * batch;
+  int nslots = per_sample ? a.nchunks : a.nchunks * batch;
+  const size_t sample_stride = (size_t)nslots * total;
+  const int step = per_sample ? 1 : wgrad_prereduce(partial, total, &nslots, s);
   dim3 rg((unsigned)((total + 255) / 256), per_sample ? batch : 1);
   hipLaunchKernelGGL(wgrad_reduce_kernel, rg, dim3(256), 0, s, partial, dw, A, Bc, T, nslots, accumulate ? 1 : 0,
-                     transposed_out ? 1 : 0, (size_t)nslots * total, total, b_total, b_off);
+                     transposed_out ? 1 : 0, sample_stride, total, b_total, b_off, step);
   CD_HIP(hipGetLastError());
 }
 
