@@ -284,7 +284,7 @@ __device__ __forceinline__ void zs_matrix_wave(const ConvZsArgs& a, char* lds) {
 // stores on every path, so the compiler can count the vector-memory operations between a plane's loads and their use
 // (s_waitcnt vmcnt(8 + k) instead of vmcnt(k): in-order retirement would otherwise make every conversion wait for the previous
 // step's output stores as well).
-__device__ float zs_sink[256];
+__device__ float zs_sink[8 * 256];  // one cell per (row, lane): eight stores to ONE address would be merged by the compiler
 
 // ---- helper waves 4..7: stage incoming planes; sum / store half a tile of the previous step ----------------------------
 template <bool ACC, int DBG>
@@ -321,10 +321,9 @@ __device__ __forceinline__ void zs_helper_wave(const ConvZsArgs& a, char* lds, c
   static_assert(ZS_NSL == 5, "landed() names the five staging registers");
   // Plane loads are issued and awaited by hand: vmcnt retires in order, and between a plane's loads (issued in interval s-1) and
   // their conversion (start of interval s) the wave issues exactly NYOUNG vector-memory operations -- the 8 output stores of
-  // epilogue(s-2) (plus its 8 read-backs in a continuation launch) -- so `s_waitcnt vmcnt(NYOUNG)` waits for the loads and not
-  // for those stores.  (Left to the compiler the wait is vmcnt(4..0): conditional paths make it assume no younger operation,
+  // epilogue(s-2), themselves asm statements -- so `s_waitcnt vmcnt(NYOUNG)` waits for the loads and not for those stores.  (Left to the compiler the wait is vmcnt(4..0): conditional paths make it assume no younger operation,
   // and every conversion then also waits a store round trip.)  Out-of-range planes are clamped and zero-filled by convert().
-  constexpr int NYOUNG = ACC ? 16 : 8;
+  constexpr int NYOUNG = ACC ? 0 : 8;  // (a continuation launch also reads its rows back: it simply waits for everything)
   auto issue_to = [&](f32x4 (&dst)[ZS_NSL], int z) {
     const int zc = min(max(z, 0), a.D - 1);
     const float* src = src_b + (size_t)zc * PV * a.ldc;
@@ -445,7 +444,7 @@ __device__ __forceinline__ void zs_helper_wave(const ConvZsArgs& a, char* lds, c
     for (int r = 0; r < 8; ++r) {
       const int row = (r & 3) + 8 * ((r >> 2) + 2 * rh) + 4 * half;
       ok[r] = live && vt + row < G.cend;
-      dst[r] = ok[r] ? out_b + (size_t)gvox(vt + row) * a.cout : sink;
+      dst[r] = ok[r] ? out_b + (size_t)gvox(vt + row) * a.cout : sink + r * 256;
     }
     if (ACC) {  // continuation launch of a wider-K conv: add to what the previous launch stored
       float prev[8];
@@ -460,7 +459,9 @@ __device__ __forceinline__ void zs_helper_wave(const ConvZsArgs& a, char* lds, c
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       const float v = sum[r] + bv;
-      *dst[r] = v;
+      // exactly one store instruction per row on every path (ZS_LANDED counts them): not left to the compiler, which
+      // merged the eight sink stores of the peeled first interval into one and let a plane be converted before it landed
+      asm volatile("global_store_dword %0, %1, off" ::"v"(dst[r]), "v"(v) : "memory");
       const float m = ok[r] ? v : 0.f;
       s1 += m;
       s2 += m * m;

@@ -143,6 +143,32 @@ def test_full_resolution_conv_kernel(ops):
         assert err < 2e-6, (B, c0, c1, cout, shape, err)
 
 
+def test_strip_conv_many_samples_every_sample_checked(ops):
+    """Regression: with many workgroups in flight a staged plane was once converted before its loads had landed (the count
+    of vector-memory operations the kernel's `s_waitcnt vmcnt(n)` relies on had been changed by the compiler): wrong rows in
+    a few random samples of a large batch only.  Every sample of a 16-shower Dataset-3 batch is compared."""
+    gen = torch.Generator().manual_seed(12)
+    for B, c0, c1, cout, shape in ((16, 32, 0, 32, (45, 50, 18)), (24, 32, 32, 32, (12, 16, 9))):
+        err = _conv_case(ops, gen, B, c0, c1, cout, shape, nb=B)
+        assert err < 2e-6, (B, c0, c1, cout, shape, err)
+
+
+def test_batched_denoise_equals_single_samples_dataset3():
+    """Showers are independent: a Dataset-3 batch of 12 equals its showers denoised one at a time (catches races that only
+    show with many workgroups in flight)."""
+    m = _model("dataset3")
+    gen = torch.Generator().manual_seed(5)
+    B = 12
+    x = torch.randn([B] + list(m.config["SHAPE_PAD"][1:]), generator=gen).cuda()
+    E = torch.rand((B, 1), generator=gen).cuda()
+    sig = torch.full((B,), 0.9, device="cuda")
+    y = m.denoise(x, E=E, sigma=sig, layers=None)
+    assert torch.isfinite(y).all()
+    for i in (0, 5, 11):
+        yi = m.denoise(x[i:i + 1], E=E[i:i + 1], sigma=sig[i:i + 1], layers=None)
+        assert rel_l2(y[i:i + 1].cpu().numpy(), yi.cpu().numpy()) < 2e-6, i
+
+
 def test_whole_sample_conv_kernel(ops):
     """Grids of at most 128 voxels per sample (Dataset-2's level 2: 12x4x2) take the whole-sample-in-LDS kernel
     (kernels_conv_small.hip): single-row / single-column grids, >64 input channels (two staging passes), concatenated inputs."""
