@@ -31,10 +31,10 @@ if ROOT not in sys.path:
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32-in MFMA = vector fp32 peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA
-# HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, profiles/r01f_zslide_traffic.txt):
+# HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, profiles/r01g_zslide_traffic.txt):
 # PMC counters cannot be collected inside this process, so the figure of the committed profile is attached when the dominant
 # kernel and batch are the profiled ones (f16x2 default path only).
-MEASURED_TRAFFIC_BYTES = {("conv3x3x3_s1 C32->32 @45x16x9", 64): 121.7e6}
+MEASURED_TRAFFIC_BYTES = {("conv3x3x3_s1 C32->32 @45x16x9", 64): 118.4e6}
 BF16X3_TERMS = 6                # bf16 MFMAs per fp32 product in the split-bf16 convolution
 PEAK_HBM_GBS = 8000.0
 
