@@ -24,15 +24,30 @@ namespace cd {
 typedef __fp16 fh4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 typedef __fp16 fh8 __attribute__((__vector_size__(8 * sizeof(__fp16))));
 
-__global__ void absmax_bits_kernel(const float* __restrict__ x, size_t n4, unsigned* __restrict__ out) {
+// max |x| as a bit pattern (non-negative floats order like their bit patterns).  Four loads in flight per thread and ONE
+// atomic per workgroup (one load per trip and one atomic per wave made this HBM-sized pass 50 us: 4096 same-address atomics).
+__global__ void __launch_bounds__(256) absmax_bits_kernel(const float* __restrict__ x, size_t n4, unsigned* __restrict__ out) {
+  __shared__ float sm[4];
   float m = 0.f;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = ((const f32x4*)x)[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      m = fmaxf(m, fmaxf(fmaxf(fabsf(v[u][0]), fabsf(v[u][1])), fmaxf(fabsf(v[u][2]), fabsf(v[u][3]))));
+  }
+  for (; i < n4; i += stride) {
     const f32x4 v = ((const f32x4*)x)[i];
     m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
   }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));  // non-negative floats order like their bit patterns
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(out, __float_as_uint(fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]))));
 }
 
 namespace {
@@ -263,7 +278,7 @@ const unsigned* launch_absmax_bits(const float* x, size_t n, hipStream_t s) {
   if (!g_absmax_word) CD_HIP(hipMalloc((void**)&g_absmax_word, 64));
   CD_REQUIRE(n % 4 == 0, "absmax: element count must be a multiple of 4");
   CD_HIP(hipMemsetAsync(g_absmax_word, 0, sizeof(unsigned), s));
-  hipLaunchKernelGGL(absmax_bits_kernel, dim3(1024), dim3(256), 0, s, x, n / 4, g_absmax_word);
+  hipLaunchKernelGGL(absmax_bits_kernel, dim3(2048), dim3(256), 0, s, x, n / 4, g_absmax_word);
   CD_HIP(hipGetLastError());
   g_absmax_of = x;
   return g_absmax_word;

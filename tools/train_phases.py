@@ -1,0 +1,34 @@
+"""Where a training step's wall time goes: GPU time per phase (events) and host time, dataset2 batch 64."""
+import sys, time
+import torch
+sys.path.insert(0, ".")
+from calodiffusion_amd.calodiffusion import CaloDiffusion
+from calodiffusion_amd.configs import load_config
+from calodiffusion_amd.optim import FusedAdam
+cfg = load_config("dataset2"); B = 64
+torch.manual_seed(1234)
+m = CaloDiffusion(cfg, n_steps=cfg["NSTEPS"], loss_type=cfg["LOSS_TYPE"])
+opt = FusedAdam(m.parameters(), lr=4e-4)
+g = torch.Generator().manual_seed(1)
+shape = [B] + list(cfg["SHAPE_PAD"][1:])
+data, noise = torch.randn(shape, generator=g).cuda(), torch.randn(shape, generator=g).cuda()
+E = torch.rand((B, 1), generator=g).cuda(); layers = torch.randn((B, 46), generator=g).cuda(); rnd = torch.randn((B,), generator=g).cuda()
+eng = m.engine()
+def step(timers=None):
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+    t = [time.perf_counter()]
+    ev[0].record(); opt.zero_grad(set_to_none=True)
+    eng.sync_weights(); ev[1].record(); t.append(time.perf_counter())
+    loss = m.compute_loss(data, E, noise=noise, layers=layers, rnd_normal=rnd); ev[2].record(); t.append(time.perf_counter())
+    loss.backward(); ev[3].record(); t.append(time.perf_counter())
+    opt.step(); ev[4].record(); t.append(time.perf_counter())
+    torch.cuda.synchronize(); t.append(time.perf_counter())
+    if timers is not None:
+        timers.append(([ev[i].elapsed_time(ev[i + 1]) for i in range(4)], [1e3 * (t[i + 1] - t[i]) for i in range(5)]))
+for _ in range(3): step()
+T = []
+for _ in range(5): step(T)
+import numpy as np
+gpu = np.mean([a for a, _ in T], axis=0); host = np.mean([b for _, b in T], axis=0)
+print("GPU ms  : sync_weights %.2f | compute_loss (cd_train_step) %.2f | backward (grad views) %.2f | adam %.2f" % tuple(gpu))
+print("host ms : sync_weights %.2f | compute_loss %.2f | backward %.2f | adam %.2f | final sync %.2f  (sum %.2f)" % (tuple(host) + (host.sum(),)))
