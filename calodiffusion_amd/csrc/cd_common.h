@@ -362,6 +362,9 @@ void launch_adam(const AdamChunk& c, int ntensors, int64_t max_numel, double lr,
 
 size_t init_wgrad_partial_floats(int batch, int64_t vox, int cin, int cout);
 void launch_init_wgrad(const InitConvArgs& a, const float* g, float* part, float* dw, hipStream_t s);
+// the same through the general weight-gradient kernels (padded 32-channel input); scratch: init_wgrad_mfma_floats floats
+size_t init_wgrad_mfma_floats(int batch, int64_t vox, int cout);
+void launch_init_wgrad_mfma(const InitConvArgs& a, const float* g, float* scratch, float* dw, hipStream_t s);
 // per-sample record the embedding backward leaves for the Linear weight gradients
 struct EmbedTapeLayout {
   int t_in, a1t, a2t, a1c, a2c, sc;      // inputs of the Linears (time: 1, q, half; cond: cond(copied), hidden, half; proj: 2*half)
