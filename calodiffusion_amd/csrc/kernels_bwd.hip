@@ -885,13 +885,32 @@ __global__ void __launch_bounds__(256) head_loss_bwd_kernel(const float* __restr
   __syncthreads();
   if (tid < 33) part[(size_t)blockIdx.x * 33 + tid] = sAcc[0][tid] + sAcc[2][tid] + sAcc[4][tid] + sAcc[6][tid];
 }
-__global__ void head_grad_reduce_kernel(const float* __restrict__ part, int nblocks, float* __restrict__ dwh, float* __restrict__ dbh) {
-  const int c = threadIdx.x;
-  if (c >= 33) return;
-  double s = 0.0;
-  for (int k = 0; k < nblocks; ++k) s += (double)part[(size_t)k * 33 + c];
-  if (c < 32) dwh[c] = (float)s;
-  else dbh[0] = (float)s;
+// 7 slices of the partial rows per column, eight loads in flight, fixed-order tree (33 threads walking 1024 rows each was
+// a 237 us serial chain)
+__global__ void __launch_bounds__(256) head_grad_reduce_kernel(const float* __restrict__ part, int nblocks, float* __restrict__ dwh,
+                                                               float* __restrict__ dbh) {
+  __shared__ double sh[7][33];
+  const int c = threadIdx.x % 33, sl = threadIdx.x / 33;
+  if (sl < 7) {
+    double s = 0.0;
+    int k = sl;
+    for (; k + 7 * 7 < nblocks; k += 7 * 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(k + 7 * u) * 33 + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += (double)v[u];
+    }
+    for (; k < nblocks; k += 7) s += (double)part[(size_t)k * 33 + c];
+    sh[sl][c] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 33) {
+    double s = 0.0;
+    for (int i = 0; i < 7; ++i) s += sh[i][threadIdx.x];
+    if (threadIdx.x < 32) dwh[threadIdx.x] = (float)s;
+    else dbh[0] = (float)s;
+  }
 }
 int head_bwd_blocks(int batch, int64_t vox) {
   int64_t n = ((int64_t)batch * vox + 255) / 256;
@@ -901,7 +920,7 @@ void launch_head_loss_bwd(const float* x0, const float* data, const float* scal,
                           float* part, float* dwh, float* dbh, int batch, int64_t vox, hipStream_t s) {
   const int nb = head_bwd_blocks(batch, vox);
   hipLaunchKernelGGL(head_loss_bwd_kernel, dim3(nb), dim3(256), 0, s, x0, data, scal, h, wh, dh, part, batch, vox);
-  hipLaunchKernelGGL(head_grad_reduce_kernel, dim3(1), dim3(64), 0, s, part, nb, dwh, dbh);
+  hipLaunchKernelGGL(head_grad_reduce_kernel, dim3(1), dim3(256), 0, s, part, nb, dwh, dbh);
   CD_HIP(hipGetLastError());
 }
 
@@ -1119,16 +1138,35 @@ __global__ void __launch_bounds__(256) embed_bwd_kernel(EmbedArgs a, const float
   }
   __syncthreads();
   // ---- backward: dsc = sum_l W_l^T demb_l ; dcat = dsc * silu'(cat) ----
-  for (int k = tid; k < 2 * half; k += blockDim.x) {
+  // (two thread groups take the even / odd projection layers, eight weight loads in flight each: one thread per k walking all
+  // ~800 rows alone was a 200 us chain of L2 round trips)
+  {
+    const int nk = 2 * half, grp = tid / nk, k = tid - grp * nk, ngrp = blockDim.x / nk;  // nk <= 128 => ngrp >= 2
     float acc = 0.f;
-    for (int l = 0; l < a.n_layers; ++l) {
-      const EmbedLayer Ly = a.layers[l];
-      const float* d = demb + (size_t)b * a.emb_ld + Ly.offset;
-      for (int j = 0; j < Ly.cout; ++j) acc = fmaf(Ly.w[(size_t)j * 2 * half + k], d[j], acc);
+    if (grp < 2) {
+      for (int l = grp; l < a.n_layers; l += 2) {
+        const EmbedLayer Ly = a.layers[l];
+        const float* d = demb + (size_t)b * a.emb_ld + Ly.offset;
+        const float* wk = Ly.w + k;
+        int j = 0;
+        for (; j + 8 <= Ly.cout; j += 8) {
+          float wv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) wv[u] = wk[(size_t)(j + u) * nk];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) acc = fmaf(wv[u], d[j + u], acc);
+        }
+        for (; j < Ly.cout; ++j) acc = fmaf(wk[(size_t)j * nk], d[j], acc);
+      }
+      (grp == 0 ? tmpA : tmpB)[k] = acc;
     }
-    const float v = cat[k];
-    const float sg = 1.f / (1.f + expf(-v));
-    dcat[k] = acc * sg * (1.f + v * (1.f - sg));
+    (void)ngrp;
+    __syncthreads();
+    if (tid < nk) {
+      const float v = cat[tid];
+      const float sg = 1.f / (1.f + expf(-v));
+      dcat[tid] = (tmpA[tid] + tmpB[tid]) * sg * (1.f + v * (1.f - sg));
+    }
   }
   __syncthreads();
   // time branch: cat[0:half] = W3 a2t + b3
