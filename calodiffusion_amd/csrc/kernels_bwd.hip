@@ -590,7 +590,15 @@ __global__ void param_grad_from_samples_kernel(const float* __restrict__ sums_bc
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= channels) return;
   double g = 0.0, bt = 0.0;
-  for (int n = 0; n < batch; ++n) { bt += (double)sums_bc[((size_t)n * channels + c) * 2]; g += (double)sums_bc[((size_t)n * channels + c) * 2 + 1]; }
+  int n = 0;
+  for (; n + 8 <= batch; n += 8) {  // eight samples' pairs in flight (fixed summation order)
+    float2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *(const float2*)(sums_bc + ((size_t)(n + u) * channels + c) * 2);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { bt += (double)v[u].x; g += (double)v[u].y; }
+  }
+  for (; n < batch; ++n) { bt += (double)sums_bc[((size_t)n * channels + c) * 2]; g += (double)sums_bc[((size_t)n * channels + c) * 2 + 1]; }
   dgamma[c] = accumulate ? dgamma[c] + (float)g : (float)g;
   dbeta[c] = accumulate ? dbeta[c] + (float)bt : (float)bt;
 }
