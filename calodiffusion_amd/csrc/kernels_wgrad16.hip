@@ -291,8 +291,10 @@ static size_t wgrad16_lds(Dims3 d) {
 }
 bool wgrad_f16x2_eligible(Dims3 d) {
   if (getenv("CD_NO_WGRAD16")) return false;
-  // tiny planes: a unit's few 16-voxel K steps do not amortise its staging; the fp32 kernels win there
-  return d.d >= 1 && d.h * d.w >= 64 && wgrad16_lds(d) <= 160 * 1024;
+  // (planes under 64 voxels were once left to the fp32 kernels: with the max-|dy| pass shared and at HBM speed the fp16 pipe
+  // wins down to 8-voxel planes: 14.46 -> 13.3 ms per training step; CD_WGRAD16_MINPV restores a floor)
+  static const int min_pv = getenv("CD_WGRAD16_MINPV") ? atoi(getenv("CD_WGRAD16_MINPV")) : 8;
+  return d.d >= 1 && d.h * d.w >= min_pv && wgrad16_lds(d) <= 160 * 1024;
 }
 bool try_launch_wgrad_f16x2(const float* g, int A, const float* x, int Bc, int xld, int xoff, Dims3 d, int batch, float* partial,
                             unsigned* gmax_word, int* nblk_out, hipStream_t s) {
