@@ -607,7 +607,8 @@ __global__ void param_grad_from_samples_kernel(const float* __restrict__ sums_bc
 __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ h,
                                                            const float* __restrict__ coef, const float* __restrict__ gcoef,
                                                            float* __restrict__ dh, int channels, int64_t vox, int silu,
-                                                           int blocks_per_sample) {
+                                                           int blocks_per_sample, unsigned* __restrict__ amax_out) {
+  __shared__ float sAmax[4];
   const int tid = threadIdx.x;
   const int b = blockIdx.x / blocks_per_sample, blk = blockIdx.x % blocks_per_sample;
   const int cols = channels >> 2, rows = 256 / cols;
@@ -615,7 +616,8 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const float* __restri
   const int64_t v0 = blk * vper, v1 = (v0 + vper < vox) ? v0 + vper : vox;
   const int colid = tid % cols, row = tid / cols;
   const int c = colid * 4;
-  if (row >= rows) return;
+  float am = 0.f;
+  if (row < rows) {
   f32x4 cf[4], gc[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -634,6 +636,15 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const float* __restri
       o[e] = gc[e][0] * dz + gc[e][1] * hv[e] + gc[e][2];
     }
     *(f32x4*)(dh + sb + (size_t)v * channels) = o;
+    am = fmaxf(am, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
+  }
+  }
+  if (amax_out) {  // max |dh| for the power-of-two rescaling of the conv gradients that consume dh (saves their own pass over it)
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) am = fmaxf(am, __shfl_xor(am, o, 64));
+    if ((tid & 63) == 0) sAmax[tid >> 6] = am;
+    __syncthreads();
+    if (tid == 0) atomicMax(amax_out, __float_as_uint(fmaxf(fmaxf(sAmax[0], sAmax[1]), fmaxf(sAmax[2], sAmax[3]))));
   }
 }
 
@@ -652,7 +663,9 @@ void launch_gn_backward(const float* dy, const float* h, const float* coef, cons
   hipLaunchKernelGGL(param_grad_from_samples_kernel, dim3((channels + 63) / 64), dim3(64), 0, s, sums_bc, batch, channels, dgamma,
                      dbeta, accumulate_params ? 1 : 0);
   const int bps = gn_apply_blocks_per_sample(batch, channels, vox);
-  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)(batch * bps)), dim3(256), 0, s, dy, h, coef, gcoef, dh, channels, vox, silu, bps);
+  unsigned* amax_word = absmax_word_fresh(dh, s);  // zeroed; the consumer's launch_absmax_bits(dh) finds it instead of re-reading dh
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)(batch * bps)), dim3(256), 0, s, dy, h, coef, gcoef, dh, channels, vox, silu, bps,
+                     amax_word);
   CD_HIP(hipGetLastError());
 }
 // out[v][c] = a[v][aoff + c] + (b ? b[v][boff + c] : 0)   (row strides lda / ldb / C): gradient fan-in, channel slices of

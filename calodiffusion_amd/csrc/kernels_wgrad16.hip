@@ -274,7 +274,25 @@ namespace {
 unsigned* g_absmax_word = nullptr;
 const float* g_absmax_of = nullptr;  // tensor the word currently describes (stream order)
 }  // namespace
+namespace {
+bool g_absmax_fresh = false;  // the word was filled by the producer of g_absmax_of and has not been claimed yet
+}
+// A producer that can track max |x| while it writes x (gn_bwd_apply_kernel) takes the zeroed word here; the next
+// launch_absmax_bits call claims it if (and only if) it asks for the same tensor -- a later tensor at a recycled workspace
+// address can never match a stale note.
+unsigned* absmax_word_fresh(const float* x, hipStream_t s) {
+  if (!g_absmax_word) CD_HIP(hipMalloc((void**)&g_absmax_word, 64));
+  CD_HIP(hipMemsetAsync(g_absmax_word, 0, sizeof(unsigned), s));
+  g_absmax_of = x;
+  g_absmax_fresh = true;
+  return g_absmax_word;
+}
 const unsigned* launch_absmax_bits(const float* x, size_t n, hipStream_t s) {
+  if (g_absmax_fresh && g_absmax_of == x && g_absmax_word) {
+    g_absmax_fresh = false;
+    return g_absmax_word;
+  }
+  g_absmax_fresh = false;
   if (!g_absmax_word) CD_HIP(hipMalloc((void**)&g_absmax_word, 64));
   CD_REQUIRE(n % 4 == 0, "absmax: element count must be a multiple of 4");
   CD_HIP(hipMemsetAsync(g_absmax_word, 0, sizeof(unsigned), s));
