@@ -151,7 +151,7 @@ bool try_launch_conv_small(const float* in0, int c0, const float* in1, int c1, c
                            int batch, int cout, const ConvGeom& g, hipStream_t s, const ConvFusion& fu);
 void launch_conv_transpose_mfma(const float* in, int cin, const float* wpk, const float* bias, float* out, int batch,
                                 int cout, Dims3 din, Dims3 dout, int kz, int sz, hipStream_t s,
-                                const void* wpk_f16x2 = nullptr, int* status = nullptr);
+                                const void* wpk_f16x2 = nullptr, int* status = nullptr, const unsigned* in_absmax = nullptr);
 
 enum A_Prologue { A_NONE = 0, A_AFFINE = 1, A_SOFTMAX32 = 2, A_EXPNORM = 3 };
 struct PointwiseArgs {

@@ -1721,6 +1721,7 @@ struct ConvTArgs {
   int CS;                // LDS voxel stride in floats
   const u32x4* wpk16;    // f16x2 image [k-step][tap][ct][term][lane] (conv_transpose_f16x2_kernel)
   int* status;           // bit 0: a staged value exceeded the fp16 range
+  const unsigned* in_absmax;  // power-of-two input rescaling (gradients: ConvFusion::in_absmax) or null
 };
 
 template <int CT>
@@ -1846,6 +1847,8 @@ __global__ void __launch_bounds__(256) conv_transpose_f16x2_kernel(ConvTArgs a) 
   const int half = lane >> 5, col = lane & 31;
   for (int i = tid; i < a.CS; i += blockDim.x) lds[ZERO + i] = 0.f;
 
+  float gscale = 1.f, ginv = 1.f;
+  if (a.in_absmax) pow2_scale_for(*a.in_absmax, &gscale, &ginv);
   {  // stage + split all input channels of the haloed tile
     const int c4 = a.cin >> 2;
     const int items = tileVox * c4;
@@ -1861,6 +1864,7 @@ __global__ void __launch_bounds__(256) conv_transpose_f16x2_kernel(ConvTArgs a) 
       if (gh < 0) gh += a.Hin;
       f32x4 val = {0.f, 0.f, 0.f, 0.f};
       if (gz >= 0 && gz < a.Din) val = *(const f32x4*)(src + ((size_t)(gz * a.Hin + gh) * a.Win + iw) * a.cin + q * 4);
+      val *= gscale;
       amax = fmaxf(amax, fmaxf(fmaxf(fabsf(val[0]), fabsf(val[1])), fmaxf(fabsf(val[2]), fabsf(val[3]))));
       u32x2 t1, t2;
       split2(val, t1, t2);
@@ -1928,7 +1932,7 @@ __global__ void __launch_bounds__(256) conv_transpose_f16x2_kernel(ConvTArgs a) 
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
           const int co = ct * 32 + col;
-          outb[off + co] = accA[ct][r] + accB[ct][r] * (1.f / 2048.f) + (a.bias ? a.bias[co] : 0.f);
+          outb[off + co] = (accA[ct][r] + accB[ct][r] * (1.f / 2048.f)) * ginv + (a.bias ? a.bias[co] : 0.f);
         }
       }
     }
@@ -1950,7 +1954,7 @@ static void launch_convT_inst(const ConvTArgs& a, dim3 grid, size_t lds, hipStre
 
 void launch_conv_transpose_mfma(const float* in, int cin, const float* wpk, const float* bias, float* out, int batch,
                                 int cout, Dims3 din, Dims3 dout, int kz, int sz, hipStream_t s, const void* wpk_f16x2,
-                                int* status) {
+                                int* status, const unsigned* in_absmax) {
   CD_REQUIRE(cin % 32 == 0 && cout % 32 == 0, "conv_transpose: channels must be multiples of 32");
   CD_REQUIRE(sz == 1 || sz == 2, "conv_transpose: z stride must be 1 or 2");
   static const bool full_range = getenv("CD_CONV_PRECISION") && (!strcmp(getenv("CD_CONV_PRECISION"), "f32") ||
@@ -1958,6 +1962,7 @@ void launch_conv_transpose_mfma(const float* in, int cin, const float* wpk, cons
   ConvTArgs a;
   a.wpk16 = full_range ? nullptr : (const u32x4*)wpk_f16x2;
   a.status = status;
+  a.in_absmax = in_absmax;
   a.in = in; a.cin = cin; a.wpk = wpk; a.bias = bias; a.out = out;
   a.Din = din.d; a.Hin = din.h; a.Win = din.w; a.Do = dout.d; a.Ho = dout.h; a.Wo = dout.w;
   a.KZ = kz; a.SZ = sz; a.cout = cout; a.CTtot = cout / 32;

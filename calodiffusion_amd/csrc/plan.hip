@@ -640,11 +640,16 @@ void conv_backward(Run& r, const float* x0, int c0, const float* x1, int c1, con
       if (!r.dry()) launch_strided_dgrad_naive(dy, w_raw, dx, r.B, cin, cout, g.in, g.out, g.kd, g.sz, r.s);
     } else {
       // strided conv: its adjoint is the transposed-conv gather kernel
+      // (on the fp16 pipe like the forward up-conv, the tiny gradients rescaled by a power of two from their max)
       float* wp = ws->get<float>(packed_weight_floats(cout, cin, T));
+      float* wp16 = ws->get<float>(packed_f16x2_bytes(cout, cin, T) / 4 + 64);
       if (!r.dry()) {
         launch_pack_weights(w_raw, wp, cin, cout, T, true, r.s);
-        launch_conv_transpose_mfma(dy, cout, wp, nullptr, dx, r.B, cin, g.out, g.in, g.kd, g.sz, r.s);
+        launch_pack_weights_f16x2(w_raw, wp16, cin, cout, T, r.s, true, false);
+        const unsigned* amax = launch_absmax_bits(dy, (size_t)r.B * g.out.vox() * cout, r.s);
+        launch_conv_transpose_mfma(dy, cout, wp, nullptr, dx, r.B, cin, g.out, g.in, g.kd, g.sz, r.s, wp16, r.status, amax);
       }
+      ws->release(wp16);
       ws->release(wp);
     }
   }
