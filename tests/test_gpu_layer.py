@@ -113,3 +113,33 @@ def test_layer_batch_64_full_steps_properties():
     y2 = torch.cat([m.sample_layers(E[:32], start=start[:32], sample_offset=0),
                     m.sample_layers(E[32:], start=start[32:], sample_offset=0)])
     assert torch.isfinite(y).all() and torch.equal(y, y2)
+
+
+def test_layer_model_other_widths_against_oracle():
+    """HGCal-style layer model (3 conditioning inputs, 29 entries) and a wider / shallower one: forward, denoise for the three
+    objectives' scalings and a DDim trajectory against the CPU oracle (no reference fixture: the oracle is pinned above)."""
+    from calodiffusion_amd.resnet import ResNet
+    from calodiffusion_amd import schedule
+    for dim, cond_size, layers, hidden in ((29, 3, 5, 256), (46, 1, 3, 512), (7, 2, 2, 64)):
+        torch.manual_seed(77)
+        net = ResNet(dim_in=dim, num_layers=layers, hidden_dim=hidden, cond_size=cond_size)
+        net._engine_opts = dict(time_kind="log", objective="hybrid", sigma_data=0.5)
+        net.cuda()
+        sd = {k: v.cpu() for k, v in net.state_dict().items()}
+        gen = torch.Generator().manual_seed(3)
+        B = 5
+        x, c, tm = torch.randn((B, dim), generator=gen), torch.rand((B, cond_size), generator=gen), torch.randn((B,), generator=gen)
+        with torch.no_grad():
+            want = O.resnet_mlp_forward(sd, x, c, tm)
+        assert rel_l2(net(x.cuda(), cond=c.cuda(), time=tm.cuda()).cpu().numpy(), want.numpy()) < TOL_OP, (dim, "forward")
+        om = O.OracleLayerModel({"TIME_EMBED": "log", "TRAINING_OBJ": "hybrid_weight", "NOISE_SCHED": "linear"}, sd)
+        sig = torch.tensor([50.0, 3.0, 0.7, 0.1, 0.01])
+        with torch.no_grad():
+            want = om.denoise(x, c, sig)
+        got = net.engine().denoise(x.cuda(), sig.cuda(), c.cuda())
+        assert rel_l2(got.cpu().numpy(), want.numpy()) < TOL_OP, (dim, "denoise")
+        table = schedule.ddim_step_table(20, 0.0, 0)
+        got, _, _ = net.engine().ddim_sample(x.cuda(), c.cuda(), table)
+        with torch.no_grad():
+            want, _, _ = om.ddim_sample(x, c, None, 20)
+        assert rel_l2(got.cpu().numpy(), want.numpy()) < TOL_TRAJ, (dim, "ddim")
