@@ -97,11 +97,17 @@ class Diffusion(torch.nn.Module, ABC):
                 layers.append(layers_.detach().cpu().numpy())
         generated, energies = np.concatenate(generated), np.concatenate(energies)
         layers = np.concatenate(layers) if layers else None
+        return self._to_physical(generated, energies, layers, reverse_norm, debug)
+
+    def _to_physical(self, generated, energies, layers, reverse_norm, debug=False):
+        """Inverse pre-processing of generated showers (shared with LayerDiffusion.generate)."""
         cfg = self.config
+        device_form = (reverse_norm is None and not debug and cfg.get("DATASET_NUM", 2) in (2, 3)
+                       and cfg.get("SHOWERMAP") in ("layer-logit-norm", "logit-norm")
+                       and all(k in cfg for k in ("EMAX", "EMIN", "logE", "MAXDEP", "ECUT")))
         if callable(reverse_norm):
             generated, energies = reverse_norm(generated, energies, layers, cfg)
-        elif reverse_norm is None and not debug and all(k in cfg for k in ("EMAX", "EMIN", "logE", "MAXDEP", "ECUT")) \
-                and cfg.get("DATASET_NUM", 2) in (2, 3) and cfg["SHOWERMAP"] in ("layer-logit-norm", "logit-norm"):
+        elif device_form:
             from .postprocess import ReverseNorm
             generated, energies = ReverseNorm(generated, energies, shape=cfg["SHAPE_FINAL"], config=cfg, emax=cfg["EMAX"],
                                               emin=cfg["EMIN"], layerE=layers, logE=cfg["logE"], max_deposit=cfg["MAXDEP"],

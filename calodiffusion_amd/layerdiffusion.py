@@ -69,39 +69,43 @@ class LayerDiffusion(CaloDiffusion):
                                       "reference and load the checkpoint with load_layer_model_state")
         return super().compute_loss(data, energy, noise, layers, time, rnd_normal)
 
-    def load_layer_model_state(self, strict=True):
-        """layerdiffusion.py:59-85."""
+    @staticmethod
+    def _without_prefix(sd, prefixes):
+        """Checkpoint keys with the first matching module prefix stripped (other modules' entries dropped)."""
+        heads = {k.split(".", 1)[0] for k in sd}
+        for pre in prefixes:
+            if pre in heads:
+                cut = len(pre) + 1
+                return {k[cut:]: v for k, v in sd.items() if k.startswith(pre + ".")}
+        return sd
+
+    @staticmethod
+    def _load_tolerant(module, sd, strict):
+        """Strict load; shape or missing-key errors propagate, anything else (unexpected extras) retries non-strictly --
+        the behaviour of both loaders of the reference (layerdiffusion.py:76-85, 97-105)."""
         try:
-            path = self.config["layer_model"]
-        except KeyError:
+            return module.load_state_dict(sd, strict=strict)
+        except RuntimeError as err:
+            if any(tag in str(err) for tag in ("size mismatch", "Missing key(s) in state_dict")):
+                raise
+            return module.load_state_dict(sd, strict=False)
+
+    def load_layer_model_state(self, strict=True):
+        """The layer model comes from its own checkpoint: config['layer_model'], else <checkpoint>/checkpoint.pth
+        (layerdiffusion.py:59-85)."""
+        path = self.config.get("layer_model")
+        if path is None:
             path = os.path.join(self.config.get("checkpoint", ""), "checkpoint.pth")
             if not os.path.exists(path):
                 raise RuntimeError("Could not load layer model from either config or checkpoint path")
-        ckpt = torch.load(path, map_location=self.device, weights_only=False)
-        sd = ckpt if "model_state_dict" not in ckpt else ckpt["model_state_dict"]
-        if "layer_model" in {k.split(".")[0] for k in sd}:
-            sd = {k.removeprefix("layer_model."): v for k, v in sd.items()}
-        try:
-            self.layer_model.load_state_dict(sd, strict=strict)
-        except RuntimeError as e:
-            if "size mismatch" in str(e) or "Missing key(s) in state_dict" in str(e):
-                raise
-            self.layer_model.load_state_dict(sd, strict=False)
+        blob = torch.load(path, map_location=self.device, weights_only=False)
+        sd = blob.get("model_state_dict", blob) if isinstance(blob, dict) else blob
+        self._load_tolerant(self.layer_model, self._without_prefix(sd, ("layer_model",)), strict)
 
     def load_state_dict(self, state_dict, strict=True):
         """layerdiffusion.py:87-105: layer model from its own checkpoint, then the base U-Net from `state_dict`."""
         self.load_layer_model_state(strict)
-        prefixes = {k.split(".")[0] for k in state_dict}
-        if "base_model" in prefixes:
-            state_dict = {k.removeprefix("base_model."): v for k, v in state_dict.items() if k.startswith("base_model.")}
-        elif "model" in prefixes:
-            state_dict = {k.removeprefix("model."): v for k, v in state_dict.items() if k.startswith("model.")}
-        try:
-            return self.base_model.load_state_dict(state_dict, strict)
-        except RuntimeError as e:
-            if "size mismatch" in str(e) or "Missing key(s) in state_dict" in str(e):
-                raise
-            return self.base_model.load_state_dict(state_dict, strict=False)
+        return self._load_tolerant(self.base_model, self._without_prefix(state_dict, ("base_model", "model")), strict)
 
     def state_dict(self, *a, **k):
         sd = super().state_dict(*a, **k)
@@ -156,15 +160,4 @@ class LayerDiffusion(CaloDiffusion):
             layers.append(out["layers"].detach().cpu().numpy())
             energies.append(E.detach().cpu().numpy())
         generated, energies, layers = np.concatenate(generated), np.concatenate(energies), np.concatenate(layers)
-        cfg = self.config
-        if callable(reverse_norm):
-            generated, energies = reverse_norm(generated, energies, layers, cfg)
-        elif reverse_norm is None and all(k in cfg for k in ("EMAX", "EMIN", "logE", "MAXDEP", "ECUT")) \
-                and cfg.get("DATASET_NUM", 2) in (2, 3) and cfg["SHOWERMAP"] in ("layer-logit-norm", "logit-norm"):
-            from .postprocess import ReverseNorm
-            generated, energies = ReverseNorm(generated, energies, shape=cfg["SHAPE_FINAL"], config=cfg, emax=cfg["EMAX"],
-                                              emin=cfg["EMIN"], layerE=layers, logE=cfg["logE"], max_deposit=cfg["MAXDEP"],
-                                              showerMap=cfg["SHOWERMAP"], dataset_num=cfg.get("DATASET_NUM", 2),
-                                              ecut=float(cfg["ECUT"]))
-            generated = generated.reshape(cfg["SHAPE_ORIG"])
-        return generated, np.reshape(energies, (energies.shape[0], -1))
+        return self._to_physical(generated, energies, layers, reverse_norm)
