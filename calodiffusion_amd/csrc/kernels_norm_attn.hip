@@ -243,7 +243,8 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
 int gn_apply_blocks_per_sample(int batch, int channels, int64_t vox) {
   const int rows = 256 / (channels / 4);
   int64_t bps = (vox + (int64_t)rows * 8 - 1) / ((int64_t)rows * 8);  // >= 8 float4 per thread
-  const int64_t want = (4096 + batch - 1) / batch;
+  static const int target = getenv("CD_GN_APPLY_WGS") ? atoi(getenv("CD_GN_APPLY_WGS")) : 1024;  // fewer, longer-lived workgroups: each repeats the GroupNorm fold (0.386 -> 0.368 ms per step against 4096)
+  const int64_t want = (target + batch - 1) / batch;
   if (bps > want) bps = want;
   if (bps < 1) bps = 1;
   return (int)bps;
