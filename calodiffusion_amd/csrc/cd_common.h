@@ -64,6 +64,12 @@ struct ConvGeom {
   int sz, sh, sw;   // strides
 };
 
+// SiLU on the transcendental unit: t * rcp(1 + exp2(-t log2 e)), ~3 ulp (libm's expf + a division is ~30 VALU instructions
+// per element in kernels whose staging is VALU-bound)
+__device__ __forceinline__ float cd_fast_silu(float t) {
+  return t * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(t * -1.4426950408889634f));
+}
+
 // GroupNorm fusion around a conv (all optional):
 //   coef     [B][Cin][4] = {scale, shift, add, -}: y = act(scale*x + shift) + add applied to the input as it is staged
 //            (GroupNorm affine folded per sample and channel by launch_gn_finalize; `add` = the time/cond embedding);

@@ -168,7 +168,7 @@ __global__ void __launch_bounds__(512) conv_mfma_kernel(ConvKArgs a) {
           for (int e = 0; e < 4; ++e) {
             const f32x4 cf = *(const f32x4*)(cfp + e * 4);
             float t = cf[0] * val[e] + cf[1];
-            if (a.act) t = t / (1.f + expf(-t));
+            if (a.act) t = cd_fast_silu(t);
             val[e] = t + cf[2];
           }
         }
@@ -456,7 +456,7 @@ __global__ void __launch_bounds__(512, (VT * CT <= 2 ? 3 : 2)) conv3_flat_kernel
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               float t = cf[e][0] * val[k][e] + cf[e][1];
-              if (a.act) t = t / (1.f + expf(-t));
+              if (a.act) t = cd_fast_silu(t);
               val[k][e] = t + cf[e][2];
             }
           }
@@ -789,7 +789,7 @@ __global__ void __launch_bounds__(512, (VT * CT * (NTERM == 2 ? 2 : 1) <= 2 ? 3 
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               float t = cf[e][0] * val[k][e] + cf[e][1];
-              if (a.act) t = t / (1.f + expf(-t));
+              if (a.act) t = cd_fast_silu(t);
               val[k][e] = t + cf[e][2];
             }
           }
@@ -1009,7 +1009,7 @@ __global__ void __launch_bounds__(768) conv_flat_ws_kernel(ConvFlatArgs a, int n
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               float t = cf[e][0] * val[k][e] + cf[e][1];
-              if (a.act) t = t / (1.f + expf(-t));
+              if (a.act) t = cd_fast_silu(t);
               val[k][e] = t + cf[e][2];
             }
           }
@@ -1335,7 +1335,7 @@ __global__ void __launch_bounds__(512, (VT * CT <= 2 ? 3 : 2)) conv_tiled_bf16x3
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
                 float t = cf[e][0] * val[k][e] + cf[e][1];
-                if (a.act) t = t / (1.f + expf(-t));
+                if (a.act) t = cd_fast_silu(t);
                 val[k][e] = t + cf[e][2];
               }
             }

@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(256, 1) conv_small_f16x2_kernel(ConvSmallArgs 
             const f32x4 cf = a.defer.part ? *(const f32x4*)(cs_lds + a.coef_lds_off + (c + e) * 16)
                                           : *(const f32x4*)(a.coef + ((size_t)b * cin + c + e) * 4);
             float t = cf[0] * x[e] + cf[1];
-            if (a.act) t = t / (1.f + expf(-t));
+            if (a.act) t = cd_fast_silu(t);
             x[e] = t + cf[2];
           }
         }
