@@ -136,6 +136,8 @@ def roofline_leg(model, cfg, batch, E, layers):
             "traffic": MEASURED_TRAFFIC_BYTES.get((dom_name, batch)) if mode == "f16x2" else None,
             "pipe": pipe,
             "frac_of_fp32_mfma_peak": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+            # all 256 CUs under matrix load run at ~1.97 GHz: 2.06 PFLOP/s of dense fp16 MFMA measured (tools/micro/mfma_chain.hip)
+            "frac_of_sustained_clock_peak": round(achieved / (2060.0 / 3), 4) if mode == "f16x2" else None,
             "avg_launch_us": round(avg_ms * 1e3, 2), "alg_flops_per_launch": dom["flops"],
             "alg_bytes_per_launch": dom["bytes"],
             "hbm_frac_of_same_kernel": round(dom["bytes"] / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
