@@ -323,6 +323,8 @@ void launch_ddim_update(const float* x, const float* x0, const float* noise, con
 void launch_load_step(const float* table, int* counter, float* stepvals, float* sigma_b, int batch, hipStream_t s);
 void launch_scale(const float* x, float* y, const float* stepvals_sigma, int64_t n, hipStream_t s);
 void launch_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, hipStream_t s);
+// noise of sampler step (*step_counter - 1) from {seed, base offset} in device memory (graph-replayable)
+void launch_randn_step(float* out, int64_t n, const uint64_t* seed_offset_dev, const int* step_counter, hipStream_t s);
 void launch_axpy_sigma(const float* data, const float* noise, const float* sigma_b, float* out, int batch, int64_t per,
                        hipStream_t s);
 void launch_loss_partial(const float* x0, const float* data, const float* sigma_b, double* partial, int batch,

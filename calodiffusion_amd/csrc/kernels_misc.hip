@@ -259,7 +259,14 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32
   }
 }
 
-__global__ void __launch_bounds__(256) randn_kernel(float* __restrict__ out, int64_t n, uint64_t seed, uint64_t offset) {
+// dev (optional): {seed, base offset} in device memory and the sampler's step counter -- the stream position then is
+// base + (step - 1) * n, so that one captured step graph serves every step and every trajectory of a stochastic sampler
+__global__ void __launch_bounds__(256) randn_kernel(float* __restrict__ out, int64_t n, uint64_t seed, uint64_t offset,
+                                                    const uint64_t* __restrict__ dev, const int* __restrict__ step_counter) {
+  if (dev) {
+    seed = dev[0];
+    offset = dev[1] + (uint64_t)(*step_counter - 1) * (uint64_t)n;
+  }
   const uint64_t first = offset >> 2, last = (offset + (uint64_t)n + 3) >> 2;  // counter range [first, last)
   for (uint64_t ctr = first + (uint64_t)blockIdx.x * 256 + threadIdx.x; ctr < last; ctr += (uint64_t)gridDim.x * 256) {
     uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
@@ -286,7 +293,16 @@ void launch_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, hipStre
   if (n <= 0) return;
   int64_t blocks = (n / 4 + 256) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(randn_kernel, dim3((unsigned)blocks), dim3(256), 0, s, out, n, seed, offset);
+  hipLaunchKernelGGL(randn_kernel, dim3((unsigned)blocks), dim3(256), 0, s, out, n, seed, offset, (const uint64_t*)nullptr,
+                     (const int*)nullptr);
+  CD_HIP(hipGetLastError());
+}
+void launch_randn_step(float* out, int64_t n, const uint64_t* seed_offset_dev, const int* step_counter, hipStream_t s) {
+  if (n <= 0) return;
+  int64_t blocks = (n / 4 + 256) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(randn_kernel, dim3((unsigned)blocks), dim3(256), 0, s, out, n, (uint64_t)0, (uint64_t)0, seed_offset_dev,
+                     step_counter);
   CD_HIP(hipGetLastError());
 }
 

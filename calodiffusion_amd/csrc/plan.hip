@@ -1142,6 +1142,12 @@ int cd_ddim_sample(CdPlan* plan, int batch, const float* start, const float* con
     float* x0 = plan->ws.get<float>((size_t)n);
     float* noise_buf = plan->ws.get<float>((size_t)n);
     float* sigma_b = plan->ws.get<float>((size_t)batch + 64);
+    uint64_t* noise_dev = (uint64_t*)plan->ws.get<double>(4);  // {seed, base offset}
+    if (noisy && !step_noise) {
+      const uint64_t so[2] = {seed, offset};
+      CD_HIP(hipMemcpyAsync(noise_dev, so, sizeof(so), hipMemcpyHostToDevice, s));
+      CD_HIP(hipStreamSynchronize(s));  // `so` lives on this stack frame
+    }
     // remaining workspace for the network: a nested arena view
     const size_t used = plan->ws.high();
     char* sub = (char*)workspace + used;
@@ -1153,18 +1159,21 @@ int cd_ddim_sample(CdPlan* plan, int batch, const float* start, const float* con
       forward_impl(plan, batch, x_out, cond, sigma_b, x0, false, st);
       const float* nz = noise_i;
       if (!nz && noisy) {
-        launch_randn(noise_buf, n, seed, offset + (uint64_t)i * (uint64_t)n, st);
+        // stream position = offset + i * n, read from device memory (the step counter is i + 1 after load_step): the same
+        // launch serves every step, so stochastic samplers replay one captured graph as well
+        launch_randn_step(noise_buf, n, noise_dev, plan->d_counter, st);
         nz = noise_buf;
       }
       launch_ddim_update(x_out, x0, nz, plan->d_stepvals, x_out, xs_i, x0s_i, n, st);
     };
 
-    // A hipGraph of one step can be replayed only if nothing in it depends on the host-side step index:
-    // deterministic DDIM (eta = 0) without trajectories.
-    const bool graphable = use_graph && !noisy && !step_noise && !xs && !x0s && !prof::enabled();
+    // A hipGraph of one step can be replayed only if nothing in it depends on the host-side step index: no trajectories and
+    // no caller-supplied per-step noise (the device Philox noise of a stochastic sampler reads its stream position from the
+    // step counter, see one_step).
+    const bool graphable = use_graph && !step_noise && !xs && !x0s && !prof::enabled();
     if (graphable) {
       CdPlan::GraphKey key;
-      key.batch = batch; key.ws = workspace; key.cond = cond; key.x = x_out; key.noisy = 0;
+      key.batch = batch; key.ws = workspace; key.cond = cond; key.x = x_out; key.noisy = noisy ? 1 : 0;
       if (!(plan->graph_exec && plan->graph_key == key)) {
         destroy_graph(plan);
         hipGraph_t graph = nullptr;

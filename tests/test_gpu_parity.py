@@ -377,6 +377,28 @@ def test_graph_replay_equals_eager_bitwise():
     assert np.isfinite(a).all()
 
 
+def test_stochastic_sampler_graph_replay_equals_eager_bitwise():
+    """DDPM draws its per-step noise from the device Philox stream at a position read from the step counter, so one captured
+    step graph serves a stochastic trajectory too: same (seed, offset) => graph and eager runs are bitwise identical, and a
+    second trajectory (new offset) re-uses the graph and differs."""
+    from calodiffusion_amd import sample
+    m = _model("tiny")
+    g = gold("ddpm_tiny")
+    start, E, layers = t(g["start"]).cuda(), t(g["E"]).cuda(), t(g["layers"]).cuda()
+    outs = {}
+    for use_graph in (True, False):
+        cfg = dict(m.config)
+        cfg["SAMPLER_OPTIONS"] = {"HIP_GRAPH": use_graph, "SEED": 7}
+        ddpm = sample.DDPM(cfg)
+        m.noise_offset = 1000
+        x1, _, _ = ddpm(m, start, E, layers, 20, 0, False)
+        m.noise_offset = 999000
+        x2, _, _ = ddpm(m, start, E, layers, 20, 0, False)
+        outs[use_graph] = (x1.clone(), x2.clone())
+    assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
+    assert not torch.equal(outs[True][0], outs[True][1]) and torch.isfinite(outs[True][1]).all()
+
+
 def test_ddpm_tiny_with_reference_noise_stream():
     g = gold("ddpm_tiny")
     m = _model("tiny")
