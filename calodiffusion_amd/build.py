@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libcalodiff_hip.so")
-SOURCES = ["kernels_conv.hip", "kernels_conv_zs.hip", "kernels_attn.hip", "kernels_conv_small.hip", "kernels_wgrad16.hip", "kernels_norm_attn.hip", "kernels_misc.hip", "kernels_mlp.hip", "kernels_bwd.hip", "profiler.hip", "plan.hip"]
+SOURCES = ["kernels_conv.hip", "kernels_conv_zs.hip", "kernels_attn.hip", "kernels_conv_small.hip", "kernels_wgrad16.hip", "kernels_norm_attn.hip", "kernels_misc.hip", "kernels_mlp.hip", "kernels_mlp_train.hip", "kernels_bwd.hip", "profiler.hip", "plan.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
 FLAGS += os.environ.get("CD_EXTRA_HIPCC_FLAGS", "").split()  # e.g. -DCD_ZS_EXPERIMENTS (tools/zs_phases.sh)

@@ -359,6 +359,25 @@ struct LayerMlpArgs {
 };
 void launch_layer_mlp(const LayerMlpArgs& a, hipStream_t s);
 
+// training step of the layer-energy MLP (kernels_mlp_train.hip)
+struct LayerTapeLayout {
+  int xin, t_in, a1t, a2t, cin, a1c, a2c, g, hprev[8], h1[8], hfin;       // inputs of the Linear layers
+  int dpred, dv[8], du[8], de[8], dh0, d3t, d2t, d1t, d3c, d2c, d1c;     // their output deltas
+  int total;
+};
+LayerTapeLayout layer_tape_layout(int dim, int hidden, int cond_emb, int cond_size, int n_res);
+struct LayerMlpTrainArgs {
+  const float* w[64];
+  int dim_in, hidden, cond_emb, cond_size, n_res, time_kind, batch;
+  float sigma_data;
+  const float *data, *noise, *sigma, *cond;  // (B, dim), (B, dim), (B), (B, cond_size)
+  LayerTapeLayout layout;
+  float* tape;        // [B][layout.total]
+  double* loss_part;  // [B]
+};
+size_t layer_train_workspace_bytes(const LayerMlpTrainArgs& a);
+void launch_layer_mlp_train(LayerMlpTrainArgs a, float* grads, double* loss_out, void* workspace, hipStream_t s);
+
 // fused Adam over up to 48 tensors per launch (kernel-argument table)
 struct AdamChunk {
   float* p[48];

@@ -1103,6 +1103,39 @@ int cd_layer_sample(const CdLayerMlpDesc* desc, const float* const* weights, int
   });
 }
 
+static LayerMlpTrainArgs layer_train_args(const CdLayerMlpDesc* d, int batch) {
+  CD_REQUIRE(d && batch > 0, "bad argument");
+  CD_REQUIRE(d->n_res >= 0 && d->n_res <= 8 && d->time_embed_kind >= 0 && d->time_embed_kind <= 2, "bad descriptor");
+  LayerMlpTrainArgs a{};
+  a.dim_in = d->dim_in; a.hidden = d->hidden; a.cond_emb = d->cond_emb; a.cond_size = d->cond_size; a.n_res = d->n_res;
+  a.time_kind = d->time_embed_kind; a.batch = batch; a.sigma_data = d->sigma_data;
+  a.layout = layer_tape_layout(a.dim_in, a.hidden, a.cond_emb, a.cond_size, a.n_res);
+  return a;
+}
+int cd_layer_train_workspace_bytes(const CdLayerMlpDesc* desc, int batch, size_t* bytes) {
+  return guarded([&] {
+    CD_REQUIRE(bytes, "bad argument");
+    *bytes = layer_train_workspace_bytes(layer_train_args(desc, batch));
+  });
+}
+int cd_layer_train_step(const CdLayerMlpDesc* desc, const float* const* weights, int n_weights, int batch, const float* data,
+                        const float* noise, const float* sigma, const float* cond, double* loss_out, float* grads,
+                        void* workspace, size_t workspace_bytes, void* stream) {
+  return guarded([&] {
+    CD_REQUIRE(weights && data && noise && sigma && cond && loss_out && grads && workspace, "bad argument");
+    LayerMlpTrainArgs a = layer_train_args(desc, batch);
+    CD_REQUIRE(desc->objective == CD_OBJ_HYBRID, "cd_layer_train_step implements the hybrid_weight objective");
+    CD_REQUIRE(n_weights == 2 * (8 + 3 * desc->n_res), "layer MLP: n_weights must be 2*(8 + 3*n_res)");
+    CD_REQUIRE(workspace_bytes >= layer_train_workspace_bytes(a), "workspace too small: call cd_layer_train_workspace_bytes");
+    for (int i = 0; i < n_weights; ++i) {
+      CD_REQUIRE(weights[i], "null weight pointer");
+      a.w[i] = weights[i];
+    }
+    a.data = data; a.noise = noise; a.sigma = sigma; a.cond = cond;
+    launch_layer_mlp_train(a, grads, loss_out, workspace, (hipStream_t)stream);
+  });
+}
+
 int cd_profile_begin(void) {
   return guarded([&] { prof::begin(); });
 }

@@ -72,6 +72,8 @@ _SIGNATURES = {
     "cd_layer_forward": (C.c_int, [_P, C.POINTER(C.c_void_p), C.c_int, C.c_int, _P, _P, _P, _P, _P]),
     "cd_layer_denoise": (C.c_int, [_P, C.POINTER(C.c_void_p), C.c_int, C.c_int, _P, _P, _P, _P, _P]),
     "cd_layer_sample": (C.c_int, [_P, C.POINTER(C.c_void_p), C.c_int, C.c_int, _P, _P, _P, C.c_int, _P, _P, _P, _P, _P]),
+    "cd_layer_train_workspace_bytes": (C.c_int, [_P, C.c_int, C.POINTER(C.c_size_t)]),
+    "cd_layer_train_step": (C.c_int, [_P, C.POINTER(C.c_void_p), C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "cd_reverse_norm": (C.c_int, [_P, _P, _P, _P, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.c_float, C.c_float, _P]),
     "cd_adam_step": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                C.POINTER(C.c_int64), C.c_double, C.c_double, C.c_double, C.c_float, C.c_float, C.c_int, _P]),
@@ -428,6 +430,43 @@ class LayerMlpEngine:
         _check(self.lib.cd_layer_denoise(C.byref(self.desc), w, n, B, x.data_ptr(), sigma.data_ptr(), cond.data_ptr(),
                                          out.data_ptr(), _stream()))
         return out
+
+    # ------------------------------------------------------------------ training (same contract as UnetEngine's)
+    def grad_layout(self):
+        """{state_dict name: (offset, numel)} into the flat gradient buffer (state_dict order), and its total length."""
+        lay, off = {}, 0
+        for k, p in self.net.state_dict().items():
+            lay[k] = (off, p.numel())
+            off += p.numel()
+        return lay, off
+
+    def train_step(self, data, noise, sigma, cond):
+        """hybrid_weight / l2 loss and the gradient of every parameter of the layer model (cd_layer_train_step)."""
+        data, cond, B = self._io(data, cond)
+        noise = _dev32(noise, "noise")
+        sigma = _dev32(sigma, "sigma").reshape(-1)
+        if noise.shape != data.shape or sigma.numel() != B:
+            raise ValueError("noise must have the shape of data and sigma must be (B,)")
+        w, n = self._weights()
+        nbytes = C.c_size_t()
+        _check(self.lib.cd_layer_train_workspace_bytes(C.byref(self.desc), B, C.byref(nbytes)))
+        ws = torch.empty(nbytes.value, dtype=torch.uint8, device=data.device)
+        _, total = self.grad_layout()
+        flat = torch.empty(total, dtype=torch.float32, device=data.device)
+        loss = torch.empty((), dtype=torch.float64, device=data.device)
+        _check(self.lib.cd_layer_train_step(C.byref(self.desc), w, n, B, data.data_ptr(), noise.data_ptr(), sigma.data_ptr(),
+                                            cond.data_ptr(), loss.data_ptr(), flat.data_ptr(), ws.data_ptr(), ws.numel(),
+                                            _stream()))
+        return loss, flat
+
+    def param_grads(self, flat):
+        """Views of the flat gradient buffer, one per parameter of the bound ResNet, in .parameters() order."""
+        lay, _ = self.grad_layout()
+        names = {id(p): k for k, p in self.net.named_parameters()}
+        return [flat[lay[names[id(p)]][0]: lay[names[id(p)]][0] + p.numel()].view_as(p) for p in self.net.parameters()]
+
+    def loss_hybrid_l2(self, data, noise, sigma, cond):
+        return self.train_step(data, noise, sigma, cond)[0].to(torch.float32)
 
     def ddim_sample(self, start, cond, steps: np.ndarray, step_noise=None, seed=0, offset=0, debug=False, use_graph=True,
                     out=None):

@@ -64,9 +64,12 @@ class LayerDiffusion(CaloDiffusion):
         return self.layer_model(x, cond=E.to(torch.float32), time=time.to(torch.float32))
 
     def compute_loss(self, data, energy, noise, layers, time=None, rnd_normal=None):
+        """layerdiffusion.py:52-57: in the layer state the layer model is trained on the layer energies themselves (fresh noise
+        of their shape); one cd_layer_train_step call gives the loss and every gradient."""
         if self.layer_loss:
-            raise NotImplementedError("training the layer model is outside the HIP hot path (SURVEY.md 8f): train it with the "
-                                      "reference and load the checkpoint with load_layer_model_state")
+            layers = layers.to(torch.float32)
+            noise = self.noise_generation(layers.shape).to(torch.float32)
+            return self.loss_function(self, layers, energy, noise=noise, layers=layers, rnd_normal=rnd_normal)
         return super().compute_loss(data, energy, noise, layers, time, rnd_normal)
 
     @staticmethod

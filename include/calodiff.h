@@ -186,6 +186,16 @@ int cd_layer_sample(const CdLayerMlpDesc* desc, const float* const* weights, int
                     const float* cond, const CdStep* steps_dev, int n_steps, const float* step_noise, float* x_out, float* xs,
                     float* x0s, void* stream);
 
+/* Training step of the layer model (LayerDiffusion.compute_loss in the layer state, models/layerdiffusion.py:52-57, with
+ * the hybrid_weight / l2 loss of models/loss.py:103-104,118-142,163-179): data = layer energies (B, dim_in), noise (B, dim_in),
+ * sigma (B), cond (B, cond_size).  loss_out: one double; grads: ONE flat device buffer holding the gradient of every parameter
+ * in the order of `weights` (weight, bias, weight, bias, ...), each with the parameter's element count.  The objective must be
+ * CD_OBJ_HYBRID.  workspace: cd_layer_train_workspace_bytes. */
+int cd_layer_train_workspace_bytes(const CdLayerMlpDesc* desc, int batch, size_t* bytes);
+int cd_layer_train_step(const CdLayerMlpDesc* desc, const float* const* weights, int n_weights, int batch, const float* data,
+                        const float* noise, const float* sigma, const float* cond, double* loss_out, float* grads,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- measurement ---------------------------------------------------------------------------------------------- */
 /* Per-launch timing with HIP events on the launch stream (eager mode; graphs are bypassed while active).
  * cd_profile_end synchronises the device and writes a JSON object

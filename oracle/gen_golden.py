@@ -398,6 +398,16 @@ def gold_layer():
         res = m.sample(E, layers=None, num_steps=3, sample_offset=0, return_layers=True)
         out["sample_3_x"], out["sample_3_layers"] = np.asarray(res["x"], dtype=np.float32), npf(res["layers"])
         print("two-stage sample", float(np.abs(out["sample_3_x"]).mean()))
+        # layer-state training loss (layerdiffusion.py:52-57): the noise it draws is pinned through noise_generation
+        lay = torch.randn((B, dim), generator=g)
+        lnoise = torch.randn((B, dim), generator=g)
+        lrnd = torch.randn((B,), generator=g)
+        m.set_layer_state(is_layer=True)
+        draws[:] = [lnoise]
+        out["loss"] = np.array(float(m.compute_loss(None, E, None, lay, rnd_normal=lrnd)), dtype=np.float64)
+        m.set_layer_state(is_layer=False)
+        out["loss_layers"], out["loss_noise"], out["loss_rnd"] = npf(lay), npf(lnoise), npf(lrnd)
+        print("layer loss", float(out["loss"]))
     save("layer_dataset2", **out)
 
 

@@ -96,12 +96,6 @@ def test_two_stage_sample_and_generate():
     assert np.array_equal(a, b)
     sd = m.state_dict()
     assert "layer_model" in sd and any(k.startswith("base_model.") for k in sd)
-    with pytest.raises(NotImplementedError):
-        m.set_layer_state(True)
-        try:
-            m.compute_loss(None, E, None, None)
-        finally:
-            m.set_layer_state(False)
 
 
 def test_layer_batch_64_full_steps_properties():
@@ -143,3 +137,42 @@ def test_layer_model_other_widths_against_oracle():
         with torch.no_grad():
             want, _, _ = om.ddim_sample(x, c, None, 20)
         assert rel_l2(got.cpu().numpy(), want.numpy()) < TOL_TRAJ, (dim, "ddim")
+
+
+def test_layer_model_training_step_against_autograd():
+    """LayerDiffusion.compute_loss in the layer state (layerdiffusion.py:52-57): loss and every parameter gradient of the layer
+    model from one cd_layer_train_step call against torch autograd through the oracle; FusedAdam then steps the layer model."""
+    from calodiffusion_amd.optim import FusedAdam
+    m = _model()
+    gen = torch.Generator().manual_seed(21)
+    B = 9
+    layers = torch.randn((B, 46), generator=gen)
+    E = torch.rand((B, 1), generator=gen)
+    noise = torch.randn((B, 46), generator=gen)
+    rnd = torch.randn((B,), generator=gen)
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.layer_model.state_dict().items()}
+    om = O.OracleLayerModel(m.config, sd)
+    want = om.hybrid_l2_loss(layers, E, noise, rnd_normal=rnd)
+    want.backward()
+    m.set_layer_state(True)
+    m.noise_generation = lambda shape: noise.cuda()
+    params = dict(m.layer_model.named_parameters())
+    opt = FusedAdam(m.layer_model.parameters(), lr=1e-3)
+    opt.zero_grad()
+    loss = m.compute_loss(None, E.cuda(), None, layers.cuda(), rnd_normal=rnd.cuda())
+    loss.backward()
+    assert abs(float(loss.detach()) - float(want.detach())) < 2e-6 * abs(float(want.detach()))
+    num = den = 0.0
+    worst = 0.0
+    for k, p in params.items():
+        g, w = p.grad.cpu().double(), sd[k].grad.double()
+        num += float(((g - w) ** 2).sum()); den += float((w ** 2).sum())
+        worst = max(worst, float(((g - w) ** 2).sum().sqrt() / (w ** 2).sum().sqrt().clamp_min(1e-30)))
+    assert (num / den) ** 0.5 < 5e-6 and worst < 1e-4, ((num / den) ** 0.5, worst)
+    with torch.no_grad():
+        assert abs(float(m.compute_loss(None, E.cuda(), None, layers.cuda(), rnd_normal=rnd.cuda())) - float(want.detach())) < 2e-6 * abs(float(want.detach()))
+    before = m.layer_model.out_lay.weight.detach().clone()
+    opt.step()
+    assert not torch.equal(before, m.layer_model.out_lay.weight)
+    m.set_layer_state(False)
+    assert all(p.grad is None for p in m.base_model.parameters())

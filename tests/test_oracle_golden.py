@@ -208,3 +208,16 @@ def test_layer_model_against_reference():
         u = O.OracleModel(cfg, unet.state_dict())
         xs, _, _ = u.ddim_sample(t(g["shower_start"]), E, t(g["sample_3_layers"]), 3)
         assert rel_l2(xs.numpy(), g["sample_3_x"]) < 1e-5
+
+
+def test_layer_model_loss_matches_reference():
+    """The oracle's layer-state loss against the reference's LayerDiffusion.compute_loss (golden made with a fixed noise draw)."""
+    from helpers import seeded_layer_models
+    g = gold("layer_dataset2")
+    if "loss" not in g.files:
+        pytest.skip("golden without the layer loss")
+    layer, _ = seeded_layer_models("dataset2")
+    m = O.OracleLayerModel(load_config("dataset2"), layer.state_dict())
+    with torch.no_grad():
+        loss = m.hybrid_l2_loss(t(g["loss_layers"]), t(g["E"]), t(g["loss_noise"]), rnd_normal=t(g["loss_rnd"]))
+    assert abs(float(loss) - float(g["loss"])) < 2e-6 * abs(float(g["loss"]))
