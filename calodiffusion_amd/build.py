@@ -33,7 +33,11 @@ def build_all(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     objdir = os.path.join(LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "cd_common.h"), os.path.join(os.path.dirname(HERE), "include", "calodiff.h")]
+    # every header / include fragment is a dependency of every object (split16.h, gn_defer.h and train.inc are shared across
+    # translation units: a stale object would mix producer and consumer layouts)
+    inc = os.path.join(os.path.dirname(HERE), "include")
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc")))
+    headers += sorted(os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h"))
     jobs = []
     objs = []
     for src in SOURCES:
@@ -56,7 +60,22 @@ def build_all(force: bool = False, verbose: bool = True) -> str:
         list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
+    with open(LIB + ".srchash", "w") as fh:  # which sources the library next to it was built from
+        fh.write(source_hash() + "\n")
     return LIB
+
+
+def source_hash() -> str:
+    """sha256 over every HIP source, header and include fragment (and the flags) that goes into the library."""
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    inc = os.path.join(os.path.dirname(HERE), "include")
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))] + [os.path.join(inc, f) for f in sorted(os.listdir(inc))]
+    for f in files:
+        if f.endswith((".hip", ".h", ".inc")):
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()
 
 
 if __name__ == "__main__":

@@ -41,6 +41,12 @@ struct Scope {
 };
 }  // namespace prof
 
+// ---- arithmetic of the 3x3x3 / strided / transposed convolutions (process-wide; CD_CONV_PRECISION sets the initial value) ---
+//   0 = f16x2 (default: two-term fp16 split, fp16 range), 1 = bf16x3 (exact three-term bf16 split, fp32 range), 2 = f32 MFMA
+enum ConvPrecision { PREC_F16X2 = 0, PREC_BF16X3 = 1, PREC_F32 = 2 };
+int conv_precision();
+void set_conv_precision(int p);
+
 // ---- channels-last tensor view ------------------------------------------------------------------------
 // Internal activation layout: (B, D, H, W, C) fp32, C a multiple of 32 => every voxel is a whole number of 128-B lines.
 struct Dims3 {
@@ -298,6 +304,9 @@ struct EmbedArgs {
   int emb_ld = 0;
   float* scal = nullptr;  // (B, 4): c_in, c_skip, c_out, sigma
   int batch = 0;
+  // SinusoidalPositionEmbeddings(half/2) (models.py:132-144) in place of the first Linear+GELU of the time / cond branch
+  // (CondUnet(time_embed=True / cond_embed=True), models.py:578-601): tw1/tb1 resp. cw1/cb1 are unused then, and cond is (B,)
+  int time_sin = 0, cond_sin = 0;
 };
 void launch_embed(const EmbedArgs& a, hipStream_t s);
 void launch_silu_linear(const float* cond, const float* w, const float* bias, float* out, int batch, int nin, int nout,
@@ -322,9 +331,21 @@ void launch_ddim_update(const float* x, const float* x0, const float* noise, con
 // stepvals <- table[*counter]; sigma_b[0..B) <- stepvals.sigma; (*counter)++
 void launch_load_step(const float* table, int* counter, float* stepvals, float* sigma_b, int batch, hipStream_t s);
 void launch_scale(const float* x, float* y, const float* stepvals_sigma, int64_t n, hipStream_t s);
+void launch_scale_imm(const float* x, float* y, float scale, int64_t n, hipStream_t s);
 void launch_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, hipStream_t s);
-// noise of sampler step (*step_counter - 1) from {seed, base offset} in device memory (graph-replayable)
-void launch_randn_step(float* out, int64_t n, const uint64_t* seed_offset_dev, const int* step_counter, hipStream_t s);
+// noise tensor number (*step_counter - 1) * per_step + index of a sampler run, from {seed, base offset, stride} in device
+// memory: stream position = base + tensor number * stride (graph-replayable; stride = the GLOBAL tensor size, so that batch
+// shards on different GPUs draw their slices of the one stream a single-GPU run of the whole batch would use)
+void launch_randn_step(float* out, int64_t n, const uint64_t* seed_offset_stride_dev, const int* step_counter, hipStream_t s,
+                       int per_step = 1, int index = 0);
+// generic sampler programs (cd_sampler_run): per-step scalars are columns of row (*step_counter - 1) of a device table
+void launch_step_advance(int* counter, hipStream_t s);  // (*counter)++
+void launch_fill_from_table(float* dst, int count, const float* table, int ncol, int col, const int* step_counter, hipStream_t s);
+// out[i] = sum_k table[row][col + k] * src[k][i]   (nsrc <= 6; out may alias a source)
+void launch_lincomb(float* out, const float* const* src, int nsrc, const float* table, int ncol, int col, const int* step_counter,
+                    int64_t n, hipStream_t s);
+// traj[(*step_counter - 1) * n + i] = src[i]
+void launch_record_step(float* traj, const float* src, const int* step_counter, int64_t n, hipStream_t s);
 void launch_axpy_sigma(const float* data, const float* noise, const float* sigma_b, float* out, int batch, int64_t per,
                        hipStream_t s);
 void launch_loss_partial(const float* x0, const float* data, const float* sigma_b, double* partial, int batch,

@@ -20,6 +20,18 @@
 
 namespace cd {
 
+// process-wide arithmetic of the convolutions (cd_common.h); the plan flips it to bf16x3 for the re-run of a trajectory
+// whose f16x2 pass left the fp16 range
+static int g_conv_precision = -1;
+int conv_precision() {
+  if (g_conv_precision < 0) {
+    const char* e = getenv("CD_CONV_PRECISION");
+    g_conv_precision = !e ? PREC_F16X2 : (!strcmp(e, "f32") ? PREC_F32 : (!strcmp(e, "bf16x3") ? PREC_BF16X3 : PREC_F16X2));
+  }
+  return g_conv_precision;
+}
+void set_conv_precision(int p) { g_conv_precision = p; }
+
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
 static constexpr int LDS_VOX_PAD = 4;  // floats of padding per LDS voxel: stride 36/68/100 words => conflict-free ds_read_b128
@@ -1605,8 +1617,7 @@ void launch_conv_mfma(const float* in0, int c0, const float* in1, int c1, const 
     fu.defer = GnDefer();
   };
   {
-    static const bool want_f32 = getenv("CD_CONV_PRECISION") && !strcmp(getenv("CD_CONV_PRECISION"), "f32");
-    static const bool want_bf16x3 = getenv("CD_CONV_PRECISION") && !strcmp(getenv("CD_CONV_PRECISION"), "bf16x3");
+    const bool want_f32 = conv_precision() == PREC_F32, want_bf16x3 = conv_precision() == PREC_BF16X3;
     if (fu.wpk_bf16x3 && !want_f32 && !want_bf16x3 &&
         try_launch_conv_zslide(in0, c0, in1, c1, (const char*)fu.wpk_bf16x3 + packed_bf16x3_bytes(c0 + c1, cout, g.kd * g.kh * g.kw),
                                bias, out, batch, cout, g, s, fu))
@@ -1625,7 +1636,7 @@ void launch_conv_mfma(const float* in0, int c0, const float* in1, int c1, const 
     if (try_launch_conv3_flat(in0, c0, in1, c1, wpk, bias, out, batch, cout, g, s, fu, 0)) return;
   }
   {
-    static const bool want_f32 = getenv("CD_CONV_PRECISION") && !strcmp(getenv("CD_CONV_PRECISION"), "f32");
+    const bool want_f32 = conv_precision() == PREC_F32;
     if (fu.wpk_bf16x3 && !want_f32) {
       const std::vector<ConvTile> cand3 = conv_tile_candidates(g, batch, CT, 14, 96);
       auto launch3 = [&](const ConvTile& t) {
@@ -1957,8 +1968,7 @@ void launch_conv_transpose_mfma(const float* in, int cin, const float* wpk, cons
                                 int* status, const unsigned* in_absmax) {
   CD_REQUIRE(cin % 32 == 0 && cout % 32 == 0, "conv_transpose: channels must be multiples of 32");
   CD_REQUIRE(sz == 1 || sz == 2, "conv_transpose: z stride must be 1 or 2");
-  static const bool full_range = getenv("CD_CONV_PRECISION") && (!strcmp(getenv("CD_CONV_PRECISION"), "f32") ||
-                                                                  !strcmp(getenv("CD_CONV_PRECISION"), "bf16x3"));
+  const bool full_range = conv_precision() != PREC_F16X2;
   ConvTArgs a;
   a.wpk16 = full_range ? nullptr : (const u32x4*)wpk_f16x2;
   a.status = status;
@@ -2359,8 +2369,7 @@ void launch_init_coord_table(const InitConvArgs& a, hipStream_t s) {
 void launch_init_conv(const InitConvArgs& a, hipStream_t s) {
   CD_REQUIRE(a.cout % 32 == 0, "init conv: output channels must be a multiple of 32");
   CD_REQUIRE(a.cin >= 1 && a.cin <= 4 && a.cx <= a.cin, "init conv: 1..4 input channels supported");
-  static const bool full_range = getenv("CD_CONV_PRECISION") && (!strcmp(getenv("CD_CONV_PRECISION"), "f32") ||
-                                                                  !strcmp(getenv("CD_CONV_PRECISION"), "bf16x3"));
+  const bool full_range = conv_precision() != PREC_F16X2;
   static const bool no_mfma = getenv("CD_NO_INIT_MFMA") != nullptr;
   if (a.coord_table && a.cx == 1 && a.x && !full_range && !no_mfma) {
     prof::Scope scope("init_conv", s, 2.0 * 27 * a.cin * a.cout * (double)a.dims.vox() * a.batch,

@@ -323,19 +323,21 @@ __device__ __forceinline__ void zs_helper_wave(const ConvZsArgs& a, char* lds, c
   // their conversion (start of interval s) the wave issues exactly NYOUNG vector-memory operations -- the 8 output stores of
   // epilogue(s-2), themselves asm statements -- so `s_waitcnt vmcnt(NYOUNG)` waits for the loads and not for those stores.  (Left to the compiler the wait is vmcnt(4..0): conditional paths make it assume no younger operation,
   // and every conversion then also waits a store round trip.)  Out-of-range planes are clamped and zero-filled by convert().
-  constexpr int NYOUNG = ACC ? 0 : 8;  // (a continuation launch also reads its rows back: it simply waits for everything)
+  // (a continuation launch also reads its rows back: it simply waits for everything; so does the timing experiment that
+  // drops the epilogue and with it the eight stores)
+  constexpr int NYOUNG = (ACC || (DBG & 4)) ? 0 : 8;
   auto issue_to = [&](f32x4 (&dst)[ZS_NSL], int z) {
     const int zc = min(max(z, 0), a.D - 1);
     const float* src = src_b + (size_t)zc * PV * a.ldc;
 #pragma unroll
     for (int k = 0; k < ZS_NSL; ++k) {
       const float* p = src + (size_t)srcv[k] * a.ldc;
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[k]) : "v"(p) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off ; zs_plane_load" : "=v"(dst[k]) : "v"(p) : "memory");
     }
   };
   auto issue = [&](int z) { issue_to(ld, z); };
 #define ZS_LANDED(younger)                                                                                   \
-  asm volatile("s_waitcnt vmcnt(%5)"                                                                         \
+  asm volatile("s_waitcnt vmcnt(%5) ; zs_landed"                                                             \
                : "+v"(ld[0]), "+v"(ld[1]), "+v"(ld[2]), "+v"(ld[3]), "+v"(ld[4])                             \
                : "n"(younger)                                                                                \
                : "memory")
@@ -461,7 +463,7 @@ __device__ __forceinline__ void zs_helper_wave(const ConvZsArgs& a, char* lds, c
       const float v = sum[r] + bv;
       // exactly one store instruction per row on every path (ZS_LANDED counts them): not left to the compiler, which
       // merged the eight sink stores of the peeled first interval into one and let a plane be converted before it landed
-      asm volatile("global_store_dword %0, %1, off" ::"v"(dst[r]), "v"(v) : "memory");
+      asm volatile("global_store_dword %0, %1, off ; zs_row_store" ::"v"(dst[r]), "v"(v) : "memory");
       const float m = ok[r] ? v : 0.f;
       s1 += m;
       s2 += m * m;

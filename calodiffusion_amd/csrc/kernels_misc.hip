@@ -76,16 +76,37 @@ __global__ void __launch_bounds__(512) embed_kernel(EmbedArgs a) {
     a.scal[b * 4 + 3] = tv;
   }
   const int half = a.half, q = half / 2;
-  // time branch: Linear(1, half/2) GELU Linear(half/2, half) GELU Linear(half, half)
-  if (tid == 0) bufA[0] = t_in;
-  __syncthreads();
-  dense(a.tw1, a.tb1, bufA, bufB, 1, q, true);
+  // SinusoidalPositionEmbeddings(q) (models.py:132-144): [sin(v f_i), cos(v f_i)], f_i = exp(-i ln(1e4) / (q/2 - 1))
+  auto sinusoidal = [&](float v, float* dst) {
+    const int hd = q / 2;
+    const float step = (float)(9.210340371976184 / (double)(hd - 1));  // np.log(10000) / (half_dim - 1): a double, rounded to
+                                                                       // fp32 when it multiplies the arange tensor
+    for (int i = tid; i < hd; i += blockDim.x) {
+      const float ang = v * expf((float)i * -step);
+      dst[i] = sinf(ang);
+      dst[hd + i] = cosf(ang);
+    }
+    __syncthreads();
+  };
+  // time branch: Linear(1, half/2) GELU | sinusoidal(half/2);  Linear(half/2, half) GELU Linear(half, half)
+  if (a.time_sin) {
+    sinusoidal(t_in, bufB);
+  } else {
+    if (tid == 0) bufA[0] = t_in;
+    __syncthreads();
+    dense(a.tw1, a.tb1, bufA, bufB, 1, q, true);
+  }
   dense(a.tw2, a.tb2, bufB, bufA, q, half, true);
   dense(a.tw3, a.tb3, bufA, cat, half, half, false);
-  // cond branch: Linear(cond_size, hidden) GELU Linear(hidden, half) GELU Linear(half, half)
-  for (int i = tid; i < a.cond_size; i += blockDim.x) bufA[i] = a.cond[(size_t)b * a.cond_size + i];
-  __syncthreads();
-  dense(a.cw1, a.cb1, bufA, bufB, a.cond_size, a.cond_hidden, true);
+  // cond branch: Linear(cond_size, hidden) GELU | sinusoidal(half/2) of the scalar condition;  Linear(hidden, half) GELU
+  // Linear(half, half)
+  if (a.cond_sin) {
+    sinusoidal(a.cond[b], bufB);
+  } else {
+    for (int i = tid; i < a.cond_size; i += blockDim.x) bufA[i] = a.cond[(size_t)b * a.cond_size + i];
+    __syncthreads();
+    dense(a.cw1, a.cb1, bufA, bufB, a.cond_size, a.cond_hidden, true);
+  }
   dense(a.cw2, a.cb2, bufB, bufA, a.cond_hidden, half, true);
   dense(a.cw3, a.cb3, bufA, cat + half, half, half, false);
   // SiLU of conditions = cat(t, c)  (models.py:707; ResnetBlock.mlp[0])
@@ -239,6 +260,16 @@ void launch_scale(const float* x, float* y, const float* sc, int64_t n, hipStrea
   CD_HIP(hipGetLastError());
 }
 
+__global__ void scale_imm_kernel(const float* __restrict__ x, float* __restrict__ y, float f, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = x[i] * f;
+}
+void launch_scale_imm(const float* x, float* y, float scale, int64_t n, hipStream_t s) {
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(scale_imm_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, y, scale, n);
+  CD_HIP(hipGetLastError());
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Philox4x32-10 + Box-Muller unit normals.  Element i of a stream is a pure function of (seed, offset + i):
 // counter = (offset+i)/4, lane = (offset+i)%4, so batch shards on different GPUs draw disjoint slices of one stream.
@@ -259,13 +290,15 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32
   }
 }
 
-// dev (optional): {seed, base offset} in device memory and the sampler's step counter -- the stream position then is
-// base + (step - 1) * n, so that one captured step graph serves every step and every trajectory of a stochastic sampler
+// dev (optional): {seed, base offset, stride} in device memory and the sampler's step counter -- the stream position then is
+// base + ((step - 1) * per_step + index) * stride, so that one captured step graph serves every step and every trajectory of a
+// stochastic sampler
 __global__ void __launch_bounds__(256) randn_kernel(float* __restrict__ out, int64_t n, uint64_t seed, uint64_t offset,
-                                                    const uint64_t* __restrict__ dev, const int* __restrict__ step_counter) {
+                                                    const uint64_t* __restrict__ dev, const int* __restrict__ step_counter,
+                                                    int per_step, int index) {
   if (dev) {
     seed = dev[0];
-    offset = dev[1] + (uint64_t)(*step_counter - 1) * (uint64_t)n;
+    offset = dev[1] + ((uint64_t)(*step_counter - 1) * (uint64_t)per_step + (uint64_t)index) * dev[2];
   }
   const uint64_t first = offset >> 2, last = (offset + (uint64_t)n + 3) >> 2;  // counter range [first, last)
   for (uint64_t ctr = first + (uint64_t)blockIdx.x * 256 + threadIdx.x; ctr < last; ctr += (uint64_t)gridDim.x * 256) {
@@ -294,15 +327,71 @@ void launch_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, hipStre
   int64_t blocks = (n / 4 + 256) / 256;
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(randn_kernel, dim3((unsigned)blocks), dim3(256), 0, s, out, n, seed, offset, (const uint64_t*)nullptr,
-                     (const int*)nullptr);
+                     (const int*)nullptr, 1, 0);
   CD_HIP(hipGetLastError());
 }
-void launch_randn_step(float* out, int64_t n, const uint64_t* seed_offset_dev, const int* step_counter, hipStream_t s) {
+void launch_randn_step(float* out, int64_t n, const uint64_t* seed_offset_stride_dev, const int* step_counter, hipStream_t s,
+                       int per_step, int index) {
   if (n <= 0) return;
   int64_t blocks = (n / 4 + 256) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(randn_kernel, dim3((unsigned)blocks), dim3(256), 0, s, out, n, (uint64_t)0, (uint64_t)0, seed_offset_dev,
-                     step_counter);
+  hipLaunchKernelGGL(randn_kernel, dim3((unsigned)blocks), dim3(256), 0, s, out, n, (uint64_t)0, (uint64_t)0,
+                     seed_offset_stride_dev, step_counter, per_step, index);
+  CD_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Generic sampler programs (cd_sampler_run): every per-step scalar is a column of row (*counter - 1) of a device table, so a
+// step whose op list does not change is one captured graph replayed for the whole trajectory.
+// ------------------------------------------------------------------------------------------------------------
+__global__ void step_advance_kernel(int* counter) { *counter = *counter + 1; }
+void launch_step_advance(int* counter, hipStream_t s) {
+  hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, counter);
+  CD_HIP(hipGetLastError());
+}
+__global__ void fill_from_table_kernel(float* __restrict__ dst, int count, const float* __restrict__ table, int ncol, int col,
+                                       const int* __restrict__ counter) {
+  const float v = table[(size_t)(*counter - 1) * ncol + col];
+  for (int i = threadIdx.x; i < count; i += blockDim.x) dst[i] = v;
+}
+void launch_fill_from_table(float* dst, int count, const float* table, int ncol, int col, const int* step_counter, hipStream_t s) {
+  hipLaunchKernelGGL(fill_from_table_kernel, dim3(1), dim3(256), 0, s, dst, count, table, ncol, col, step_counter);
+  CD_HIP(hipGetLastError());
+}
+struct LincombSrc { const float* p[6]; };
+__global__ void __launch_bounds__(256) lincomb_kernel(float* out, LincombSrc src, int nsrc, const float* __restrict__ table,
+                                                      int ncol, int col, const int* __restrict__ counter, int64_t n) {
+  float c[6];
+  const float* row = table + (size_t)(*counter - 1) * ncol + col;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) c[k] = k < nsrc ? row[k] : 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float acc = c[0] * src.p[0][i];
+#pragma unroll
+    for (int k = 1; k < 6; ++k)
+      if (k < nsrc) acc += c[k] * src.p[k][i];
+    out[i] = acc;
+  }
+}
+void launch_lincomb(float* out, const float* const* src, int nsrc, const float* table, int ncol, int col, const int* step_counter,
+                    int64_t n, hipStream_t s) {
+  CD_REQUIRE(nsrc >= 1 && nsrc <= 6, "lincomb: 1..6 terms");
+  LincombSrc ls{};
+  for (int k = 0; k < 6; ++k) ls.p[k] = src[k < nsrc ? k : 0];
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(lincomb_kernel, dim3((unsigned)blocks), dim3(256), 0, s, out, ls, nsrc, table, ncol, col, step_counter, n);
+  CD_HIP(hipGetLastError());
+}
+__global__ void __launch_bounds__(256) record_step_kernel(float* __restrict__ traj, const float* __restrict__ src,
+                                                          const int* __restrict__ counter, int64_t n) {
+  float* dst = traj + (size_t)(*counter - 1) * n;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
+}
+void launch_record_step(float* traj, const float* src, const int* step_counter, int64_t n, hipStream_t s) {
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(record_step_kernel, dim3((unsigned)blocks), dim3(256), 0, s, traj, src, step_counter, n);
   CD_HIP(hipGetLastError());
 }
 

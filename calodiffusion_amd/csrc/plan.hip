@@ -156,6 +156,16 @@ struct CdPlan {
       return batch == o.batch && ws == o.ws && cond == o.cond && x == o.x && noisy == o.noisy && seed == o.seed && offset == o.offset;
     }
   } graph_key;
+  // cached step graph of a uniform sampler program (cd_sampler_run)
+  hipGraphExec_t prog_exec = nullptr;
+  struct ProgKey {
+    int batch = 0, n_coef = 0, n_bufs = 0; const void* ws = nullptr; const void* cond = nullptr; const void* x = nullptr;
+    const void* xs = nullptr; const void* x0s = nullptr; uint64_t ops_hash = 0;
+    bool operator==(const ProgKey& o) const {
+      return batch == o.batch && n_coef == o.n_coef && n_bufs == o.n_bufs && ws == o.ws && cond == o.cond && x == o.x && xs == o.xs &&
+             x0s == o.x0s && ops_hash == o.ops_hash;
+    }
+  } prog_key;
 
   // training: flat gradient layout and the device job list of the small Linear weight gradients
   size_t grad_floats = 0;
@@ -270,15 +280,23 @@ void build_plan(CdPlan* p) {
   const int half = d.cond_dim / 2, hidden = d.cond_size > half / 2 ? d.cond_size : half / 2;
   p->init_w = add_weight(p, "init_conv.conv.weight", (int64_t)d.layer_sizes[0] * d.in_channels * 27, PK_INIT, d.in_channels, d.layer_sizes[0], 27);
   p->init_b = add_weight(p, "init_conv.conv.bias", d.layer_sizes[0]);
+  // Linear branch: time_mlp = [Unflatten, Linear(1, q), GELU, Linear(q, half), GELU, Linear(half, half)] (keys 1, 3, 5);
+  // sinusoidal branch: [SinusoidalPositionEmbeddings(q), Linear(q, half), GELU, Linear(half, half)] (keys 1, 3).  The cond
+  // MLP likewise (keys 0, 2, 4 resp. 1, 3; its sinusoidal form embeds a scalar condition, so hidden must equal q).
+  CD_REQUIRE(!(d.time_sin || d.cond_sin) || (half / 2) % 2 == 0 && half / 2 >= 4, "sinusoidal embeddings need cond_dim / 4 even and >= 4");
+  CD_REQUIRE(!d.cond_sin || hidden == half / 2,
+             "cond_embed 'sin' embeds one scalar per sample into cond_dim/4 features: cond_size must not exceed cond_dim/4");
   const int tin[3] = {1, half / 2, half}, tout[3] = {half / 2, half, half};
-  for (int i = 0; i < 3; ++i) {
-    p->tw[i] = add_weight(p, "time_mlp." + std::to_string(2 * i + 1) + ".weight", (int64_t)tin[i] * tout[i]);
-    p->tb[i] = add_weight(p, "time_mlp." + std::to_string(2 * i + 1) + ".bias", tout[i]);
+  for (int i = d.time_sin ? 1 : 0; i < 3; ++i) {
+    const std::string key = "time_mlp." + std::to_string(d.time_sin ? 2 * i - 1 : 2 * i + 1);
+    p->tw[i] = add_weight(p, key + ".weight", (int64_t)tin[i] * tout[i]);
+    p->tb[i] = add_weight(p, key + ".bias", tout[i]);
   }
   const int cin3[3] = {d.cond_size, hidden, half}, cout3[3] = {hidden, half, half};
-  for (int i = 0; i < 3; ++i) {
-    p->cw[i] = add_weight(p, "cond_mlp." + std::to_string(2 * i) + ".weight", (int64_t)cin3[i] * cout3[i]);
-    p->cb[i] = add_weight(p, "cond_mlp." + std::to_string(2 * i) + ".bias", cout3[i]);
+  for (int i = d.cond_sin ? 1 : 0; i < 3; ++i) {
+    const std::string key = "cond_mlp." + std::to_string(d.cond_sin ? 2 * i - 1 : 2 * i);
+    p->cw[i] = add_weight(p, key + ".weight", (int64_t)cin3[i] * cout3[i]);
+    p->cb[i] = add_weight(p, key + ".bias", cout3[i]);
   }
   p->downs.resize(nres);
   p->ups.resize(nres);
@@ -794,6 +812,11 @@ float* unet_body(CdPlan* p, Run& r, const float* emb, float* h) {
 }
 
 void check_ready(CdPlan* p, bool need_coords) {
+  // need_coords = a denoise-based entry point: the reference's do_time_embed raises KeyError for TIME_EMBED 'sin'
+  // (calodiffusion.py:148-152); only CondUnet.forward reaches the sinusoidal embeddings
+  if (need_coords && (p->desc.time_sin || p->desc.cond_sin))
+    throw Fail{CD_EINVAL, "sinusoidal time/cond embeddings are reachable through cd_unet_forward only (the reference's denoise "
+                          "path raises KeyError for TIME_EMBED 'sin')"};
   for (auto& w : p->weights)
     if (!w.set) throw Fail{CD_EWEIGHTS, "weight '" + w.name + "' was never set (cd_plan_set_weight)"};
   if (need_coords && (p->desc.rz_input || p->desc.phi_input) && !p->coords_set)
@@ -806,9 +829,12 @@ EmbedArgs embed_args(CdPlan* p, int B, const float* cond, const float* t, int ki
   e.cond = cond; e.time_or_sigma = t; e.time_kind = kind; e.sigma_data = d.sigma_data;
   e.cond_size = d.cond_size; e.half = d.cond_dim / 2;
   e.cond_hidden = d.cond_size > e.half / 2 ? d.cond_size : e.half / 2;
-  e.tw1 = p->raw(p->tw[0]); e.tb1 = p->raw(p->tb[0]); e.tw2 = p->raw(p->tw[1]); e.tb2 = p->raw(p->tb[1]);
+  e.time_sin = d.time_sin; e.cond_sin = d.cond_sin;
+  e.tw1 = d.time_sin ? nullptr : p->raw(p->tw[0]); e.tb1 = d.time_sin ? nullptr : p->raw(p->tb[0]);
+  e.tw2 = p->raw(p->tw[1]); e.tb2 = p->raw(p->tb[1]);
   e.tw3 = p->raw(p->tw[2]); e.tb3 = p->raw(p->tb[2]);
-  e.cw1 = p->raw(p->cw[0]); e.cb1 = p->raw(p->cb[0]); e.cw2 = p->raw(p->cw[1]); e.cb2 = p->raw(p->cb[1]);
+  e.cw1 = d.cond_sin ? nullptr : p->raw(p->cw[0]); e.cb1 = d.cond_sin ? nullptr : p->raw(p->cb[0]);
+  e.cw2 = p->raw(p->cw[1]); e.cb2 = p->raw(p->cb[1]);
   e.cw3 = p->raw(p->cw[2]); e.cb3 = p->raw(p->cb[2]);
   e.layers = p->d_embed_layers; e.n_layers = p->n_embed_layers; e.emb = emb; e.emb_ld = p->emb_ld; e.scal = scal; e.batch = B;
   return e;
@@ -888,6 +914,36 @@ void destroy_graph(CdPlan* p) {
     p->graph_exec = nullptr;
   }
 }
+void destroy_prog_graph(CdPlan* p) {
+  if (p->prog_exec) {
+    hipGraphExecDestroy(p->prog_exec);
+    p->prog_exec = nullptr;
+  }
+}
+
+// Range fallback of the sampler entry points: `run(eager)` enqueues the whole trajectory.  If the f16x2 convolutions left the
+// fp16 range on the way (sticky flag bit 0), the trajectory is run again with the exact bf16x3 convolutions (full fp32 range;
+// eagerly, the cached step graph holds the f16x2 kernels) and bit 1 replaces bit 0.
+template <typename F>
+void run_with_range_fallback(CdPlan* plan, hipStream_t s, F&& run) {
+  run(false);
+  if (conv_precision() != PREC_F16X2) return;
+  int flags = 0;
+  CD_HIP(hipMemcpyAsync(&flags, plan->d_counter + 2, sizeof(int), hipMemcpyDeviceToHost, s));
+  CD_HIP(hipStreamSynchronize(s));
+  if (!(flags & 1)) return;
+  set_conv_precision(PREC_BF16X3);
+  try {
+    run(true);
+  } catch (...) {
+    set_conv_precision(PREC_F16X2);
+    throw;
+  }
+  set_conv_precision(PREC_F16X2);
+  flags = (flags & ~1) | 2;
+  CD_HIP(hipMemcpyAsync(plan->d_counter + 2, &flags, sizeof(int), hipMemcpyHostToDevice, s));
+  CD_HIP(hipStreamSynchronize(s));  // `flags` lives on this stack frame
+}
 
 }  // namespace
 
@@ -928,6 +984,7 @@ int cd_plan_destroy(CdPlan* plan) {
   return guarded([&] {
     if (!plan) return;
     destroy_graph(plan);
+    destroy_prog_graph(plan);
     if (plan->cap_stream) hipStreamDestroy(plan->cap_stream);
     if (plan->arena) hipFree(plan->arena);
     if (plan->d_embed_layers) hipFree(plan->d_embed_layers);
@@ -1154,8 +1211,8 @@ int cd_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream
 }
 
 int cd_ddim_sample(CdPlan* plan, int batch, const float* start, const float* cond, const CdStep* steps, int n_steps,
-                   const float* step_noise, uint64_t seed, uint64_t offset, float* x_out, float* xs, float* x0s,
-                   int use_graph, void* workspace, size_t workspace_bytes, void* stream) {
+                   const float* step_noise, uint64_t seed, uint64_t offset, uint64_t noise_stride, float* x_out, float* xs,
+                   float* x0s, int use_graph, void* workspace, size_t workspace_bytes, void* stream) {
   return guarded([&] {
     CD_REQUIRE(plan && start && cond && steps && x_out && workspace && batch > 0, "bad argument");
     CD_REQUIRE(n_steps >= 1 && n_steps <= CdPlan::kMaxSteps, "n_steps out of range (1..4096)");
@@ -1167,17 +1224,14 @@ int cd_ddim_sample(CdPlan* plan, int batch, const float* start, const float* con
 
     static_assert(sizeof(CdStep) == 16, "CdStep must be 4 floats");
     CD_HIP(hipMemcpyAsync(plan->d_table, steps, sizeof(CdStep) * n_steps, hipMemcpyHostToDevice, s));
-    CD_HIP(hipMemsetAsync(plan->d_counter, 0, sizeof(int), s));
-    // x = start * sigma_start (sample.py:62-66); x_out doubles as the running x
-    launch_scale(start, x_out, plan->d_table, n, s);
 
     plan->ws.reset((char*)workspace, workspace_bytes, false);
     float* x0 = plan->ws.get<float>((size_t)n);
     float* noise_buf = plan->ws.get<float>((size_t)n);
     float* sigma_b = plan->ws.get<float>((size_t)batch + 64);
-    uint64_t* noise_dev = (uint64_t*)plan->ws.get<double>(4);  // {seed, base offset}
+    uint64_t* noise_dev = (uint64_t*)plan->ws.get<double>(4);  // {seed, base offset, stride}
     if (noisy && !step_noise) {
-      const uint64_t so[2] = {seed, offset};
+      const uint64_t so[3] = {seed, offset, noise_stride ? noise_stride : (uint64_t)n};
       CD_HIP(hipMemcpyAsync(noise_dev, so, sizeof(so), hipMemcpyHostToDevice, s));
       CD_HIP(hipStreamSynchronize(s));  // `so` lives on this stack frame
     }
@@ -1192,7 +1246,7 @@ int cd_ddim_sample(CdPlan* plan, int batch, const float* start, const float* con
       forward_impl(plan, batch, x_out, cond, sigma_b, x0, false, st);
       const float* nz = noise_i;
       if (!nz && noisy) {
-        // stream position = offset + i * n, read from device memory (the step counter is i + 1 after load_step): the same
+        // stream position = offset + i * stride, read from device memory (the step counter is i + 1 after load_step): the same
         // launch serves every step, so stochastic samplers replay one captured graph as well
         launch_randn_step(noise_buf, n, noise_dev, plan->d_counter, st);
         nz = noise_buf;
@@ -1200,48 +1254,225 @@ int cd_ddim_sample(CdPlan* plan, int batch, const float* start, const float* con
       launch_ddim_update(x_out, x0, nz, plan->d_stepvals, x_out, xs_i, x0s_i, n, st);
     };
 
-    // A hipGraph of one step can be replayed only if nothing in it depends on the host-side step index: no trajectories and
-    // no caller-supplied per-step noise (the device Philox noise of a stochastic sampler reads its stream position from the
-    // step counter, see one_step).
-    const bool graphable = use_graph && !step_noise && !xs && !x0s && !prof::enabled();
-    if (graphable) {
-      CdPlan::GraphKey key;
-      key.batch = batch; key.ws = workspace; key.cond = cond; key.x = x_out; key.noisy = noisy ? 1 : 0;
-      if (!(plan->graph_exec && plan->graph_key == key)) {
-        destroy_graph(plan);
-        hipGraph_t graph = nullptr;
-        // one eager pass first: per-geometry kernel tuning (and lazy function attributes) cannot happen during capture.
-        // It only writes x0 / scratch, which the replayed steps overwrite.
-        launch_load_step(plan->d_table, plan->d_counter, plan->d_stepvals, sigma_b, batch, s);
-        plan->ws.reset(sub, sub_bytes, false);
-        forward_impl(plan, batch, x_out, cond, sigma_b, x0, false, s);
-        CD_HIP(hipMemsetAsync(plan->d_counter, 0, sizeof(int), s));
-        CD_HIP(hipStreamSynchronize(s));
-        if (!plan->cap_stream) CD_HIP(hipStreamCreateWithFlags(&plan->cap_stream, hipStreamNonBlocking));
-        hipStream_t cs = plan->cap_stream;
-        CD_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed));
-        try {
-          one_step(cs, 0, nullptr, nullptr, nullptr);
-        } catch (...) {
-          hipStreamEndCapture(cs, &graph);
-          if (graph) hipGraphDestroy(graph);
-          throw;
+    run_with_range_fallback(plan, s, [&](bool eager) {
+      CD_HIP(hipMemsetAsync(plan->d_counter, 0, sizeof(int), s));
+      // x = start * sigma_start (sample.py:62-66); x_out doubles as the running x
+      launch_scale(start, x_out, plan->d_table, n, s);
+      // A hipGraph of one step can be replayed only if nothing in it depends on the host-side step index: no trajectories and
+      // no caller-supplied per-step noise (the device Philox noise of a stochastic sampler reads its stream position from the
+      // step counter, see one_step).
+      const bool graphable = use_graph && !eager && !step_noise && !xs && !x0s && !prof::enabled();
+      if (graphable) {
+        CdPlan::GraphKey key;
+        key.batch = batch; key.ws = workspace; key.cond = cond; key.x = x_out; key.noisy = noisy ? 1 : 0;
+        if (!(plan->graph_exec && plan->graph_key == key)) {
+          destroy_graph(plan);
+          hipGraph_t graph = nullptr;
+          // one eager pass first: per-geometry kernel tuning (and lazy function attributes) cannot happen during capture.
+          // It only writes x0 / scratch, which the replayed steps overwrite.
+          launch_load_step(plan->d_table, plan->d_counter, plan->d_stepvals, sigma_b, batch, s);
+          plan->ws.reset(sub, sub_bytes, false);
+          forward_impl(plan, batch, x_out, cond, sigma_b, x0, false, s);
+          CD_HIP(hipMemsetAsync(plan->d_counter, 0, sizeof(int), s));
+          CD_HIP(hipStreamSynchronize(s));
+          if (!plan->cap_stream) CD_HIP(hipStreamCreateWithFlags(&plan->cap_stream, hipStreamNonBlocking));
+          hipStream_t cs = plan->cap_stream;
+          CD_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed));
+          try {
+            one_step(cs, 0, nullptr, nullptr, nullptr);
+          } catch (...) {
+            hipStreamEndCapture(cs, &graph);
+            if (graph) hipGraphDestroy(graph);
+            throw;
+          }
+          CD_HIP(hipStreamEndCapture(cs, &graph));
+          hipError_t e = hipGraphInstantiate(&plan->graph_exec, graph, nullptr, nullptr, 0);
+          hipGraphDestroy(graph);
+          if (e != hipSuccess) {
+            plan->graph_exec = nullptr;
+            throw Fail{CD_EHIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)};
+          }
+          plan->graph_key = key;
         }
-        CD_HIP(hipStreamEndCapture(cs, &graph));
-        hipError_t e = hipGraphInstantiate(&plan->graph_exec, graph, nullptr, nullptr, 0);
-        hipGraphDestroy(graph);
-        if (e != hipSuccess) {
-          plan->graph_exec = nullptr;
-          throw Fail{CD_EHIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)};
-        }
-        plan->graph_key = key;
+        for (int i = 0; i < n_steps; ++i) CD_HIP(hipGraphLaunch(plan->graph_exec, s));
+      } else {
+        for (int i = 0; i < n_steps; ++i)
+          one_step(s, i, step_noise ? step_noise + (size_t)i * n : nullptr, xs ? xs + (size_t)i * n : nullptr,
+                   x0s ? x0s + (size_t)i * n : nullptr);
       }
-      for (int i = 0; i < n_steps; ++i) CD_HIP(hipGraphLaunch(plan->graph_exec, s));
-    } else {
-      for (int i = 0; i < n_steps; ++i)
-        one_step(s, i, step_noise ? step_noise + (size_t)i * n : nullptr, xs ? xs + (size_t)i * n : nullptr,
-                 x0s ? x0s + (size_t)i * n : nullptr);
+    });
+  });
+}
+
+// workspace of cd_sampler_run: the buffers, the coefficient table, sigma / Philox words, and the network's own
+static size_t sampler_front_bytes(CdPlan* plan, int batch, int n_bufs, size_t table_floats, float** bufs, float** table, float** sigma_b,
+                                  uint64_t** noise_dev) {
+  const int64_t n = (int64_t)batch * plan->shapes[0].vox();
+  for (int k = 1; k < n_bufs; ++k) {
+    float* b = plan->ws.get<float>((size_t)n);
+    if (bufs) bufs[k] = b;
+  }
+  float* t = plan->ws.get<float>(table_floats + 64);
+  float* sg = plan->ws.get<float>((size_t)batch + 64);
+  uint64_t* nd = (uint64_t*)plan->ws.get<double>(4);
+  if (table) *table = t;
+  if (sigma_b) *sigma_b = sg;
+  if (noise_dev) *noise_dev = nd;
+  return plan->ws.high();
+}
+
+int cd_plan_sampler_workspace_bytes(CdPlan* plan, int batch, int n_bufs, int n_steps, int n_coef, size_t* bytes) {
+  return guarded([&] {
+    CD_REQUIRE(plan && bytes && batch > 0 && n_bufs >= 2 && n_bufs <= 16 && n_steps >= 1 && n_coef >= 1, "bad argument");
+    plan->ws.reset(nullptr, 0, true);
+    const size_t front = sampler_front_bytes(plan, batch, n_bufs, (size_t)n_steps * n_coef, nullptr, nullptr, nullptr, nullptr);
+    plan->ws.reset(nullptr, 0, true);
+    forward_impl(plan, batch, nullptr, nullptr, nullptr, nullptr, false, nullptr);
+    *bytes = front + plan->ws.high() + 8192;
+  });
+}
+
+int cd_sampler_run(CdPlan* plan, int batch, const float* start, float start_scale, const float* cond, int n_bufs, int n_steps,
+                   const CdSamplerOp* ops, int n_ops, const int32_t* op_begin, const float* coefs, int n_coef,
+                   const float* step_noise, uint64_t seed, uint64_t offset, uint64_t noise_stride, float* x_out, float* xs,
+                   float* x0s, int use_graph, void* workspace, size_t workspace_bytes, void* stream) {
+  return guarded([&] {
+    CD_REQUIRE(plan && start && cond && ops && coefs && x_out && workspace && batch > 0, "bad argument");
+    CD_REQUIRE(n_bufs >= 2 && n_bufs <= 16 && n_steps >= 1 && n_steps <= 1 << 20 && n_ops >= 1 && n_coef >= 1, "bad program size");
+    check_ready(plan, true);
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n = (int64_t)batch * plan->shapes[0].vox();
+    const bool uniform = op_begin == nullptr;
+    if (!uniform) {
+      CD_REQUIRE(op_begin[0] == 0 && op_begin[n_steps] == n_ops, "op_begin must run from 0 to n_ops");
+      for (int i = 0; i < n_steps; ++i) CD_REQUIRE(op_begin[i] <= op_begin[i + 1], "op_begin must be non-decreasing");
     }
+    // validate the program before anything is enqueued: a bad buffer index would be a wild device pointer
+    int randn_per_step = 0;
+    for (int k = 0; k < n_ops; ++k) {
+      const CdSamplerOp& o = ops[k];
+      CD_REQUIRE(o.kind >= CD_SOP_LINCOMB && o.kind <= CD_SOP_RECORD, "sampler op: unknown kind");
+      const int ns = o.kind == CD_SOP_LINCOMB ? o.nsrc : (o.kind == CD_SOP_RANDN ? 0 : 1);
+      CD_REQUIRE(ns >= 0 && ns <= 6 && (o.kind != CD_SOP_LINCOMB || ns >= 1), "sampler op: 1..6 sources");
+      for (int j = 0; j < ns; ++j) CD_REQUIRE(o.src[j] >= 0 && o.src[j] < n_bufs, "sampler op: source buffer out of range");
+      if (o.kind == CD_SOP_RECORD) CD_REQUIRE(o.dst == 0 || o.dst == 1, "record op: dst is 0 (xs) or 1 (x0s)");
+      else CD_REQUIRE(o.dst >= 0 && o.dst < n_bufs, "sampler op: destination buffer out of range");
+      if (o.kind == CD_SOP_LINCOMB) CD_REQUIRE(o.col >= 0 && o.col + ns <= n_coef, "lincomb op: coefficient columns out of range");
+      if (o.kind == CD_SOP_DENOISE) {
+        CD_REQUIRE(o.col >= 0 && o.col < n_coef, "denoise op: sigma column out of range");
+        CD_REQUIRE(o.dst != o.src[0], "denoise op: output must not alias its input");
+      }
+      if (o.kind == CD_SOP_RANDN) ++randn_per_step;
+    }
+
+    plan->ws.reset((char*)workspace, workspace_bytes, false);
+    float* bufs[16] = {nullptr};
+    bufs[0] = x_out;
+    float *table = nullptr, *sigma_b = nullptr;
+    uint64_t* noise_dev = nullptr;
+    const size_t used = sampler_front_bytes(plan, batch, n_bufs, (size_t)n_steps * n_coef, bufs, &table, &sigma_b, &noise_dev);
+    CD_REQUIRE(used <= workspace_bytes, "workspace too small: call cd_plan_sampler_workspace_bytes");
+    char* sub = (char*)workspace + used;
+    const size_t sub_bytes = workspace_bytes - used;
+    const uint64_t stride = noise_stride ? noise_stride : (uint64_t)n;
+    CD_HIP(hipMemcpyAsync(table, coefs, sizeof(float) * (size_t)n_steps * n_coef, hipMemcpyHostToDevice, s));
+    {
+      const uint64_t so[3] = {seed, offset, stride};
+      CD_HIP(hipMemcpyAsync(noise_dev, so, sizeof(so), hipMemcpyHostToDevice, s));
+      CD_HIP(hipStreamSynchronize(s));  // `so` lives on this stack frame (and the caller's coefs may be a temporary)
+    }
+    int* counter = plan->d_counter;
+
+    // one op; `draw` = running number of the RANDN op (eager), or -1 when the position comes from the device counter (graph)
+    int64_t draws = 0;
+    auto run_op = [&](hipStream_t st, const CdSamplerOp& o, int index_in_step, bool from_counter) {
+      switch (o.kind) {
+        case CD_SOP_LINCOMB: {
+          const float* src[6];
+          for (int j = 0; j < o.nsrc; ++j) src[j] = bufs[o.src[j]];
+          launch_lincomb(bufs[o.dst], src, o.nsrc, table, n_coef, o.col, counter, n, st);
+          break;
+        }
+        case CD_SOP_DENOISE:
+          launch_fill_from_table(sigma_b, batch, table, n_coef, o.col, counter, st);
+          plan->ws.reset(sub, sub_bytes, false);
+          forward_impl(plan, batch, bufs[o.src[0]], cond, sigma_b, bufs[o.dst], false, st);
+          break;
+        case CD_SOP_RANDN:
+          if (step_noise) CD_HIP(hipMemcpyAsync(bufs[o.dst], step_noise + (size_t)draws * n, sizeof(float) * n, hipMemcpyDeviceToDevice, st));
+          else if (from_counter) launch_randn_step(bufs[o.dst], n, noise_dev, counter, st, randn_per_step, index_in_step);
+          else launch_randn(bufs[o.dst], n, seed, offset + (uint64_t)draws * stride, st);
+          ++draws;
+          break;
+        case CD_SOP_RECORD: {
+          float* traj = o.dst == 0 ? xs : x0s;
+          if (traj) launch_record_step(traj, bufs[o.src[0]], counter, n, st);
+          break;
+        }
+      }
+    };
+    auto run_step = [&](hipStream_t st, int i, bool from_counter) {
+      launch_step_advance(counter, st);
+      const int b = uniform ? 0 : op_begin[i], e = uniform ? n_ops : op_begin[i + 1];
+      int ri = 0;
+      for (int k = b; k < e; ++k) {
+        run_op(st, ops[k], ri, from_counter);
+        if (ops[k].kind == CD_SOP_RANDN) ++ri;
+      }
+    };
+
+    run_with_range_fallback(plan, s, [&](bool eager) {
+      draws = 0;
+      CD_HIP(hipMemsetAsync(counter, 0, sizeof(int), s));
+      for (int k = 1; k < n_bufs; ++k) CD_HIP(hipMemsetAsync(bufs[k], 0, sizeof(float) * n, s));
+      launch_scale_imm(start, x_out, start_scale, n, s);
+      const bool graphable = use_graph && !eager && uniform && !step_noise && !prof::enabled();
+      if (graphable) {
+        CdPlan::ProgKey key;
+        key.batch = batch; key.n_coef = n_coef; key.n_bufs = n_bufs; key.ws = workspace; key.cond = cond; key.x = x_out;
+        key.xs = xs; key.x0s = x0s;
+        uint64_t h = 1469598103934665603ull;  // FNV-1a over the op list
+        for (size_t b = 0; b < sizeof(CdSamplerOp) * (size_t)n_ops; ++b) h = (h ^ ((const unsigned char*)ops)[b]) * 1099511628211ull;
+        key.ops_hash = h ^ ((uint64_t)n_steps << 40) ^ (uint64_t)n_ops;
+        if (!(plan->prog_exec && plan->prog_key == key)) {
+          destroy_prog_graph(plan);
+          // one eager denoise first (kernel tuning / lazy function attributes cannot happen during capture): x -> buffer 1
+          for (int k = 0; k < n_ops; ++k)
+            if (ops[k].kind == CD_SOP_DENOISE) {
+              launch_step_advance(counter, s);
+              launch_fill_from_table(sigma_b, batch, table, n_coef, ops[k].col, counter, s);
+              plan->ws.reset(sub, sub_bytes, false);
+              forward_impl(plan, batch, x_out, cond, sigma_b, bufs[1], false, s);
+              CD_HIP(hipMemsetAsync(counter, 0, sizeof(int), s));
+              CD_HIP(hipMemsetAsync(bufs[1], 0, sizeof(float) * n, s));
+              break;
+            }
+          CD_HIP(hipStreamSynchronize(s));
+          if (!plan->cap_stream) CD_HIP(hipStreamCreateWithFlags(&plan->cap_stream, hipStreamNonBlocking));
+          hipStream_t cs = plan->cap_stream;
+          hipGraph_t graph = nullptr;
+          CD_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed));
+          try {
+            run_step(cs, 0, true);
+          } catch (...) {
+            hipStreamEndCapture(cs, &graph);
+            if (graph) hipGraphDestroy(graph);
+            throw;
+          }
+          CD_HIP(hipStreamEndCapture(cs, &graph));
+          hipError_t e = hipGraphInstantiate(&plan->prog_exec, graph, nullptr, nullptr, 0);
+          hipGraphDestroy(graph);
+          if (e != hipSuccess) {
+            plan->prog_exec = nullptr;
+            throw Fail{CD_EHIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)};
+          }
+          plan->prog_key = key;
+        }
+        for (int i = 0; i < n_steps; ++i) CD_HIP(hipGraphLaunch(plan->prog_exec, s));
+      } else {
+        for (int i = 0; i < n_steps; ++i) run_step(s, i, false);
+      }
+    });
   });
 }
 
@@ -1269,6 +1500,7 @@ int cd_plan_grad_layout(const CdPlan* plan, int idx, int64_t* offset, int64_t* t
 int cd_plan_train_workspace_bytes(CdPlan* plan, int batch, size_t* bytes) {
   return guarded([&] {
     CD_REQUIRE(plan && bytes && batch > 0, "bad argument");
+    CD_REQUIRE(!plan->desc.time_sin && !plan->desc.cond_sin, "the training step needs the Linear time/cond embeddings");
     plan->ws.reset(nullptr, 0, true);
     train_step_impl(plan, batch, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     *bytes = plan->ws.high() + 4096;

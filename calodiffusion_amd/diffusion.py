@@ -31,9 +31,12 @@ class Diffusion(torch.nn.Module, ABC):
             self._data_shape = self.config["SHAPE_PAD"][1:]
         else:
             self._data_shape = self.config["SHAPE_ORIG"][1:]
-        # device Philox stream for noise_generation: (seed, running offset); ranks of a sharded job set disjoint offsets
+        # device Philox stream for noise_generation: (seed, running offset).  A rank of a batch-sharded job calls
+        # set_noise_shard(): every rank then walks the SAME global stream and draws only its rows of every tensor, so the
+        # union of the shards is the single-GPU result of the same seed.
         self.noise_seed = int(self.config.get("SEED", 1234))
         self.noise_offset = 0
+        self.noise_shard = None  # (first row of this rank, rows of the global batch)
 
     @abstractmethod
     def init_model(self):
@@ -42,13 +45,35 @@ class Diffusion(torch.nn.Module, ABC):
     def init_embedding_model(self):
         return None
 
+    def set_noise_shard(self, first_row: int, global_batch: int):
+        """This process samples rows [first_row, first_row + B) of a global batch of `global_batch` showers
+        (utils.shard_batch); None-like (0, 0) switches sharding off."""
+        self.noise_shard = (int(first_row), int(global_batch)) if global_batch else None
+
+    def _shard_geometry(self, shape):
+        """(elements per row, first element of this shard in a global tensor, elements of the global tensor)"""
+        per = int(np.prod(shape[1:]))
+        if self.noise_shard is None:
+            return per, 0, int(shape[0]) * per
+        lo, gb = self.noise_shard
+        if lo + shape[0] > gb:
+            raise ValueError(f"noise shard rows [{lo}, {lo + shape[0]}) exceed the global batch {gb}")
+        return per, lo * per, gb * per
+
     @abstractmethod
     def noise_generation(self, shape):
-        """Unit normal start tensor (diffusion.py:58-61); drawn from the device Philox stream."""
+        """Unit normal start tensor (diffusion.py:58-61); drawn from the device Philox stream (this rank's rows of it)."""
         from .engine import randn
-        out = randn(shape, self.device, self.noise_seed, self.noise_offset)
-        self.noise_offset += out.numel()
+        _, first, total = self._shard_geometry(shape)
+        out = randn(shape, self.device, self.noise_seed, self.noise_offset + first)
+        self.noise_offset += total
         return out
+
+    def step_noise_stream(self, start):
+        """(offset, stride) of a sampler's per-step noise tensors: they follow the start tensor in the stream, one global
+        tensor apart (samplers call this after noise_generation has advanced the stream past the start tensor)."""
+        _, first, total = self._shard_geometry(start.shape)
+        return self.noise_offset + first, total
 
     @abstractmethod
     def forward(self):
@@ -65,8 +90,8 @@ class Diffusion(torch.nn.Module, ABC):
         if start is None:
             start = self.noise_generation(shape)
         x, xs, x0s = self.sampler_algorithm(self, start, energy, layers, num_steps, sample_offset, debug)
-        # every step of a stochastic sampler consumed start.numel() normals after the start tensor's own
-        self.noise_offset += start.numel() * num_steps
+        # every noise tensor the sampler drew took one (global) tensor's worth of normals behind the start tensor's own
+        self.noise_offset += self._shard_geometry(shape)[2] * getattr(self.sampler_algorithm, "noise_tensors_drawn", num_steps)
         if debug:
             return x.detach().cpu().numpy(), xs, x0s
         return x.detach().cpu().numpy()
@@ -102,7 +127,7 @@ class Diffusion(torch.nn.Module, ABC):
     def _to_physical(self, generated, energies, layers, reverse_norm, debug=False):
         """Inverse pre-processing of generated showers (shared with LayerDiffusion.generate)."""
         cfg = self.config
-        device_form = (reverse_norm is None and not debug and cfg.get("DATASET_NUM", 2) in (2, 3)
+        device_form = (reverse_norm is None and cfg.get("DATASET_NUM", 2) in (2, 3)
                        and cfg.get("SHOWERMAP") in ("layer-logit-norm", "logit-norm")
                        and all(k in cfg for k in ("EMAX", "EMIN", "logE", "MAXDEP", "ECUT")))
         if callable(reverse_norm):
@@ -114,4 +139,11 @@ class Diffusion(torch.nn.Module, ABC):
                                               showerMap=cfg["SHOWERMAP"], dataset_num=cfg.get("DATASET_NUM", 2),
                                               ecut=float(cfg["ECUT"]))
             generated = generated.reshape(cfg["SHAPE_ORIG"])
+        elif reverse_norm is not False:
+            # the reference always applies utils.ReverseNorm (diffusion.py:171-195): never hand back normalised-space showers
+            # silently.  HGCal / Dataset-1 need geometry files outside this package: pass the reference's function.
+            raise ValueError(
+                "generate(): no inverse pre-processing for this config on the device path (needs DATASET_NUM 2/3 with a "
+                "[layer-]logit-norm SHOWERMAP and the EMAX/EMIN/logE/MAXDEP/ECUT keys); pass reverse_norm=<callable "
+                "(generated, energies, layers, config)> or reverse_norm=False for normalised-space showers")
         return generated, np.reshape(energies, (energies.shape[0], -1))

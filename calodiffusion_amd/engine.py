@@ -37,7 +37,16 @@ class CdUnetDesc(C.Structure):
         ("time_embed_kind", C.c_int32),
         ("objective", C.c_int32),
         ("sigma_data", C.c_float),
+        ("time_sin", C.c_int32),
+        ("cond_sin", C.c_int32),
     ]
+
+
+SOP_LINCOMB, SOP_DENOISE, SOP_RANDN, SOP_RECORD = 0, 1, 2, 3
+
+
+class CdSamplerOp(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("dst", C.c_int32), ("nsrc", C.c_int32), ("src", C.c_int32 * 6), ("col", C.c_int32)]
 
 
 class CdLayerMlpDesc(C.Structure):
@@ -63,8 +72,12 @@ _SIGNATURES = {
     "cd_plan_workspace_bytes": (C.c_int, [_P, C.c_int, C.POINTER(C.c_size_t)]),
     "cd_unet_forward": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "cd_denoise": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, C.c_size_t, _P]),
-    "cd_ddim_sample": (C.c_int, [_P, C.c_int, _P, _P, C.POINTER(CdStep), C.c_int, _P, C.c_uint64, C.c_uint64, _P, _P, _P,
+    "cd_ddim_sample": (C.c_int, [_P, C.c_int, _P, _P, C.POINTER(CdStep), C.c_int, _P, C.c_uint64, C.c_uint64, C.c_uint64, _P, _P, _P,
                                  C.c_int, _P, C.c_size_t, _P]),
+    "cd_plan_sampler_workspace_bytes": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
+    "cd_sampler_run": (C.c_int, [_P, C.c_int, _P, C.c_float, _P, C.c_int, C.c_int, C.POINTER(CdSamplerOp), C.c_int,
+                                 C.POINTER(C.c_int32), _P, C.c_int, _P, C.c_uint64, C.c_uint64, C.c_uint64, _P, _P, _P, C.c_int,
+                                 _P, C.c_size_t, _P]),
     "cd_randn": (C.c_int, [_P, C.c_int64, C.c_uint64, C.c_uint64, _P]),
     "cd_plan_grad_layout": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "cd_plan_train_workspace_bytes": (C.c_int, [_P, C.c_int, C.POINTER(C.c_size_t)]),
@@ -182,6 +195,7 @@ class UnetEngine:
         d.time_embed_kind = TIME_KINDS[time_kind]
         d.objective = OBJECTIVES[objective]
         d.sigma_data = float(sigma_data)
+        d.time_sin, d.cond_sin = int(bool(getattr(unet, "time_embed", False))), int(bool(getattr(unet, "cond_embed", False)))
         self.desc = d
         self.grid = tuple(unet.grid)
         self.voxels = int(np.prod(self.grid))
@@ -248,7 +262,7 @@ class UnetEngine:
             nbytes = C.c_size_t()
             _check(self.lib.cd_plan_workspace_bytes(self.plan, batch, C.byref(nbytes)))
             ws = torch.empty(nbytes.value, dtype=torch.uint8, device=self.device)
-            self._ws = {batch: ws}  # keep one: workspaces are large
+            self._ws = {batch: ws}  # keep one (and the sampler-program workspace of sampler_run): workspaces are large
         return ws
 
     # ------------------------------------------------------------------ compute
@@ -257,8 +271,13 @@ class UnetEngine:
         B = x.shape[0]
         if tuple(x.shape[1:]) != (self.unet.channels,) + self.grid:
             raise ValueError(f"x has shape {tuple(x.shape)}, expected (B, {self.unet.channels}, {self.grid})")
-        if cond.shape != (B, self.unet.cond_size) or time.numel() != B:
-            raise ValueError("cond must be (B, cond_size) and time (B,)")
+        if self.desc.cond_sin:  # sinusoidal cond embedding: one scalar per sample (models.py:132-144 broadcasts a (B,) tensor)
+            if cond.numel() != B:
+                raise ValueError("cond_embed='sin' takes cond of shape (B,)")
+        elif cond.shape != (B, self.unet.cond_size):
+            raise ValueError("cond must be (B, cond_size)")
+        if time.numel() != B:
+            raise ValueError("time must be (B,)")
         self.sync_weights()
         ws = self.workspace(B)
         out = torch.empty((B, 1) + self.grid, dtype=torch.float32, device=x.device)
@@ -282,8 +301,10 @@ class UnetEngine:
         return out
 
     def ddim_sample(self, start, cond, steps: np.ndarray, step_noise=None, seed=0, offset=0, debug=False, use_graph=True,
-                    out=None):
-        """steps: float32 array (n_steps, 4) = (sigma, sigma_prev*[t>0], ddim_sigma, denom)."""
+                    out=None, noise_stride=0):
+        """steps: float32 array (n_steps, 4) = (sigma, sigma_prev*[t>0], ddim_sigma, denom).  noise_stride: Philox stream
+        distance between the noise tensors of consecutive steps (0 = this batch's own size; a batch shard passes the global
+        tensor size so that the union of the shards is the single-GPU result)."""
         start, cond = _dev32(start, "start"), _dev32(cond, "cond")
         B = start.shape[0]
         steps = np.ascontiguousarray(steps, dtype=np.float32)
@@ -301,15 +322,60 @@ class UnetEngine:
             assert step_noise.shape[0] == n_steps and step_noise[0].numel() == start.numel()
         _check(self.lib.cd_ddim_sample(self.plan, B, start.data_ptr(), cond.data_ptr(),
                                        steps.ctypes.data_as(C.POINTER(CdStep)), n_steps, _ptr(step_noise), int(seed),
-                                       int(offset), x_out.data_ptr(), _ptr(xs), _ptr(x0s), int(bool(use_graph)),
-                                       ws.data_ptr(), ws.numel(), _stream()))
+                                       int(offset), int(noise_stride), x_out.data_ptr(), _ptr(xs), _ptr(x0s),
+                                       int(bool(use_graph)), ws.data_ptr(), ws.numel(), _stream()))
+        self.check_status()
+        return x_out, xs, x0s
+
+    def sampler_run(self, start, cond, program, step_noise=None, seed=0, offset=0, noise_stride=0, debug=False, use_graph=True):
+        """Run a sampler step program (calodiffusion_amd.sample.Program) on the device loop (cd_sampler_run).
+        Returns (x, xs, x0s); the trajectories (n_steps, B, 1, D, H, W) only when ``debug`` and the program records them."""
+        start, cond = _dev32(start, "start"), _dev32(cond, "cond")
+        B = start.shape[0]
+        coefs = np.ascontiguousarray(program.coefs, dtype=np.float32)
+        n_steps, n_coef = coefs.shape
+        ops = (CdSamplerOp * len(program.ops))()
+        for o, (kind, dst, src, col) in zip(ops, program.ops):
+            o.kind, o.dst, o.nsrc, o.col = kind, dst, len(src), col
+            for j, v in enumerate(src):
+                o.src[j] = v
+        op_begin = None
+        if program.op_begin is not None:
+            assert len(program.op_begin) == n_steps + 1
+            op_begin = (C.c_int32 * (n_steps + 1))(*program.op_begin)
+        self.sync_weights()
+        nbytes = C.c_size_t()
+        _check(self.lib.cd_plan_sampler_workspace_bytes(self.plan, B, program.n_bufs, n_steps, n_coef, C.byref(nbytes)))
+        key = ("sampler", B)
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < nbytes.value:
+            ws = torch.empty(nbytes.value, dtype=torch.uint8, device=self.device)
+            self._ws[key] = ws
+        x_out = torch.empty_like(start)
+        xs = x0s = None
+        if debug:
+            kinds = [(k, d) for k, d, _, _ in program.ops if k == SOP_RECORD]
+            if (SOP_RECORD, 0) in kinds:
+                xs = torch.zeros((n_steps,) + tuple(start.shape), dtype=torch.float32, device=start.device)
+            if (SOP_RECORD, 1) in kinds:
+                x0s = torch.zeros((n_steps,) + tuple(start.shape), dtype=torch.float32, device=start.device)
+        if step_noise is not None:
+            step_noise = _dev32(step_noise, "step_noise")
+            assert step_noise.numel() == program.n_randn * start.numel(), "step_noise: one (B,1,D,H,W) tensor per RANDN op executed"
+        _check(self.lib.cd_sampler_run(self.plan, B, start.data_ptr(), float(program.start_scale), cond.data_ptr(), program.n_bufs,
+                                       n_steps, ops, len(program.ops), op_begin, coefs.ctypes.data, n_coef, _ptr(step_noise),
+                                       int(seed), int(offset), int(noise_stride), x_out.data_ptr(), _ptr(xs), _ptr(x0s),
+                                       int(bool(use_graph)), ws.data_ptr(), ws.numel(), _stream()))
         self.check_status()
         return x_out, xs, x0s
 
     def check_status(self):
-        """Raise if a compute call since the last check left the fp16 range of the f16x2 convolution path (synchronises)."""
+        """Raise if a compute call since the last check left the fp16 range of the f16x2 convolution path (synchronises).
+        The sampler entry points recover by themselves (bf16x3 re-run of the trajectory): that only sets ``range_fallbacks``."""
         flags = C.c_int(0)
         _check(self.lib.cd_plan_status(self.plan, C.byref(flags), _stream()))
+        if flags.value & 2:
+            self.range_fallbacks = getattr(self, "range_fallbacks", 0) + 1
         if flags.value & 1:
             raise FloatingPointError("calodiff: an activation exceeded the fp16 range of the f16x2 convolution kernels "
                                      "(outputs contain inf/NaN); set CD_CONV_PRECISION=bf16x3 for the full fp32 range")
@@ -469,8 +535,9 @@ class LayerMlpEngine:
         return self.train_step(data, noise, sigma, cond)[0].to(torch.float32)
 
     def ddim_sample(self, start, cond, steps: np.ndarray, step_noise=None, seed=0, offset=0, debug=False, use_graph=True,
-                    out=None):
-        """Same contract as UnetEngine.ddim_sample; the whole trajectory is one launch (use_graph is irrelevant)."""
+                    out=None, noise_stride=0):
+        """Same contract as UnetEngine.ddim_sample; the whole trajectory is one launch (use_graph is irrelevant; the noise of
+        a stochastic sampler is drawn as one (n_steps, B, dim) block, so batch shards are not slices of a global stream)."""
         start, cond, B = self._io(start, cond)
         steps = np.ascontiguousarray(steps, dtype=np.float32)
         n_steps = steps.shape[0]

@@ -49,4 +49,7 @@ class FusedAdam(torch.optim.Optimizer):
                                                  arr([self.state[p]["exp_avg_sq"] for p in ps]), numel, float(group["lr"]), float(b1),
                                                  float(b2), float(group["eps"]), float(group["weight_decay"]), steps.pop(),
                                                  engine._stream()))
+            # cd_adam_step writes through raw pointers: tell torch (and UnetEngine.sync_weights, which keys its re-pack of the
+            # plan's weight arena on the parameters' versions) that the tensors changed
+            torch.autograd.graph.increment_version(ps)
         return loss

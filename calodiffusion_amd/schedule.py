@@ -59,3 +59,10 @@ def edm_euler_step_table(num_steps: int, sample_offset: int = 0, **kw) -> np.nda
     t = edm_time_steps(num_steps, sample_offset, **kw)
     n = t.numel() - 1
     return torch.stack([t[:-1], t[1:], torch.zeros(n), torch.ones(n)], dim=1).numpy().astype(np.float32)
+
+
+def karras_steps(num_step: int, min_t, max_t, rho: float = 7) -> torch.Tensor:
+    """num_step Karras noise levels from max_t down to min_t in fp32 (utils/sampling.py:44-51; the Restart sampler's
+    excursions)."""
+    step_indices = torch.arange(num_step, dtype=torch.float32)
+    return (max_t ** (1 / rho) + step_indices / (num_step - 1) * (min_t ** (1 / rho) - max_t ** (1 / rho))) ** rho

@@ -96,9 +96,10 @@ def _attn(dim):
 class CondUnet(nn.Module):
     """Drop-in for reference ``CondUnet`` (models.py:523-748) backed by the HIP engine.
 
-    Only what the shipped configs instantiate is supported: cylindrical convolutions, ResNet blocks,
-    linear attention, Linear (non-sinusoidal) cond/time embeddings.  Anything else raises here, at
-    construction, rather than silently computing something different.
+    Supported: what the shipped configs instantiate -- cylindrical convolutions, ResNet blocks, linear attention, Linear
+    cond/time embeddings -- plus the sinusoidal embeddings (``time_embed`` / ``cond_embed`` = True; with ``cond_embed`` the
+    condition is one scalar per sample, ``cond`` of shape (B,), as the reference's broadcasting requires).  Anything else
+    raises here, at construction, rather than silently computing something different.
     """
 
     def __init__(self, out_dim=1, layer_sizes=None, channels=1, cond_dim=128, resnet_block_groups=8,
@@ -106,10 +107,10 @@ class CondUnet(nn.Module):
                  cylindrical=False, data_shape=(-1, 1, 45, 16, 9), time_embed=True, cond_embed=True,
                  cond_size=1, no_time=False):
         super().__init__()
-        if use_convnext or not cylindrical or time_embed or cond_embed or no_time or out_dim != 1:
+        if use_convnext or not cylindrical or no_time or out_dim != 1:
             raise NotImplementedError(
-                "HIP CondUnet supports the shipped configurations only: cylindrical ResNet U-Net with Linear "
-                "time/cond embeddings (TIME_EMBED/COND_EMBED != 'sin'), out_dim=1")
+                "HIP CondUnet supports the shipped configurations only: cylindrical ResNet U-Net with time conditioning, "
+                "out_dim=1")
         layer_sizes = list(layer_sizes)
         self.channels, self.cond_dim, self.cond_size = channels, cond_dim, cond_size
         self.layer_sizes, self.groups = layer_sizes, resnet_block_groups
@@ -119,12 +120,19 @@ class CondUnet(nn.Module):
         g = resnet_block_groups
         zs = 2 if compress_Z else 1
 
+        self.time_embed, self.cond_embed = bool(time_embed), bool(cond_embed)
         self.init_conv = _CylConv(channels, layer_sizes[0], 3, pad_zr=1)
-        self.time_mlp = nn.Sequential(nn.Unflatten(-1, (-1, 1)), nn.Linear(1, half // 2), nn.GELU(),
-                                      nn.Linear(half // 2, half), nn.GELU(), nn.Linear(half, half))
+        # (models.py:575-608) sinusoidal branch: SinusoidalPositionEmbeddings(half // 2) -- parameter-free, computed in the
+        # embedding kernel -- stands where the first Linear + GELU of the Linear branch are, so the state_dict keys are
+        # time_mlp.{1,3} / cond_mlp.{1,3} instead of time_mlp.{1,3,5} / cond_mlp.{0,2,4}
+        if time_embed:
+            time_layers = [_Holder()]
+        else:
+            time_layers = [nn.Unflatten(-1, (-1, 1)), nn.Linear(1, half // 2), nn.GELU()]
+        self.time_mlp = nn.Sequential(*time_layers, nn.Linear(half // 2, half), nn.GELU(), nn.Linear(half, half))
         hidden = max(cond_size, half // 2)
-        self.cond_mlp = nn.Sequential(nn.Linear(cond_size, hidden), nn.GELU(), nn.Linear(hidden, half), nn.GELU(),
-                                      nn.Linear(half, half))
+        cond_layers = [_Holder()] if cond_embed else [nn.Linear(cond_size, hidden), nn.GELU()]
+        self.cond_mlp = nn.Sequential(*cond_layers, nn.Linear(hidden, half), nn.GELU(), nn.Linear(half, half))
 
         self.downs, self.ups = nn.ModuleList([]), nn.ModuleList([])
         self.downs_attn, self.ups_attn = nn.ModuleList([]), nn.ModuleList([])

@@ -64,6 +64,10 @@ typedef struct CdUnetDesc {
   int32_t time_embed_kind;         /* CD_TIME_* used by cd_denoise */
   int32_t objective;               /* CD_OBJ_*  used by cd_denoise */
   float sigma_data;                /* Loss.sigma_data (models/loss.py:18-25) */
+  /* CondUnet(time_embed=True / cond_embed=True): SinusoidalPositionEmbeddings (models.py:132-144, 578-601) instead of the
+   * first Linear of the time / cond MLP.  Reachable through cd_unet_forward only: the reference's own denoise path raises
+   * KeyError for TIME_EMBED 'sin' (calodiffusion.py:148-152), and so do cd_denoise / the samplers / cd_train_step. */
+  int32_t time_sin, cond_sin;
 } CdUnetDesc;
 
 /* One row per sampler loop iteration; computed on the host exactly as DDim.__call__ does in fp32
@@ -113,8 +117,43 @@ int cd_denoise(CdPlan* plan, int batch, const float* x, const float* sigma, cons
  * xs / x0s: NULL or device (n_steps, B,1,D,H,W) trajectories (`debug`). use_graph: capture one step as a
  * hipGraph and replay it. */
 int cd_ddim_sample(CdPlan* plan, int batch, const float* start, const float* cond, const CdStep* steps, int n_steps,
-                   const float* step_noise, uint64_t seed, uint64_t offset, float* x_out, float* xs, float* x0s,
-                   int use_graph, void* workspace, size_t workspace_bytes, void* stream);
+                   const float* step_noise, uint64_t seed, uint64_t offset, uint64_t noise_stride, float* x_out, float* xs,
+                   float* x0s, int use_graph, void* workspace, size_t workspace_bytes, void* stream);
+/* noise_stride (both sampler entry points): distance in the Philox stream between the noise tensors of consecutive draws;
+ * 0 = this call's own tensor size.  A rank holding rows [lo, hi) of a global batch passes offset + lo * voxels and
+ * noise_stride = global_batch * voxels: the union of the shards then IS the single-GPU result of the same seed.
+ *
+ * Range fallback (both sampler entry points): the f16x2 convolutions cover the fp16 range only.  If a trajectory leaves it
+ * (sticky flag, cd_plan_status bit 0) the call re-runs the whole trajectory with the exact bf16x3 convolutions (full fp32
+ * range) before it returns, synchronising `stream` for the check; cd_plan_status then reports bit 1 (fallback taken)
+ * instead of bit 0. */
+
+/* ---- every other sampler of models/sample.py on the same device loop ------------------------------------------------
+ * A sampler is a "step program": per step a short list of ops over a few (B,1,D,H,W) buffers, whose scalars are columns of
+ * that step's row of a host coefficient table.  Buffer 0 is the running sample x (= x_out); buffers 1 .. n_bufs-1 live in
+ * the workspace and start as zeros.  Steps that share one op list (op_begin == NULL) are captured once as a hipGraph and
+ * replayed (the device step counter selects the table row, the Philox position and the trajectory slot); otherwise
+ * step i runs ops[op_begin[i] .. op_begin[i+1]) eagerly (Restart, DPM-Solver-fast).
+ * The host side (calodiffusion_amd/sample.py) builds the programs of EDM Euler(+churn) / Heun / DPM2 (sample.py:577-727,
+ * 771-851), LMS (:729-769), Restart (:853-954), DPM / DPM++2S / DPM++2M (:124-186, 311-344, 415-449) and Consistency
+ * (:957-1011). */
+#define CD_SOP_LINCOMB 0 /* buf[dst] = sum_k coef[col + k] * buf[src[k]], k < nsrc <= 6 (dst may be a source) */
+#define CD_SOP_DENOISE 1 /* buf[dst] = denoise(buf[src[0]], sigma = coef[col])  (CaloDiffusion.denoise, as cd_denoise) */
+#define CD_SOP_RANDN 2   /* buf[dst] = unit normals: the next tensor of step_noise, or of the Philox stream */
+#define CD_SOP_RECORD 3  /* trajectory slot of this step <- buf[src[0]]; dst: 0 = xs, 1 = x0s (skipped if that pointer is NULL) */
+typedef struct CdSamplerOp {
+  int32_t kind, dst, nsrc;
+  int32_t src[6];
+  int32_t col;
+} CdSamplerOp;
+int cd_plan_sampler_workspace_bytes(CdPlan* plan, int batch, int n_bufs, int n_steps, int n_coef, size_t* bytes);
+/* start: (B,1,D,H,W) unit normal, x = start * start_scale first.  coefs: HOST (n_steps, n_coef) fp32.  ops: n_ops entries
+ * (op_begin == NULL: the one list of every step; else op_begin has n_steps + 1 entries).  step_noise: NULL or DEVICE
+ * (number of RANDN ops executed, B,1,D,H,W), consumed in execution order.  xs / x0s: NULL or (n_steps, B,1,D,H,W). */
+int cd_sampler_run(CdPlan* plan, int batch, const float* start, float start_scale, const float* cond, int n_bufs, int n_steps,
+                   const CdSamplerOp* ops, int n_ops, const int32_t* op_begin, const float* coefs, int n_coef,
+                   const float* step_noise, uint64_t seed, uint64_t offset, uint64_t noise_stride, float* x_out, float* xs,
+                   float* x0s, int use_graph, void* workspace, size_t workspace_bytes, void* stream);
 /* Diffusion.noise_generation (diffusion.py:58-61): n unit normals from Philox4x32-10 + Box-Muller;
  * element i depends only on (seed, offset + i), so shards of one global stream can be drawn per rank. */
 int cd_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
@@ -135,7 +174,9 @@ int cd_plan_train_workspace_bytes(CdPlan* plan, int batch, size_t* bytes);
 
 /* Sticky range flags of the compute calls issued on this plan since the last query (synchronises `stream`, then clears):
  *   bit 0: an activation fed to an f16x2 convolution exceeded the fp16 range (|x| > 65504): the outputs of that call
- *          contain inf/NaN.  The reference computes in fp32 throughout; rerun with CD_CONV_PRECISION=bf16x3 (full fp32 range). */
+ *          contain inf/NaN.  The reference computes in fp32 throughout; rerun with CD_CONV_PRECISION=bf16x3 (full fp32 range).
+ *          (cd_denoise / cd_unet_forward / cd_train_step; the sampler entry points recover by themselves, see above)
+ *   bit 1: a sampler call took the bf16x3 fallback (its result is valid). */
 int cd_plan_status(CdPlan* plan, int* flags, void* stream);
 int cd_train_step(CdPlan* plan, int batch, const float* data, const float* noise, const float* sigma, const float* cond,
                   double* loss_out, float* grads, void* workspace, size_t workspace_bytes, void* stream);

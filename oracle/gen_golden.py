@@ -411,6 +411,191 @@ def gold_layer():
     save("layer_dataset2", **out)
 
 
+class count_draws:
+    """Counts the torch.randn / torch.randn_like calls a reference sampler makes (the tests replay the same sequence of draws
+    from the recorded seed: the CPU generator is deterministic for a given torch version)."""
+
+    def __enter__(self):
+        self.n, self.shapes = 0, []
+        self._rl, self._r = torch.randn_like, torch.randn
+
+        def randn_like(t, *a, **k):
+            self.n += 1
+            self.shapes.append(tuple(t.shape))
+            return self._rl(t, *a, **k)
+
+        def randn(*a, **k):
+            self.n += 1
+            out = self._r(*a, **k)
+            self.shapes.append(tuple(out.shape))
+            return out
+
+        torch.randn_like, torch.randn = randn_like, randn
+        return self
+
+    def __exit__(self, *exc):
+        torch.randn_like, torch.randn = self._rl, self._r
+
+
+def gold_samplers():
+    """Trajectories of the reference's other samplers (models/sample.py: EDM Euler with churn / Heun / DPM2 / LMS / Restart,
+    DPM / DPM++2S / DPM++2M, Consistency) on the tiny config (batch 3), plus one Heun case on Dataset-2.  Stochastic samplers
+    draw from the global torch generator, seeded right before the call; the number and order of draws is recorded."""
+    cfgt = my_configs.load_config("tiny")
+    mt = build_ref(cfgt)
+    x, E, layers = synth_inputs(cfgt, 3, SEED + 60)
+    out = {"start": npf(x), "E": npf(E), "layers": npf(layers)}
+
+    def run(tag, cls, n, cfg_over=None, opts=None, offset=0, keep=("x",), rows=3):
+        cfg = copy.deepcopy(cfgt)
+        cfg.update(cfg_over or {})
+        if opts:
+            cfg["SAMPLER_OPTIONS"] = opts
+        smp = cls(cfg)
+        seed = 4000 + len(out)
+        torch.manual_seed(seed)
+        with count_draws() as cd:
+            with torch.no_grad():
+                xf, xs, x0s = smp(mt, x[:rows].clone(), E[:rows], layers[:rows], n, offset, False)
+        mt.loss_function.update_step(cfgt["NSTEPS"])  # DPM.setup / Consistency change the model's tables
+        out[f"{tag}.n"], out[f"{tag}.seed"], out[f"{tag}.draws"] = np.array(n), np.array(seed), np.array(cd.n)
+        out[f"{tag}.x"] = npf(xf)
+        for k in keep:
+            if k.startswith("xs"):
+                out[f"{tag}.{k}"] = npf(xs[int(k[2:])])
+            elif k.startswith("x0s"):
+                out[f"{tag}.{k}"] = npf(x0s[int(k[3:])])
+        fin = bool(torch.isfinite(xf).all())
+        print(f"sampler {tag}: n={n} draws={cd.n} finite={fin} mean|x|={float(xf.abs().mean()) if fin else float('nan'):.4f}")
+        return smp
+
+    S = ref_sample
+    run("euler_noisy", S.Euler, 8, {"NOISY_SAMPLE": True}, keep=("xs3", "x0s3", "xs7", "x0s7"))
+    run("heun", S.Heun, 6, keep=("xs3", "x0s3", "xs5", "x0s5"))
+    run("heun_noisy", S.Heun, 5, {"NOISY_SAMPLE": True}, keep=("xs4", "x0s4"))
+    run("dpm2", S.DPM2, 6, keep=("xs3", "x0s3", "xs5", "x0s5"))
+    run("dpm2_off1", S.DPM2, 6, offset=1, keep=("xs4",))
+    run("lms", S.LMS, 9)
+    run("lms_o2", S.LMS, 6, opts={"ORDER": 2})
+    run("restart_default", S.Restart, 6, keep=("x0s5",))
+    smp = S.Euler(copy.deepcopy(cfgt))
+    tk = smp.setup(6, 0)
+    rl = {2: [3, 1, 0.0, float(tk[2]) * 3.0], 4: [4, 2, 0.0, float(tk[4]) * 5.0]}
+    run("restart_int", S.Restart, 6, opts={"RESTART_LIST": rl}, keep=("x0s5",))
+    out["restart_int.keys"] = np.array(sorted(rl))
+    out["restart_int.vals"] = np.array([rl[k] for k in sorted(rl)], dtype=np.float64)
+    run("restart_noisy", S.Restart, 5, {"NOISY_SAMPLE": True}, opts={"RESTART_LIST": {3: [3, 1, 0.0, float(smp.setup(5, 0)[3]) * 4.0]}})
+    out["restart_noisy.tmax"] = np.array(float(smp.setup(5, 0)[3]) * 4.0)
+    # The DPM family hands the model a (B,)-shaped sigma, which the reference's denoise multiplies into the (B,1,D,H,W) state
+    # (calodiffusion.py:159): that broadcasts only for B = 1 (or, wrongly, B = W).  Batch 1 therefore.
+    run("dpmpp2m", S.DPMPP2M, 9, rows=1)
+    run("dpmpp2s", S.DPMPP2S, 5, rows=1)
+    run("dpmpp2s_eta", S.DPMPP2S, 4, opts={"ETA": 1.0}, rows=1)
+    run("dpm_7", S.DPM, 7, rows=1)
+    run("dpm_6", S.DPM, 6, rows=1)
+    run("dpm_2", S.DPM, 2, rows=1)
+    run("consistency", S.Consistency, 3, {"CONSIS_NSTEPS": 40}, keep=("xs1",))
+    # Consistency returns (x, xs, x0): the last denoised tensor
+    save("samplers_tiny", **out)
+
+    cfg2 = my_configs.load_config("dataset2")
+    m2 = build_ref(cfg2)
+    x2, E2, l2 = synth_inputs(cfg2, 1, SEED + 61)
+    with torch.no_grad():
+        xf, xs, x0s = S.Heun(copy.deepcopy(cfg2))(m2, x2.clone(), E2, l2, 4, 0, False)
+        lf, _, _ = S.LMS(copy.deepcopy(cfg2))(m2, x2.clone(), E2, l2, 6, 0, False)
+    save("samplers_dataset2", start=npf(x2), E=npf(E2), layers=npf(l2), heun_xs3=npf(xs[3]), heun_x0s3=npf(x0s[3]), lms_6=npf(lf))
+
+
+def gold_sinusoidal():
+    """CondUnet with sinusoidal time / cond embeddings (models.py:132-144, 578-601), called directly: CaloDiffusion cannot reach
+    this branch (do_time_embed raises KeyError for 'sin', calodiffusion.py:148-152)."""
+    out = {"seed": np.array(SEED)}
+    for tag, kw_over, cond_shape in (("both", dict(time_embed=True, cond_embed=True, cond_size=1), (3,)),
+                                     ("time", dict(time_embed=True, cond_embed=False, cond_size=10), (3, 10)),
+                                     ("cond", dict(time_embed=False, cond_embed=True, cond_size=1), (3,))):
+        kw = dict(out_dim=1, layer_sizes=[32, 32, 64, 32], channels=4, cond_dim=128, resnet_block_groups=8, mid_attn=True,
+                  block_attn=True, compress_Z=True, cylindrical=True, data_shape=[1, 4, 8, 8, 8])
+        kw.update(kw_over)
+        torch.manual_seed(SEED)
+        u = ref_models.CondUnet(**copy.deepcopy(kw)).eval()
+        torch.manual_seed(SEED)
+        mine = MyCondUnet(**copy.deepcopy(kw))
+        rsd, msd = u.state_dict(), mine.state_dict()
+        assert list(rsd.keys()) == list(msd.keys()), (list(rsd.keys())[:8], list(msd.keys())[:8])
+        for k, v in rsd.items():
+            assert torch.equal(v, msd[k]), k
+        keys, cks = checksums(rsd)
+        g = torch.Generator().manual_seed(SEED + 70)
+        xx = torch.randn((3, 4, 8, 8, 8), generator=g)
+        cc = torch.rand(cond_shape, generator=g) * 3.0
+        tt = torch.rand((3,), generator=g) * 5.0 - 1.0
+        with torch.no_grad():
+            yy = u(xx, cond=cc, time=tt)
+        out.update({f"{tag}.ck_keys": keys, f"{tag}.ck_vals": cks, f"{tag}.x": npf(xx), f"{tag}.cond": npf(cc), f"{tag}.time": npf(tt),
+                    f"{tag}.y": npf(yy)})
+        print("sinusoidal", tag, float(yy.abs().mean()))
+    save("unet_sinusoidal", **out)
+
+
+def gold_grads():
+    """.grad of the reference's own compute_loss(...).backward() (models/loss.py:163-179, train/train_diffusion.py:52-63) on the
+    inputs of loss_dataset2 / loss_dataset3: a few whole tensors and fp64 (sum, sum of squares) of every parameter's gradient."""
+    pick = {"dataset2": ["init_conv.conv.weight", "downs.0.0.block1.proj.conv.weight", "downs_attn.1.fn.fn.to_qkv.conv.weight",
+                         "ups.1.2.convTrans.weight", "time_mlp.1.weight", "cond_mlp.4.bias", "final_conv.1.conv.weight",
+                         "mid_block1.block2.norm.weight"],
+            "dataset3": ["init_conv.conv.weight", "downs.1.2.conv.weight", "ups_attn.0.fn.fn.to_out.0.conv.weight",
+                         "ups.2.1.block2.proj.conv.weight", "cond_mlp.0.weight", "final_conv.0.block1.norm.bias"]}
+    for name in ("dataset2", "dataset3"):
+        cfg = my_configs.load_config(name)
+        m = build_ref(cfg)
+        m.train()
+        g = np.load(os.path.join(GOLD, f"loss_{name}.npz"))
+        data, E, noise = (torch.from_numpy(g[k]) for k in ("data", "E", "noise"))
+        layers = torch.from_numpy(g["layers"]) if "layers" in g else None
+        m.zero_grad()
+        if name == "dataset2":
+            loss = m.compute_loss(data, E, noise=noise, layers=layers, rnd_normal=torch.from_numpy(g["rnd_normal"]))
+        else:
+            torch.manual_seed(99)  # the reference re-draws `time` inside Loss.__call__ (see gold_models)
+            loss = m.compute_loss(data, E, noise=noise, layers=layers)
+        assert abs(float(loss) - float(g["loss"])) <= 1e-6 * abs(float(g["loss"])), (float(loss), float(g["loss"]))
+        loss.backward()
+        grads = {k: p.grad for k, p in m.model.named_parameters()}
+        keys, cks = checksums(grads)
+        out = {"ck_keys": keys, "ck_vals": cks, "loss": np.array(float(loss), dtype=np.float64)}
+        for k in pick[name]:
+            out["grad." + k] = npf(grads[k])
+        save(f"grads_{name}", **out)
+        print("grads", name, float(loss), float(sum(float((v.double() ** 2).sum()) for v in grads.values()) ** 0.5))
+
+
+def gold_trajectories():
+    """Dataset-3 DDIM (10 and 50 steps, batch 1) and HGCal DDPM (200 steps, batch 2, seeded noise stream) end points."""
+    cfg3 = my_configs.load_config("dataset3")
+    m3 = build_ref(cfg3)
+    x, E, layers = synth_inputs(cfg3, 1, SEED + 80)
+    out = {"start": npf(x), "E": npf(E)}
+    ddim = ref_sample.DDim(cfg3)
+    with torch.no_grad():
+        for n in (10, 50):
+            xf, xs, x0s = ddim(m3, x, E, layers, n, 0, False)
+            out[f"ddim_{n}"] = npf(xf)
+            print("d3 ddim", n, float(xf.abs().mean()))
+    save("ddim_dataset3", **out)
+    del m3
+    cfgh = my_configs.load_config("hgcal")
+    mh = build_ref(cfgh)
+    x, E, layers = synth_inputs(cfgh, 2, SEED + 81)
+    ddpm = ref_sample.DDPM(cfgh)
+    torch.manual_seed(778)
+    with torch.no_grad():
+        xf, xs, x0s = ddpm(mh, x, E, layers, 200, 0, False)
+    print("hgcal ddpm 200", float(xf.abs().mean()))
+    save("ddpm_hgcal", start=npf(x), E=npf(E), layers=npf(layers), noise_seed=np.array(778), ddpm_200=npf(xf),
+         x_step100=npf(xs[100]), x0_step100=npf(x0s[100]))
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     which = sys.argv[1:] or ["known", "prims", "sched", "models"]
@@ -428,3 +613,11 @@ if __name__ == "__main__":
         gold_reverse_norm()
     if "layer" in which:
         gold_layer()
+    if "samplers" in which:
+        gold_samplers()
+    if "sin" in which:
+        gold_sinusoidal()
+    if "grads" in which:
+        gold_grads()
+    if "traj" in which:
+        gold_trajectories()

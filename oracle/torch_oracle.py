@@ -161,6 +161,8 @@ class UnetSpec:
     compress_z: bool = True
     cylindrical: bool = True
     data_shape: Tuple[int, int, int] = (45, 16, 9)
+    time_sin: bool = False  # SinusoidalPositionEmbeddings instead of the first Linear of the time / cond MLP
+    cond_sin: bool = False  # (models/models.py:578-601; reachable through CondUnet.forward only)
     # derived
     level_shapes: List[Tuple[int, int, int]] = field(default_factory=list)
     up_kernel_z: List[int] = field(default_factory=list)
@@ -214,12 +216,22 @@ def spec_from_config(cfg: dict) -> UnetSpec:
     )
 
 
+def sinusoidal_embedding(v: Tensor, dim: int) -> Tensor:
+    """SinusoidalPositionEmbeddings.forward (models/models.py:132-144) of a (B,) tensor."""
+    half = dim // 2
+    freq = torch.exp(torch.arange(half) * -(np.log(10000) / (half - 1)))
+    arg = v[:, None] * freq[None, :]
+    return torch.cat((arg.sin(), arg.cos()), dim=-1)
+
+
 def cond_unet_forward(sd: SD, spec: UnetSpec, x: Tensor, cond: Tensor, time: Tensor) -> Tensor:
-    """CondUnet.forward (models/models.py:701-748), Linear-branch embeddings (:583-587, :601)."""
+    """CondUnet.forward (models/models.py:701-748); embeddings: Linear branch (:583-587, :601) or sinusoidal (:581, :599)."""
     cyl, g = spec.cylindrical, spec.groups
     x = _conv(sd, "init_conv", x, cyl, padding=(1, 1, 1))
-    c = _mlp(sd, "cond_mlp", cond, (0, 2, 4))
-    t = _mlp(sd, "time_mlp", time.reshape(-1, 1), (1, 3, 5))
+    q = spec.cond_dim // 4
+    c = _mlp(sd, "cond_mlp", sinusoidal_embedding(cond.reshape(-1), q), (1, 3)) if spec.cond_sin else _mlp(sd, "cond_mlp", cond, (0, 2, 4))
+    t = _mlp(sd, "time_mlp", sinusoidal_embedding(time.reshape(-1), q), (1, 3)) if spec.time_sin else \
+        _mlp(sd, "time_mlp", time.reshape(-1, 1), (1, 3, 5))
     conditions = torch.cat([t, c], dim=-1)
 
     nres = len(spec.layer_sizes) - 1
@@ -370,7 +382,7 @@ class OracleModel:
     @torch.no_grad()
     def ddim_sample(self, start: Tensor, E: Tensor, layers: Optional[Tensor], num_steps: int, eta: float = 0.0,
                     sample_offset: int = 0, step_noise: Optional[Sequence[Tensor]] = None,
-                    keep: bool = False):
+                    keep: bool = False, stop_after: Optional[int] = None):
         """DDim.__call__ / DDPM (models/sample.py:41-121).
 
         ``step_noise[i]`` is the noise tensor of loop iteration i (only read when eta != 0;
@@ -383,6 +395,8 @@ class OracleModel:
         xs, x0s = [], []
         B = start.shape[0]
         for i, t in enumerate(steps):
+            if stop_after is not None and i >= stop_after:  # (tests: the first part of a long trajectory)
+                break
             a, a_prev = tb.alphas_cumprod[t], tb.alphas_cumprod_prev[t]
             denom = tb.sqrt_alphas_cumprod[max(t - 1, 0)]
             sigma = tb.sqrt_one_minus_alphas_cumprod[t] / tb.sqrt_alphas_cumprod[t]

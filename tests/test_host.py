@@ -151,3 +151,98 @@ def test_layerdiffusion_surface_and_checkpoints(tmp_path):
         with pytest.raises(RuntimeError, match="no CPU fallback|GPU"):
             m.sample_layers(torch.zeros(2, 1), start=torch.zeros(2, 46))
         assert not m.layer_loss  # the state is restored on failure
+
+
+def _interpret_program(prog, denoise, start, noise):
+    """Host-side interpreter of a sampler step program (the semantics of cd_sampler_run, include/calodiff.h) in torch on the
+    CPU, with the oracle as the denoiser: checks the program BUILDERS without a GPU."""
+    from calodiffusion_amd.engine import SOP_DENOISE, SOP_LINCOMB, SOP_RANDN, SOP_RECORD
+    bufs = [torch.zeros_like(start) for _ in range(prog.n_bufs)]
+    bufs[0] = start * np.float32(prog.start_scale)
+    n_steps = prog.coefs.shape[0]
+    xs, x0s = [None] * n_steps, [None] * n_steps
+    it = iter(noise)
+    for i in range(n_steps):
+        ops = prog.ops if prog.op_begin is None else prog.ops[prog.op_begin[i]:prog.op_begin[i + 1]]
+        row = torch.from_numpy(prog.coefs[i])
+        for kind, dst, src, col in ops:
+            if kind == SOP_LINCOMB:
+                acc = row[col] * bufs[src[0]]
+                for k in range(1, len(src)):
+                    acc = acc + row[col + k] * bufs[src[k]]
+                bufs[dst] = acc
+            elif kind == SOP_DENOISE:
+                bufs[dst] = denoise(bufs[src[0]], row[col])
+            elif kind == SOP_RANDN:
+                bufs[dst] = next(it)
+            elif kind == SOP_RECORD:
+                (xs if dst == 0 else x0s)[i] = bufs[src[0]]
+    return bufs[0], xs, x0s
+
+
+def test_sampler_programs_reproduce_the_reference_trajectories():
+    """Every step program of calodiffusion_amd.sample (EDM Euler+churn / Heun / DPM2 / LMS / Restart, DPM / DPM++2S / DPM++2M,
+    Consistency), interpreted on the CPU with the oracle as denoiser, against trajectories of the reference's own sampler
+    classes (tests/golden/samplers_tiny.npz)."""
+    import copy
+    from sampler_cases import CASES, options, replay_noise
+    from test_oracle_golden import check_sampler_case
+    g = gold("samplers_tiny")
+    base = load_config("tiny")
+    om = O.OracleModel(base, seeded_unet("tiny").state_dict())
+    for tag, (name, over, _, off, rows) in CASES.items():
+        cfg = copy.deepcopy(base)
+        cfg.update(over)
+        cfg["SAMPLER"] = name
+        if options(g, tag):
+            cfg["SAMPLER_OPTIONS"] = options(g, tag)
+        m = CaloDiffusion(cfg, n_steps=cfg["NSTEPS"], loss_type=cfg["LOSS_TYPE"])
+        smp = m.sampler_algorithm
+        assert type(smp).__name__ == name
+        n = int(g[f"{tag}.n"])
+        prog = smp.build(m, n, off).finalize()
+        start, E, layers = t(g["start"])[:rows], t(g["E"])[:rows], t(g["layers"])[:rows]
+        noise = replay_noise(g, tag, start.shape)
+        if prog.n_randn:
+            assert prog.n_randn == len(noise), (tag, prog.n_randn, len(noise))
+        den = lambda x, s: om.denoise(x, E, s.float().expand(rows), layers)  # noqa: E731
+        with torch.no_grad():
+            x, xs, x0s = _interpret_program(prog, den, start, noise if prog.n_randn else [])
+        if name == "Restart":
+            xs, x0s = None, [x0s[i] for i in smp._main_steps]
+        if name in ("LMS", "DPM", "DPMPP2S", "DPMPP2M"):
+            xs = x0s = None
+        if name == "Consistency":
+            x0s = None
+        # (dpm_2: ONE second-order step from the largest to the smallest noise level: the update cancels terms of order
+        # sigma_max against each other, so any fp32 re-association shows at a few 1e-5)
+        check_sampler_case(tag, g, x, xs, x0s, 1e-4 if tag == "dpm_2" else 2e-5)
+        # uniform programs replay one captured step graph; nested / order-changing ones run their steps eagerly
+        if tag in ("euler_noisy", "heun", "heun_noisy", "dpm2", "lms", "dpmpp2m", "dpmpp2s", "restart_default"):
+            assert prog.op_begin is None, tag
+        if tag in ("restart_int", "restart_noisy", "dpm_7", "dpm_6", "consistency", "dpmpp2s_eta"):
+            assert prog.op_begin is not None, tag
+
+
+def test_generate_never_returns_normalised_showers_silently():
+    m = CaloDiffusion("tiny", 50, "l2")
+    gen_, en = np.zeros((2, 1, 8, 8, 8), np.float32), np.zeros((2, 3), np.float32)
+    with pytest.raises(ValueError, match="inverse pre-processing"):
+        m._to_physical(gen_, en, None, None)
+    out, e = m._to_physical(gen_, en, None, False)
+    assert out is gen_ and e.shape == (2, 3)
+    out, _ = m._to_physical(gen_, en, None, lambda a, b, c, d: (a + 1, b))
+    assert float(out.mean()) == 1.0
+
+
+def test_noise_shard_bookkeeping():
+    """set_noise_shard: offsets / strides of a rank's rows of the global Philox tensors (no GPU needed for the arithmetic)."""
+    m = CaloDiffusion("tiny", 50, "l2")
+    start = torch.zeros(2, 1, 8, 8, 8)
+    assert m.step_noise_stream(start) == (0, 1024)
+    m.set_noise_shard(4, 6)
+    m.noise_offset = 100
+    assert m._shard_geometry(start.shape) == (512, 2048, 3072)
+    assert m.step_noise_stream(start) == (100 + 2048, 3072)
+    with pytest.raises(ValueError):
+        m._shard_geometry((3, 1, 8, 8, 8))

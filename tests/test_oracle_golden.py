@@ -221,3 +221,119 @@ def test_layer_model_loss_matches_reference():
     with torch.no_grad():
         loss = m.hybrid_l2_loss(t(g["loss_layers"]), t(g["E"]), t(g["loss_noise"]), rnd_normal=t(g["loss_rnd"]))
     assert abs(float(loss) - float(g["loss"])) < 2e-6 * abs(float(g["loss"]))
+
+
+def test_unet_sinusoidal_embeddings():
+    """CondUnet(time_embed / cond_embed = True) (reference models.py:132-144, 578-601), called directly as the reference's own
+    denoise path cannot (do_time_embed raises KeyError for 'sin'): parameter container and oracle forward."""
+    g = gold("unet_sinusoidal")
+    for tag, over in (("both", dict(time_embed=True, cond_embed=True, cond_size=1)),
+                      ("time", dict(time_embed=True, cond_embed=False, cond_size=10)),
+                      ("cond", dict(time_embed=False, cond_embed=True, cond_size=1))):
+        kw = dict(out_dim=1, layer_sizes=[32, 32, 64, 32], channels=4, cond_dim=128, resnet_block_groups=8, mid_attn=True,
+                  block_attn=True, compress_Z=True, cylindrical=True, data_shape=[1, 4, 8, 8, 8])
+        kw.update(over)
+        net = seeded_unet(kw, int(g["seed"]))
+        verify_checksums(net.state_dict(), {"ck_keys": g[f"{tag}.ck_keys"], "ck_vals": g[f"{tag}.ck_vals"]})
+        spec = O.UnetSpec(layer_sizes=[32, 32, 64, 32], channels=4, cond_size=kw["cond_size"], data_shape=(8, 8, 8),
+                          time_sin=kw["time_embed"], cond_sin=kw["cond_embed"])
+        with torch.no_grad():
+            y = O.cond_unet_forward(net.state_dict(), spec, t(g[f"{tag}.x"]), t(g[f"{tag}.cond"]), t(g[f"{tag}.time"]))
+        assert rel_l2(y.numpy(), g[f"{tag}.y"]) < TOL, tag
+
+
+def oracle_sampler(tag, g, m, start, E, layers, noise):
+    """One case of sampler_cases.CASES on the oracle (oracle/samplers_oracle.py) -> (x, xs, x0s)."""
+    from oracle import samplers_oracle as S
+    from sampler_cases import CASES, options
+    name, over, _, off, rows = CASES[tag]
+    n = int(g[f"{tag}.n"])
+    B = start.shape[0]
+    den = lambda x, s: m.denoise(x, E, torch.as_tensor(s, dtype=torch.float32).expand(B), layers)  # noqa: E731
+    it = iter(noise)
+    noisy = bool(over.get("NOISY_SAMPLE", False))
+    opts = options(g, tag) or {}
+    if name in ("Euler", "Heun", "DPM2"):
+        return S.edm_loop(name.lower(), den, start, n, it, noisy=noisy, sample_offset=off)
+    if name == "LMS":
+        return S.lms(den, start, n, order=opts.get("ORDER", 4)), None, None
+    if name == "Restart":
+        rl = opts.get("RESTART_LIST", {"0": 0, "1": 0})  # the default table has string keys: never matched
+        x, x0s = S.restart(den, start, n, it, rl, noisy=noisy)
+        return x, None, x0s
+    sig = S.model_sigmas(O.ddim_tables(n), n)
+    if name == "DPMPP2M":
+        return S.dpmpp2m(den, start, sig), None, None
+    if name == "DPMPP2S":
+        return S.dpmpp2s(den, start, sig, it, eta=opts.get("ETA", 0.0)), None, None
+    if name == "DPM":
+        return S.dpm_fast(den, start, sig, n), None, None
+    if name == "Consistency":
+        x, xs, x0 = S.consistency(den, start, O.ddim_tables(over["CONSIS_NSTEPS"]), over["CONSIS_NSTEPS"], n, it)
+        return x, xs, None
+    raise KeyError(name)
+
+
+def check_sampler_case(tag, g, x, xs, x0s, tol):
+    """Final tensor (where the reference's is finite) and the stored trajectory slots of one sampler case."""
+    want = g[f"{tag}.x"]
+    if np.isfinite(want).all():
+        assert rel_l2(np.asarray(x), want) < tol, (tag, rel_l2(np.asarray(x), want))
+    else:  # Heun / DPM2 divide by t_next = 0 on their last step (see calodiffusion_amd/sample.py): not finite here either
+        assert not np.isfinite(np.asarray(x)).all(), tag
+    for k in g.files:
+        if k.startswith(tag + ".xs") and xs is not None:
+            assert rel_l2(np.asarray(xs[int(k.split("xs")[1])]), g[k]) < tol, k
+        if k.startswith(tag + ".x0s") and x0s is not None:
+            assert rel_l2(np.asarray(x0s[int(k.split("x0s")[1])]), g[k]) < tol, k
+
+
+def test_other_samplers_against_reference_trajectories():
+    """oracle/samplers_oracle.py (EDM Euler+churn / Heun / DPM2 / LMS / Restart, DPM / DPM++2S / DPM++2M, Consistency) against
+    trajectories of the reference's own sampler classes on the tiny config, with the reference's noise draws replayed."""
+    from sampler_cases import CASES, replay_noise
+    g = gold("samplers_tiny")
+    cfg = load_config("tiny")
+    m = O.OracleModel(cfg, seeded_unet("tiny").state_dict())
+    for tag, (_, _, _, _, rows) in CASES.items():
+        start, E, layers = t(g["start"])[:rows], t(g["E"])[:rows], t(g["layers"])[:rows]
+        noise = replay_noise(g, tag, start.shape)
+        with torch.no_grad():
+            x, xs, x0s = oracle_sampler(tag, g, m, start, E, layers, noise)
+        check_sampler_case(tag, g, x, xs, x0s, 2e-5)
+
+
+def test_reference_gradients():
+    """torch autograd through the oracle against .grad of the reference's own compute_loss(...).backward()
+    (models/loss.py:163-179, train/train_diffusion.py:52-63): whole tensors and checksums of every parameter's gradient."""
+    for name in ("dataset2", "dataset3"):
+        g, gl = gold(f"grads_{name}"), gold(f"loss_{name}")
+        cfg = load_config(name)
+        sd = {k: v.detach().clone().requires_grad_(True) for k, v in seeded_unet(name).state_dict().items()}
+        m = O.OracleModel(cfg, sd)
+        kw = dict(rnd_normal=t(gl["rnd_normal"])) if name == "dataset2" else dict(time=torch.from_numpy(gl["time"]))
+        layers = t(gl["layers"]) if "layers" in gl.files else None
+        loss = m.hybrid_l2_loss(t(gl["data"]), t(gl["E"]), t(gl["noise"]), layers, **kw)
+        loss.backward()
+        assert abs(float(loss) - float(g["loss"])) <= 2e-6 * abs(float(g["loss"]))
+        for k in g.files:
+            if k.startswith("grad."):
+                assert rel_l2(m.sd[k[5:]].grad.numpy(), g[k]) < 2e-5, (name, k)
+        for k, (s1, s2) in zip(g["ck_keys"], g["ck_vals"]):
+            gr = m.sd[str(k)].grad.double()
+            assert abs(float((gr * gr).sum()) - s2) <= 1e-4 * max(s2, 1e-30), (name, k)
+
+
+def test_dataset3_and_hgcal_trajectories():
+    """Dataset-3 DDIM (10 steps) and the first half of the HGCal 200-step DDPM trajectory with the reference's seeded noise."""
+    g = gold("ddim_dataset3")
+    m = O.OracleModel(load_config("dataset3"), seeded_unet("dataset3").state_dict())
+    x, _, _ = m.ddim_sample(t(g["start"]), t(g["E"]), None, 10)
+    assert rel_l2(x.numpy(), g["ddim_10"]) < 1e-5
+    g = gold("ddpm_hgcal")
+    m = O.OracleModel(load_config("hgcal"), seeded_unet("hgcal").state_dict())
+    start = t(g["start"])
+    torch.manual_seed(int(g["noise_seed"]))
+    noise = [torch.randn(start.shape) for _ in range(101)]
+    _, xs, x0s = m.ddim_sample(start, t(g["E"]), t(g["layers"]), 200, eta=1.0, step_noise=noise, keep=True, stop_after=101)
+    assert rel_l2(xs[100].numpy(), g["x_step100"]) < 1e-5 and rel_l2(x0s[100].numpy(), g["x0_step100"]) < 1e-5
