@@ -31,10 +31,23 @@ if ROOT not in sys.path:
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32-in MFMA = vector fp32 peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA
-# HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, profiles/r01g_zslide_traffic.txt):
-# PMC counters cannot be collected inside this process, so the figure of the committed profile is attached when the dominant
-# kernel and batch are the profiled ones (f16x2 default path only).
-MEASURED_TRAFFIC_BYTES = {("conv3x3x3_s1 C32->32 @45x16x9", 64): 118.4e6}
+
+
+def measured_traffic(kernel: str, batch: int):
+    """HBM-side bytes per launch of the dominant kernel from rocprofv3 PMC passes (tools/zs_traffic.py writes
+    profiles/zslide_traffic.json: FETCH_SIZE x 2 on gfx950 + WRITE_SIZE).  PMC counters cannot be collected inside this
+    process, so the committed figure is attached -- only while the kernel source is the one that was measured (sha256 stamp),
+    and only for the profiled kernel and batch; otherwise None."""
+    import hashlib
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "zslide_traffic.json")))
+        src = open(os.path.join(ROOT, "calodiffusion_amd", "csrc", "kernels_conv_zs.hip"), "rb").read()
+    except OSError:
+        return None
+    if rec.get("kernel") != kernel or rec.get("batch") != batch or rec.get("kernel_source_sha256") != hashlib.sha256(src).hexdigest():
+        return None
+    return rec["traffic_bytes"]
+
 BF16X3_TERMS = 6                # bf16 MFMAs per fp32 product in the split-bf16 convolution (DESIGN.md section 4)
 PEAK_HBM_GBS = 8000.0
 
@@ -60,24 +73,27 @@ def barrier():
         dist.barrier()
 
 
-def synthetic_inputs(cfg, batch, rank, device):
-    """E ~ U(0,1), layers ~ N(0,1) in normalised space; per-rank seeds so ranks hold different showers."""
-    g = torch.Generator().manual_seed(1234 + rank)
+def synthetic_inputs(cfg, batch, rank, world, device):
+    """E ~ U(0,1), layers ~ N(0,1) in normalised space.  ONE global set of world * batch showers (fixed seed), of
+    which this rank holds its contiguous shard: together with set_noise_shard the union of the ranks' outputs is the
+    single-GPU result of the same seed."""
+    from calodiffusion_amd.utils import shard_batch
+    g = torch.Generator().manual_seed(1234)
     n_e = 3 if cfg.get("HGCAL", False) else 1
-    E = torch.rand((batch, n_e), generator=g).to(device)
+    sl = shard_batch(world * batch, world, rank)
+    E = torch.rand((world * batch, n_e), generator=g)[sl].contiguous().to(device)
     layers = None
     if "layer" in cfg.get("SHOWERMAP", ""):
-        layers = torch.randn((batch, 1 + cfg["SHAPE_FINAL"][2]), generator=g).to(device)
-    return E, layers
+        layers = torch.randn((world * batch, 1 + cfg["SHAPE_FINAL"][2]), generator=g)[sl].contiguous().to(device)
+    return E, layers, sl
 
 
-def cpu_baseline(cfg, sample_steps, batch=32, timed=3):
-    """The oracle on the host cores: `timed` denoise steps at `batch` showers after one warm-up, extrapolated to
-    sample_steps steps per shower (every DDIM step costs the same U-Net forward)."""
+def cpu_baseline(cfg, sample_steps, batch, timed=3):
+    """The oracle on the host cores at the SAME batch as the GPU run: `timed` denoise steps after a warm-up, extrapolated to
+    sample_steps steps per shower (every DDIM step costs the same U-Net forward).  The thread count is the best of a quick
+    {8, 32, all cores} probe (one denoise step each): PyTorch's CPU convolutions stop scaling long before 128 threads."""
     from oracle import torch_oracle as O
     from tests.helpers import seeded_unet  # same seeded weights as the GPU model
-    from calodiffusion_amd.unet import unet_kwargs_from_config  # noqa: F401
-    threads = torch.get_num_threads()
     net = seeded_unet(cfg["_name"])
     model = O.OracleModel(cfg, net.state_dict())
     g = torch.Generator().manual_seed(7)
@@ -86,16 +102,27 @@ def cpu_baseline(cfg, sample_steps, batch=32, timed=3):
     E = torch.rand((batch, n_e), generator=g)
     layers = torch.randn((batch, 1 + cfg["SHAPE_FINAL"][2]), generator=g) if "layer" in cfg.get("SHOWERMAP", "") else None
     sig = torch.full((batch,), 1.0)
+    ncpu = os.cpu_count() or 1
+    default_threads = torch.get_num_threads()
+    probe = {}
     with torch.no_grad():
-        model.denoise(x, E, sig, layers)
+        for th in sorted({min(8, ncpu), min(32, ncpu), ncpu}):
+            torch.set_num_threads(th)
+            model.denoise(x, E, sig, layers)  # warm-up at this thread count
+            t0 = time.perf_counter()
+            model.denoise(x, E, sig, layers)
+            probe[th] = time.perf_counter() - t0
+        threads = min(probe, key=probe.get)
+        torch.set_num_threads(threads)
         t0 = time.perf_counter()
         for _ in range(timed):
             model.denoise(x, E, sig, layers)
         dt = (time.perf_counter() - t0) / timed
+    torch.set_num_threads(default_threads)
     return {"value": batch / (dt * sample_steps), "unit": "showers/s", "cores": threads, "kind": "port",
-            "host_cpus": os.cpu_count(), "s_per_denoise_step": dt,
-            "sample": f"{timed} denoise steps (oracle/torch_oracle.py, PyTorch CPU fp32) at batch {batch} after 1 warm-up, "
-                      f"extrapolated x{sample_steps} steps"}
+            "host_cpus": ncpu, "s_per_denoise_step": dt, "thread_probe_s_per_step": {str(k): round(v, 3) for k, v in probe.items()},
+            "sample": f"{timed} denoise steps (oracle/torch_oracle.py, PyTorch CPU fp32) at batch {batch} on {threads} threads "
+                      f"(best of a {sorted(probe)} probe) after a warm-up, extrapolated x{sample_steps} steps"}
 
 
 def roofline_leg(model, cfg, batch, E, layers):
@@ -126,14 +153,14 @@ def roofline_leg(model, cfg, batch, E, layers):
     # fp16 terms and a MAC block takes 3 fp16 MFMAs, so the roof of the algorithm that runs is fp16-dense / 3.
     # CD_CONV_PRECISION=bf16x3 selects the exact 3-term bf16 split (6 MFMAs, roof bf16-dense / 6), =f32 the f32-input MFMA
     # kernels (roof = the fp32 matrix peak).
-    mode = os.environ.get("CD_CONV_PRECISION", "f16x2")
+    mode = engine.get_conv_precision()
     peak = {"f32": PEAK_FP32_MFMA_TFLOPS, "bf16x3": PEAK_BF16_MFMA_TFLOPS / BF16X3_TERMS}.get(mode, PEAK_BF16_MFMA_TFLOPS / 3)
     pipe = {"f32": "f32 MFMA (157.3 TFLOP/s)",
             "bf16x3": "bf16 MFMA, fp32 operands split exactly into 3 bf16 terms, 6 MFMAs per MAC (2500/6 TFLOP/s)"}.get(
         mode, "fp16 MFMA, fp32 operands split into 2 fp16 terms (22 bits), 3 MFMAs per MAC block (2500/3 TFLOP/s)")
     roof = {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 3), "peak": round(peak, 1),
             "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-            "traffic": MEASURED_TRAFFIC_BYTES.get((dom_name, batch)) if mode == "f16x2" else None,
+            "traffic": measured_traffic(dom_name, batch) if mode == "f16x2" else None,
             "pipe": pipe,
             "frac_of_fp32_mfma_peak": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
             # all 256 CUs under matrix load run at ~1.97 GHz: 2.06 PFLOP/s of dense fp16 MFMA measured (tools/micro/mfma_chain.hip)
@@ -213,6 +240,7 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    from calodiffusion_amd import engine as engine_mod
     from calodiffusion_amd.calodiffusion import CaloDiffusion
     from calodiffusion_amd.configs import load_config
     cfg = dict(load_config(args.config))
@@ -222,10 +250,9 @@ def main():
     torch.manual_seed(1234)  # identical random-init weights on every rank
     model = CaloDiffusion(cfg, n_steps=cfg["NSTEPS"], loss_type=cfg["LOSS_TYPE"])
     B = args.batch
-    vox = int(np.prod(cfg["SHAPE_PAD"][1:]))
-    # disjoint slices of one Philox stream per rank: (start + per-step noise) * steps per sample() call
-    model.noise_offset = rank * (args.steps + args.warmup + 4) * (args.sample_steps + 2) * B * vox
-    E, layers = synthetic_inputs(cfg, B, rank, "cuda")
+    E, layers, shard = synthetic_inputs(cfg, B, rank, world, "cuda")
+    # every rank walks the one global Philox stream and draws its own rows of each tensor (weak scaling: world * B showers)
+    model.set_noise_shard(shard.start, world * B)
 
     if args.mode == "train":
         return train_bench(args, model, cfg, E, layers, rank, world)
@@ -258,7 +285,8 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32 (convs: fp32 operands as 2-term fp16 splits on the fp16 MFMA pipe, fp32 accumulate; attention/norms fp32)",
+        "dtype": "f32 (convs: fp32 operands as 2-term fp16 splits on the fp16 MFMA pipe, fp32 accumulate; attention/norms fp32)"
+        if engine_mod.get_conv_precision() == "f16x2" else f"f32 (convs: {engine_mod.get_conv_precision()})",
         "data": "synthetic",
         "config": {"workload": f"{args.config}: {'x'.join(str(v) for v in cfg['SHAPE_PAD'][2:])} voxels, "
                                f"{args.sample_steps}-step DDIM, batch {B} per GPU, random-init weights (seed 1234)",
@@ -271,8 +299,18 @@ def main():
         if args.breakdown:
             print(json.dumps(breakdown, indent=1), file=sys.stderr)
         result["kernel_breakdown_ms_per_denoise"] = {k: v["ms_per_step"] for k, v in list(breakdown.items())[:8]}
+        if engine_mod.get_conv_precision() == "f16x2":
+            # the exact-24-bit arithmetic (three-term bf16 split, 6 MFMAs per block) on record beside the headline
+            engine_mod.set_conv_precision("bf16x3")
+            one_pass()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            one_pass()
+            torch.cuda.synchronize()
+            roof["bf16x3_showers_per_s"] = round(B / (time.perf_counter() - t0), 2)
+            engine_mod.set_conv_precision("f16x2")
         if not args.no_cpu:
-            result["cpu_baseline"] = cpu_baseline(cfg, args.sample_steps)
+            result["cpu_baseline"] = cpu_baseline(cfg, args.sample_steps, B)
             result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
     if rank == 0:
         print(json.dumps(result))

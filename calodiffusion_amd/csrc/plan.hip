@@ -152,17 +152,19 @@ struct CdPlan {
   hipGraphExec_t graph_exec = nullptr;
   struct GraphKey {
     int batch = 0; const void* ws = nullptr; const void* cond = nullptr; const void* x = nullptr; int noisy = 0; uint64_t seed = 0, offset = 0;
+    int precision = 0;  // the captured kernels are those of the convolution precision in force at capture time
     bool operator==(const GraphKey& o) const {
-      return batch == o.batch && ws == o.ws && cond == o.cond && x == o.x && noisy == o.noisy && seed == o.seed && offset == o.offset;
+      return batch == o.batch && ws == o.ws && cond == o.cond && x == o.x && noisy == o.noisy && seed == o.seed && offset == o.offset &&
+             precision == o.precision;
     }
   } graph_key;
   // cached step graph of a uniform sampler program (cd_sampler_run)
   hipGraphExec_t prog_exec = nullptr;
   struct ProgKey {
     int batch = 0, n_coef = 0, n_bufs = 0; const void* ws = nullptr; const void* cond = nullptr; const void* x = nullptr;
-    const void* xs = nullptr; const void* x0s = nullptr; uint64_t ops_hash = 0;
+    const void* xs = nullptr; const void* x0s = nullptr; uint64_t ops_hash = 0; int precision = 0;
     bool operator==(const ProgKey& o) const {
-      return batch == o.batch && n_coef == o.n_coef && n_bufs == o.n_bufs && ws == o.ws && cond == o.cond && x == o.x && xs == o.xs &&
+      return precision == o.precision && batch == o.batch && n_coef == o.n_coef && n_bufs == o.n_bufs && ws == o.ws && cond == o.cond && x == o.x && xs == o.xs &&
              x0s == o.x0s && ops_hash == o.ops_hash;
     }
   } prog_key;
@@ -1193,6 +1195,20 @@ int cd_layer_train_step(const CdLayerMlpDesc* desc, const float* const* weights,
   });
 }
 
+int cd_set_conv_precision(const char* mode) {
+  return guarded([&] {
+    CD_REQUIRE(mode, "null argument");
+    if (!std::strcmp(mode, "f16x2")) set_conv_precision(PREC_F16X2);
+    else if (!std::strcmp(mode, "bf16x3")) set_conv_precision(PREC_BF16X3);
+    else if (!std::strcmp(mode, "f32")) set_conv_precision(PREC_F32);
+    else throw Fail{CD_EINVAL, std::string("unknown convolution precision '") + mode + "' (f16x2, bf16x3, f32)"};
+  });
+}
+const char* cd_get_conv_precision(void) {
+  static const char* names[3] = {"f16x2", "bf16x3", "f32"};
+  return names[conv_precision()];
+}
+
 int cd_profile_begin(void) {
   return guarded([&] { prof::begin(); });
 }
@@ -1265,6 +1281,7 @@ int cd_ddim_sample(CdPlan* plan, int batch, const float* start, const float* con
       if (graphable) {
         CdPlan::GraphKey key;
         key.batch = batch; key.ws = workspace; key.cond = cond; key.x = x_out; key.noisy = noisy ? 1 : 0;
+        key.precision = conv_precision();
         if (!(plan->graph_exec && plan->graph_key == key)) {
           destroy_graph(plan);
           hipGraph_t graph = nullptr;
@@ -1430,7 +1447,7 @@ int cd_sampler_run(CdPlan* plan, int batch, const float* start, float start_scal
       if (graphable) {
         CdPlan::ProgKey key;
         key.batch = batch; key.n_coef = n_coef; key.n_bufs = n_bufs; key.ws = workspace; key.cond = cond; key.x = x_out;
-        key.xs = xs; key.x0s = x0s;
+        key.xs = xs; key.x0s = x0s; key.precision = conv_precision();
         uint64_t h = 1469598103934665603ull;  // FNV-1a over the op list
         for (size_t b = 0; b < sizeof(CdSamplerOp) * (size_t)n_ops; ++b) h = (h ^ ((const unsigned char*)ops)[b]) * 1099511628211ull;
         key.ops_hash = h ^ ((uint64_t)n_steps << 40) ^ (uint64_t)n_ops;

@@ -91,6 +91,8 @@ _SIGNATURES = {
     "cd_adam_step": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                C.POINTER(C.c_int64), C.c_double, C.c_double, C.c_double, C.c_float, C.c_float, C.c_int, _P]),
     "cd_train_step": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "cd_set_conv_precision": (C.c_int, [C.c_char_p]),
+    "cd_get_conv_precision": (C.c_char_p, []),
     "cd_profile_begin": (C.c_int, []),
     "cd_profile_end": (C.c_int, [C.c_char_p, C.c_int]),
     "cd_loss_hybrid_l2": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
@@ -557,6 +559,15 @@ class LayerMlpEngine:
         _check(self.lib.cd_layer_sample(C.byref(self.desc), w, n, B, start.data_ptr(), cond.data_ptr(), table.data_ptr(),
                                         n_steps, _ptr(step_noise), x_out.data_ptr(), _ptr(xs), _ptr(x0s), _stream()))
         return x_out, xs, x0s
+
+
+def set_conv_precision(mode: str):
+    """'f16x2' (default), 'bf16x3' or 'f32' arithmetic of the convolutions, process-wide (cd_set_conv_precision)."""
+    _check(load_library().cd_set_conv_precision(mode.encode()))
+
+
+def get_conv_precision() -> str:
+    return load_library().cd_get_conv_precision().decode()
 
 
 def profile_begin():

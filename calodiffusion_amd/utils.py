@@ -90,6 +90,12 @@ def allreduce_mean_(flat: torch.Tensor) -> torch.Tensor:
     multi-process job.  This is the only collective of the training path."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        if flat.is_cuda and dist.get_backend() == "gloo":
+            # gloo moves host memory: bounce the buffer (tests with several ranks on one GPU; RCCL reduces in place on the device)
+            host = flat.detach().cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            flat.copy_(host)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         flat.div_(dist.get_world_size())
     return flat

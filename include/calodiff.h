@@ -237,6 +237,12 @@ int cd_layer_train_step(const CdLayerMlpDesc* desc, const float* const* weights,
                         const float* noise, const float* sigma, const float* cond, double* loss_out, float* grads,
                         void* workspace, size_t workspace_bytes, void* stream);
 
+/* Arithmetic of the 3x3x3 / strided / transposed convolutions, process-wide: "f16x2" (default; fp32 operands as two-term fp16
+ * splits, 3 MFMAs per block, fp16 range), "bf16x3" (exact three-term bf16 split, 6 MFMAs, full fp32 range) or "f32" (f32-input
+ * MFMA).  Initial value: environment variable CD_CONV_PRECISION.  Cached step graphs are dropped by the next sampler call. */
+int cd_set_conv_precision(const char* mode);
+const char* cd_get_conv_precision(void);
+
 /* ---- measurement ---------------------------------------------------------------------------------------------- */
 /* Per-launch timing with HIP events on the launch stream (eager mode; graphs are bypassed while active).
  * cd_profile_end synchronises the device and writes a JSON object

@@ -12,6 +12,17 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (gfx950); run with -m gpu on the GPU box")
+    # Multi-process GPU tests start their ranks from a fork server that is launched HERE, before anything in this process has
+    # touched the GPU: the ranks are then forks of a GPU-free process (no exec from, and no fork of, a process holding the GPU).
+    if "gpu" in (config.getoption("-m") or "") and "not gpu" not in (config.getoption("-m") or ""):
+        import multiprocessing as mp
+        from multiprocessing import forkserver
+        try:
+            mp.set_start_method("forkserver", force=True)
+            forkserver.set_forkserver_preload(["numpy"])
+            forkserver.ensure_running()
+        except Exception as err:  # pragma: no cover
+            print(f"conftest: fork server not started ({err}); multi-process GPU tests will skip")
 
 
 def gold(name):

@@ -118,9 +118,6 @@ def test_unet_sinusoidal_embeddings():
 def test_sampler_recovers_from_fp16_range_overflow():
     """An activation beyond the fp16 range trips the f16x2 convolutions' flag; the sampler loops then re-run the trajectory
     with the exact bf16x3 convolutions instead of losing the batch: finite, and equal to a run in bf16x3 mode from the start."""
-    import os
-    import subprocess
-    import sys
     m = _model("dataset2")
     gen = torch.Generator().manual_seed(8)
     start = torch.randn((2, 1, 45, 16, 9), generator=gen).cuda()
@@ -134,25 +131,17 @@ def test_sampler_recovers_from_fp16_range_overflow():
     m.sampler_algorithm = sample.Heun(dict(m.config, NOISY_SAMPLE=False))
     _, xs, _ = m.sample(E, layers, num_steps=3, start=start, debug=True)
     assert torch.isfinite(torch.stack(xs)).all() and m.engine().range_fallbacks == 2
-    # the same trajectory in a process that runs bf16x3 from the start
-    np.save("/tmp/cd_fallback_out.npy", out)
-    code = (
-        "import os, sys, numpy as np, torch\n"
-        f"sys.path[:0] = {[p for p in sys.path if p]!r}\n"
-        "from test_gpu_round2 import _model\n"
-        "m = _model('dataset2')\n"
-        "gen = torch.Generator().manual_seed(8)\n"
-        "start = torch.randn((2, 1, 45, 16, 9), generator=gen).cuda()\n"
-        "E, layers = torch.rand((2, 1), generator=gen).cuda(), torch.randn((2, 46), generator=gen).cuda()\n"
-        "with torch.no_grad():\n"
-        "    m.model.init_conv.conv.bias.fill_(1.0e6)\n"
-        "out = m.sample(E, layers, num_steps=3, start=start)\n"
-        "want = np.load('/tmp/cd_fallback_out.npy')\n"
-        "assert getattr(m.engine(), 'range_fallbacks', 0) == 0\n"
-        "assert np.array_equal(out, want), float(np.abs(out - want).max())\n")
-    env = dict(os.environ, CD_CONV_PRECISION="bf16x3")
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
+    # the same trajectory with bf16x3 arithmetic from the start: identical, and no fallback
+    from calodiffusion_amd import engine
+    assert engine.get_conv_precision() == "f16x2"
+    engine.set_conv_precision("bf16x3")
+    try:
+        m.sampler_algorithm = sample.DDim(m.config)
+        want = m.sample(E, layers, num_steps=3, start=start)
+        assert m.engine().range_fallbacks == 2
+    finally:
+        engine.set_conv_precision("f16x2")
+    assert np.array_equal(out, want), float(np.abs(out - want).max())
 
 
 # ---------------------------------------------------------------------------------------------- gradients
