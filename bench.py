@@ -91,7 +91,8 @@ def synthetic_inputs(cfg, batch, rank, world, device):
 def cpu_baseline(cfg, sample_steps, batch, timed=3):
     """The oracle on the host cores at the SAME batch as the GPU run: `timed` denoise steps after a warm-up, extrapolated to
     sample_steps steps per shower (every DDIM step costs the same U-Net forward).  The thread count is the best of a quick
-    {8, 32, all cores} probe (one denoise step each): PyTorch's CPU convolutions stop scaling long before 128 threads."""
+    {8, 16, 32} probe (one denoise step each).  More is pointless and expensive to find out: the box's CPU share is 16 for one
+    GPU, PyTorch's CPU convolutions stop scaling long before, and at all 256 visible cores one step took 64 s (r2b)."""
     from oracle import torch_oracle as O
     from tests.helpers import seeded_unet  # same seeded weights as the GPU model
     net = seeded_unet(cfg["_name"])
@@ -106,7 +107,7 @@ def cpu_baseline(cfg, sample_steps, batch, timed=3):
     default_threads = torch.get_num_threads()
     probe = {}
     with torch.no_grad():
-        for th in sorted({min(8, ncpu), min(32, ncpu), ncpu}):
+        for th in sorted({min(8, ncpu), min(16, ncpu), min(32, ncpu)}):
             torch.set_num_threads(th)
             model.denoise(x, E, sig, layers)  # warm-up at this thread count
             t0 = time.perf_counter()

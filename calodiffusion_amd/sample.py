@@ -432,7 +432,7 @@ class DPM(_ProgramSampler):
             raise ValueError("sigma_min and sigma_max must not be 0")
         if self.eta:
             raise NotImplementedError("DPM: ETA > 0 (ancestral noise) is not provided")
-        t_start, t_end = self.time_fn(torch.tensor(sigma_max)), self.time_fn(torch.tensor(sigma_min))
+        t_start, t_end = self.time_fn(sigma_max.clone()), self.time_fn(sigma_min.clone())
         nfe = num_steps
         m = math.floor(nfe / 3) + 1
         ts = torch.linspace(t_start, t_end, m + 1)
