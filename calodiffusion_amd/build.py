@@ -15,7 +15,10 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
-LIB = os.path.join(LIBDIR, "libcalodiff_hip.so")
+# CD_BUILD_TAG=<tag>: an experiment build (e.g. with CD_EXTRA_HIPCC_FLAGS=-DCD_ZS_EXPERIMENTS) next to the product library, in
+# its own object directory; load it with CALODIFF_LIB=.../libcalodiff_hip_<tag>.so
+TAG = os.environ.get("CD_BUILD_TAG", "")
+LIB = os.path.join(LIBDIR, f"libcalodiff_hip{'_' + TAG if TAG else ''}.so")
 SOURCES = ["kernels_conv.hip", "kernels_conv_zs.hip", "kernels_attn.hip", "kernels_conv_small.hip", "kernels_wgrad16.hip", "kernels_norm_attn.hip", "kernels_misc.hip", "kernels_mlp.hip", "kernels_mlp_train.hip", "kernels_bwd.hip", "profiler.hip", "plan.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
@@ -31,7 +34,7 @@ def _stale(target: str, deps) -> bool:
 
 def build_all(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
-    objdir = os.path.join(LIBDIR, "obj")
+    objdir = os.path.join(LIBDIR, "obj" + ("_" + TAG if TAG else ""))
     os.makedirs(objdir, exist_ok=True)
     # every header / include fragment is a dependency of every object (split16.h, gn_defer.h and train.inc are shared across
     # translation units: a stale object would mix producer and consumer layouts)

@@ -517,6 +517,583 @@ __global__ void __launch_bounds__(512, 1) conv_zslide_f16x2_kernel(ConvZsArgs a)
   }
 }
 
+
+// ============================================================================================================
+// Ping-pong form (the default).  The kernel above gives each SIMD one matrix wave and one helper wave; the matrix wave then
+// pays, serially and with the matrix pipe idle, for everything around its MFMAs: the tap-address table of the step, the
+// latency of its first fragment reads, the fold and LDS write of its partial tiles and the step barrier (~900 of every
+// ~3500 cycles).  Here all eight waves run ONE program in two groups of four (waves 0-3 / 4-7: the two waves that share a
+// SIMD are in different groups and hold the same K-slice of the weights).  Group g owns the 64-voxel steps of parity g and
+// alternates between
+//   * a MATRIX phase   -- the 81 MFMAs of its K-slice over the two row tiles of its step; partial tiles to the exchange
+//                         buffer of its group, and
+//   * a SUPPORT phase  -- while the other group's matrix phase runs on the same SIMDs: convert the input plane its own next
+//                         step is the first to read (raw image in LDS -> GroupNorm + SiLU + embedding -> fp16 split -> ring);
+//                         start the LDS-DMA of the plane the step after that needs; sum the four K-slices of its own previous
+//                         step, bias, store, channel statistics; build the tap-address table of its next step,
+// one workgroup barrier per phase.  Every SIMD so always has one wave feeding the matrix pipe while its partner does the
+// vector / LDS / memory work in the issue slots the MFMAs leave free (an MFMA holds the vector issue port 8 of its 32 cycles).
+//
+// Registers are the scarce resource (2 waves per SIMD = 256 per wave: 112 weights + 64 accumulators + fragments): nothing of
+// the support role may stay live across a matrix phase.  Hence the raw planes travel global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4: no destination registers; issued at the start of a support phase, awaited at its end by count, read
+// by the other group one phase later), the GroupNorm coefficients live in LDS, and the addresses are re-derived.
+// The K-slice exchange keeps each wave's own slice of the rows it reduces in registers: 24 KB per group instead of 32.
+//
+// LDS: [zeros 512][coef, bias, flag 1024][ring NR planes][exchange 2 x 24 KB][raw plane 20 KB]  (Dataset-2: 150.5 KB)
+// ============================================================================================================
+constexpr int ZP_PD = 2;                  // fragment pairs requested ahead of their MFMAs (registers: 8 per pair in flight)
+constexpr int ZP_COEF = 1024;             // [32][4] floats: the GroupNorm coefficients of this launch's 32 input channels;
+                                          // +512: bias[32]; +640: range flag word
+constexpr int ZP_XCH = 4 * 3 * 2048;      // exchange buffer of one group: 4 reducers x 3 foreign K-slices x (8 rows x 64 lanes x 4 B)
+constexpr int ZP_RAW = ZS_NSL * 32 * 128; // raw fp32 image of one plane: 160 voxel slots x 32 channels
+
+// The interval loop of zp_wave is register-bound: loop-invariant address arithmetic that the compiler hoists out of it (five
+// 64-bit source addresses, sink offsets, ...) stays live across the matrix phases and pushes weights into scratch.  Values
+// laundered through these look loop-variant, so what is derived from them is recomputed inside the phase that uses it.
+__device__ __forceinline__ int zp_opaque_v(int x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+
+// LDS access by byte address: an address_space(3) pointer made from the integer -- through the generic `lds + offset` form
+// every access pays a `v_add_u32 addr, 0, offset` for the (zero) base of the dynamic LDS symbol
+template <typename T>
+__device__ __forceinline__ __attribute__((address_space(3))) T* zp_lds(int byte_addr) {
+  return (__attribute__((address_space(3))) T*)(uintptr_t)(unsigned)byte_addr;
+}
+
+// diagnostic build only (DBG & 2048): per-wave cycle sums of {matrix phases, support phases, barrier waits, phases counted}
+__device__ unsigned long long zp_stamp_buf[256 * 8 * 4];
+__device__ unsigned long long zp_stamp_fine[256 * 8 * 8];  // (DBG & 4096) support phase: head, convert, reduce, prepare, DMA wait, #conv phases
+__device__ __forceinline__ unsigned long long zp_stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+
+struct ZpGeo : ZsGeo {
+  int XCH, RAW;
+};
+__device__ __forceinline__ ZpGeo zp_geo(const ConvZsArgs& a) {
+  ZpGeo g;
+  (ZsGeo&)g = zs_geo(a);
+  g.RB = ZS_ZERO + ZP_COEF;
+  g.XCH = g.RB + a.NR * g.PLB;
+  g.RAW = g.XCH + 2 * ZP_XCH;
+  g.ZPART = g.XCH;  // (prologue scratch of gn_defer_to_lds: the exchange + raw regions are still unused then)
+  return g;
+}
+
+// DBG (builds with -DCD_ZS_EXPERIMENTS, CD_ZS_DBG): timing experiments, results are wrong -- 1 = no plane DMA / wait, 2 = no plane
+// conversion, 4 = no reduction / stores, 8 = no MFMAs, 16 = no fragment reads, 32 = tap addresses prepared once, 64 = no hand-over
+// MODE (compile-time specialisation: the support phase is issue-bound, every run-time switch in it costs select / branch
+// instructions in all 256 threads): 1 = NORMED (input = GroupNorm + SiLU + embedding of the tensor read), 2 = HALO (phi strips
+// with halo rows instead of whole planes), 4 = SCALED (input rescaled by a power of two from its max: the training gradients)
+template <int WV, bool ACC, int MODE, int DBG = 0>
+__device__ __forceinline__ void zp_wave(const ConvZsArgs& a, char* lds) {
+  constexpr bool NORMED = (MODE & 1) != 0, HALO = (MODE & 2) != 0, SCALED = (MODE & 4) != 0;
+  constexpr int KSTEP = WV >> 1, ODD = WV & 1, T0 = ODD ? 13 : 0;  // K-slice: k-step and taps T0 .. T0+13 (as zs_matrix_wave)
+  constexpr int TH = WV >> 1, RH = WV & 1;  // reduction role: rows 16*RH .. 16*RH+15 (accumulator registers 8*RH..8*RH+7) of tile TH
+  static_assert(ZS_TILES == 2, "the tap split alternates over the two tiles of a step");
+  const int lane = threadIdx.x & 63, half = lane >> 5, col = lane & 31;
+  // this wave's group (it owns the steps of parity grp): wave-uniform, and pinned to a scalar register so that the phase
+  // selection, the plane tracking and everything else that hangs on it stay on the scalar unit
+  const int grp = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
+  const int tid = threadIdx.x & 255;  // thread within the group (staging and reduction roles)
+  const int b = blockIdx.y, ct = blockIdx.z;
+  const ZpGeo G = zp_geo(a);
+  const int H = a.HS, W = a.W, PV = G.PV, SPV = G.SPV;
+  const int NIMG = G.rows * W;  // voxels staged per plane (strip rows + halo rows)
+  const int nsteps = G.nsteps;
+  const int chunk = G.chunk + G.strip * a.nchunk;
+  float* const coef_lds = (float*)(lds + ZS_ZERO);
+  const int xch = G.XCH + grp * ZP_XCH;  // this group's exchange buffer (LDS byte address)
+
+  // ---- weights of this wave's K-slice: registers for the whole chunk --------------------------------------------
+  u32x4 w1[14], w2[14];
+  {
+    const u32x4* wq = a.wpk + ((size_t)(KSTEP * 27 + T0) * a.CTtot + ct) * 128 + lane;
+#pragma unroll
+    for (int j = 0; j < 14; ++j) {
+      w1[j] = wq[(size_t)j * a.CTtot * 128];
+      w2[j] = wq[(size_t)j * a.CTtot * 128 + 64];
+    }
+  }
+
+  // ---- support role: staging (thread tq of the group = channel quad q = tq & 7 of image voxels p0 + 32k, p0 = tq >> 3, k < 5)
+  float* const bias_lds = (float*)(lds + ZS_ZERO + 512);
+  int* const flag_lds = (int*)(lds + ZS_ZERO + 640);
+  const float* const src_b = a.in + (size_t)b * G.vox * a.ldc;
+  const int src_off = (G.h0 - G.halo) * W;  // image voxel p comes from plane voxel p + src_off (mod PV: phi halo rows wrap)
+  float gscale = 1.f, ginv = 1.f;
+  if (SCALED) pow2_scale_for(*a.in_absmax, &gscale, &ginv);
+  auto src_of = [&](int tq, int z, int k) {  // global address of thread tq's piece k of plane z (prologue)
+    const int q = tq & 7, p0 = tq >> 3;
+    const int zc = min(max(z, 0), a.D - 1);
+    int v = min(p0 + 32 * k, NIMG - 1) + src_off;
+    v = v < 0 ? v + PV : (v >= PV ? v - PV : v);
+    return src_b + ((size_t)zc * PV + v) * a.ldc + q * 4;
+  };
+  // raw plane -> LDS by LDS-DMA: wave-instruction k lands this wave's 64 pieces (8 voxels x 8 quads = 1 KiB) at
+  // RAW + (32 k + 8 wave) * 128 + lane * 16, i.e. voxel-major [voxel][32 ch] fp32, the order convert() reads them back in.
+  // Source = (wave-uniform plane base) + (32-bit byte offset per lane): a handful of vector instructions per plane.
+  const int raw_wave = __builtin_amdgcn_readfirstlane(G.RAW + ((tid >> 3) & ~7) * 128);
+  auto dma_plane = [&](int tq, int z) {
+    const int q = tq & 7, p0 = tq >> 3;
+    const int zc = min(max(z, 0), a.D - 1);
+    const unsigned long long pb64 = (unsigned long long)(src_b + (size_t)zc * PV * a.ldc);  // wave-uniform: pin it to SGPRs
+    const unsigned long long pbase = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(pb64 >> 32)) << 32) |
+                                     (unsigned)__builtin_amdgcn_readfirstlane((int)pb64);
+    const int vstride = a.ldc * 4;
+    unsigned off[ZS_NSL];
+    if (HALO) {  // strips: phi halo rows wrap around the plane
+#pragma unroll
+      for (int k = 0; k < ZS_NSL; ++k) {
+        int v = min(p0 + 32 * k, NIMG - 1) + src_off;
+        v = v < 0 ? v + PV : (v >= PV ? v - PV : v);
+        off[k] = (unsigned)(v * vstride + q * 16);
+      }
+    } else {  // whole planes: consecutive pieces are 32 voxels apart; only the last one can run past the plane
+      const unsigned off0 = (unsigned)(tq * 16);  // = p0 * 128 + q * 16 for 32-channel sources ...
+      const unsigned o0 = a.ldc == 32 ? off0 : (unsigned)(p0 * vstride + q * 16);
+#pragma unroll
+      for (int k = 0; k < ZS_NSL - 1; ++k) off[k] = o0 + (unsigned)(k * 32) * (unsigned)vstride;
+      off[ZS_NSL - 1] = (unsigned)(min(p0 + 32 * (ZS_NSL - 1), NIMG - 1) * vstride + q * 16);
+    }
+#pragma unroll
+    for (int k = 0; k < ZS_NSL; ++k) {
+      const int dst = raw_wave + k * 32 * 128;
+      unsigned keep;
+      asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 ; zs_plane_load\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep)
+                   : "v"(off[k]), "s"(pbase), "s"(dst)
+                   : "memory");
+    }
+  };
+  // normalise + split the five pieces in v[] (this thread's quad of image voxels p0 + 32k) into the ring slot of plane z
+  auto convert = [&](int tq, f32x4 (&v)[ZS_NSL], int z) {
+    const int q = tq & 7, p0 = tq >> 3;
+    float amax = 0.f;
+    // ring slot (z + NR) mod NR, z >= -1, NR = 4 or 5, without a division
+    const int zz = z + a.NR;
+    const int slot = a.NR == 4 ? (zz & 3) : zz - 5 * ((zz * 205) >> 10);
+    const bool zero = z < 0 || z >= a.D;
+    const int dst = slot * G.PLB + G.RB + p0 * ZS_VB + (q >> 2) * 64 + (q & 3) * 8;
+    f32x4 cf[4], cn[4];  // {scale, shift, add, -} per channel; cn = {scale, shift} * -log2(e) for the sigmoid's exponent
+    if (NORMED) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        cf[e] = *zp_lds<const f32x4>(ZS_ZERO + (q * 4 + e) * 16);
+        cn[e][0] = cf[e][0] * -1.4426950408889634f;
+        cn[e][1] = cf[e][1] * -1.4426950408889634f;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < ZS_NSL; ++k) {
+      if (p0 + 32 * k < NIMG) {
+        u32x2 t1 = {0u, 0u}, t2 = {0u, 0u};
+        if (!zero) {
+          f32x4 x = v[k];
+          if (SCALED) x = x * gscale;  // (training: input gradients rescaled by a power of two)
+          if (NORMED) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              // SiLU(t) + add, t = scale x + shift: t / (1 + 2^(-t log2 e)) + add on the transcendental unit -- fma, exp, add,
+              // rcp, fma, fma
+              const float t = cf[e][0] * x[e] + cf[e][1];
+              const float ex = __builtin_amdgcn_exp2f(cn[e][0] * x[e] + cn[e][1]);
+              x[e] = t * __builtin_amdgcn_rcpf(1.f + ex) + cf[e][2];
+            }
+          }
+          amax = fmaxf(fmaxf(amax, fabsf(x[0])), fabsf(x[1]));
+          amax = fmaxf(fmaxf(amax, fabsf(x[2])), fabsf(x[3]));
+          split2(x, t1, t2);
+        }
+        *zp_lds<u32x2>(dst + k * 32 * ZS_VB) = t1;
+        *zp_lds<u32x2>(dst + k * 32 * ZS_VB + 32) = t2;
+      }
+    }
+    if (amax > 65504.f) *flag_lds = 1;  // (rare; flushed to a.status at the end: no register and no memory operation here)
+  };
+  auto read_raw = [&](int tq, f32x4 (&v)[ZS_NSL]) {
+#pragma unroll
+    for (int k = 0; k < ZS_NSL; ++k) v[k] = *zp_lds<const f32x4>(G.RAW + tq * 16 + k * 32 * 128);  // = (p0 + 32k) * 128 + q * 16
+  };
+  auto need = [&](int k) {  // highest plane that step k reads
+    k = min(k, nsteps - 1);
+    return min(G.v0 + k * ZS_STEP + ZS_STEP - 1, G.cend - 1) / SPV + 1;
+  };
+  auto new_plane = [&](int k) { return (k >= 1 && k < nsteps && need(k) > need(k - 1)) ? need(k) : -2; };  // first read by step k
+  // the same, incrementally (the divisions above are ~60 instructions each; a support phase asks twice): `trk` follows the last
+  // voxel of consecutive steps; a step reads a new plane when that voxel enters the next plane of the strip
+  struct { int k, vend, zlim, need; } trk;
+  auto trk_init = [&](int k) {  // state of step k (k < nsteps)
+    trk.k = k;
+    trk.vend = min(G.v0 + k * ZS_STEP + ZS_STEP - 1, G.cend - 1);
+    const int zv = trk.vend / SPV;
+    trk.zlim = (zv + 1) * SPV;
+    trk.need = zv + 1;
+  };
+  auto trk_next = [&]() {  // advance to the next step; returns the plane it is the first to read, or -2
+    trk.k += 1;
+    if (trk.k >= nsteps) return -2;
+    trk.vend = min(trk.vend + ZS_STEP, G.cend - 1);
+    if (trk.vend < trk.zlim) return -2;
+    trk.zlim += SPV;  // (a plane holds at least one step: at most one new plane per step)
+    trk.need += 1;
+    return trk.need;
+  };
+
+  // ---- prologue: zero area, GroupNorm table, the planes of step 0 (3 or 4) through registers, shared by the groups ----
+  if (threadIdx.x < ZS_ZERO / 4) ((float*)lds)[threadIdx.x] = 0.f;
+  if (threadIdx.x < 32) bias_lds[threadIdx.x] = a.bias ? a.bias[ct * 32 + threadIdx.x] : 0.f;
+  if (threadIdx.x == 32) *flag_lds = 0;
+  const int zstaged0 = need(0);
+  const int zp0 = G.zfirst - 1, npro = zstaged0 - zp0 + 1;
+  {
+    f32x4 ldp[2][ZS_NSL];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      if (grp + 2 * i < npro) {
+#pragma unroll
+        for (int k = 0; k < ZS_NSL; ++k) ldp[i][k] = *(const f32x4*)src_of(tid, zp0 + grp + 2 * i, k);
+      }
+    if (a.defer.part) {  // table of all defer.C channels built by the whole workgroup in the (still unused) exchange region
+      char* scratch = lds + G.ZPART;
+      gn_defer_to_lds(a.defer, b, (float*)scratch, scratch + a.defer.C * 16);
+      if (threadIdx.x < 32) *(f32x4*)(coef_lds + threadIdx.x * 4) = *(const f32x4*)(scratch + (a.choff + threadIdx.x) * 16);
+    } else if (a.coef) {
+      if (threadIdx.x < 32) *(f32x4*)(coef_lds + threadIdx.x * 4) = *(const f32x4*)(a.coef + ((size_t)b * a.coef_c + threadIdx.x) * 4);
+    }
+    __syncthreads();  // the table is complete
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      if (grp + 2 * i < npro) convert(tid, ldp[i], zp0 + grp + 2 * i);
+    if (grp == 0) {
+      for (int z = zp0 + 4; z <= zstaged0; ++z) {  // (not reached for planes of >= 64 voxels)
+#pragma unroll
+        for (int k = 0; k < ZS_NSL; ++k) ldp[0][k] = *(const f32x4*)src_of(tid, z, k);
+        convert(tid, ldp[0], z);
+      }
+    }
+  }
+  // raw image of the plane step 1 is the first to read: support phase 0 (group 1) converts it
+  if (grp == 1 && new_plane(1) != -2) dma_plane(tid, new_plane(1));
+
+  // ---- matrix role: per-lane geometry of its row (voxel) in the next tile of this group, advanced tile by tile ----
+  // per-lane position of its row (voxel) in the next tile of this group, advanced tile by tile: phi row gh and r column gw in the
+  // strip-plane, po = byte offset of its record in a plane image (+ this wave's constants), sb = byte offset of the ring slot of plane z - 1
+  int gh, gw, po, sb;
+  const int RWB = W * ZS_VB;               // bytes per image row
+  const int ring_bytes = a.NR * G.PLB;
+  {
+    const int v = G.v0 + grp * ZS_STEP + col;
+    const int gz = v / SPV;
+    const int p = v - gz * SPV;
+    gh = p / W;
+    gw = p - gh * W;
+    po = ((gh + (HALO ? 1 : 0)) * W + gw) * ZS_VB + G.RB + KSTEP * 64 + half * 16 - ZS_VB;  // (- ZS_VB: the kw = 0 tap is one record back)
+    sb = ((gz + a.NR - 1) % a.NR) * G.PLB;
+  }
+  const int W1 = W - 1;
+  auto advance = [&](int nvox) {  // by nvox voxels < one strip-plane (a plane holds >= 64)
+    const int dh = nvox / W, dw = nvox - dh * W;  // (nvox is a literal: constants after inlining ... W is not; two scalar ops)
+    gw += dw;
+    gh += dh;
+    po += nvox * ZS_VB;
+    if (gw >= W) { gw -= W; gh += 1; }
+    if (gh >= H) {  // into the next plane
+      gh -= H;
+      po -= SPV * ZS_VB;
+      sb += G.PLB;
+      sb = sb == ring_bytes ? 0 : sb;
+    }
+  };
+  // tap addresses of the two tiles of the next step: fragment of tap (kz, kh, kw) = bz[t][kz] + {ro0, 0, ro2}[kh] + kw * ZS_VB
+  int bz[ZS_TILES][3], ro0[ZS_TILES], ro2[ZS_TILES];
+  bool eL[ZS_TILES], eR[ZS_TILES];  // first / last column: the kw = 0 / kw = 2 taps read zeros
+  auto prepare = [&]() {            // ... of this group's next step; then skip the other group's step
+#pragma unroll
+    for (int t = 0; t < ZS_TILES; ++t) {
+      eL[t] = gw == 0;
+      eR[t] = gw == W1;
+      if (HALO) {  // strips carry their phi neighbours as halo rows
+        ro0[t] = -RWB;
+        ro2[t] = RWB;
+      } else {     // whole planes wrap around
+        ro0[t] = gh > 0 ? -RWB : (H - 1) * RWB;
+        ro2[t] = gh < H - 1 ? RWB : -(H - 1) * RWB;
+      }
+      bz[t][0] = sb + po;
+#pragma unroll
+      for (int kz = 1; kz < 3; ++kz) {
+        const unsigned x = (unsigned)(sb + kz * G.PLB);
+        bz[t][kz] = (int)min(x, x - (unsigned)ring_bytes) + po;  // slot wrap: x < ring ? x : x - ring
+      }
+      advance(32);
+    }
+    advance(ZS_STEP);
+  };
+
+  constexpr int N0 = ODD ? 13 : 14;  // pairs of tile 0: even wave taps [0,14), odd wave [14,27); tile 1: [0,13) / [13,27)
+  constexpr int NI = 27;
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float own[8];  // this wave's own K-slice of the rows it reduces: stays in registers from the matrix phase to the support phase
+
+  // ---- MATRIX phase (tap addresses prepared by the preceding support phase) --------------------------------------
+  auto matrix_phase = [&]() {
+    constexpr int PD = (DBG & 256) ? 3 : ZP_PD;  // fragments are requested PD pairs ahead of their MFMAs
+    // (s_setprio 3 for this phase was measured: 3 us slower -- the support phase beside it is the longer one, see below)
+    if (DBG & 512) __builtin_amdgcn_s_setprio(3);
+    u32x4 fa[PD + 1][2];
+    auto pair_tile = [](int i) { return i < N0 ? 0 : 1; };
+    auto pair_tap = [](int i) {
+      if (i < N0) return ODD ? 14 + i : i;
+      const int j = i - N0;
+      return ODD ? 13 + j : j;
+    };
+    auto load_frag = [&](int i) {
+      const int t = pair_tile(i), tap = pair_tap(i);
+      const int kz = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+      int base = bz[t][kz] + kw * ZS_VB;
+      if (kh == 0) base += ro0[t];
+      if (kh == 2) base += ro2[t];
+      if (kw == 0) base = eL[t] ? (base & 255) : base;  // into the zero area, same bank quad
+      if (kw == 2) base = eR[t] ? (base & 255) : base;
+      if (DBG & 1024) base = G.RB + col * ZS_VB + half * 16 + KSTEP * 64 + (i % 24) * ZS_VB * 8;  // experiment: synthetic addresses
+      fa[i % (PD + 1)][0] = *zp_lds<const u32x4>(base);
+      fa[i % (PD + 1)][1] = *zp_lds<const u32x4>(base + 32);
+    };
+    // K-slice partial of tile t: rows 8*rh .. of reducer (t, rh) go to its region of the exchange buffer -- or stay here
+    auto hand_over = [&](int t, const f32x16& A, const f32x16& B) {
+      f32x16 pt;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pt[r] = A[r] + B[r] * (1.f / 2048.f);
+#pragma unroll
+      for (int rh = 0; rh < 2; ++rh) {
+        const int R = 2 * t + rh;  // reducer wave
+        if (R == WV) {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) own[r] = pt[8 * rh + r];
+        } else {
+          const int d = xch + (R * 3 + (WV < R ? WV : WV - 1)) * 2048 + lane * 16;
+          *zp_lds<f32x4>(d) = f32x4{pt[8 * rh], pt[8 * rh + 1], pt[8 * rh + 2], pt[8 * rh + 3]};
+          *zp_lds<f32x4>(d + 1024) = f32x4{pt[8 * rh + 4], pt[8 * rh + 5], pt[8 * rh + 6], pt[8 * rh + 7]};
+        }
+      }
+    };
+    f32x16 accA[2], accB[2];
+    if (DBG & 16) {
+#pragma unroll
+      for (int i = 0; i <= PD; ++i) fa[i][0] = fa[i][1] = u32x4{0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int i = 0; i < PD; ++i)
+      if (!(DBG & 16)) load_frag(i);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int t = pair_tile(i), j = pair_tap(i) - T0;
+      const bool first = i == 0 || i == N0;
+      if (i + PD < NI && !(DBG & 16)) load_frag(i + PD);
+      __builtin_amdgcn_sched_barrier(0);
+      if (DBG & 8) {
+        asm volatile("" ::"v"(fa[i % (PD + 1)][0]), "v"(fa[i % (PD + 1)][1]));
+        if (first) { accA[t] = zero16; accB[t] = zero16; }
+      } else {
+        accA[t] = MFMA_F16(fa[i % (PD + 1)][0], w1[j], first ? zero16 : accA[t]);
+        accB[t] = MFMA_F16(fa[i % (PD + 1)][0], w2[j], first ? zero16 : accB[t]);
+        accB[t] = MFMA_F16(fa[i % (PD + 1)][1], w1[j], accB[t]);
+      }
+      if (i == N0 + 3 && !(DBG & 64)) hand_over(0, accA[0], accB[0]);
+    }
+    if (!(DBG & 64)) hand_over(1, accA[1], accB[1]);
+    else asm volatile("" ::"v"(accA[0]), "v"(accB[0]), "v"(accA[1]), "v"(accB[1]));
+    if (DBG & 512) __builtin_amdgcn_s_setprio(0);
+  };
+
+  // ---- SUPPORT phase of interval i: stage the plane of own step i+1, DMA the plane of step i+2, reduce own step i-1 ----
+  float s1 = 0.f, s2 = 0.f;
+  float* const out_sb = a.out + ((size_t)b * G.vox + (size_t)G.h0 * W) * a.cout + ct * 32;  // wave-uniform
+  const float inv_spv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, 1.f / (float)SPV)));
+  auto gvox = [&](int v) {  // exact: (v + 0.5) / SPV is never within float error of an integer
+    const int z = (int)(((float)v + 0.5f) * inv_spv);
+    return z * PV + (v - z * SPV);
+  };
+
+  constexpr int NYOUNG = (ACC || (DBG & 4) || (DBG & 16384)) ? 0 : 8;  // the 8 row stores issued between the DMA of a plane and the wait for it
+  auto reduce_store = [&](int tq, int s, bool live) {
+    const int lq = tq & 63, colq = lq & 31, halfq = lq >> 5;
+    float sum[8];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {  // K-slices in fixed order: deterministic, and the same sum whichever wave reduces
+      if (w == WV) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) sum[r] = w == 0 ? own[r] : sum[r] + own[r];
+      } else {
+        const int d = xch + (WV * 3 + (w < WV ? w : w - 1)) * 2048 + lq * 16;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const f32x4 x = (DBG & 32768) ? f32x4{own[0], own[1], own[2], own[3]} : *zp_lds<const f32x4>(d + g * 1024);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sum[4 * g + e] = w == 0 ? x[e] : sum[4 * g + e] + x[e];
+        }
+      }
+    }
+    const int vt = G.v0 + s * ZS_STEP + TH * 32;
+    float* dst[8];
+    float val[8];
+    const float bvv = *zp_lds<const float>(ZS_ZERO + 512 + colq * 4);
+    if (!ACC && !HALO && live && vt + 32 <= G.cend) {
+      // whole planes, whole tile inside the chunk (all but the last step): output row = strip voxel; one base address and a
+      // constant stride instead of the tail / strip logic per row
+      float* const d0 = out_sb + (size_t)(vt + 16 * RH + 4 * halfq) * a.cout + colq;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        dst[r] = d0 + ((r & 3) + 8 * (r >> 2)) * a.cout;
+        float v = sum[r];
+        if (SCALED) v *= ginv;
+        v += bvv;
+        val[r] = v;
+        s1 += v;
+        s2 += v * v;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int row = (r & 3) + 8 * ((r >> 2) + 2 * RH) + 4 * halfq;
+        const bool ok = live && vt + row < G.cend;
+        // rows this lane does not own (chunk tail, the dummy first epilogue) go to the lane's sink cell
+        dst[r] = ok ? out_sb + (size_t)gvox(vt + row) * a.cout + colq : zs_sink + tq;
+        float v = sum[r];
+        if (SCALED) v *= ginv;
+        if (ACC) v += *dst[r];  // continuation launch of a wider-K conv: add to what the previous launch stored
+        v += bvv;
+        val[r] = v;
+        const float m = ok ? v : 0.f;
+        s1 += m;
+        s2 += m * m;
+      }
+    }
+    // exactly one store instruction per row on every path: the wait for the DMA counts them (tools/isa_vmcnt_check.py)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      if (DBG & 16384) asm volatile("" ::"v"(dst[r]), "v"(val[r]));
+      else asm volatile("global_store_dword %0, %1, off ; zs_row_store" ::"v"(dst[r]), "v"(val[r]) : "memory");
+    }
+  };
+  unsigned long long fine[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto support_phase = [&](int i) {
+    const int zconv = trk_next(), zload = trk_next();  // = new_plane(i + 1), new_plane(i + 2): trk stands at step i on entry
+    const int tq = zp_opaque_v(tid);  // (see zp_opaque_v: keeps this phase's address arithmetic inside the phase)
+    unsigned long long f0 = 0, f1 = 0, f2 = 0, f3 = 0, f4 = 0;
+    if (DBG & 8192) __builtin_amdgcn_s_setprio(2);  // experiment: the support phase outranks the partner's matrix phase
+    if (DBG & 4096) f0 = zp_stamp();
+    f32x4 v[ZS_NSL];
+    if (zconv != -2 && !(DBG & 2)) {
+      read_raw(tq, v);  // landed before the last barrier (awaited by the group that issued the DMA)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4])::"memory");
+    }
+    if (zload != -2 && !(DBG & 1)) dma_plane(tq, zload);  // overwrites exactly the pieces this wave has just read
+    __builtin_amdgcn_sched_barrier(0);
+    if (DBG & 4096) f1 = zp_stamp();
+    if (zconv != -2 && !(DBG & 2)) convert(tq, v, zconv);
+    __builtin_amdgcn_sched_barrier(0);
+    if (DBG & 4096) f2 = zp_stamp();
+    if (!(DBG & 4)) reduce_store(tq, i - 1, i >= 1);  // (i = 0: nothing to sum yet, the eight stores go to the sink)
+    __builtin_amdgcn_sched_barrier(0);
+    if (DBG & 4096) f3 = zp_stamp();
+    if (i + 1 < nsteps && !(DBG & 32)) prepare();
+    if (DBG & 4096) f4 = zp_stamp();
+    // the DMA must have landed before the barrier that lets the other group read it; the 8 younger row stores may stay in flight
+    if (zload != -2 && !(DBG & 1)) asm volatile("s_waitcnt vmcnt(%0) ; zs_landed" ::"n"(NYOUNG) : "memory");
+    if (DBG & 4096) {
+      const unsigned long long f5 = zp_stamp();
+      fine[0] += f1 - f0; fine[1] += f2 - f1; fine[2] += f3 - f2; fine[3] += f4 - f3; fine[4] += f5 - f4;
+      fine[5] += zconv != -2; fine[6] += zload != -2; fine[7] += 1;
+    }
+    if (DBG & 8192) __builtin_amdgcn_s_setprio(0);
+  };
+
+  if (grp == 0) prepare();  // group 0 opens with the matrix phase of step 0
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), as a builtin so that the compiler knows it: the weights (and the raw plane
+                                       // of step 1) have landed, no compiler-inserted vmcnt wait inside the loop
+  zs_barrier_lds();  // P: the planes of step 0 are staged
+
+  trk_init(min(grp == 1 ? 0 : 1, nsteps - 1));  // this group's first support phase is interval 0 (group 1) / 1 (group 0) ...
+  if (grp == 0 && nsteps == 1) trk.k = 1;        // (... a one-step chunk: interval 1 only reduces)
+  unsigned long long st_m = 0, st_s = 0, st_b = 0;
+  for (int i = 0; i <= nsteps; ++i) {
+    unsigned long long t0 = 0, t1 = 0;
+    if (DBG & 2048) t0 = zp_stamp();
+    if ((i & 1) == grp) {
+      if (i < nsteps) matrix_phase();
+      if (DBG & 2048) { t1 = zp_stamp(); if (i < nsteps) st_m += t1 - t0; }
+    } else {
+      support_phase(i);
+      if (DBG & 2048) { t1 = zp_stamp(); st_s += t1 - t0; }
+    }
+    zs_barrier_lds();
+    if (DBG & 2048) st_b += zp_stamp() - t1;
+  }
+  if ((DBG & 2048) && lane == 0 && blockIdx.z == 0) {
+    unsigned long long* d = zp_stamp_buf + ((size_t)((blockIdx.y * gridDim.x + blockIdx.x) & 255) * 8 + (threadIdx.x >> 6)) * 4;
+    d[0] = st_m; d[1] = st_s; d[2] = st_b; d[3] = (unsigned long long)nsteps;
+    if (DBG & 4096) {
+      unsigned long long* f = zp_stamp_fine + ((size_t)((blockIdx.y * gridDim.x + blockIdx.x) & 255) * 8 + (threadIdx.x >> 6)) * 8;
+      for (int k = 0; k < 8; ++k) f[k] = fine[k];
+    }
+  }
+
+  if (a.ch_part) {
+    const float t1 = s1 + __shfl_xor(s1, 32, 64), t2 = s2 + __shfl_xor(s2, 32, 64);
+    if (half == 0) {
+      float* dst = a.ch_part + ((((size_t)b * gridDim.x + chunk) * 8 + grp * 4 + WV) * a.cout + ct * 32 + col) * 2;
+      dst[0] = t1;
+      dst[1] = t2;
+    }
+  }
+  if (a.status && threadIdx.x == 0 && *flag_lds) atomicOr(a.status, 1);  // (the loop ends with a barrier)
+}
+
+template <bool ACC, int MODE, int DBG = 0>
+__global__ void __launch_bounds__(512, 1) conv_zslide_pp_f16x2_kernel(ConvZsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char zs_lds[];
+  if (DBG & 128) {  // experiment: one program for all waves (instruction-cache footprint)
+    zp_wave<0, ACC, MODE, DBG>(a, zs_lds);
+    return;
+  }
+  switch ((threadIdx.x >> 6) & 3) {
+    case 0: zp_wave<0, ACC, MODE, DBG>(a, zs_lds); break;
+    case 1: zp_wave<1, ACC, MODE, DBG>(a, zs_lds); break;
+    case 2: zp_wave<2, ACC, MODE, DBG>(a, zs_lds); break;
+    default: zp_wave<3, ACC, MODE, DBG>(a, zs_lds); break;
+  }
+}
+
+// launch of one K-block: the specialisation for (continuation, normed input, strips, rescaled input)
+template <int DBG = 0>
+void zp_launch(const ConvZsArgs& a, bool acc, dim3 grid, size_t lds, hipStream_t s) {
+  const int mode = ((a.coef || a.defer.part) ? 1 : 0) | (a.HS < a.H ? 2 : 0) | (a.in_absmax ? 4 : 0);
+#define ZP_CASE(ACCV, M)                                                                                                        \
+  if (acc == ACCV && mode == M) {                                                                                               \
+    static bool attr = false;                                                                                                   \
+    if (!attr) {                                                                                                                \
+      CD_HIP(hipFuncSetAttribute((const void*)conv_zslide_pp_f16x2_kernel<ACCV, M, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                 160 * 1024));                                                                                  \
+      attr = true;                                                                                                              \
+    }                                                                                                                           \
+    hipLaunchKernelGGL((conv_zslide_pp_f16x2_kernel<ACCV, M, DBG>), grid, dim3(512), lds, s, a);                                 \
+    return;                                                                                                                     \
+  }
+  ZP_CASE(false, 0) ZP_CASE(false, 1) ZP_CASE(false, 2) ZP_CASE(false, 3) ZP_CASE(false, 4) ZP_CASE(false, 6)
+  if (DBG == 0) { ZP_CASE(true, 0) ZP_CASE(true, 2) ZP_CASE(true, 4) ZP_CASE(true, 6) }
+#undef ZP_CASE
+  CD_REQUIRE(false, "z-slide conv: no kernel instance for this combination of continuation / normalised / strip / rescaled input");
+}
+
 }  // namespace
 
 // Eligible: 3x3x3 stride 1 on grids whose planes -- or phi strips of them (HS rows, HS | H, with one halo row either side) --
@@ -529,9 +1106,15 @@ bool try_launch_conv_zslide(const float* in0, int c0, const float* in1, int c1, 
   if (cout % 32 || c0 % 32 || c1 % 32) return false;
   const int H = g.in.h, W = g.in.w;
   auto ring_for = [&](int hs) { return hs * W >= 2 * ZS_STEP ? 4 : 5; };
+  // the ping-pong form is specialised at compile time; anything outside its instances (a normalised input without the
+  // activation, a normalised AND rescaled input) takes the matrix-wave / helper-wave form, as does CD_ZS_V1=1 (A/B)
+  static const bool v1_env = getenv("CD_ZS_V1") != nullptr;
+  const bool normed_in = fu.coef || fu.defer.part;
+  const bool v1 = v1_env || (normed_in && !fu.act) || (normed_in && fu.in_absmax) || (normed_in && (c0 + c1) > 32);
   auto lds_for = [&](int hs) {
     const int rows = hs + (hs < H ? 2 : 0);
-    return (size_t)ZS_ZERO + (size_t)ring_for(hs) * (((size_t)rows * W * ZS_VB + 255) & ~(size_t)255) + ZS_PART;
+    const size_t ring = (size_t)ring_for(hs) * (((size_t)rows * W * ZS_VB + 255) & ~(size_t)255);
+    return v1 ? (size_t)ZS_ZERO + ring + ZS_PART : (size_t)ZS_ZERO + ZP_COEF + ring + 2 * ZP_XCH + ZP_RAW;
   };
   int HS = 0;
   for (int hs = H; hs >= 1; --hs) {  // the largest strip that fits: least halo restaging
@@ -599,13 +1182,52 @@ bool try_launch_conv_zslide(const float* in0, int c0, const float* in1, int c1, 
     a.dbg = getenv("CD_ZS_DBG") ? atoi(getenv("CD_ZS_DBG")) : 0;
     const dim3 grid((unsigned)(nstrip * nchunk), (unsigned)batch, (unsigned)CTtot);
 #ifdef CD_ZS_EXPERIMENTS
+#define ZP_DBG_CASE(D) \
+  case D:              \
+    zp_launch<D>(a, false, grid, lds, s); \
+    break;
+    if (kb == 0 && a.dbg && !v1) {
+      switch (a.dbg) {
+        ZP_DBG_CASE(7) ZP_DBG_CASE(15) ZP_DBG_CASE(23) ZP_DBG_CASE(71) ZP_DBG_CASE(87) ZP_DBG_CASE(95) ZP_DBG_CASE(39)
+        ZP_DBG_CASE(88) ZP_DBG_CASE(127) ZP_DBG_CASE(6144) ZP_DBG_CASE(22528) ZP_DBG_CASE(38912) ZP_DBG_CASE(55296)
+        default: CD_REQUIRE(false, "CD_ZS_DBG: not an instantiated experiment");
+      }
+      CD_HIP(hipGetLastError());
+      if (a.dbg & 2048) {  // stamps: print the per-wave cycle sums of one launch
+        static int nlaunch = 0;
+        if (++nlaunch == 10) {
+          CD_HIP(hipDeviceSynchronize());
+          static unsigned long long h[256 * 8 * 4];
+          CD_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(zp_stamp_buf), sizeof h));
+          for (int wg : {0, 1, 2, 3, 100, 255})
+            for (int w = 0; w < 8; ++w) {
+              const unsigned long long* d = h + ((size_t)wg * 8 + w) * 4;
+              std::fprintf(stderr, "[zp stamps] wg %3d wave %d: matrix %6.0f cyc/phase  support %6.0f cyc/phase  barrier wait %6.0f cyc/interval  (nsteps %llu)\n",
+                           wg, w, d[0] / (double)((d[3] + 1 - (w >> 2)) / 2 ? (d[3] + 1 - (w >> 2)) / 2 : 1), d[1] / (double)((d[3] + 1 + (w >> 2)) / 2),
+                           d[2] / (double)(d[3] + 1), d[3]);
+            }
+          if (a.dbg & 4096) {
+            static unsigned long long hf[256 * 8 * 8];
+            CD_HIP(hipMemcpyFromSymbol(hf, HIP_SYMBOL(zp_stamp_fine), sizeof hf));
+            for (int wg : {0, 100})
+              for (int w : {0, 4}) {
+                const unsigned long long* f = hf + ((size_t)wg * 8 + w) * 8;
+                const double n = (double)f[7];
+                std::fprintf(stderr, "[zp fine] wg %3d wave %d: per support phase: head+dma %5.0f  convert %5.0f  reduce %5.0f  prepare %5.0f  dma wait %5.0f   (%llu of %llu phases convert, %llu load)\n",
+                             wg, w, f[0] / n, f[1] / n, f[2] / n, f[3] / n, f[4] / n, f[5], f[7], f[6]);
+              }
+          }
+        }
+      }
+      continue;
+    }
 #define ZS_DBG_CASE(D)                                                                                                     \
   case D:                                                                                                                  \
     CD_HIP(hipFuncSetAttribute((const void*)conv_zslide_f16x2_kernel<false, D>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                160 * 1024));                                                                               \
     hipLaunchKernelGGL((conv_zslide_f16x2_kernel<false, D>), grid, dim3(512), lds, s, a);                                   \
     break;
-    if (kb == 0 && a.dbg) {
+    if (kb == 0 && a.dbg && v1) {
       switch (a.dbg) {
         ZS_DBG_CASE(2) ZS_DBG_CASE(4) ZS_DBG_CASE(6) ZS_DBG_CASE(22) ZS_DBG_CASE(38) ZS_DBG_CASE(70)
         default: CD_REQUIRE(false, "CD_ZS_DBG: not an instantiated experiment");
@@ -614,11 +1236,15 @@ bool try_launch_conv_zslide(const float* in0, int c0, const float* in1, int c1, 
       continue;
     }
 #endif
-    if (kb == 0) hipLaunchKernelGGL(conv_zslide_f16x2_kernel<false>, grid, dim3(512), lds, s, a);
-    else hipLaunchKernelGGL(conv_zslide_f16x2_kernel<true>, grid, dim3(512), lds, s, a);
+    if (v1) {
+      if (kb == 0) hipLaunchKernelGGL(conv_zslide_f16x2_kernel<false>, grid, dim3(512), lds, s, a);
+      else hipLaunchKernelGGL(conv_zslide_f16x2_kernel<true>, grid, dim3(512), lds, s, a);
+    } else {
+      zp_launch<0>(a, kb != 0, grid, lds, s);
+    }
     CD_HIP(hipGetLastError());
   }
-  if (fu.units) *fu.units = nstrip * nchunk * 4;
+  if (fu.units) *fu.units = nstrip * nchunk * (v1 ? 4 : 8);
   return true;
 }
 

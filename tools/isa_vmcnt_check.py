@@ -14,8 +14,8 @@ instructions, until it meets a plane load on each path, and asserts
 
   * every instruction counted is a marked row store (no compiler-generated load/store sneaks into the window),
   * the count at the first plane load met is a multiple of N on every path (statically there are paths on which an interval
-    issues no loads -- the wait is skipped on those at run time -- so 2N, 3N are legitimate; anything else means an interval
-    does not issue exactly N stores), and N itself occurs,
+    issues no loads -- the wait is skipped on those at run time -- so 2N, 3N are legitimate; anything else, 0 included, means
+    an interval does not issue exactly N stores), and N itself occurs,
   * plane loads come in whole groups (ZS_NSL per plane).
 A path that meets an `s_waitcnt vmcnt(0)` first is trivially fine (everything older has landed; the prologue's planes).
 
@@ -168,7 +168,7 @@ def check_kernel(sym: str, body: List[str], verbose=True) -> Tuple[int, List[str
                     if key not in seen:
                         seen.add(key)
                         stack.append((p, len(blocks[p].ins) - 1, c))
-            bad = sorted(c for c in counts if c % n)
+            bad = sorted(c for c in counts if c % n or c < n)
             if bad:
                 errors.append(f"{sym}: `{t}` in {b.label}: paths with {bad} vector-memory operations between the plane loads and "
                               f"the wait (every interval must issue exactly {n})")

@@ -1,23 +1,13 @@
 #!/bin/bash
-# PMC counters of the z-slide conv kernel (one rocprofv3 pass per counter group)
+# Instruction counts / busy cycles of the z-slide conv kernels (rocprofv3 PMC, one pass per counter group; conv_bench launches)
+#   bash tools/zs_pmc.sh <tag>      (CD_ZS_V1=1 in the environment profiles the matrix/helper-wave form)
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-mkdir -p gpurun_out/pmc
+out=gpurun_out/${1:-pmc}; rm -rf $out; mkdir -p $out
 i=0
-for grp in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU" "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU"; do
+for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_VMEM SQ_WAVES" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  echo "== group $i: $grp" | tee -a gpurun_out/pmc/log.txt
-  CD_ZS_DBG=${ZS_DBG:-0} timeout -k 5 150 rocprofv3 --pmc $grp --kernel-trace -d gpurun_out/pmc/g$i -o pmc -- python3 tools/conv_bench.py --iters 5 >> gpurun_out/pmc/log.txt 2>&1
-  echo "rc=$?" | tee -a gpurun_out/pmc/log.txt
+  timeout -k 5 150 rocprofv3 --pmc $grp --kernel-trace -d $out/g$i -o pmc -- python3 tools/conv_bench.py --iters 5 ${ZS_BENCH_ARGS} >> $out/log.txt 2>&1
+  echo "group $i rc=$?" | tee -a $out/log.txt
 done
-python3 - <<'PY'
-import csv,glob,collections
-for g in sorted(glob.glob('gpurun_out/pmc/g*')):
-    for f in glob.glob(g+'/**/*counter_collection.csv', recursive=True):
-        acc=collections.defaultdict(list)
-        for r in csv.DictReader(open(f)):
-            if 'zslide' in r.get('Kernel_Name',''):
-                acc[r['Counter_Name']].append(float(r['Counter_Value']))
-        for k,v in acc.items():
-            print(g.split('/')[-1], k, 'n=%d mean=%.4g'%(len(v), sum(v)/len(v)))
-PY
+python3 tools/pmc_read.py $out zslide | tee $out/summary.txt
