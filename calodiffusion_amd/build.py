@@ -23,6 +23,10 @@ SOURCES = ["kernels_conv.hip", "kernels_conv_zs.hip", "kernels_attn.hip", "kerne
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
 FLAGS += os.environ.get("CD_EXTRA_HIPCC_FLAGS", "").split()  # e.g. -DCD_ZS_EXPERIMENTS (tools/zs_phases.sh)
+# per-file flags.  kernels_conv_zs.hip: MFMA results in vector registers (the one-wave-per-SIMD kernel keeps its weights in the
+# accumulation file and sums its partial tiles straight from the MFMA destinations; the default AGPR form costs a
+# v_accvgpr_read per accumulator register and step)
+FILE_FLAGS = {"kernels_conv_zs.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _stale(target: str, deps) -> bool:
@@ -48,7 +52,7 @@ def build_all(force: bool = False, verbose: bool = True) -> str:
         op = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(op)
         if force or _stale(op, [sp] + headers):
-            jobs.append([HIPCC, *FLAGS, "-c", sp, "-o", op])
+            jobs.append([HIPCC, *FLAGS, *FILE_FLAGS.get(os.path.basename(sp), []), "-c", sp, "-o", op])
 
     def run(cmd):
         if verbose:
@@ -71,7 +75,7 @@ def build_all(force: bool = False, verbose: bool = True) -> str:
 def source_hash() -> str:
     """sha256 over every HIP source, header and include fragment (and the flags) that goes into the library."""
     import hashlib
-    h = hashlib.sha256(" ".join(FLAGS).encode())
+    h = hashlib.sha256((" ".join(FLAGS) + repr(sorted(FILE_FLAGS.items()))).encode())
     inc = os.path.join(os.path.dirname(HERE), "include")
     files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))] + [os.path.join(inc, f) for f in sorted(os.listdir(inc))]
     for f in files:

@@ -519,54 +519,40 @@ __global__ void __launch_bounds__(512, 1) conv_zslide_f16x2_kernel(ConvZsArgs a)
 
 
 // ============================================================================================================
-// Ping-pong form (the default).  The kernel above gives each SIMD one matrix wave and one helper wave; the matrix wave then
-// pays, serially and with the matrix pipe idle, for everything around its MFMAs: the tap-address table of the step, the
-// latency of its first fragment reads, the fold and LDS write of its partial tiles and the step barrier (~900 of every
-// ~3500 cycles).  Here all eight waves run ONE program in two groups of four (waves 0-3 / 4-7: the two waves that share a
-// SIMD are in different groups and hold the same K-slice of the weights).  Group g owns the 64-voxel steps of parity g and
-// alternates between
-//   * a MATRIX phase   -- the 81 MFMAs of its K-slice over the two row tiles of its step; partial tiles to the exchange
-//                         buffer of its group, and
-//   * a SUPPORT phase  -- while the other group's matrix phase runs on the same SIMDs: convert the input plane its own next
-//                         step is the first to read (raw image in LDS -> GroupNorm + SiLU + embedding -> fp16 split -> ring);
-//                         start the LDS-DMA of the plane the step after that needs; sum the four K-slices of its own previous
-//                         step, bias, store, channel statistics; build the tap-address table of its next step,
-// one workgroup barrier per phase.  Every SIMD so always has one wave feeding the matrix pipe while its partner does the
-// vector / LDS / memory work in the issue slots the MFMAs leave free (an MFMA holds the vector issue port 8 of its 32 cycles).
+// One-wave-per-SIMD form (the default).
 //
-// Registers are the scarce resource (2 waves per SIMD = 256 per wave: 112 weights + 64 accumulators + fragments): nothing of
-// the support role may stay live across a matrix phase.  Hence the raw planes travel global -> LDS by LDS-DMA
-// (global_load_lds_dwordx4: no destination registers; issued at the start of a support phase, awaited at its end by count, read
-// by the other group one phase later), the GroupNorm coefficients live in LDS, and the addresses are re-derived.
-// The K-slice exchange keeps each wave's own slice of the rows it reduces in registers: 24 KB per group instead of 32.
+// What the kernel above is bound by (round 2: in-kernel s_memtime stamps, PMC instruction counts, tools/micro/lds_mfma{2,3,4}):
+// NOT the matrix pipe (SQ_VALU_MFMA_BUSY 43 %) but the vector instructions around it.  Beside a wave's OWN stream of
+// v_mfma_f32_32x32x16_f16 every other vector instruction costs ~3 cycles of wall time (none hide: lds_mfma4), and the same
+// instruction issued by the OTHER wave of the SIMD -- the helper wave here, the support phase of the ping-pong form tried in
+// between -- proceeds at one per 10-17 cycles: ~330 helper instructions per 64-voxel step take as long as the step's 81 MFMAs
+// (2,965 cycles with their LDS fragment reads), and the two roles wait for each other at every step barrier.
 //
-// LDS: [zeros 512][coef, bias, flag 1024][ring NR planes][exchange 2 x 24 KB][raw plane 20 KB]  (Dataset-2: 150.5 KB)
+// So: 4 waves, one per SIMD, 512 registers each, every wave doing BOTH jobs in one instruction stream -- its K-slice of the
+// MFMAs (as zs_matrix_wave) and a quarter of the staging / reduction work (as zs_helper_wave): the vector instructions then cost
+// their ~3 cycles each and nothing waits on a partner.  Per 64-voxel step and wave:
+//   convert the plane the NEXT step is the first to read (loads issued a step earlier, in registers: there is room now) ->
+//   issue the loads of the plane after that -> sum the four K-slices of the PREVIOUS step's rows this wave owns (its own slice
+//   never left its registers), bias, store, statistics -> tap addresses -> 81 MFMAs over the two row tiles, partial tiles to
+//   the exchange buffer (double buffered by step parity) -> one barrier.
+// LDS: [zeros 512][coef, bias, flag 1024][ring NR planes][exchange 2 x 24 KB]  (Dataset-2: 130.5 KB)
 // ============================================================================================================
-constexpr int ZP_PD = 2;                  // fragment pairs requested ahead of their MFMAs (registers: 8 per pair in flight)
-constexpr int ZP_COEF = 1024;             // [32][4] floats: the GroupNorm coefficients of this launch's 32 input channels;
+typedef float f32x2 __attribute__((ext_vector_type(2)));  // pairs: v_pk_add_f32 / v_pk_fma_f32
+constexpr int Z3_PD = 3;                  // fragment pairs requested ahead of their MFMAs
+constexpr int Z3_COEF = 1024;             // [32][4] floats: the GroupNorm coefficients of this launch's 32 input channels;
                                           // +512: bias[32]; +640: range flag word
-constexpr int ZP_XCH = 4 * 3 * 2048;      // exchange buffer of one group: 4 reducers x 3 foreign K-slices x (8 rows x 64 lanes x 4 B)
-constexpr int ZP_RAW = ZS_NSL * 32 * 128; // raw fp32 image of one plane: 160 voxel slots x 32 channels
-
-// The interval loop of zp_wave is register-bound: loop-invariant address arithmetic that the compiler hoists out of it (five
-// 64-bit source addresses, sink offsets, ...) stays live across the matrix phases and pushes weights into scratch.  Values
-// laundered through these look loop-variant, so what is derived from them is recomputed inside the phase that uses it.
-__device__ __forceinline__ int zp_opaque_v(int x) {
-  asm volatile("" : "+v"(x));
-  return x;
-}
+constexpr int Z3_XCH = 4 * 3 * 2048;      // exchange buffer of one step: 4 reducers x 3 foreign K-slices x (8 rows x 64 lanes x 4 B)
 
 // LDS access by byte address: an address_space(3) pointer made from the integer -- through the generic `lds + offset` form
 // every access pays a `v_add_u32 addr, 0, offset` for the (zero) base of the dynamic LDS symbol
 template <typename T>
-__device__ __forceinline__ __attribute__((address_space(3))) T* zp_lds(int byte_addr) {
+__device__ __forceinline__ __attribute__((address_space(3))) T* z3_lds(int byte_addr) {
   return (__attribute__((address_space(3))) T*)(uintptr_t)(unsigned)byte_addr;
 }
 
-// diagnostic build only (DBG & 2048): per-wave cycle sums of {matrix phases, support phases, barrier waits, phases counted}
-__device__ unsigned long long zp_stamp_buf[256 * 8 * 4];
-__device__ unsigned long long zp_stamp_fine[256 * 8 * 8];  // (DBG & 4096) support phase: head, convert, reduce, prepare, DMA wait, #conv phases
-__device__ __forceinline__ unsigned long long zp_stamp() {
+// diagnostic build only (-DCD_ZS_EXPERIMENTS, CD_ZS_DBG=2048): per-wave cycle sums of the parts of a step
+__device__ unsigned long long z3_stamp_buf[256 * 4 * 12];
+__device__ __forceinline__ unsigned long long z3_stamp() {
   unsigned long long t;
   __builtin_amdgcn_sched_barrier(0);
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
@@ -574,43 +560,44 @@ __device__ __forceinline__ unsigned long long zp_stamp() {
   return t;
 }
 
-struct ZpGeo : ZsGeo {
-  int XCH, RAW;
+struct Z3Geo : ZsGeo {
+  int XCH;
 };
-__device__ __forceinline__ ZpGeo zp_geo(const ConvZsArgs& a) {
-  ZpGeo g;
+__device__ __forceinline__ Z3Geo z3_geo(const ConvZsArgs& a) {
+  Z3Geo g;
   (ZsGeo&)g = zs_geo(a);
-  g.RB = ZS_ZERO + ZP_COEF;
+  // plane image with one zero record before every row and one after the last: the kw = 0 / kw = 2 taps of the first / last column
+  // read a pad instead of selecting the zero area per lane
+  g.pitch = a.W + 1;
+  g.PLB = ((g.rows * g.pitch + 1) * ZS_VB + 255) & ~255;
+  g.RB = ZS_ZERO + Z3_COEF;
   g.XCH = g.RB + a.NR * g.PLB;
-  g.RAW = g.XCH + 2 * ZP_XCH;
-  g.ZPART = g.XCH;  // (prologue scratch of gn_defer_to_lds: the exchange + raw regions are still unused then)
+  g.ZPART = g.XCH;  // (prologue scratch of gn_defer_to_lds: the exchange region is still unused then)
   return g;
 }
 
-// DBG (builds with -DCD_ZS_EXPERIMENTS, CD_ZS_DBG): timing experiments, results are wrong -- 1 = no plane DMA / wait, 2 = no plane
-// conversion, 4 = no reduction / stores, 8 = no MFMAs, 16 = no fragment reads, 32 = tap addresses prepared once, 64 = no hand-over
-// MODE (compile-time specialisation: the support phase is issue-bound, every run-time switch in it costs select / branch
-// instructions in all 256 threads): 1 = NORMED (input = GroupNorm + SiLU + embedding of the tensor read), 2 = HALO (phi strips
-// with halo rows instead of whole planes), 4 = SCALED (input rescaled by a power of two from its max: the training gradients)
+// MODE (compile-time specialisation: every run-time switch costs select / branch instructions in all 256 threads):
+//   1 = NORMED (input = GroupNorm + SiLU + embedding of the tensor read), 2 = HALO (phi strips with halo rows instead of whole
+//   planes), 4 = SCALED (input rescaled by a power of two from its max: the training gradients)
 template <int WV, bool ACC, int MODE, int DBG = 0>
-__device__ __forceinline__ void zp_wave(const ConvZsArgs& a, char* lds) {
+__device__ __forceinline__ void z3_wave(const ConvZsArgs& a, char* lds) {
   constexpr bool NORMED = (MODE & 1) != 0, HALO = (MODE & 2) != 0, SCALED = (MODE & 4) != 0;
   constexpr int KSTEP = WV >> 1, ODD = WV & 1, T0 = ODD ? 13 : 0;  // K-slice: k-step and taps T0 .. T0+13 (as zs_matrix_wave)
   constexpr int TH = WV >> 1, RH = WV & 1;  // reduction role: rows 16*RH .. 16*RH+15 (accumulator registers 8*RH..8*RH+7) of tile TH
   static_assert(ZS_TILES == 2, "the tap split alternates over the two tiles of a step");
   const int lane = threadIdx.x & 63, half = lane >> 5, col = lane & 31;
-  // this wave's group (it owns the steps of parity grp): wave-uniform, and pinned to a scalar register so that the phase
-  // selection, the plane tracking and everything else that hangs on it stay on the scalar unit
-  const int grp = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
-  const int tid = threadIdx.x & 255;  // thread within the group (staging and reduction roles)
+  const int tid = threadIdx.x;  // 256 threads: staging and reduction roles
   const int b = blockIdx.y, ct = blockIdx.z;
-  const ZpGeo G = zp_geo(a);
+  unsigned long long t_begin = 0, t_loop = 0;
+  if (DBG) t_begin = z3_stamp();
+  const Z3Geo G = z3_geo(a);
   const int H = a.HS, W = a.W, PV = G.PV, SPV = G.SPV;
   const int NIMG = G.rows * W;  // voxels staged per plane (strip rows + halo rows)
   const int nsteps = G.nsteps;
   const int chunk = G.chunk + G.strip * a.nchunk;
   float* const coef_lds = (float*)(lds + ZS_ZERO);
-  const int xch = G.XCH + grp * ZP_XCH;  // this group's exchange buffer (LDS byte address)
+  float* const bias_lds = (float*)(lds + ZS_ZERO + 512);
+  int* const flag_lds = (int*)(lds + ZS_ZERO + 640);
 
   // ---- weights of this wave's K-slice: registers for the whole chunk --------------------------------------------
   u32x4 w1[14], w2[14];
@@ -621,114 +608,99 @@ __device__ __forceinline__ void zp_wave(const ConvZsArgs& a, char* lds) {
       w1[j] = wq[(size_t)j * a.CTtot * 128];
       w2[j] = wq[(size_t)j * a.CTtot * 128 + 64];
     }
+    // in accumulation registers (MFMA reads its A/B operands from either file): the 112 of them leave the vector registers to
+    // the accumulators, whose hand-over then needs no v_accvgpr_read
+#pragma unroll
+    for (int j = 0; j < 14; ++j) asm volatile("" : "+a"(w1[j]), "+a"(w2[j]));
   }
 
-  // ---- support role: staging (thread tq of the group = channel quad q = tq & 7 of image voxels p0 + 32k, p0 = tq >> 3, k < 5)
-  float* const bias_lds = (float*)(lds + ZS_ZERO + 512);
-  int* const flag_lds = (int*)(lds + ZS_ZERO + 640);
-  const float* const src_b = a.in + (size_t)b * G.vox * a.ldc;
+  // ---- staging role (thread = channel quad q = tid & 7 of image voxels p0 + 32k, p0 = tid >> 3, k < 5) -------------
+  // Pieces beyond the image (p0 + 32k >= NIMG) repeat its last voxel: the same bytes written twice instead of a branch per piece.
+  const int q = tid & 7, p0 = tid >> 3;
+  const float* const src_b = a.in + (size_t)b * G.vox * a.ldc;  // wave-uniform: the loads take it as their scalar base
   const int src_off = (G.h0 - G.halo) * W;  // image voxel p comes from plane voxel p + src_off (mod PV: phi halo rows wrap)
   float gscale = 1.f, ginv = 1.f;
   if (SCALED) pow2_scale_for(*a.in_absmax, &gscale, &ginv);
-  auto src_of = [&](int tq, int z, int k) {  // global address of thread tq's piece k of plane z (prologue)
-    const int q = tq & 7, p0 = tq >> 3;
-    const int zc = min(max(z, 0), a.D - 1);
-    int v = min(p0 + 32 * k, NIMG - 1) + src_off;
+  int srco[ZS_NSL];  // byte offset in a plane of the quad this thread's piece k is filled from
+  int dsto[ZS_NSL];  // byte offset in a plane image of the record quad it fills
+#pragma unroll
+  for (int k = 0; k < ZS_NSL; ++k) {
+    const int pi = min(p0 + 32 * k, NIMG - 1);
+    int v = pi + src_off;
     v = v < 0 ? v + PV : (v >= PV ? v - PV : v);
-    return src_b + ((size_t)zc * PV + v) * a.ldc + q * 4;
+    srco[k] = (v * a.ldc + q * 4) * 4;
+    dsto[k] = (pi + pi / W + 1) * ZS_VB + (q >> 2) * 64 + (q & 3) * 8 + G.RB;
+  }
+  f32x4 ld[ZS_NSL];
+  static_assert(ZS_NSL == 5, "Z3_LANDED names the five staging registers");
+  // Plane loads are issued and awaited by hand, but -- unlike zs_helper_wave -- with nothing to count: they are the LAST
+  // vector-memory operations of a step (after the reduction's row stores), so the wait one step later is a plain vmcnt(0); the
+  // stores it also covers were issued a whole matrix phase before the loads and have long been acknowledged.
+  constexpr int NYOUNG = 0;
+  auto uniform_ptr = [](const void* p) {  // the pointer as a scalar register pair
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const float*)(((unsigned long long)hi << 32) | lo);
   };
-  // raw plane -> LDS by LDS-DMA: wave-instruction k lands this wave's 64 pieces (8 voxels x 8 quads = 1 KiB) at
-  // RAW + (32 k + 8 wave) * 128 + lane * 16, i.e. voxel-major [voxel][32 ch] fp32, the order convert() reads them back in.
-  // Source = (wave-uniform plane base) + (32-bit byte offset per lane): a handful of vector instructions per plane.
-  const int raw_wave = __builtin_amdgcn_readfirstlane(G.RAW + ((tid >> 3) & ~7) * 128);
-  auto dma_plane = [&](int tq, int z) {
-    const int q = tq & 7, p0 = tq >> 3;
+  auto issue = [&](int z) {
     const int zc = min(max(z, 0), a.D - 1);
-    const unsigned long long pb64 = (unsigned long long)(src_b + (size_t)zc * PV * a.ldc);  // wave-uniform: pin it to SGPRs
-    const unsigned long long pbase = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(pb64 >> 32)) << 32) |
-                                     (unsigned)__builtin_amdgcn_readfirstlane((int)pb64);
-    const int vstride = a.ldc * 4;
-    unsigned off[ZS_NSL];
-    if (HALO) {  // strips: phi halo rows wrap around the plane
+    const float* src = uniform_ptr(src_b + (size_t)zc * PV * a.ldc);
 #pragma unroll
-      for (int k = 0; k < ZS_NSL; ++k) {
-        int v = min(p0 + 32 * k, NIMG - 1) + src_off;
-        v = v < 0 ? v + PV : (v >= PV ? v - PV : v);
-        off[k] = (unsigned)(v * vstride + q * 16);
-      }
-    } else {  // whole planes: consecutive pieces are 32 voxels apart; only the last one can run past the plane
-      const unsigned off0 = (unsigned)(tq * 16);  // = p0 * 128 + q * 16 for 32-channel sources ...
-      const unsigned o0 = a.ldc == 32 ? off0 : (unsigned)(p0 * vstride + q * 16);
-#pragma unroll
-      for (int k = 0; k < ZS_NSL - 1; ++k) off[k] = o0 + (unsigned)(k * 32) * (unsigned)vstride;
-      off[ZS_NSL - 1] = (unsigned)(min(p0 + 32 * (ZS_NSL - 1), NIMG - 1) * vstride + q * 16);
-    }
-#pragma unroll
-    for (int k = 0; k < ZS_NSL; ++k) {
-      const int dst = raw_wave + k * 32 * 128;
-      unsigned keep;
-      asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 ; zs_plane_load\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep)
-                   : "v"(off[k]), "s"(pbase), "s"(dst)
-                   : "memory");
-    }
+    for (int k = 0; k < ZS_NSL; ++k)
+      asm volatile("global_load_dwordx4 %0, %1, %2 ; zs_plane_load" : "=v"(ld[k]) : "v"(srco[k]), "s"(src) : "memory");
   };
+#define Z3_LANDED(younger)                                                                                   \
+  asm volatile("s_waitcnt vmcnt(%5) ; zs_landed"                                                             \
+               : "+v"(ld[0]), "+v"(ld[1]), "+v"(ld[2]), "+v"(ld[3]), "+v"(ld[4])                             \
+               : "n"(younger)                                                                                \
+               : "memory")
   // normalise + split the five pieces in v[] (this thread's quad of image voxels p0 + 32k) into the ring slot of plane z
-  auto convert = [&](int tq, f32x4 (&v)[ZS_NSL], int z) {
-    const int q = tq & 7, p0 = tq >> 3;
+  auto convert = [&](f32x4 (&v)[ZS_NSL], int z) {
     float amax = 0.f;
-    // ring slot (z + NR) mod NR, z >= -1, NR = 4 or 5, without a division
-    const int zz = z + a.NR;
+    const int zz = z + a.NR;  // ring slot (z + NR) mod NR, z >= -1, NR = 4 or 5, without a division
     const int slot = a.NR == 4 ? (zz & 3) : zz - 5 * ((zz * 205) >> 10);
     const bool zero = z < 0 || z >= a.D;
-    const int dst = slot * G.PLB + G.RB + p0 * ZS_VB + (q >> 2) * 64 + (q & 3) * 8;
+    const int sbase = slot * G.PLB;
     f32x4 cf[4], cn[4];  // {scale, shift, add, -} per channel; cn = {scale, shift} * -log2(e) for the sigmoid's exponent
     if (NORMED) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        cf[e] = *zp_lds<const f32x4>(ZS_ZERO + (q * 4 + e) * 16);
+        cf[e] = *z3_lds<const f32x4>(ZS_ZERO + (q * 4 + e) * 16);
         cn[e][0] = cf[e][0] * -1.4426950408889634f;
         cn[e][1] = cf[e][1] * -1.4426950408889634f;
       }
     }
 #pragma unroll
     for (int k = 0; k < ZS_NSL; ++k) {
-      if (p0 + 32 * k < NIMG) {
-        u32x2 t1 = {0u, 0u}, t2 = {0u, 0u};
-        if (!zero) {
-          f32x4 x = v[k];
-          if (SCALED) x = x * gscale;  // (training: input gradients rescaled by a power of two)
-          if (NORMED) {
+      u32x2 t1 = {0u, 0u}, t2 = {0u, 0u};
+      if (!zero) {
+        f32x4 x = v[k];
+        if (SCALED) x = x * gscale;  // (training: input gradients rescaled by a power of two)
+        if (NORMED) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              // SiLU(t) + add, t = scale x + shift: t / (1 + 2^(-t log2 e)) + add on the transcendental unit -- fma, exp, add,
-              // rcp, fma, fma
-              const float t = cf[e][0] * x[e] + cf[e][1];
-              const float ex = __builtin_amdgcn_exp2f(cn[e][0] * x[e] + cn[e][1]);
-              x[e] = t * __builtin_amdgcn_rcpf(1.f + ex) + cf[e][2];
-            }
+          for (int e = 0; e < 4; ++e) {
+            // SiLU(t) + add, t = scale x + shift: t / (1 + 2^(-t log2 e)) + add on the transcendental unit -- fma, exp, add,
+            // rcp, fma, fma
+            const float t = cf[e][0] * x[e] + cf[e][1];
+            const float ex = __builtin_amdgcn_exp2f(cn[e][0] * x[e] + cn[e][1]);
+            x[e] = t * __builtin_amdgcn_rcpf(1.f + ex) + cf[e][2];
           }
-          amax = fmaxf(fmaxf(amax, fabsf(x[0])), fabsf(x[1]));
-          amax = fmaxf(fmaxf(amax, fabsf(x[2])), fabsf(x[3]));
-          split2(x, t1, t2);
         }
-        *zp_lds<u32x2>(dst + k * 32 * ZS_VB) = t1;
-        *zp_lds<u32x2>(dst + k * 32 * ZS_VB + 32) = t2;
+        amax = fmaxf(fmaxf(amax, fabsf(x[0])), fabsf(x[1]));
+        amax = fmaxf(fmaxf(amax, fabsf(x[2])), fabsf(x[3]));
+        split2(x, t1, t2);
       }
+      *z3_lds<u32x2>(dsto[k] + sbase) = t1;
+      *z3_lds<u32x2>(dsto[k] + sbase + 32) = t2;
     }
-    if (amax > 65504.f) *flag_lds = 1;  // (rare; flushed to a.status at the end: no register and no memory operation here)
+    if (amax > 65504.f) *flag_lds = 1;  // (rare; flushed to a.status at the end)
   };
-  auto read_raw = [&](int tq, f32x4 (&v)[ZS_NSL]) {
-#pragma unroll
-    for (int k = 0; k < ZS_NSL; ++k) v[k] = *zp_lds<const f32x4>(G.RAW + tq * 16 + k * 32 * 128);  // = (p0 + 32k) * 128 + q * 16
-  };
+
+  // ---- which step is the first to read which plane: scalar, incremental (no divisions in the loop) ----------------
   auto need = [&](int k) {  // highest plane that step k reads
     k = min(k, nsteps - 1);
     return min(G.v0 + k * ZS_STEP + ZS_STEP - 1, G.cend - 1) / SPV + 1;
   };
-  auto new_plane = [&](int k) { return (k >= 1 && k < nsteps && need(k) > need(k - 1)) ? need(k) : -2; };  // first read by step k
-  // the same, incrementally (the divisions above are ~60 instructions each; a support phase asks twice): `trk` follows the last
-  // voxel of consecutive steps; a step reads a new plane when that voxel enters the next plane of the strip
   struct { int k, vend, zlim, need; } trk;
   auto trk_init = [&](int k) {  // state of step k (k < nsteps)
     trk.k = k;
@@ -747,79 +719,79 @@ __device__ __forceinline__ void zp_wave(const ConvZsArgs& a, char* lds) {
     return trk.need;
   };
 
-  // ---- prologue: zero area, GroupNorm table, the planes of step 0 (3 or 4) through registers, shared by the groups ----
-  if (threadIdx.x < ZS_ZERO / 4) ((float*)lds)[threadIdx.x] = 0.f;
-  if (threadIdx.x < 32) bias_lds[threadIdx.x] = a.bias ? a.bias[ct * 32 + threadIdx.x] : 0.f;
-  if (threadIdx.x == 32) *flag_lds = 0;
+  // ---- prologue: zero area, GroupNorm table, bias, the planes of step 0 (3 or 4) ------------------------------------
+  if (tid < ZS_ZERO / 4) ((float*)lds)[tid] = 0.f;
+  for (int i = tid * 16; i < a.NR * G.PLB; i += 256 * 16) *z3_lds<f32x4>(G.RB + i) = f32x4{0.f, 0.f, 0.f, 0.f};  // (the pad records)
+  if (tid < 32) bias_lds[tid] = a.bias ? a.bias[ct * 32 + tid] : 0.f;
+  if (tid == 32) *flag_lds = 0;
   const int zstaged0 = need(0);
-  const int zp0 = G.zfirst - 1, npro = zstaged0 - zp0 + 1;
+  const int zp0 = G.zfirst - 1;
+  // the plane step 1 is the first to read: its loads go out first (converted during step 0), then -- all at once, one memory
+  // latency for the lot -- the three or four planes of step 0
+  trk_init(0);
+  int zpend = trk_next();
+  if (zpend != -2) issue(zpend);
   {
-    f32x4 ldp[2][ZS_NSL];
+    f32x4 ldp[4][ZS_NSL];
+    auto fetch = [&](f32x4 (&dst)[ZS_NSL], int z) {
+      const int zc = min(max(z, 0), a.D - 1);
+      const char* src = (const char*)(src_b + (size_t)zc * PV * a.ldc);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-      if (grp + 2 * i < npro) {
+      for (int k = 0; k < ZS_NSL; ++k) dst[k] = *(const f32x4*)(src + srco[k]);
+    };
 #pragma unroll
-        for (int k = 0; k < ZS_NSL; ++k) ldp[i][k] = *(const f32x4*)src_of(tid, zp0 + grp + 2 * i, k);
-      }
-    if (a.defer.part) {  // table of all defer.C channels built by the whole workgroup in the (still unused) exchange region
-      char* scratch = lds + G.ZPART;
-      gn_defer_to_lds(a.defer, b, (float*)scratch, scratch + a.defer.C * 16);
-      if (threadIdx.x < 32) *(f32x4*)(coef_lds + threadIdx.x * 4) = *(const f32x4*)(scratch + (a.choff + threadIdx.x) * 16);
-    } else if (a.coef) {
-      if (threadIdx.x < 32) *(f32x4*)(coef_lds + threadIdx.x * 4) = *(const f32x4*)(a.coef + ((size_t)b * a.coef_c + threadIdx.x) * 4);
-    }
-    __syncthreads();  // the table is complete
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-      if (grp + 2 * i < npro) convert(tid, ldp[i], zp0 + grp + 2 * i);
-    if (grp == 0) {
-      for (int z = zp0 + 4; z <= zstaged0; ++z) {  // (not reached for planes of >= 64 voxels)
-#pragma unroll
-        for (int k = 0; k < ZS_NSL; ++k) ldp[0][k] = *(const f32x4*)src_of(tid, z, k);
-        convert(tid, ldp[0], z);
+    for (int i = 0; i < 3; ++i) fetch(ldp[i], zp0 + i);
+    if (zp0 + 3 <= zstaged0) fetch(ldp[3], zp0 + 3);
+    if (NORMED) {
+      if (a.defer.part) {  // table of all defer.C channels built by the whole workgroup in the (still unused) exchange region
+        char* scratch = lds + G.ZPART;
+        gn_defer_to_lds(a.defer, b, (float*)scratch, scratch + a.defer.C * 16);
+        if (tid < 32) *(f32x4*)(coef_lds + tid * 4) = *(const f32x4*)(scratch + (a.choff + tid) * 16);
+      } else {
+        if (tid < 32) *(f32x4*)(coef_lds + tid * 4) = *(const f32x4*)(a.coef + ((size_t)b * a.coef_c + tid) * 4);
       }
     }
+    __syncthreads();  // the table is complete, the ring zeroed
+#pragma unroll
+    for (int i = 0; i < 3; ++i) convert(ldp[i], zp0 + i);
+    if (zp0 + 3 <= zstaged0) convert(ldp[3], zp0 + 3);
   }
-  // raw image of the plane step 1 is the first to read: support phase 0 (group 1) converts it
-  if (grp == 1 && new_plane(1) != -2) dma_plane(tid, new_plane(1));
 
-  // ---- matrix role: per-lane geometry of its row (voxel) in the next tile of this group, advanced tile by tile ----
-  // per-lane position of its row (voxel) in the next tile of this group, advanced tile by tile: phi row gh and r column gw in the
-  // strip-plane, po = byte offset of its record in a plane image (+ this wave's constants), sb = byte offset of the ring slot of plane z - 1
+  // ---- matrix role: per-lane position of its row (voxel) in the next tile, advanced tile by tile: phi row gh and r column
+  // gw in the strip-plane, po = byte offset of its record in a plane image (+ this wave's constants), sb = byte offset of the ring
+  // slot of plane z - 1
   int gh, gw, po, sb;
-  const int RWB = W * ZS_VB;               // bytes per image row
+  const int RWB = G.pitch * ZS_VB;  // bytes per image row (with its pad record)
   const int ring_bytes = a.NR * G.PLB;
   {
-    const int v = G.v0 + grp * ZS_STEP + col;
+    const int v = G.v0 + col;
     const int gz = v / SPV;
     const int p = v - gz * SPV;
     gh = p / W;
     gw = p - gh * W;
-    po = ((gh + (HALO ? 1 : 0)) * W + gw) * ZS_VB + G.RB + KSTEP * 64 + half * 16 - ZS_VB;  // (- ZS_VB: the kw = 0 tap is one record back)
+    // (record of (row, column) = row * pitch + column + 1; the kw = 0 tap is one record back)
+    po = ((gh + (HALO ? 1 : 0)) * G.pitch + gw) * ZS_VB + G.RB + KSTEP * 64 + half * 16;
     sb = ((gz + a.NR - 1) % a.NR) * G.PLB;
   }
-  const int W1 = W - 1;
-  auto advance = [&](int nvox) {  // by nvox voxels < one strip-plane (a plane holds >= 64)
-    const int dh = nvox / W, dw = nvox - dh * W;  // (nvox is a literal: constants after inlining ... W is not; two scalar ops)
-    gw += dw;
-    gh += dh;
-    po += nvox * ZS_VB;
-    if (gw >= W) { gw -= W; gh += 1; }
+  const int adv_h = 32 / W, adv_w = 32 - adv_h * W;
+  const int adv_po = (adv_h * G.pitch + adv_w) * ZS_VB, plane_po = H * RWB;
+  auto advance32 = [&]() {
+    gw += adv_w;
+    gh += adv_h;
+    po += adv_po;
+    if (gw >= W) { gw -= W; gh += 1; po += (G.pitch - W) * ZS_VB; }
     if (gh >= H) {  // into the next plane
       gh -= H;
-      po -= SPV * ZS_VB;
+      po -= plane_po;
       sb += G.PLB;
       sb = sb == ring_bytes ? 0 : sb;
     }
   };
-  // tap addresses of the two tiles of the next step: fragment of tap (kz, kh, kw) = bz[t][kz] + {ro0, 0, ro2}[kh] + kw * ZS_VB
+  // tap addresses of the two tiles of the step: fragment of tap (kz, kh, kw) = bz[t][kz] + {ro0, 0, ro2}[kh] + kw * ZS_VB
   int bz[ZS_TILES][3], ro0[ZS_TILES], ro2[ZS_TILES];
-  bool eL[ZS_TILES], eR[ZS_TILES];  // first / last column: the kw = 0 / kw = 2 taps read zeros
-  auto prepare = [&]() {            // ... of this group's next step; then skip the other group's step
+  auto prepare = [&]() {
 #pragma unroll
     for (int t = 0; t < ZS_TILES; ++t) {
-      eL[t] = gw == 0;
-      eR[t] = gw == W1;
       if (HALO) {  // strips carry their phi neighbours as halo rows
         ro0[t] = -RWB;
         ro2[t] = RWB;
@@ -833,21 +805,19 @@ __device__ __forceinline__ void zp_wave(const ConvZsArgs& a, char* lds) {
         const unsigned x = (unsigned)(sb + kz * G.PLB);
         bz[t][kz] = (int)min(x, x - (unsigned)ring_bytes) + po;  // slot wrap: x < ring ? x : x - ring
       }
-      advance(32);
+      advance32();
     }
-    advance(ZS_STEP);
   };
 
   constexpr int N0 = ODD ? 13 : 14;  // pairs of tile 0: even wave taps [0,14), odd wave [14,27); tile 1: [0,13) / [13,27)
   constexpr int NI = 27;
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  float own[8];  // this wave's own K-slice of the rows it reduces: stays in registers from the matrix phase to the support phase
+  f32x2 own[4];  // this wave's own K-slice of the rows it reduces: stays in registers until the next step's reduction
 
-  // ---- MATRIX phase (tap addresses prepared by the preceding support phase) --------------------------------------
-  auto matrix_phase = [&]() {
-    constexpr int PD = (DBG & 256) ? 3 : ZP_PD;  // fragments are requested PD pairs ahead of their MFMAs
-    // (s_setprio 3 for this phase was measured: 3 us slower -- the support phase beside it is the longer one, see below)
-    if (DBG & 512) __builtin_amdgcn_s_setprio(3);
+  // ---- the 81 MFMAs of step s; partial tiles to the exchange buffer of parity s & 1 ---------------------------------
+  auto matrix = [&](int s) {
+    constexpr int PD = Z3_PD;
+    const int xch = G.XCH + (s & 1) * Z3_XCH;
     u32x4 fa[PD + 1][2];
     auto pair_tile = [](int i) { return i < N0 ? 0 : 1; };
     auto pair_tap = [](int i) {
@@ -861,236 +831,203 @@ __device__ __forceinline__ void zp_wave(const ConvZsArgs& a, char* lds) {
       int base = bz[t][kz] + kw * ZS_VB;
       if (kh == 0) base += ro0[t];
       if (kh == 2) base += ro2[t];
-      if (kw == 0) base = eL[t] ? (base & 255) : base;  // into the zero area, same bank quad
-      if (kw == 2) base = eR[t] ? (base & 255) : base;
-      if (DBG & 1024) base = G.RB + col * ZS_VB + half * 16 + KSTEP * 64 + (i % 24) * ZS_VB * 8;  // experiment: synthetic addresses
-      fa[i % (PD + 1)][0] = *zp_lds<const u32x4>(base);
-      fa[i % (PD + 1)][1] = *zp_lds<const u32x4>(base + 32);
+      fa[i % (PD + 1)][0] = *z3_lds<const u32x4>(base);
+      fa[i % (PD + 1)][1] = *z3_lds<const u32x4>(base + 32);
     };
     // K-slice partial of tile t: rows 8*rh .. of reducer (t, rh) go to its region of the exchange buffer -- or stay here
     auto hand_over = [&](int t, const f32x16& A, const f32x16& B) {
-      f32x16 pt;
+      f32x2 pt[8];
+      const f32x2 lo = {1.f / 2048.f, 1.f / 2048.f};
 #pragma unroll
-      for (int r = 0; r < 16; ++r) pt[r] = A[r] + B[r] * (1.f / 2048.f);
+      for (int r = 0; r < 8; ++r) pt[r] = f32x2{A[2 * r], A[2 * r + 1]} + f32x2{B[2 * r], B[2 * r + 1]} * lo;
 #pragma unroll
       for (int rh = 0; rh < 2; ++rh) {
         const int R = 2 * t + rh;  // reducer wave
         if (R == WV) {
 #pragma unroll
-          for (int r = 0; r < 8; ++r) own[r] = pt[8 * rh + r];
+          for (int r = 0; r < 4; ++r) own[r] = pt[4 * rh + r];
         } else {
           const int d = xch + (R * 3 + (WV < R ? WV : WV - 1)) * 2048 + lane * 16;
-          *zp_lds<f32x4>(d) = f32x4{pt[8 * rh], pt[8 * rh + 1], pt[8 * rh + 2], pt[8 * rh + 3]};
-          *zp_lds<f32x4>(d + 1024) = f32x4{pt[8 * rh + 4], pt[8 * rh + 5], pt[8 * rh + 6], pt[8 * rh + 7]};
+          *z3_lds<f32x4>(d) = f32x4{pt[4 * rh][0], pt[4 * rh][1], pt[4 * rh + 1][0], pt[4 * rh + 1][1]};
+          *z3_lds<f32x4>(d + 1024) = f32x4{pt[4 * rh + 2][0], pt[4 * rh + 2][1], pt[4 * rh + 3][0], pt[4 * rh + 3][1]};
         }
       }
     };
     f32x16 accA[2], accB[2];
-    if (DBG & 16) {
 #pragma unroll
-      for (int i = 0; i <= PD; ++i) fa[i][0] = fa[i][1] = u32x4{0u, 0u, 0u, 0u};
-    }
-#pragma unroll
-    for (int i = 0; i < PD; ++i)
-      if (!(DBG & 16)) load_frag(i);
+    for (int i = 0; i < PD; ++i) load_frag(i);
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int t = pair_tile(i), j = pair_tap(i) - T0;
       const bool first = i == 0 || i == N0;
-      if (i + PD < NI && !(DBG & 16)) load_frag(i + PD);
+      if (i + PD < NI) load_frag(i + PD);
       __builtin_amdgcn_sched_barrier(0);
-      if (DBG & 8) {
-        asm volatile("" ::"v"(fa[i % (PD + 1)][0]), "v"(fa[i % (PD + 1)][1]));
-        if (first) { accA[t] = zero16; accB[t] = zero16; }
-      } else {
-        accA[t] = MFMA_F16(fa[i % (PD + 1)][0], w1[j], first ? zero16 : accA[t]);
-        accB[t] = MFMA_F16(fa[i % (PD + 1)][0], w2[j], first ? zero16 : accB[t]);
-        accB[t] = MFMA_F16(fa[i % (PD + 1)][1], w1[j], accB[t]);
-      }
-      if (i == N0 + 3 && !(DBG & 64)) hand_over(0, accA[0], accB[0]);
+      accA[t] = MFMA_F16(fa[i % (PD + 1)][0], w1[j], first ? zero16 : accA[t]);
+      accB[t] = MFMA_F16(fa[i % (PD + 1)][0], w2[j], first ? zero16 : accB[t]);
+      accB[t] = MFMA_F16(fa[i % (PD + 1)][1], w1[j], accB[t]);
+      if (i == N0 + 3) hand_over(0, accA[0], accB[0]);
     }
-    if (!(DBG & 64)) hand_over(1, accA[1], accB[1]);
-    else asm volatile("" ::"v"(accA[0]), "v"(accB[0]), "v"(accA[1]), "v"(accB[1]));
-    if (DBG & 512) __builtin_amdgcn_s_setprio(0);
+    hand_over(1, accA[1], accB[1]);
   };
 
-  // ---- SUPPORT phase of interval i: stage the plane of own step i+1, DMA the plane of step i+2, reduce own step i-1 ----
-  float s1 = 0.f, s2 = 0.f;
+  // ---- reduction of step s: this wave's 16 rows of tile TH ------------------------------------------------------------
+  f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
   float* const out_sb = a.out + ((size_t)b * G.vox + (size_t)G.h0 * W) * a.cout + ct * 32;  // wave-uniform
-  const float inv_spv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, 1.f / (float)SPV)));
+  const float inv_spv = 1.f / (float)SPV;
   auto gvox = [&](int v) {  // exact: (v + 0.5) / SPV is never within float error of an integer
     const int z = (int)(((float)v + 0.5f) * inv_spv);
     return z * PV + (v - z * SPV);
   };
-
-  constexpr int NYOUNG = (ACC || (DBG & 4) || (DBG & 16384)) ? 0 : 8;  // the 8 row stores issued between the DMA of a plane and the wait for it
-  auto reduce_store = [&](int tq, int s, bool live) {
-    const int lq = tq & 63, colq = lq & 31, halfq = lq >> 5;
-    float sum[8];
+  // accumulator register r of this wave's half tile = row (r & 3) + 8 (r >> 2) + 4 half + 16 RH; byte offsets of its 8 rows from
+  // the tile's first output row (whole planes: output row = strip voxel, so the tile base is a scalar)
+  int rowo[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) rowo[r] = (((r & 3) + 8 * (r >> 2) + 4 * half + 16 * RH) * a.cout + col) * 4;
+  auto reduce_store = [&](int s) {
+    const int xch = G.XCH + (s & 1) * Z3_XCH;
+    const int vt = G.v0 + s * ZS_STEP + TH * 32;
+    f32x2 prev[4];
+    if (ACC && !HALO && vt + 32 <= G.cend) {
+      const char* const tb = (const char*)uniform_ptr(out_sb + (size_t)vt * a.cout);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) prev[r >> 1][r & 1] = *(const float*)(tb + rowo[r]);
+    }
+    f32x2 sum[4];
 #pragma unroll
     for (int w = 0; w < 4; ++w) {  // K-slices in fixed order: deterministic, and the same sum whichever wave reduces
       if (w == WV) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) sum[r] = w == 0 ? own[r] : sum[r] + own[r];
+        for (int r = 0; r < 4; ++r) sum[r] = w == 0 ? own[r] : sum[r] + own[r];
       } else {
-        const int d = xch + (WV * 3 + (w < WV ? w : w - 1)) * 2048 + lq * 16;
+        const int d = xch + (WV * 3 + (w < WV ? w : w - 1)) * 2048 + lane * 16;
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-          const f32x4 x = (DBG & 32768) ? f32x4{own[0], own[1], own[2], own[3]} : *zp_lds<const f32x4>(d + g * 1024);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) sum[4 * g + e] = w == 0 ? x[e] : sum[4 * g + e] + x[e];
+          const f32x4 x = *z3_lds<const f32x4>(d + g * 1024);
+          const f32x2 x0 = {x[0], x[1]}, x1 = {x[2], x[3]};
+          sum[2 * g] = w == 0 ? x0 : sum[2 * g] + x0;
+          sum[2 * g + 1] = w == 0 ? x1 : sum[2 * g + 1] + x1;
         }
       }
     }
-    const int vt = G.v0 + s * ZS_STEP + TH * 32;
-    float* dst[8];
-    float val[8];
-    const float bvv = *zp_lds<const float>(ZS_ZERO + 512 + colq * 4);
-    if (!ACC && !HALO && live && vt + 32 <= G.cend) {
-      // whole planes, whole tile inside the chunk (all but the last step): output row = strip voxel; one base address and a
-      // constant stride instead of the tail / strip logic per row
-      float* const d0 = out_sb + (size_t)(vt + 16 * RH + 4 * halfq) * a.cout + colq;
+    const float bv1 = *z3_lds<const float>(ZS_ZERO + 512 + col * 4);
+    const f32x2 bvv = {bv1, bv1};
+    if (SCALED) {
+      const f32x2 gi = {ginv, ginv};
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        dst[r] = d0 + ((r & 3) + 8 * (r >> 2)) * a.cout;
-        float v = sum[r];
-        if (SCALED) v *= ginv;
-        v += bvv;
-        val[r] = v;
-        s1 += v;
-        s2 += v * v;
+      for (int r = 0; r < 4; ++r) sum[r] = sum[r] * gi;
+    }
+    if (!HALO && vt + 32 <= G.cend) {
+      // whole planes, whole tile inside the chunk (all but the last step): scalar tile base + the row offsets
+      if (ACC) {  // continuation launch of a wider-K conv: add to what the previous launch stored
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sum[r] = sum[r] + prev[r];
       }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        sum[r] = sum[r] + bvv;
+        s1 = s1 + sum[r];
+        s2 = s2 + sum[r] * sum[r];
+      }
+      const float* const tb = uniform_ptr(out_sb + (size_t)vt * a.cout);
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+        asm volatile("global_store_dword %0, %1, %2" ::"v"(rowo[r]), "v"(sum[r >> 1][r & 1]), "s"(tb) : "memory");
     } else {
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
-        const int row = (r & 3) + 8 * ((r >> 2) + 2 * RH) + 4 * halfq;
-        const bool ok = live && vt + row < G.cend;
-        // rows this lane does not own (chunk tail, the dummy first epilogue) go to the lane's sink cell
-        dst[r] = ok ? out_sb + (size_t)gvox(vt + row) * a.cout + colq : zs_sink + tq;
-        float v = sum[r];
-        if (SCALED) v *= ginv;
-        if (ACC) v += *dst[r];  // continuation launch of a wider-K conv: add to what the previous launch stored
-        v += bvv;
-        val[r] = v;
-        const float m = ok ? v : 0.f;
-        s1 += m;
-        s2 += m * m;
+        const int row = (r & 3) + 8 * ((r >> 2) + 2 * RH) + 4 * half;
+        if (vt + row < G.cend) {  // (chunk tail)
+          float* dst = out_sb + (size_t)gvox(vt + row) * a.cout + col;
+          float v = sum[r >> 1][r & 1];
+          if (ACC) v += *dst;  // continuation launch of a wider-K conv: add to what the previous launch stored
+          v += bv1;
+          *dst = v;
+          s1[r & 1] += v;
+          s2[r & 1] += v * v;
+        }
       }
     }
-    // exactly one store instruction per row on every path: the wait for the DMA counts them (tools/isa_vmcnt_check.py)
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      if (DBG & 16384) asm volatile("" ::"v"(dst[r]), "v"(val[r]));
-      else asm volatile("global_store_dword %0, %1, off ; zs_row_store" ::"v"(dst[r]), "v"(val[r]) : "memory");
-    }
-  };
-  unsigned long long fine[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  auto support_phase = [&](int i) {
-    const int zconv = trk_next(), zload = trk_next();  // = new_plane(i + 1), new_plane(i + 2): trk stands at step i on entry
-    const int tq = zp_opaque_v(tid);  // (see zp_opaque_v: keeps this phase's address arithmetic inside the phase)
-    unsigned long long f0 = 0, f1 = 0, f2 = 0, f3 = 0, f4 = 0;
-    if (DBG & 8192) __builtin_amdgcn_s_setprio(2);  // experiment: the support phase outranks the partner's matrix phase
-    if (DBG & 4096) f0 = zp_stamp();
-    f32x4 v[ZS_NSL];
-    if (zconv != -2 && !(DBG & 2)) {
-      read_raw(tq, v);  // landed before the last barrier (awaited by the group that issued the DMA)
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4])::"memory");
-    }
-    if (zload != -2 && !(DBG & 1)) dma_plane(tq, zload);  // overwrites exactly the pieces this wave has just read
-    __builtin_amdgcn_sched_barrier(0);
-    if (DBG & 4096) f1 = zp_stamp();
-    if (zconv != -2 && !(DBG & 2)) convert(tq, v, zconv);
-    __builtin_amdgcn_sched_barrier(0);
-    if (DBG & 4096) f2 = zp_stamp();
-    if (!(DBG & 4)) reduce_store(tq, i - 1, i >= 1);  // (i = 0: nothing to sum yet, the eight stores go to the sink)
-    __builtin_amdgcn_sched_barrier(0);
-    if (DBG & 4096) f3 = zp_stamp();
-    if (i + 1 < nsteps && !(DBG & 32)) prepare();
-    if (DBG & 4096) f4 = zp_stamp();
-    // the DMA must have landed before the barrier that lets the other group read it; the 8 younger row stores may stay in flight
-    if (zload != -2 && !(DBG & 1)) asm volatile("s_waitcnt vmcnt(%0) ; zs_landed" ::"n"(NYOUNG) : "memory");
-    if (DBG & 4096) {
-      const unsigned long long f5 = zp_stamp();
-      fine[0] += f1 - f0; fine[1] += f2 - f1; fine[2] += f3 - f2; fine[3] += f4 - f3; fine[4] += f5 - f4;
-      fine[5] += zconv != -2; fine[6] += zload != -2; fine[7] += 1;
-    }
-    if (DBG & 8192) __builtin_amdgcn_s_setprio(0);
   };
 
-  if (grp == 0) prepare();  // group 0 opens with the matrix phase of step 0
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), as a builtin so that the compiler knows it: the weights (and the raw plane
-                                       // of step 1) have landed, no compiler-inserted vmcnt wait inside the loop
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), as a builtin so that the compiler knows it: the weights (and the plane of
+                                       // step 1) have landed, no compiler-inserted vmcnt wait inside the loop
   zs_barrier_lds();  // P: the planes of step 0 are staged
 
-  trk_init(min(grp == 1 ? 0 : 1, nsteps - 1));  // this group's first support phase is interval 0 (group 1) / 1 (group 0) ...
-  if (grp == 0 && nsteps == 1) trk.k = 1;        // (... a one-step chunk: interval 1 only reduces)
-  unsigned long long st_m = 0, st_s = 0, st_b = 0;
-  for (int i = 0; i <= nsteps; ++i) {
-    unsigned long long t0 = 0, t1 = 0;
-    if (DBG & 2048) t0 = zp_stamp();
-    if ((i & 1) == grp) {
-      if (i < nsteps) matrix_phase();
-      if (DBG & 2048) { t1 = zp_stamp(); if (i < nsteps) st_m += t1 - t0; }
-    } else {
-      support_phase(i);
-      if (DBG & 2048) { t1 = zp_stamp(); st_s += t1 - t0; }
+  // one step; `first`: the pending plane's loads were awaited by the full drain above
+  unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0;  // (DBG) wait, convert, reduce, prepare, matrix, barrier, #converts
+  auto step = [&](int s, bool first) {
+    if (DBG) t0 = z3_stamp();
+    if (zpend != -2) {
+      if (!first) Z3_LANDED(NYOUNG);  // (first: the loads were awaited by the full drain before the loop)
+      if (DBG) { t1 = z3_stamp(); st[0] += t1 - t0; t0 = t1; }
+      convert(ld, zpend);  // read first by step s + 1
+      if (DBG) { t1 = z3_stamp(); st[1] += t1 - t0; t0 = t1; st[6] += 1; }
     }
-    zs_barrier_lds();
-    if (DBG & 2048) st_b += zp_stamp() - t1;
-  }
-  if ((DBG & 2048) && lane == 0 && blockIdx.z == 0) {
-    unsigned long long* d = zp_stamp_buf + ((size_t)((blockIdx.y * gridDim.x + blockIdx.x) & 255) * 8 + (threadIdx.x >> 6)) * 4;
-    d[0] = st_m; d[1] = st_s; d[2] = st_b; d[3] = (unsigned long long)nsteps;
-    if (DBG & 4096) {
-      unsigned long long* f = zp_stamp_fine + ((size_t)((blockIdx.y * gridDim.x + blockIdx.x) & 255) * 8 + (threadIdx.x >> 6)) * 8;
-      for (int k = 0; k < 8; ++k) f[k] = fine[k];
-    }
+    if (s >= 1) reduce_store(s - 1);
+    __builtin_amdgcn_sched_barrier(0);
+    zpend = trk_next();  // the plane step s + 2 is the first to read
+    if (zpend != -2) issue(zpend);
+    __builtin_amdgcn_sched_barrier(0);
+    if (DBG) { t1 = z3_stamp(); st[2] += t1 - t0; t0 = t1; }
+    prepare();
+    if (DBG) { t1 = z3_stamp(); st[3] += t1 - t0; t0 = t1; }
+    matrix(s);
+    if (DBG) { t1 = z3_stamp(); st[4] += t1 - t0; t0 = t1; }
+    zs_barrier_lds();  // the partial tiles of step s are complete; the plane of step s + 1 is staged
+    if (DBG) { t1 = z3_stamp(); st[5] += t1 - t0; }
+  };
+  if (DBG) t_loop = z3_stamp();
+  step(0, true);
+  for (int s = 1; s < nsteps; ++s) step(s, false);
+  reduce_store(nsteps - 1);
+  if (DBG && lane == 0) {
+    unsigned long long* d = z3_stamp_buf + ((size_t)((blockIdx.y * gridDim.x + blockIdx.x) & 255) * 4 + WV) * 12;
+    for (int i = 0; i < 7; ++i) d[i] = st[i];
+    d[7] = nsteps;
+    d[8] = t_loop - t_begin;
+    d[9] = z3_stamp() - t_begin;
   }
 
   if (a.ch_part) {
-    const float t1 = s1 + __shfl_xor(s1, 32, 64), t2 = s2 + __shfl_xor(s2, 32, 64);
+    const float u1 = s1[0] + s1[1], u2 = s2[0] + s2[1];
+    const float t1 = u1 + __shfl_xor(u1, 32, 64), t2 = u2 + __shfl_xor(u2, 32, 64);
     if (half == 0) {
-      float* dst = a.ch_part + ((((size_t)b * gridDim.x + chunk) * 8 + grp * 4 + WV) * a.cout + ct * 32 + col) * 2;
+      float* dst = a.ch_part + ((((size_t)b * gridDim.x + chunk) * 4 + WV) * a.cout + ct * 32 + col) * 2;
       dst[0] = t1;
       dst[1] = t2;
     }
   }
-  if (a.status && threadIdx.x == 0 && *flag_lds) atomicOr(a.status, 1);  // (the loop ends with a barrier)
+  if (a.status && tid == 0 && *flag_lds) atomicOr(a.status, 1);  // (the loop ends with a barrier)
 }
 
 template <bool ACC, int MODE, int DBG = 0>
-__global__ void __launch_bounds__(512, 1) conv_zslide_pp_f16x2_kernel(ConvZsArgs a) {
+__global__ void __launch_bounds__(256, 1) conv_zslide_sw_f16x2_kernel(ConvZsArgs a) {
   extern __shared__ __attribute__((aligned(16))) char zs_lds[];
-  if (DBG & 128) {  // experiment: one program for all waves (instruction-cache footprint)
-    zp_wave<0, ACC, MODE, DBG>(a, zs_lds);
-    return;
-  }
-  switch ((threadIdx.x >> 6) & 3) {
-    case 0: zp_wave<0, ACC, MODE, DBG>(a, zs_lds); break;
-    case 1: zp_wave<1, ACC, MODE, DBG>(a, zs_lds); break;
-    case 2: zp_wave<2, ACC, MODE, DBG>(a, zs_lds); break;
-    default: zp_wave<3, ACC, MODE, DBG>(a, zs_lds); break;
+  switch (threadIdx.x >> 6) {
+    case 0: z3_wave<0, ACC, MODE, DBG>(a, zs_lds); break;
+    case 1: z3_wave<1, ACC, MODE, DBG>(a, zs_lds); break;
+    case 2: z3_wave<2, ACC, MODE, DBG>(a, zs_lds); break;
+    default: z3_wave<3, ACC, MODE, DBG>(a, zs_lds); break;
   }
 }
 
 // launch of one K-block: the specialisation for (continuation, normed input, strips, rescaled input)
-template <int DBG = 0>
-void zp_launch(const ConvZsArgs& a, bool acc, dim3 grid, size_t lds, hipStream_t s) {
+void z3_launch(const ConvZsArgs& a, bool acc, dim3 grid, size_t lds, hipStream_t s) {
   const int mode = ((a.coef || a.defer.part) ? 1 : 0) | (a.HS < a.H ? 2 : 0) | (a.in_absmax ? 4 : 0);
-#define ZP_CASE(ACCV, M)                                                                                                        \
+#define Z3_CASE(ACCV, M)                                                                                                        \
   if (acc == ACCV && mode == M) {                                                                                               \
     static bool attr = false;                                                                                                   \
     if (!attr) {                                                                                                                \
-      CD_HIP(hipFuncSetAttribute((const void*)conv_zslide_pp_f16x2_kernel<ACCV, M, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+      CD_HIP(hipFuncSetAttribute((const void*)conv_zslide_sw_f16x2_kernel<ACCV, M>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                  160 * 1024));                                                                                  \
       attr = true;                                                                                                              \
     }                                                                                                                           \
-    hipLaunchKernelGGL((conv_zslide_pp_f16x2_kernel<ACCV, M, DBG>), grid, dim3(512), lds, s, a);                                 \
+    hipLaunchKernelGGL((conv_zslide_sw_f16x2_kernel<ACCV, M>), grid, dim3(256), lds, s, a);                                      \
     return;                                                                                                                     \
   }
-  ZP_CASE(false, 0) ZP_CASE(false, 1) ZP_CASE(false, 2) ZP_CASE(false, 3) ZP_CASE(false, 4) ZP_CASE(false, 6)
-  if (DBG == 0) { ZP_CASE(true, 0) ZP_CASE(true, 2) ZP_CASE(true, 4) ZP_CASE(true, 6) }
-#undef ZP_CASE
+  Z3_CASE(false, 0) Z3_CASE(false, 1) Z3_CASE(false, 2) Z3_CASE(false, 3) Z3_CASE(false, 4) Z3_CASE(false, 6)
+  Z3_CASE(true, 0) Z3_CASE(true, 2) Z3_CASE(true, 4) Z3_CASE(true, 6)
+#undef Z3_CASE
   CD_REQUIRE(false, "z-slide conv: no kernel instance for this combination of continuation / normalised / strip / rescaled input");
 }
 
@@ -1106,7 +1043,7 @@ bool try_launch_conv_zslide(const float* in0, int c0, const float* in1, int c1, 
   if (cout % 32 || c0 % 32 || c1 % 32) return false;
   const int H = g.in.h, W = g.in.w;
   auto ring_for = [&](int hs) { return hs * W >= 2 * ZS_STEP ? 4 : 5; };
-  // the ping-pong form is specialised at compile time; anything outside its instances (a normalised input without the
+  // the one-wave-per-SIMD form is specialised at compile time; anything outside its instances (a normalised input without the
   // activation, a normalised AND rescaled input) takes the matrix-wave / helper-wave form, as does CD_ZS_V1=1 (A/B)
   static const bool v1_env = getenv("CD_ZS_V1") != nullptr;
   const bool normed_in = fu.coef || fu.defer.part;
@@ -1114,7 +1051,8 @@ bool try_launch_conv_zslide(const float* in0, int c0, const float* in1, int c1, 
   auto lds_for = [&](int hs) {
     const int rows = hs + (hs < H ? 2 : 0);
     const size_t ring = (size_t)ring_for(hs) * (((size_t)rows * W * ZS_VB + 255) & ~(size_t)255);
-    return v1 ? (size_t)ZS_ZERO + ring + ZS_PART : (size_t)ZS_ZERO + ZP_COEF + ring + 2 * ZP_XCH + ZP_RAW;
+    const size_t ring3 = (size_t)ring_for(hs) * ((((size_t)rows * (W + 1) + 1) * ZS_VB + 255) & ~(size_t)255);  // padded rows
+    return v1 ? (size_t)ZS_ZERO + ring + ZS_PART : (size_t)ZS_ZERO + Z3_COEF + ring3 + 2 * Z3_XCH;
   };
   int HS = 0;
   for (int hs = H; hs >= 1; --hs) {  // the largest strip that fits: least halo restaging
@@ -1182,42 +1120,29 @@ bool try_launch_conv_zslide(const float* in0, int c0, const float* in1, int c1, 
     a.dbg = getenv("CD_ZS_DBG") ? atoi(getenv("CD_ZS_DBG")) : 0;
     const dim3 grid((unsigned)(nstrip * nchunk), (unsigned)batch, (unsigned)CTtot);
 #ifdef CD_ZS_EXPERIMENTS
-#define ZP_DBG_CASE(D) \
-  case D:              \
-    zp_launch<D>(a, false, grid, lds, s); \
-    break;
-    if (kb == 0 && a.dbg && !v1) {
-      switch (a.dbg) {
-        ZP_DBG_CASE(7) ZP_DBG_CASE(15) ZP_DBG_CASE(23) ZP_DBG_CASE(71) ZP_DBG_CASE(87) ZP_DBG_CASE(95) ZP_DBG_CASE(39)
-        ZP_DBG_CASE(88) ZP_DBG_CASE(127) ZP_DBG_CASE(6144) ZP_DBG_CASE(22528) ZP_DBG_CASE(38912) ZP_DBG_CASE(55296)
-        default: CD_REQUIRE(false, "CD_ZS_DBG: not an instantiated experiment");
+    if (kb == 0 && a.dbg == 2048 && !v1) {  // stamps: print the per-wave cycle sums of one launch
+      const bool normed = a.coef || a.defer.part;
+      CD_REQUIRE(!a.in_absmax && a.HS == a.H, "CD_ZS_DBG=2048: whole planes, unscaled input");
+      if (normed) {
+        CD_HIP(hipFuncSetAttribute((const void*)conv_zslide_sw_f16x2_kernel<false, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL((conv_zslide_sw_f16x2_kernel<false, 1, 1>), grid, dim3(256), lds, s, a);
+      } else {
+        CD_HIP(hipFuncSetAttribute((const void*)conv_zslide_sw_f16x2_kernel<false, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL((conv_zslide_sw_f16x2_kernel<false, 0, 1>), grid, dim3(256), lds, s, a);
       }
       CD_HIP(hipGetLastError());
-      if (a.dbg & 2048) {  // stamps: print the per-wave cycle sums of one launch
-        static int nlaunch = 0;
-        if (++nlaunch == 10) {
-          CD_HIP(hipDeviceSynchronize());
-          static unsigned long long h[256 * 8 * 4];
-          CD_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(zp_stamp_buf), sizeof h));
-          for (int wg : {0, 1, 2, 3, 100, 255})
-            for (int w = 0; w < 8; ++w) {
-              const unsigned long long* d = h + ((size_t)wg * 8 + w) * 4;
-              std::fprintf(stderr, "[zp stamps] wg %3d wave %d: matrix %6.0f cyc/phase  support %6.0f cyc/phase  barrier wait %6.0f cyc/interval  (nsteps %llu)\n",
-                           wg, w, d[0] / (double)((d[3] + 1 - (w >> 2)) / 2 ? (d[3] + 1 - (w >> 2)) / 2 : 1), d[1] / (double)((d[3] + 1 + (w >> 2)) / 2),
-                           d[2] / (double)(d[3] + 1), d[3]);
-            }
-          if (a.dbg & 4096) {
-            static unsigned long long hf[256 * 8 * 8];
-            CD_HIP(hipMemcpyFromSymbol(hf, HIP_SYMBOL(zp_stamp_fine), sizeof hf));
-            for (int wg : {0, 100})
-              for (int w : {0, 4}) {
-                const unsigned long long* f = hf + ((size_t)wg * 8 + w) * 8;
-                const double n = (double)f[7];
-                std::fprintf(stderr, "[zp fine] wg %3d wave %d: per support phase: head+dma %5.0f  convert %5.0f  reduce %5.0f  prepare %5.0f  dma wait %5.0f   (%llu of %llu phases convert, %llu load)\n",
-                             wg, w, f[0] / n, f[1] / n, f[2] / n, f[3] / n, f[4] / n, f[5], f[7], f[6]);
-              }
+      static int nlaunch = 0;
+      if (++nlaunch == 10) {
+        CD_HIP(hipDeviceSynchronize());
+        static unsigned long long h[256 * 4 * 12];
+        CD_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(z3_stamp_buf), sizeof h));
+        for (int wg : {0, 100, 255})
+          for (int w = 0; w < 4; ++w) {
+            const unsigned long long* d = h + ((size_t)wg * 4 + w) * 12;
+            const double n = (double)d[7], nc = d[6] ? (double)d[6] : 1.;
+            std::fprintf(stderr, "[z3 stamps] wg %3d wave %d: per step: load wait %5.0f (per convert %5.0f)  convert %5.0f (per convert %5.0f)  issue+reduce %5.0f  prepare %5.0f  matrix %5.0f  barrier %5.0f   (%llu converts in %llu steps)  prologue %llu  kernel %llu cycles\n",
+                         wg, w, d[0] / n, d[0] / nc, d[1] / n, d[1] / nc, d[2] / n, d[3] / n, d[4] / n, d[5] / n, d[6], d[7], d[8], d[9]);
           }
-        }
       }
       continue;
     }
@@ -1240,11 +1165,11 @@ bool try_launch_conv_zslide(const float* in0, int c0, const float* in1, int c1, 
       if (kb == 0) hipLaunchKernelGGL(conv_zslide_f16x2_kernel<false>, grid, dim3(512), lds, s, a);
       else hipLaunchKernelGGL(conv_zslide_f16x2_kernel<true>, grid, dim3(512), lds, s, a);
     } else {
-      zp_launch<0>(a, kb != 0, grid, lds, s);
+      z3_launch(a, kb != 0, grid, lds, s);
     }
     CD_HIP(hipGetLastError());
   }
-  if (fu.units) *fu.units = nstrip * nchunk * (v1 ? 4 : 8);
+  if (fu.units) *fu.units = nstrip * nchunk * 4;
   return true;
 }
 

@@ -22,8 +22,8 @@ def zs_asm(tmp_path_factory):
     if not (os.path.exists(HIPCC) or shutil.which(HIPCC)):
         pytest.skip("hipcc not available")
     out = tmp_path_factory.mktemp("isa") / "zs.s"
-    from calodiffusion_amd.build import FLAGS
-    flags = [f for f in FLAGS if f not in ("-fPIC",)]
+    from calodiffusion_amd.build import FILE_FLAGS, FLAGS
+    flags = [f for f in FLAGS if f not in ("-fPIC",)] + FILE_FLAGS.get("kernels_conv_zs.hip", [])
     subprocess.run([HIPCC, *flags, "-S", "--cuda-device-only", "-o", str(out), SRC], check=True, capture_output=True)
     return str(out)
 
