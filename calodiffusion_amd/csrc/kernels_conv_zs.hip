@@ -1088,7 +1088,10 @@ bool try_launch_conv_zslide(const float* in0, int c0, const float* in1, int c1, 
     const double eff = (double)total / (rounds * 256.0) * planes / (planes + 2.5);  // halo planes + prologue
     if (eff > best_eff * 1.0001) { best_eff = eff; best = n; }
   }
-  const int nchunk = best;
+  int nchunk = best;
+#ifdef CD_ZS_EXPERIMENTS
+  if (getenv("CD_ZS_NCHUNK")) nchunk = atoi(getenv("CD_ZS_NCHUNK"));  // (tools/zs_power.sh: the same workgroup program on fewer CUs)
+#endif
   const int CV = (int)(((svox + nchunk - 1) / nchunk + ZS_STEP - 1) / ZS_STEP * ZS_STEP);
   static bool attr_set = false;
   if (!attr_set) {
