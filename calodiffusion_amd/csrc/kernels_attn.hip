@@ -455,7 +455,9 @@ void launch_attn_kv_context(const float* x, int C, const float* coef, const void
   a.x = x; a.coef = coef; a.wqkv = (const u32x4*)wqkv_f16x2; a.C = C; a.vox = vox; a.tiles_per_wg = tiles_per_wg_for(vox, nsplit);
   a.partials = partials; a.nsplit = nsplit;
   if (defer) a.defer = *defer;
-  prof::Scope scope("attn_kv_context", s, 2.0 * (2.0 * C + 32) * 32 * (double)vox * batch, 4.0 * batch * (double)vox * C);
+  char cat[64];
+  std::snprintf(cat, sizeof cat, "attn_kv_context C%d n%ld", C, (long)vox);
+  prof::Scope scope(cat, s, 2.0 * (2.0 * C + 32) * 32 * (double)vox * batch, 4.0 * batch * (double)vox * C);
   const dim3 grid((unsigned)nsplit, (unsigned)batch);
   switch (C / 32) {
     case 1: hipLaunchKernelGGL(attn_kv_context_kernel<1>, grid, dim3(512), 0, s, a); break;
@@ -476,7 +478,9 @@ void launch_attn_out(const float* x, int C, const float* coef, const void* wqkv_
   CD_REQUIRE(wT_b || (partials && w_out), "attn_out: folded weights or the pass-1 partials to fold them from");
   a.partials = const_cast<float*>(partials); a.nsplit = nsplit; a.fold_wout = w_out; a.fold_scale = scale;
   if (defer) a.defer = *defer;
-  prof::Scope scope("attn_out", s, 2.0 * (2.0 * C) * 32 * (double)vox * batch, 4.0 * batch * (double)vox * C * 2);
+  char cat[64];
+  std::snprintf(cat, sizeof cat, "attn_out C%d n%ld", C, (long)vox);
+  prof::Scope scope(cat, s, 2.0 * (2.0 * C) * 32 * (double)vox * batch, 4.0 * batch * (double)vox * C * 2);
   const dim3 grid((unsigned)nsplit, (unsigned)batch);
   switch (C / 32) {
     case 1: hipLaunchKernelGGL(attn_out_kernel<1>, grid, dim3(512), 0, s, a); break;

@@ -3,6 +3,7 @@
 // (calodiffusion/models/models.py:155,293,325) and LinearAttention.forward (models.py:301-318).
 #include "cd_common.h"
 #include "gn_defer.h"
+#include <cstdio>
 #include <cstdlib>
 
 namespace cd {
@@ -70,7 +71,9 @@ __global__ void __launch_bounds__(256) ch_stats_kernel(const float* __restrict__
 
 void launch_ch_stats(const float* x, float* part, int batch, int channels, int64_t vox, int nsplit, hipStream_t s) {
   CD_REQUIRE(channels % 4 == 0 && channels <= 256, "channel stats: channels must be a multiple of 4 and <= 256");
-  prof::Scope scope("ch_stats", s, 0, 4.0 * batch * (double)vox * channels);
+  char cat[64];
+  std::snprintf(cat, sizeof cat, "ch_stats C%d n%ld", channels, (long)vox);
+  prof::Scope scope(cat, s, 0, 4.0 * batch * (double)vox * channels);
   hipLaunchKernelGGL(ch_stats_kernel, dim3(nsplit, batch), dim3(256), 0, s, x, part, channels, vox, nsplit);
   CD_HIP(hipGetLastError());
 }
@@ -256,7 +259,9 @@ void launch_gn_apply(const float* x, float* y, const float* coef, int batch, int
   CD_REQUIRE(channels % 4 == 0 && channels <= 256, "group norm: channels must be a multiple of 4 and <= 256");
   CD_REQUIRE(!defer || !defer->part || (defer->C == channels && defer->groups <= 64), "gn_apply: bad deferred normalisation");
   const int bps = gn_apply_blocks_per_sample(batch, channels, vox);
-  prof::Scope scope("gn_apply", s, 0, 4.0 * batch * (double)vox * channels * (2 + (residual ? 1 : 0)));
+  char cat[64];
+  std::snprintf(cat, sizeof cat, "gn_apply C%d n%ld", channels, (long)vox);
+  prof::Scope scope(cat, s, 0, 4.0 * batch * (double)vox * channels * (2 + (residual ? 1 : 0)));
   hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)(batch * bps)), dim3(256), 0, s, x, y, coef, channels, vox, silu, residual,
                      residual1, res_c0, bps, part_out, defer ? *defer : GnDefer());
   CD_HIP(hipGetLastError());

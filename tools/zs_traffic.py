@@ -72,8 +72,9 @@ def main():
            "algorithmic_bytes": 2.0 * 64 * 6480 * 32 * 4, "raw": res,
            "method": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (one pass each) --kernel-trace -- python3 tools/conv_bench.py --iters 5; "
                      "KiB per dispatch; FETCH_SIZE x2 on gfx950"}
-    with open(OUT, "w") as fh:
-        json.dump(out, fh, indent=1)
+    for path in (OUT, os.path.join(ROOT, "gpurun_out", "zslide_traffic.json")):  # (gpurun merges gpurun_out/ back, not profiles/)
+        with open(path, "w") as fh:
+            json.dump(out, fh, indent=1)
     print("wrote", OUT, f"traffic {out['traffic_bytes'] / 1e6:.1f} MB vs algorithmic {out['algorithmic_bytes'] / 1e6:.1f} MB")
 
 
