@@ -1,0 +1,1 @@
+"""calodiffusion.models: the reference's module names over calodiffusion_amd (see calodiffusion/__init__.py)."""

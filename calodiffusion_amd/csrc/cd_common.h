@@ -117,6 +117,8 @@ struct ConvFusion {
 const unsigned* launch_absmax_bits(const float* x, size_t n, hipStream_t s);
 // the zeroed word for a producer that tracks max |x| itself while writing x; claimed by the next launch_absmax_bits(x)
 unsigned* absmax_word_fresh(const float* x, hipStream_t s);
+// forget which tensor the word describes (end of the convolution backward that computed it)
+void absmax_note_drop();
 // 2^s and 2^-s for a tensor whose max |x| has bit pattern mb: s = 10 - floor(log2 max)
 __host__ __device__ inline void pow2_scale_for(unsigned mb, float* scale, float* inv) {
   const int e = (int)((mb >> 23) & 0xff) - 127;

@@ -273,6 +273,7 @@ __global__ void __launch_bounds__(512, 1) wgrad_f16x2_kernel(Wgrad16Args a) {
 namespace {
 unsigned* g_absmax_word = nullptr;
 const float* g_absmax_of = nullptr;  // tensor the word currently describes (stream order)
+size_t g_absmax_n = 0;               // ... and its element count (0: a producer's note, size unknown)
 }  // namespace
 namespace {
 bool g_absmax_fresh = false;  // the word was filled by the producer of g_absmax_of and has not been claimed yet
@@ -284,8 +285,16 @@ unsigned* absmax_word_fresh(const float* x, hipStream_t s) {
   if (!g_absmax_word) CD_HIP(hipMalloc((void**)&g_absmax_word, 64));
   CD_HIP(hipMemsetAsync(g_absmax_word, 0, sizeof(unsigned), s));
   g_absmax_of = x;
+  g_absmax_n = 0;
   g_absmax_fresh = true;
   return g_absmax_word;
+}
+// The note is only good for the backward of ONE convolution: its owner drops it when that backward is enqueued, so a later tensor
+// at a recycled workspace address (or the same tensor rewritten in place) can never pick up a stale maximum.
+void absmax_note_drop() {
+  g_absmax_of = nullptr;
+  g_absmax_n = 0;
+  g_absmax_fresh = false;
 }
 const unsigned* launch_absmax_bits(const float* x, size_t n, hipStream_t s) {
   if (g_absmax_fresh && g_absmax_of == x && g_absmax_word) {
@@ -299,6 +308,7 @@ const unsigned* launch_absmax_bits(const float* x, size_t n, hipStream_t s) {
   hipLaunchKernelGGL(absmax_bits_kernel, dim3(2048), dim3(256), 0, s, x, n / 4, g_absmax_word);
   CD_HIP(hipGetLastError());
   g_absmax_of = x;
+  g_absmax_n = n;
   return g_absmax_word;
 }
 
@@ -324,7 +334,9 @@ bool try_launch_wgrad_f16x2(const float* g, int A, const float* x, int Bc, int x
   f.total_units = f.units_per_sample * batch;
   f.partial = partial; f.tilesB = Bc / 32;
   // max |dy|: reuse the word if the caller (conv_backward) already computed it for this tensor
-  f.gmax_bits = (g_absmax_of == g && g_absmax_word) ? g_absmax_word : launch_absmax_bits(g, (size_t)batch * d.vox() * A, s);
+  // (same pointer AND same size, noted since the last absmax_note_drop(): the dx convolution of this very backward)
+  const size_t gn = (size_t)batch * d.vox() * A;
+  f.gmax_bits = (g_absmax_of == g && g_absmax_n == gn && g_absmax_word) ? g_absmax_word : launch_absmax_bits(g, gn, s);
   (void)gmax_word;
   const int tiles = (A / 32) * (Bc / 32);
   int nblk = 256 / tiles;

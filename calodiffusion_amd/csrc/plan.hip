@@ -677,6 +677,7 @@ void conv_backward(Run& r, const float* x0, int c0, const float* x1, int c1, con
   if (!r.dry()) {
     launch_wgrad(dy, cout, g.out, x0, c0, c0, 0, g.in, g.kd, g.kh, g.kw, g.sz, g.sh, r.B, false, part, dw, false, false, r.s, cin, 0);
     if (c1) launch_wgrad(dy, cout, g.out, x1, c1, c1, 0, g.in, g.kd, g.kh, g.kw, g.sz, g.sh, r.B, false, part, dw, false, false, r.s, cin, c0);
+    absmax_note_drop();  // max |dy| served this backward only
   }
   ws->release(part);
   if (db) bias_grad(r, dy, cout, g.out.vox(), db);
@@ -716,7 +717,10 @@ void conv_transpose_backward(Run& r, const float* x, const float* w_raw, const f
   }
   // dw[ci][co][k] = sum_i x[i][ci] * dy[s*i + k - 1][co]: the strided-conv weight gradient with the two tensors' roles swapped
   float* part = ws->get<float>(wgrad_partial_floats(din.vox(), r.B, false, c, c, T));
-  if (!r.dry()) launch_wgrad(x, c, din, dy, c, c, 0, dout, kz, 4, 4, sz, 2, r.B, false, part, dw, false, false, r.s);
+  if (!r.dry()) {
+    launch_wgrad(x, c, din, dy, c, c, 0, dout, kz, 4, 4, sz, 2, r.B, false, part, dw, false, false, r.s);
+    absmax_note_drop();
+  }
   ws->release(part);
   if (db) bias_grad(r, dy_full, c, dout_full.vox(), db);
   if (folded) ws->release(folded);

@@ -246,3 +246,22 @@ def test_noise_shard_bookkeeping():
     assert m.step_noise_stream(start) == (100 + 2048, 3072)
     with pytest.raises(ValueError):
         m._shard_geometry((3, 1, 8, 8, 8))
+
+
+def test_reference_module_paths_resolve_to_this_package():
+    """`calodiffusion.models.*` / `calodiffusion.utils.utils` (the reference's import paths) are aliases of calodiffusion_amd."""
+    import calodiffusion.models.calodiffusion as m_cd
+    import calodiffusion.models.diffusion as m_d
+    import calodiffusion.models.layerdiffusion as m_ld
+    import calodiffusion.models.loss as m_l
+    import calodiffusion.models.models as m_m
+    import calodiffusion.models.sample as m_s
+    import calodiffusion.utils.utils as m_u
+    import calodiffusion_amd as A
+    from calodiffusion_amd import calodiffusion as a_cd, diffusion as a_d, layerdiffusion as a_ld, loss as a_l, sample as a_s, unet as a_u
+
+    assert m_d.Diffusion is a_d.Diffusion and m_cd.CaloDiffusion is a_cd.CaloDiffusion and m_ld.LayerDiffusion is a_ld.LayerDiffusion
+    assert m_s.DDim is a_s.DDim and m_s.DPMPP2M is a_s.DPMPP2M and m_l.hybrid_weight is a_l.hybrid_weight
+    assert m_m.CondUnet is a_u.CondUnet
+    assert m_u.load_attr("sampler", "Heun") is a_s.Heun and callable(m_u.ReverseNorm)
+    assert A is not None
