@@ -91,16 +91,9 @@ __device__ __forceinline__ void norm_split(const AttnArgs& a, int64_t n0, int co
 // Tiles whose loads are in flight ahead of their use, per wave (0 = load and consume in place).  Measured on MI355X with the
 // one-round grids below: depth 2-3 makes pass 1 slower (0.146 -> 0.155 ms per denoise step, register pressure) and leaves
 // pass 2 unchanged -- these kernels are bound by their VALU work (split, exp) and the f32 context MFMAs, not by load latency.
-#ifndef ATTN_KV_D1
-#define ATTN_KV_D1 0
-#endif
 #ifndef ATTN_OUT_D1
 #define ATTN_OUT_D1 0
 #endif
-template <int NCH>
-struct AttnDepthKV {
-  static constexpr int value = NCH == 1 ? ATTN_KV_D1 : 0;
-};
 template <int NCH>
 struct AttnDepthOut {
   static constexpr int value = NCH == 1 ? ATTN_OUT_D1 : 0;
@@ -173,69 +166,75 @@ __global__ void __launch_bounds__(512) attn_kv_context_kernel(AttnArgs a) {
     return pa;
   };
 
-  constexpr int PRE = AttnDepthKV<NCH>::value, DEPTH = PRE ? PRE : 1;
-  RawTile<NCH> raw[DEPTH];
+  // ONE sweep with a running maximum per wave (the two-sweep form -- maxima first, then exponentials -- projected k twice and read
+  // x twice): e = exp(k - m) against the wave's maximum so far; when a tile raises it, what the wave has accumulated is rescaled
+  // by exp(m_old - m_new) first -- rare after a wave's first tiles, so the rescale sits behind a wave-uniform branch.  The eight
+  // waves' {m, sum, ctx} are merged the same way at the end.
+  // ctx[d][e'] += e^T v on the matrix cores: the k / v accumulator registers are the A / B operands of the context MFMA (k-slot =
+  // the lane's half).  Row d of ctx lives in register r of the lanes of half h with d = (r & 3) + 8 (r >> 2) + 4 h, while the
+  // factor of channel d is computed in lane d: it reaches the rows through a 32-float line of LDS per wave.
+  __shared__ __attribute__((aligned(16))) float sFac[8][32];
+  RawTile<NCH> raw;
   const int64_t tlast = t1 - 1;
-  // sweep 1: per-channel max of k over this workgroup's voxels
-  float m = -3.0e38f;
-  if (PRE) {
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d) load_raw<NCH>(a, b, t0 + wave + 8 * d, tlast, col, half, raw[d]);
-  }
-  for (int64_t t = t0 + wave; t < t1; t += 8 * DEPTH) {
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d) {
-      const int64_t tt = t + 8 * d;
-      if (tt >= t1) break;
-      u32x4 x1[NKS], x2[NKS];
-      if (!PRE) load_raw<NCH>(a, b, tt, tlast, col, half, raw[d]);
-      norm_split<NCH>(a, tt * 32, col, cf, raw[d], x1, x2);
-      if (PRE && tt + 8 * DEPTH < t1) load_raw<NCH>(a, b, tt + 8 * DEPTH, tlast, col, half, raw[d]);
-      const f32x16 k = project(x1, x2, wk1, wk2);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (tt * 32 + row < a.vox) m = fmaxf(m, k[r]);
-      }
-    }
-  }
-  // the second sweep's first loads go out before the maxima are exchanged (LDS-only barrier: it does not wait for them)
-  if (PRE) {
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d) load_raw<NCH>(a, b, t0 + wave + 8 * d, tlast, col, half, raw[d]);
-  }
-  m = fmaxf(m, __shfl_xor(m, 32, 64));
-  if (half == 0) sMax[wave][col] = m;
-  attn_barrier_lds();
-  m = sMax[0][col];
-#pragma unroll
-  for (int w = 1; w < 8; ++w) m = fmaxf(m, sMax[w][col]);
-
-  // sweep 2: e = exp(k - m) (rows = voxels, column = channel d), ctx[d][e'] += e^T v on the matrix cores: the k / v
-  // accumulator registers are the A / B operands of the context MFMA (k-slot = the lane's half)
+  float m = -3.0e38f;  // (sentinel: never enters an exponential)
+  bool any = false;
   f32x16 ctx;
 #pragma unroll
   for (int r = 0; r < 16; ++r) ctx[r] = 0.f;
   float ssum = 0.f;
-  for (int64_t t = t0 + wave; t < t1; t += 8 * DEPTH) {
+  auto scale_rows = [&](float fac) {  // ctx[d][:] *= fac[d], fac given in lane d
+    sFac[wave][col] = fac;  // (both halves write the same value)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // one wave: its own writes are visible to its reads in order
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) {
-      const int64_t tt = t + 8 * d;
-      if (tt >= t1) break;
-      u32x4 x1[NKS], x2[NKS];
-      if (!PRE) load_raw<NCH>(a, b, tt, tlast, col, half, raw[d]);
-      norm_split<NCH>(a, tt * 32, col, cf, raw[d], x1, x2);
-      if (PRE && tt + 8 * DEPTH < t1) load_raw<NCH>(a, b, tt + 8 * DEPTH, tlast, col, half, raw[d]);
-      const f32x16 k = project(x1, x2, wk1, wk2);
-      const f32x16 v = project(x1, x2, wv1, wv2);
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 f4 = *(const f32x4*)&sFac[wave][8 * q + 4 * half];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-        const float ex = (tt * 32 + row < a.vox) ? attn_exp(k[r] - m) : 0.f;
-        ssum += ex;
-        ctx = MFMA32(ex, v[r], ctx);
-      }
+      for (int e = 0; e < 4; ++e) ctx[4 * q + e] *= f4[e];
     }
+  };
+  for (int64_t tt = t0 + wave; tt < t1; tt += 8) {
+    u32x4 x1[NKS], x2[NKS];
+    load_raw<NCH>(a, b, tt, tlast, col, half, raw);
+    norm_split<NCH>(a, tt * 32, col, cf, raw, x1, x2);
+    const f32x16 k = project(x1, x2, wk1, wk2);
+    const f32x16 v = project(x1, x2, wv1, wv2);
+    const bool full = tt * 32 + 32 <= a.vox;  // (only a sample's last tile can be partial)
+    float tm = -3.0e38f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (full || tt * 32 + row < a.vox) tm = fmaxf(tm, k[r]);
+    }
+    tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+    if (!any) {
+      m = tm;  // first tile of this wave: nothing accumulated yet
+      any = true;
+    } else if (__builtin_amdgcn_ballot_w64(tm > m) != 0) {
+      const float mn = fmaxf(m, tm);
+      const float fac = attn_exp(m - mn);
+      ssum *= fac;
+      scale_rows(fac);
+      m = mn;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+      const float ex = (full || tt * 32 + row < a.vox) ? attn_exp(k[r] - m) : 0.f;
+      ssum += ex;
+      ctx = MFMA32(ex, v[r], ctx);
+    }
+  }
+  // merge the waves: common maximum, every wave's sums and context rescaled to it
+  if (half == 0) sMax[wave][col] = m;
+  attn_barrier_lds();
+  float M = sMax[0][col];
+#pragma unroll
+  for (int w = 1; w < 8; ++w) M = fmaxf(M, sMax[w][col]);
+  {
+    const float fac = any ? attn_exp(m - M) : 0.f;  // (a workgroup has at least one tile, so M is a real maximum)
+    ssum *= fac;
+    scale_rows(fac);
+    m = M;
   }
   sSum[wave * 2 + half][col] = ssum;
 #pragma unroll
