@@ -112,6 +112,20 @@ struct ConvFusion {
   // staged input by 2^s (bringing that maximum to ~2^10) and their output by 2^-s: the input gradients of a conv are
   // O(1e-6), deep in the fp16 subnormals, and the conv is linear.  Needs bias == null and no input normalisation.
   const unsigned* in_absmax = nullptr;
+  // Output side of a ResnetBlock's second conv on a grid small enough for one workgroup to see a whole (sample, 32-channel tile)
+  // (kernels_conv_small.hip): the kernel applies the block's closing GroupNorm + SiLU and adds the shortcut itself,
+  //   out = silu(gn(conv + bias)) + (res0 | res1),
+  // and sets *gn_out.done = 1 on the host; every other kernel ignores the request and the caller runs gn_apply as before.
+  struct GnOut {
+    const float* gamma = nullptr;  // (cout); null = no request
+    const float* beta = nullptr;
+    int groups = 0;
+    const float* res0 = nullptr;   // shortcut: (B, vox, res_c0) [and res1: (B, vox, cout - res_c0), an un-materialised concat]
+    const float* res1 = nullptr;
+    int res_c0 = 0;
+    float* part_out = nullptr;     // [B][1][cout][2] channel partials of `out` (for a following PreNorm), or null
+    int* done = nullptr;
+  } gn_out;
 };
 // device word holding max |x| (bit pattern) of the tensor last passed to launch_absmax_bits; valid in stream order
 const unsigned* launch_absmax_bits(const float* x, size_t n, hipStream_t s);

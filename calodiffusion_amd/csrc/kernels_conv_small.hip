@@ -40,6 +40,12 @@ struct ConvSmallArgs {
   GnDefer defer;      // input normalisation folded in the prologue (table at cs_lds + coef_lds_off) instead of `coef`
   int coef_lds_off;
   const unsigned* in_absmax;  // power-of-two input rescaling (ConvFusion::in_absmax) or null
+  // closing GroupNorm + SiLU + shortcut of a ResnetBlock in the epilogue (ConvFusion::GnOut), gamma == null: plain conv output
+  const float *gn_gamma, *gn_beta;
+  int gn_cpg;                 // channels per group (divides 32: a group never straddles two channel tiles)
+  const float *res0, *res1;
+  int res_c0;
+  float* part_out;
 };
 
 constexpr int CS_PD = 6;  // weight fragments requested this many pairs ahead
@@ -197,6 +203,7 @@ __global__ void __launch_bounds__(256, 1) conv_small_f16x2_kernel(ConvSmallArgs 
   }
   __syncthreads();
   float s1 = 0.f, s2 = 0.f;
+  float hold[16];  // (gn_gamma: the conv output stays in registers until it is normalised)
   if (wave < NT) {
     const float bv = a.bias ? a.bias[ct * 32 + col] : 0.f;
     f32x16 sum;
@@ -216,11 +223,98 @@ __global__ void __launch_bounds__(256, 1) conv_small_f16x2_kernel(ConvSmallArgs 
       const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
       if (wave * 32 + row < vox) {
         const float v = sum[r] * ginv + bv;
-        o[(size_t)row * a.cout] = v;
+        if (!a.gn_gamma) o[(size_t)row * a.cout] = v;
+        hold[r] = v;
         s1 += v;
         s2 += v * v;
       }
     }
+  }
+  if (a.gn_gamma) {
+    // ---- the workgroup holds the whole (sample, channel tile): GroupNorm statistics, SiLU, shortcut, store -- what gn_apply does
+    // in a launch of its own, with the same arithmetic (fp64 group sums of the per-channel float sums, gn_defer.h)
+    __syncthreads();  // partial reads done: the head of the LDS block is free
+    float* red = (float*)cs_lds;        // [4][32][2] per-wave channel sums
+    float* coef = red + 4 * 32 * 2;     // [32][2] scale, shift
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    if (half == 0) {
+      red[(wave * 32 + col) * 2] = s1;
+      red[(wave * 32 + col) * 2 + 1] = s2;
+    }
+    __syncthreads();
+    if (tid < 32) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        t1 += red[(w * 32 + tid) * 2];
+        t2 += red[(w * 32 + tid) * 2 + 1];
+      }
+      // group sums over the tile's lanes: the cpg channels of a group are cpg consecutive lanes
+      double a1 = 0.0, a2 = 0.0;
+      const int g0 = tid - tid % a.gn_cpg;
+      for (int c = 0; c < a.gn_cpg; ++c) {
+        a1 += (double)__shfl(t1, g0 + c, 64);
+        a2 += (double)__shfl(t2, g0 + c, 64);
+      }
+      const double cnt = (double)vox * a.gn_cpg;
+      const double mu = a1 / cnt;
+      double var = a2 / cnt - mu * mu;
+      var = var < 0.0 ? 0.0 : var;
+      const float sc = (float)(1.0 / sqrt(var + 1e-5)) * a.gn_gamma[ct * 32 + tid];
+      coef[tid * 2] = sc;
+      coef[tid * 2 + 1] = a.gn_beta[ct * 32 + tid] - (float)mu * sc;
+    }
+    __syncthreads();
+    float y1 = 0.f, y2 = 0.f;
+    if (wave < NT) {
+      const float sc = coef[col * 2], sh = coef[col * 2 + 1];
+      const int c = ct * 32 + col;
+      float* o = a.out + ((size_t)b * vox + wave * 32) * a.cout + c;
+      const float* rp;
+      int rld;
+      if (a.res1 && c >= a.res_c0) {
+        rld = a.cout - a.res_c0;
+        rp = a.res1 + ((size_t)b * vox + wave * 32) * rld + (c - a.res_c0);
+      } else {
+        rld = a.res1 ? a.res_c0 : a.cout;
+        rp = a.res0 + ((size_t)b * vox + wave * 32) * rld + c;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (wave * 32 + row < vox) {
+          float u = sc * hold[r] + sh;
+          u = u * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(u * -1.4426950408889634f));  // (gn_apply's SiLU)
+          const float y = u + rp[(size_t)row * rld];
+          o[(size_t)row * a.cout] = y;
+          y1 += y;
+          y2 += y * y;
+        }
+      }
+    }
+    if (a.part_out) {
+      __syncthreads();
+      y1 += __shfl_xor(y1, 32, 64);
+      y2 += __shfl_xor(y2, 32, 64);
+      if (half == 0) {
+        red[(wave * 32 + col) * 2] = y1;
+        red[(wave * 32 + col) * 2 + 1] = y2;
+      }
+      __syncthreads();
+      if (tid < 32) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          t1 += red[(w * 32 + tid) * 2];
+          t2 += red[(w * 32 + tid) * 2 + 1];
+        }
+        float* dst = a.part_out + ((size_t)b * a.cout + ct * 32 + tid) * 2;
+        dst[0] = t1;
+        dst[1] = t2;
+      }
+    }
+    return;
   }
   if (a.ch_part) {
     __syncthreads();  // partial reads done: re-use the head of the LDS block for the statistics
@@ -283,6 +377,13 @@ bool try_launch_conv_small(const float* in0, int c0, const float* in1, int c1, c
   a.wpk = (const u32x4*)wpk_f16x2; a.CTtot = cout / 32; a.bias = bias; a.out = out; a.cout = cout; a.ch_part = fu.ch_part;
   a.D = g.in.d; a.H = g.in.h; a.W = g.in.w; a.VB = VB; a.status = fu.status;
   a.defer = fu.defer; a.coef_lds_off = (int)coef_off; a.in_absmax = fu.in_absmax;
+  a.gn_gamma = nullptr; a.gn_beta = nullptr; a.gn_cpg = 0; a.res0 = a.res1 = nullptr; a.res_c0 = 0; a.part_out = nullptr;
+  const ConvFusion::GnOut& go = fu.gn_out;
+  if (go.gamma && go.done && go.groups > 0 && cout % go.groups == 0 && 32 % (cout / go.groups) == 0 && go.res0 && !fu.in_absmax) {
+    a.gn_gamma = go.gamma; a.gn_beta = go.beta; a.gn_cpg = cout / go.groups;
+    a.res0 = go.res0; a.res1 = go.res1; a.res_c0 = go.res_c0; a.part_out = go.part_out;
+    *go.done = 1;
+  }
   const dim3 grid((unsigned)batch, (unsigned)(cout / 32));
   switch (NT) {
     case 1: launch_small_inst<1>(a, grid, lds, s); break;
@@ -290,7 +391,7 @@ bool try_launch_conv_small(const float* in0, int c0, const float* in1, int c1, c
     case 3: launch_small_inst<3>(a, grid, lds, s); break;
     default: launch_small_inst<4>(a, grid, lds, s); break;
   }
-  if (fu.units) *fu.units = fu.ch_part ? 1 : 0;
+  if (fu.units) *fu.units = (fu.ch_part && !a.gn_gamma) ? 1 : 0;
   return true;
 }
 

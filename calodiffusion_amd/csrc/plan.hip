@@ -448,7 +448,7 @@ float* stats_pass(Run& r, const float* x, int C, int64_t vox, int* units) {
 // kernel itself; coef_buf is the [B][Cin][4] table a kernel without that prologue gets materialised.
 float* conv3_with_stats(Run& r, const float* x0, int c0, const float* x1, int c1, const float* wpk, const void* wpk3,
                         const float* bias, float* out, int cout, Dims3 dims, const float* coef_in, int* units,
-                        const GnDefer* defer_in = nullptr, float* coef_buf = nullptr) {
+                        const GnDefer* defer_in = nullptr, float* coef_buf = nullptr, const ConvFusion::GnOut* gn_out = nullptr) {
   const int64_t vox = dims.vox();
   const int cap = (int)((vox + 31) / 32);
   float* part = r.ws->get<float>((size_t)r.B * cap * cout * 2);
@@ -458,8 +458,11 @@ float* conv3_with_stats(Run& r, const float* x0, int c0, const float* x1, int c1
     ConvFusion fu;
     fu.coef = coef_in; fu.act = 1; fu.ch_part = part; fu.units = &u; fu.wpk_bf16x3 = wpk3; fu.status = r.status;
     if (defer_in) { fu.defer = *defer_in; fu.coef_buf = coef_buf; fu.coef = nullptr; }
+    if (gn_out) fu.gn_out = *gn_out;
     launch_conv_mfma(x0, c0, x1, c1, wpk, bias, out, r.B, cout, g, r.s, fu);
-    if (u == 0) {  // kernel without a stats epilogue: separate pass, same buffer (nsplit <= cap)
+    if (gn_out && *gn_out->done) {
+      // (the kernel normalised its own output: `out` is the block output, there are no partials of the conv output)
+    } else if (u == 0) {  // kernel without a stats epilogue: separate pass, same buffer (nsplit <= cap)
       u = gn_nsplit_for(vox, r.B);
       if (u > cap) u = cap;
       launch_ch_stats(out, part, r.B, cout, vox, u, r.s);
@@ -489,8 +492,35 @@ float* res_block(Run& r, const ResP& w, const float* x0, int c0, const float* x1
   d1.vox = vox;
   if (!r.dry() && !defer_gn) launch_gn_finalize(p1, u1, w.n1g, w.n1b, w.emb, w.emb_ld, coef1, r.B, w.cout, G, vox, r.s);
   float* h2 = ws->get<float>((size_t)r.B * vox * w.cout);
+  // Grids of at most 128 voxels (one workgroup sees a whole sample, kernels_conv_small.hip): the second conv closes the block
+  // itself -- GroupNorm, SiLU, shortcut -- so the shortcut has to exist before it runs.
+  const bool small = vox <= 128;
+  float* po = nullptr;
+  const int bps = gn_apply_blocks_per_sample(r.B, w.cout, vox);  // partials per sample if gn_apply closes the block (else 1)
+  if (part_out) {
+    po = ws->get<float>((size_t)r.B * bps * w.cout * 2);
+    *part_out = po;
+  }
+  float* res = nullptr;
+  auto shortcut_conv = [&]() {
+    res = ws->get<float>((size_t)r.B * vox * w.cout);
+    if (!r.dry()) {
+      PointwiseArgs a;
+      a.in0 = x0; a.ld0 = c0; a.off0 = 0; a.c0 = c0; a.in1 = x1; a.ld1 = c1; a.c1 = c1;
+      a.wpk = w.rw; a.bias = w.rb; a.out = res; a.batch = r.B; a.cout = w.cout; a.vox = vox;
+      launch_pointwise(a, r.s);
+    }
+  };
+  if (small && w.has_res) shortcut_conv();
+  int fused = 0;
+  ConvFusion::GnOut go;
+  if (small && defer_gn) {
+    go.gamma = w.n2g; go.beta = w.n2b; go.groups = G; go.part_out = po; go.done = &fused;
+    if (w.has_res) { go.res0 = res; }
+    else { go.res0 = x0; go.res1 = c1 ? x1 : nullptr; go.res_c0 = c0; }
+  }
   float* p2 = conv3_with_stats(r, h1, w.cout, nullptr, 0, w.c2w, w.c2w3, w.c2b, h2, w.cout, dims, coef1, &u2, defer_gn ? &d1 : nullptr,
-                               coef1);
+                               coef1, go.gamma ? &go : nullptr);
   ws->release(p1);
   ws->release(h1);
   ws->release(coef1);
@@ -499,26 +529,14 @@ float* res_block(Run& r, const ResP& w, const float* x0, int c0, const float* x1
   d2.part = p2; d2.units = u2; d2.gamma = w.n2g; d2.beta = w.n2b; d2.C = w.cout; d2.groups = G; d2.vox = vox;
   if (!r.dry() && !defer_gn) launch_gn_finalize(p2, u2, w.n2g, w.n2b, nullptr, 0, coef2, r.B, w.cout, G, vox, r.s);
   const GnDefer* dp2 = defer_gn ? &d2 : nullptr;
-  float* po = nullptr;
-  if (part_out) {
-    const int bps = gn_apply_blocks_per_sample(r.B, w.cout, vox);
-    po = ws->get<float>((size_t)r.B * bps * w.cout * 2);
-    *part_out = po;
-    *units_out = bps;
-  }
+  if (part_out) *units_out = fused ? 1 : bps;
   if (w.has_res) {
-    float* res = ws->get<float>((size_t)r.B * vox * w.cout);
-    if (!r.dry()) {
-      PointwiseArgs a;
-      a.in0 = x0; a.ld0 = c0; a.off0 = 0; a.c0 = c0; a.in1 = x1; a.ld1 = c1; a.c1 = c1;
-      a.wpk = w.rw; a.bias = w.rb; a.out = res; a.batch = r.B; a.cout = w.cout; a.vox = vox;
-      launch_pointwise(a, r.s);
-      launch_gn_apply(h2, h2, coef2, r.B, w.cout, vox, 1, res, nullptr, 0, po, r.s, dp2);
-    }
+    if (!res) shortcut_conv();
+    if (!r.dry() && !fused) launch_gn_apply(h2, h2, coef2, r.B, w.cout, vox, 1, res, nullptr, 0, po, r.s, dp2);
     ws->release(res);
   } else {
     // identity shortcut; for a concatenated input it is read from the two sources (models.py:200,741)
-    if (!r.dry()) launch_gn_apply(h2, h2, coef2, r.B, w.cout, vox, 1, x0, c1 ? x1 : nullptr, c0, po, r.s, dp2);
+    if (!r.dry() && !fused) launch_gn_apply(h2, h2, coef2, r.B, w.cout, vox, 1, x0, c1 ? x1 : nullptr, c0, po, r.s, dp2);
   }
   ws->release(p2);
   ws->release(coef2);
