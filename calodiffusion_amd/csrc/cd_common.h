@@ -292,6 +292,11 @@ void launch_attn_combine(const float* partials, int nsplit, const float* w_out /
 
 // fused linear attention of the sampling path (kernels_attn.hip): qkv is never materialised
 int attn_fused_nsplit_for(int64_t vox, int batch);
+// whole attention block in one launch for small grids (kernels_attn.hip: attn_small_kernel)
+bool attn_small_eligible(int64_t vox);
+void launch_attn_small(const float* x, int C, const float* coef, const void* wqkv_f16x2, float* partials, const float* w_out,
+                       float scale, const float* bias, const float* out_gamma, const float* out_beta, float* y, float* ch_part,
+                       int batch, int64_t vox, hipStream_t s, const GnDefer* defer);
 void launch_attn_kv_context(const float* x, int C, const float* coef, const void* wqkv_f16x2, float* partials, int batch,
                             int64_t vox, int nsplit, hipStream_t s, const GnDefer* defer = nullptr);
 void launch_attn_out(const float* x, int C, const float* coef, const void* wqkv_f16x2, const float* wT_b, const float* bias,

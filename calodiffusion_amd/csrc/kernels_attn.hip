@@ -46,6 +46,7 @@ struct AttnArgs {
   float* y;           // (B, vox, C)
   float* ch_part;     // [B][units][C][2]
   GnDefer defer;      // PreNorm coefficients folded in the prologue instead of read from `coef`
+  const float *out_gamma, *out_beta;  // attn_small_kernel: affine parameters of the closing GroupNorm(1, C)
 };
 
 // A fragments of one 32-voxel tile for v_mfma_f32_32x32x16_f16: lane (voxel n0 + col, half) holds, per 16-channel k-step ks,
@@ -128,20 +129,14 @@ __device__ __forceinline__ void load_coef(const AttnArgs& a, int b, int half, f3
     }
 }
 
+// pass 1 of sample b over tiles [t0, t1): partial `split` of the sample
 template <int NCH>
-__global__ void __launch_bounds__(512) attn_kv_context_kernel(AttnArgs a) {
+__device__ __forceinline__ void attn_pass1(const AttnArgs& a, int b, int split, int64_t t0, int64_t t1, const f32x4 (&cf)[NCH][8]) {
   __shared__ float sMax[8][32];
   __shared__ float sSum[16][32];
   __shared__ float sCtx[8][1024];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, col = lane & 31;
-  const int split = blockIdx.x, b = blockIdx.y;
-  const int64_t T = (a.vox + 31) / 32;
-  const int64_t t0 = (int64_t)split * a.tiles_per_wg;
-  const int64_t t1 = (t0 + a.tiles_per_wg < T) ? t0 + a.tiles_per_wg : T;
-
-  f32x4 cf[NCH][8];
-  load_coef<NCH>(a, b, half, cf);
   constexpr int NKS = NCH * 2;
   u32x4 wk1[NKS], wk2[NKS], wv1[NKS], wv2[NKS];
 #pragma unroll
@@ -259,6 +254,18 @@ __global__ void __launch_bounds__(512) attn_kv_context_kernel(AttnArgs a) {
   }
 }
 
+template <int NCH>
+__global__ void __launch_bounds__(512) attn_kv_context_kernel(AttnArgs a) {
+  const int half = (threadIdx.x & 63) >> 5;
+  const int split = blockIdx.x, b = blockIdx.y;
+  const int64_t T = (a.vox + 31) / 32;
+  const int64_t t0 = (int64_t)split * a.tiles_per_wg;
+  const int64_t t1 = (t0 + a.tiles_per_wg < T) ? t0 + a.tiles_per_wg : T;
+  f32x4 cf[NCH][8];
+  load_coef<NCH>(a, b, half, cf);
+  attn_pass1<NCH>(a, b, split, t0, t1, cf);
+}
+
 // Merge of the pass-1 partials and fold of the context into the output projection, by every workgroup of pass 2 for its own
 // sample (same arithmetic, in the same order, as attn_combine_kernel, kernels_norm_attn.hip: the separate launch was 11 us of
 // pure latency per attention block):  W'[c][d] = scale * sum_e W_out[c][e] ctx[d][e] / sum[d]  in the k-slot order of an
@@ -296,18 +303,13 @@ __device__ __forceinline__ void attn_fold_weights(const AttnArgs& a, int b, floa
   __syncthreads();
 }
 
+// pass 2 of sample b over tiles [t0, t1): y and, as unit `unit` of `nunits`, its channel partials
 template <int NCH>
-__global__ void __launch_bounds__(512) attn_out_kernel(AttnArgs a) {
+__device__ __forceinline__ void attn_pass2(const AttnArgs& a, int b, int unit, int nunits, int64_t t0, int64_t t1,
+                                           const f32x4 (&cf)[NCH][8]) {
   __shared__ float sRed[8][NCH * 32][2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, col = lane & 31;
-  const int unit = blockIdx.x, b = blockIdx.y;
-  const int64_t T = (a.vox + 31) / 32;
-  const int64_t t0 = (int64_t)unit * a.tiles_per_wg;
-  const int64_t t1 = (t0 + a.tiles_per_wg < T) ? t0 + a.tiles_per_wg : T;
-
-  f32x4 cf[NCH][8];
-  load_coef<NCH>(a, b, half, cf);
   constexpr int NKS = NCH * 2;
   u32x4 wq1[NKS], wq2[NKS];
 #pragma unroll
@@ -414,10 +416,77 @@ __global__ void __launch_bounds__(512) attn_out_kernel(AttnArgs a) {
         r1 += sRed[w][tid][0];
         r2 += sRed[w][tid][1];
       }
-      float* dst = a.ch_part + (((size_t)b * gridDim.x + unit) * a.C + tid) * 2;
+      float* dst = a.ch_part + (((size_t)b * nunits + unit) * a.C + tid) * 2;
       dst[0] = r1;
       dst[1] = r2;
     }
+  }
+}
+
+template <int NCH>
+__global__ void __launch_bounds__(512) attn_out_kernel(AttnArgs a) {
+  const int half = (threadIdx.x & 63) >> 5;
+  const int unit = blockIdx.x, b = blockIdx.y;
+  const int64_t T = (a.vox + 31) / 32;
+  const int64_t t0 = (int64_t)unit * a.tiles_per_wg;
+  const int64_t t1 = (t0 + a.tiles_per_wg < T) ? t0 + a.tiles_per_wg : T;
+  f32x4 cf[NCH][8];
+  load_coef<NCH>(a, b, half, cf);
+  attn_pass2<NCH>(a, b, unit, (int)gridDim.x, t0, t1, cf);
+}
+
+// The whole Residual(PreNorm(LinearAttention)) of one sample in ONE workgroup, for grids of a few hundred voxels (Dataset-2 below
+// level 0: 736 and 96 voxels), where the three launches of the general path -- pass 1, pass 2, GroupNorm + residual -- are three
+// times a launch and a prologue for microseconds of work: pass 1 over all the sample's tiles, its {max, sum, context} through the
+// (L2-resident) partial buffer into the fold of pass 2, pass 2 with y written un-normalised, then the closing GroupNorm(1, C)
+// from the workgroup's own channel sums (the arithmetic of gn_defer.h) and  out = gn(y) + x  in place.
+template <int NCH>
+__global__ void __launch_bounds__(512) attn_small_kernel(AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) float sOut[NCH * 32][2];  // {scale, shift} of the closing GroupNorm per channel
+  __shared__ double sTot[2];
+  const int tid = threadIdx.x, half = (tid & 63) >> 5;
+  const int b = blockIdx.x;
+  const int64_t T = (a.vox + 31) / 32;
+  f32x4 cf[NCH][8];
+  load_coef<NCH>(a, b, half, cf);
+  attn_pass1<NCH>(a, b, 0, 0, T, cf);
+  __threadfence_block();
+  __syncthreads();  // the partial of this sample is in memory (written and read by this workgroup only)
+  attn_pass2<NCH>(a, b, 0, 1, 0, T, cf);
+  __threadfence_block();
+  __syncthreads();  // y and its channel sums are in memory
+  const int C = NCH * 32;
+  const float* cp = a.ch_part + (size_t)b * C * 2;
+  if (tid == 0) {
+    double a1 = 0.0, a2 = 0.0;
+    for (int c = 0; c < C; ++c) {
+      a1 += (double)cp[c * 2];
+      a2 += (double)cp[c * 2 + 1];
+    }
+    const double cnt = (double)a.vox * C;
+    const double mu = a1 / cnt;
+    double var = a2 / cnt - mu * mu;
+    var = var < 0.0 ? 0.0 : var;
+    sTot[0] = mu;
+    sTot[1] = 1.0 / sqrt(var + 1e-5);
+  }
+  __syncthreads();
+  if (tid < C) {
+    const float sc = (float)sTot[1] * a.out_gamma[tid];
+    sOut[tid][0] = sc;
+    sOut[tid][1] = a.out_beta[tid] - (float)sTot[0] * sc;
+  }
+  __syncthreads();
+  float* const yb = a.y + (size_t)b * a.vox * C;
+  const float* const xb = a.x + (size_t)b * a.vox * C;
+  const int64_t n4 = a.vox * C / 4;
+  for (int64_t i = tid; i < n4; i += 512) {
+    const int c = (int)((i * 4) % C);
+    const f32x4 y = ((const f32x4*)yb)[i], x = ((const f32x4*)xb)[i];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = sOut[c + e][0] * y[e] + sOut[c + e][1] + x[e];
+    ((f32x4*)yb)[i] = o;
   }
 }
 
@@ -486,6 +555,35 @@ void launch_attn_out(const float* x, int C, const float* coef, const void* wqkv_
     case 2: hipLaunchKernelGGL(attn_out_kernel<2>, grid, dim3(512), 0, s, a); break;
     case 3: hipLaunchKernelGGL(attn_out_kernel<3>, grid, dim3(512), 0, s, a); break;
     default: hipLaunchKernelGGL(attn_out_kernel<4>, grid, dim3(512), 0, s, a); break;
+  }
+  CD_HIP(hipGetLastError());
+}
+
+// One launch for the whole block (see attn_small_kernel).  partials: [B][64 + 1024]; ch_part: [B][C][2]; y: (B, vox, C), the block
+// output.  Eligible: attn_small_eligible(vox).
+bool attn_small_eligible(int64_t vox) {
+  static const int max_vox = getenv("CD_ATTN_SMALL_MAX") ? atoi(getenv("CD_ATTN_SMALL_MAX")) : 1024;  // <= 4 tiles per wave
+  return vox <= max_vox;
+}
+void launch_attn_small(const float* x, int C, const float* coef, const void* wqkv_f16x2, float* partials, const float* w_out,
+                       float scale, const float* bias, const float* out_gamma, const float* out_beta, float* y, float* ch_part,
+                       int batch, int64_t vox, hipStream_t s, const GnDefer* defer) {
+  CD_REQUIRE(C == 32 || C == 64 || C == 96 || C == 128, "fused attention: 32..128 channels");
+  CD_REQUIRE((vox * C) % 4 == 0, "fused attention: whole float4 rows");
+  AttnArgs a{};
+  a.x = x; a.coef = coef; a.wqkv = (const u32x4*)wqkv_f16x2; a.C = C; a.vox = vox; a.tiles_per_wg = tiles_per_wg_for(vox, 1);
+  a.partials = partials; a.nsplit = 1; a.wT = nullptr; a.fold_wout = w_out; a.fold_scale = scale; a.bias = bias;
+  a.y = y; a.ch_part = ch_part; a.out_gamma = out_gamma; a.out_beta = out_beta;
+  if (defer) a.defer = *defer;
+  char cat[64];
+  std::snprintf(cat, sizeof cat, "attn_small C%d n%ld", C, (long)vox);
+  prof::Scope scope(cat, s, 2.0 * (4.0 * C + 32) * 32 * (double)vox * batch, 4.0 * batch * (double)vox * C * 3);
+  const dim3 grid((unsigned)batch);
+  switch (C / 32) {
+    case 1: hipLaunchKernelGGL(attn_small_kernel<1>, grid, dim3(512), 0, s, a); break;
+    case 2: hipLaunchKernelGGL(attn_small_kernel<2>, grid, dim3(512), 0, s, a); break;
+    case 3: hipLaunchKernelGGL(attn_small_kernel<3>, grid, dim3(512), 0, s, a); break;
+    default: hipLaunchKernelGGL(attn_small_kernel<4>, grid, dim3(512), 0, s, a); break;
   }
   CD_HIP(hipGetLastError());
 }

@@ -565,6 +565,8 @@ float* attn_block(Run& r, const AttnP& w, const float* x, Dims3 dims, float* xpa
   float* y = nullptr;
   float* ypart = nullptr;
   int yu = 0;
+  // grids of a few hundred voxels: the whole block -- both passes, the closing GroupNorm and the residual -- in one launch
+  const bool single = !no_fused && defer_gn && attn_small_eligible(vox);
   if (!no_fused) {
     // fused path (kernels_attn.hip): x -> {max, sum, context} partials -> per-sample folded W_out -> y; qkv never exists
     const int nsp = attn_fused_nsplit_for(vox, r.B);
@@ -573,7 +575,10 @@ float* attn_block(Run& r, const AttnP& w, const float* x, Dims3 dims, float* xpa
     y = ws->get<float>((size_t)r.B * vox * C);
     yu = nsp;
     ypart = ws->get<float>((size_t)r.B * yu * C * 2);
-    if (!r.dry()) {
+    if (!r.dry() && single) {
+      launch_attn_small(x, C, coefn, w.qkv16, part, w.ow, 0.17677669529663689f /* 32^-1/2 */, w.ob, w.gg, w.gb, y, ypart, r.B, vox,
+                        r.s, dnp);
+    } else if (!r.dry()) {
       launch_attn_kv_context(x, C, coefn, w.qkv16, part, r.B, vox, nsp, r.s, dnp);
       static const bool sep_combine = getenv("CD_ATTN_COMBINE_LAUNCH") != nullptr;  // A/B: the separate combine launch
       if (sep_combine) {
@@ -619,7 +624,7 @@ float* attn_block(Run& r, const AttnP& w, const float* x, Dims3 dims, float* xpa
 }
   if (own) ws->release(own);
   float* coefg = ws->get<float>((size_t)r.B * C * 4);
-  if (!r.dry()) {
+  if (!r.dry() && !single) {
     GnDefer dg;
     dg.part = ypart; dg.units = yu; dg.gamma = w.gg; dg.beta = w.gb; dg.C = C; dg.groups = 1; dg.vox = vox;
     if (!defer_gn) launch_gn_finalize(ypart, yu, w.gg, w.gb, nullptr, 0, coefg, r.B, C, 1, vox, r.s);
