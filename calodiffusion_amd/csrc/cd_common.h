@@ -292,6 +292,12 @@ void launch_attn_combine(const float* partials, int nsplit, const float* w_out /
 
 // fused linear attention of the sampling path (kernels_attn.hip): qkv is never materialised
 int attn_fused_nsplit_for(int64_t vox, int batch);
+// whole ResnetBlock in one launch where a sample is <= 128 voxels and the block is 32 channels wide (kernels_conv_small.hip)
+bool try_launch_res_block_small(const float* x0, int c0, const float* x1, int c1, const void* w1_f16x2, const float* b1,
+                                const float* gn1_gamma, const float* gn1_beta, const float* emb, int emb_ld, const void* w2_f16x2,
+                                const float* b2, const float* gn2_gamma, const float* gn2_beta, int groups, const float* res0,
+                                const float* res1, int res_c0, float* h1, float* out, float* part_out, int batch, int cout,
+                                Dims3 dims, int* status, hipStream_t s);
 // whole attention block in one launch for small grids (kernels_attn.hip: attn_small_kernel)
 bool attn_small_eligible(int64_t vox);
 void launch_attn_small(const float* x, int C, const float* coef, const void* wqkv_f16x2, float* partials, const float* w_out,

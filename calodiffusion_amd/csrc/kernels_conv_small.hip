@@ -46,6 +46,14 @@ struct ConvSmallArgs {
   const float *res0, *res1;
   int res_c0;
   float* part_out;
+  // whole ResnetBlock (cout == 32: one workgroup owns all channels of the sample): wpk2 != null.  The launch runs
+  //   conv1 (wpk, bias) -> GroupNorm(gn1) + SiLU + embedding -> conv2 (wpk2, bias2) -> the closing GroupNorm + SiLU + shortcut above;
+  // conv1's raw output goes through `h1` ((B, vox, 32), L2-resident: written and re-read by this workgroup only).
+  const u32x4* wpk2;
+  const float* bias2;
+  const float *gn1_gamma, *gn1_beta, *emb;  // emb: (B, emb_ld) slice of this block or null
+  int emb_ld;
+  float* h1;
 };
 
 constexpr int CS_PD = 6;  // weight fragments requested this many pairs ahead
@@ -58,7 +66,6 @@ __global__ void __launch_bounds__(256, 1) conv_small_f16x2_kernel(ConvSmallArgs 
   const int D = a.D, H = a.H, W = a.W, PV = H * W, vox = D * PV;
   const int pitch = W + 1, prow = (H + 2) * pitch;  // records per row / per plane
   const int nrec = (D + 2) * prow;
-  const int cin = a.c0 + a.c1;
   const int VB = a.VB;
   char* const part = cs_lds;  // the partial exchange re-uses the image after the last MFMA
 
@@ -75,16 +82,20 @@ __global__ void __launch_bounds__(256, 1) conv_small_f16x2_kernel(ConvSmallArgs 
   }
 
   f32x16 accA[NT], accB[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) accA[t][r] = accB[t][r] = 0.f;
   float amax = 0.f;
   float gscale = 1.f, ginv = 1.f;
   if (a.in_absmax) pow2_scale_for(*a.in_absmax, &gscale, &ginv);
   if (a.defer.part) gn_defer_to_lds(a.defer, b, (float*)(cs_lds + a.coef_lds_off), cs_lds + a.coef_lds_off + a.defer.C * 16);
-  const bool normed = a.coef || a.defer.part;
 
+  // one convolution of the sample: input (in0 | in1), optionally normalised (coefficients from the LDS table or `coef`), into accA / accB
+  auto conv_pass = [&](const float* in0, const float* in1, int c0, int c1, const float* coef_g, bool lds_table, int act,
+                       const u32x4* wpk_pass) {
+  const int cin = c0 + c1;
+  const bool normed = coef_g || lds_table;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accA[t][r] = accB[t][r] = 0.f;
   for (int cb = 0; cb < cin; cb += 64) {  // input channels in blocks of <= 64
     const int cn = min(64, cin - cb);     // channels in this block (multiple of 16)
     const int nq = cn >> 2;               // channel quads per voxel
@@ -95,7 +106,7 @@ __global__ void __launch_bounds__(256, 1) conv_small_f16x2_kernel(ConvSmallArgs 
     // this wave's first weight fragments are requested now: their L2 latency hides behind the staging
     const int npairs = 27 * (cn >> 4);
     const int mine = (npairs - wave + 3) >> 2;
-    const u32x4* wbase = a.wpk + lane;
+    const u32x4* wbase = wpk_pass + lane;
     auto wptr = [&](int i) {  // pair index i of this wave -> weight fragment pointer
       const int p = wave + 4 * i;
       const int ks = p / 27, tap = p - ks * 27;
@@ -117,7 +128,7 @@ __global__ void __launch_bounds__(256, 1) conv_small_f16x2_kernel(ConvSmallArgs 
         const int i = min(i0 + k * 256, vox * nq - 1);
         const int v = i / nq, q = i - v * nq;
         const int c = cb + q * 4;
-        const float* src = c < a.c0 ? a.in0 + ((size_t)b * vox + v) * a.c0 + c : a.in1 + ((size_t)b * vox + v) * a.c1 + (c - a.c0);
+        const float* src = c < c0 ? in0 + ((size_t)b * vox + v) * c0 + c : in1 + ((size_t)b * vox + v) * c1 + (c - c0);
         xs[k] = *(const f32x4*)src;
       }
 #pragma unroll
@@ -130,10 +141,10 @@ __global__ void __launch_bounds__(256, 1) conv_small_f16x2_kernel(ConvSmallArgs 
         if (normed) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const f32x4 cf = a.defer.part ? *(const f32x4*)(cs_lds + a.coef_lds_off + (c + e) * 16)
-                                          : *(const f32x4*)(a.coef + ((size_t)b * cin + c + e) * 4);
+            const f32x4 cf = lds_table ? *(const f32x4*)(cs_lds + a.coef_lds_off + (c + e) * 16)
+                                       : *(const f32x4*)(coef_g + ((size_t)b * cin + c + e) * 4);
             float t = cf[0] * x[e] + cf[1];
-            if (a.act) t = cd_fast_silu(t);
+            if (act) t = cd_fast_silu(t);
             x[e] = t + cf[2];
           }
         }
@@ -188,9 +199,11 @@ __global__ void __launch_bounds__(256, 1) conv_small_f16x2_kernel(ConvSmallArgs 
       }
     }
   }
+  };  // conv_pass
 
-  if (a.status && amax > 65504.f) atomicOr(a.status, 1);
-  // ---- exchange the K-slices: wave t sums tile t -----------------------------------------------------------------
+  // ---- exchange the K-slices: wave t sums tile t -> its 16 rows x (channel = col), bias added ------------------------
+  float hold[16];
+  auto reduce_tiles = [&](const float* bias_pass) {
   __syncthreads();
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
@@ -202,10 +215,8 @@ __global__ void __launch_bounds__(256, 1) conv_small_f16x2_kernel(ConvSmallArgs 
                                       accA[t][4 * g + 3] + accB[t][4 * g + 3] * (1.f / 2048.f)};
   }
   __syncthreads();
-  float s1 = 0.f, s2 = 0.f;
-  float hold[16];  // (gn_gamma: the conv output stays in registers until it is normalised)
   if (wave < NT) {
-    const float bv = a.bias ? a.bias[ct * 32 + col] : 0.f;
+    const float bv = bias_pass ? bias_pass[ct * 32 + col] : 0.f;
     f32x16 sum;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
@@ -217,25 +228,32 @@ __global__ void __launch_bounds__(256, 1) conv_small_f16x2_kernel(ConvSmallArgs 
         for (int e = 0; e < 4; ++e) sum[4 * g + e] = w == 0 ? x[e] : sum[4 * g + e] + x[e];
       }
     }
-    float* o = a.out + ((size_t)b * vox + wave * 32) * a.cout + ct * 32 + col;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (wave * 32 + row < vox) {
-        const float v = sum[r] * ginv + bv;
-        if (!a.gn_gamma) o[(size_t)row * a.cout] = v;
-        hold[r] = v;
-        s1 += v;
-        s2 += v * v;
+    for (int r = 0; r < 16; ++r) hold[r] = sum[r] * ginv + bv;
+  }
+  };  // reduce_tiles
+  // per-channel sums of the held tile rows; store (optional) of the raw conv output
+  auto tile_stats = [&](float* store_to, int ld, float& s1, float& s2) {
+    s1 = s2 = 0.f;
+    if (wave < NT) {
+      float* o = store_to ? store_to + ((size_t)b * vox + wave * 32) * ld + ct * 32 + col : nullptr;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (wave * 32 + row < vox) {
+          const float v = hold[r];
+          if (o) o[(size_t)row * ld] = v;
+          s1 += v;
+          s2 += v * v;
+        }
       }
     }
-  }
-  if (a.gn_gamma) {
-    // ---- the workgroup holds the whole (sample, channel tile): GroupNorm statistics, SiLU, shortcut, store -- what gn_apply does
-    // in a launch of its own, with the same arithmetic (fp64 group sums of the per-channel float sums, gn_defer.h)
-    __syncthreads();  // partial reads done: the head of the LDS block is free
-    float* red = (float*)cs_lds;        // [4][32][2] per-wave channel sums
-    float* coef = red + 4 * 32 * 2;     // [32][2] scale, shift
+  };
+  // GroupNorm of the held (sample, 32-channel tile) from its own sums: {scale, shift} of channel col into out2[col * stride ...]
+  // -- the arithmetic of gn_defer.h (fp64 group sums of the per-channel float sums).  Ends with a barrier.
+  auto group_norm_coef = [&](float s1, float s2, const float* gamma, const float* beta, int cpg, float* red, float* dst, int stride,
+                             const float* add, int add_ld) {
+    __syncthreads();  // previous users of the head of the LDS block are done
     s1 += __shfl_xor(s1, 32, 64);
     s2 += __shfl_xor(s2, 32, 64);
     if (half == 0) {
@@ -252,23 +270,53 @@ __global__ void __launch_bounds__(256, 1) conv_small_f16x2_kernel(ConvSmallArgs 
       }
       // group sums over the tile's lanes: the cpg channels of a group are cpg consecutive lanes
       double a1 = 0.0, a2 = 0.0;
-      const int g0 = tid - tid % a.gn_cpg;
-      for (int c = 0; c < a.gn_cpg; ++c) {
+      const int g0 = tid - tid % cpg;
+      for (int c = 0; c < cpg; ++c) {
         a1 += (double)__shfl(t1, g0 + c, 64);
         a2 += (double)__shfl(t2, g0 + c, 64);
       }
-      const double cnt = (double)vox * a.gn_cpg;
+      const double cnt = (double)vox * cpg;
       const double mu = a1 / cnt;
       double var = a2 / cnt - mu * mu;
       var = var < 0.0 ? 0.0 : var;
-      const float sc = (float)(1.0 / sqrt(var + 1e-5)) * a.gn_gamma[ct * 32 + tid];
-      coef[tid * 2] = sc;
-      coef[tid * 2 + 1] = a.gn_beta[ct * 32 + tid] - (float)mu * sc;
+      const float sc = (float)(1.0 / sqrt(var + 1e-5)) * gamma[ct * 32 + tid];
+      dst[tid * stride] = sc;
+      dst[tid * stride + 1] = beta[ct * 32 + tid] - (float)mu * sc;
+      if (stride == 4) {
+        dst[tid * 4 + 2] = add ? add[(size_t)b * add_ld + ct * 32 + tid] : 0.f;
+        dst[tid * 4 + 3] = 0.f;
+      }
     }
     __syncthreads();
+  };
+
+  // one pass = one convolution; a whole ResnetBlock (wpk2) is two, conv1's GroupNorm + SiLU + embedding being folded into the staging
+  // of conv2 through the coefficient table in LDS.  (One loop body instead of two call sites of the lambdas: each is inlined once.)
+  float s1 = 0.f, s2 = 0.f;
+  float* const red = (float*)cs_lds;                        // [4][32][2] per-wave channel sums (head of the image region)
+  float* const table = (float*)(cs_lds + a.coef_lds_off);   // [32][4] {scale, shift, add, 0} of the GroupNorm this workgroup computes
+  const int npass = a.wpk2 ? 2 : 1;
+  for (int pass = 0; pass < npass; ++pass) {
+    const bool second = pass == 1, last = pass == npass - 1;
+    conv_pass(second ? a.h1 : a.in0, second ? nullptr : a.in1, second ? 32 : a.c0, second ? 0 : a.c1, second ? nullptr : a.coef,
+              second ? true : a.defer.part != nullptr, second ? 1 : a.act, second ? a.wpk2 : a.wpk);
+    reduce_tiles(second ? a.bias2 : a.bias);
+    tile_stats(last ? (a.gn_gamma ? nullptr : a.out) : a.h1, last ? a.cout : 32, s1, s2);
+    if (!last || a.gn_gamma)
+      group_norm_coef(s1, s2, last ? a.gn_gamma : a.gn1_gamma, last ? a.gn_beta : a.gn1_beta, a.gn_cpg, red, table, 4,
+                      last ? nullptr : a.emb, a.emb_ld);
+    if (!last) {
+      __threadfence_block();
+      __syncthreads();  // h1 is in memory
+    }
+  }
+  if (a.status && amax > 65504.f) atomicOr(a.status, 1);
+  if (a.gn_gamma) {
+    // ---- the workgroup holds the whole (sample, channel tile): GroupNorm + SiLU, shortcut, store -- what gn_apply does in a launch of
+    // its own, with the same arithmetic
     float y1 = 0.f, y2 = 0.f;
     if (wave < NT) {
-      const float sc = coef[col * 2], sh = coef[col * 2 + 1];
+      const float sc = table[col * 4], sh = table[col * 4 + 1];
       const int c = ct * 32 + col;
       float* o = a.out + ((size_t)b * vox + wave * 32) * a.cout + c;
       const float* rp;
@@ -370,7 +418,9 @@ bool try_launch_conv_small(const float* in0, int c0, const float* in1, int c1, c
   size_t lds = image > partial ? image : partial;
   lds = (lds + 255) & ~(size_t)255;
   const size_t coef_off = lds;
+  // coefficient table: of the deferred input normalisation and / or of the GroupNorm the kernel computes itself ([32][4] floats)
   if (fu.defer.part) lds += (size_t)fu.defer.C * 16 + gn_defer_scratch_bytes(fu.defer.C);
+  else if (fu.gn_out.gamma) lds += 512;
   if (lds > 160 * 1024) return false;
   ConvSmallArgs a;
   a.in0 = in0; a.in1 = in1; a.c0 = c0; a.c1 = c1; a.coef = fu.coef; a.act = fu.act;
@@ -378,6 +428,7 @@ bool try_launch_conv_small(const float* in0, int c0, const float* in1, int c1, c
   a.D = g.in.d; a.H = g.in.h; a.W = g.in.w; a.VB = VB; a.status = fu.status;
   a.defer = fu.defer; a.coef_lds_off = (int)coef_off; a.in_absmax = fu.in_absmax;
   a.gn_gamma = nullptr; a.gn_beta = nullptr; a.gn_cpg = 0; a.res0 = a.res1 = nullptr; a.res_c0 = 0; a.part_out = nullptr;
+  a.wpk2 = nullptr; a.bias2 = nullptr; a.gn1_gamma = a.gn1_beta = a.emb = nullptr; a.emb_ld = 0; a.h1 = nullptr;
   const ConvFusion::GnOut& go = fu.gn_out;
   if (go.gamma && go.done && go.groups > 0 && cout % go.groups == 0 && 32 % (cout / go.groups) == 0 && go.res0 && !fu.in_absmax) {
     a.gn_gamma = go.gamma; a.gn_beta = go.beta; a.gn_cpg = cout / go.groups;
@@ -392,6 +443,48 @@ bool try_launch_conv_small(const float* in0, int c0, const float* in1, int c1, c
     default: launch_small_inst<4>(a, grid, lds, s); break;
   }
   if (fu.units) *fu.units = (fu.ch_part && !a.gn_gamma) ? 1 : 0;
+  return true;
+}
+
+// Whole ResnetBlock in one launch (see ConvSmallArgs::wpk2): cout == 32, the sample <= 128 voxels, f16x2 arithmetic.
+//   out = silu(gn2(conv2(silu(gn1(conv1(x0 | x1))) + emb))) + shortcut;  h1: (B, vox, 32) scratch.  Returns false if not eligible.
+bool try_launch_res_block_small(const float* x0, int c0, const float* x1, int c1, const void* w1_f16x2, const float* b1,
+                                const float* gn1_gamma, const float* gn1_beta, const float* emb, int emb_ld, const void* w2_f16x2,
+                                const float* b2, const float* gn2_gamma, const float* gn2_beta, int groups, const float* res0,
+                                const float* res1, int res_c0, float* h1, float* out, float* part_out, int batch, int cout,
+                                Dims3 dims, int* status, hipStream_t s) {
+  if (getenv("CD_NO_CONV_SMALL") || getenv("CD_NO_BLOCK_SMALL")) return false;
+  const int64_t vox = dims.vox();
+  const int cin = c0 + c1;
+  if (vox > 128 || vox < 1 || cout != 32 || cin % 16 || c0 % 4 || c1 % 4 || groups <= 0 || 32 % groups || !res0) return false;
+  const int VB = (cin < 64 ? cin : 64) * 4 + 16;  // (conv2's 32 input channels need no more)
+  const int NT = (int)((vox + 31) / 32);
+  const size_t image = (size_t)(dims.d + 2) * (dims.h + 2) * (dims.w + 1) * VB;
+  const size_t partial = (size_t)NT * 4 * 4096;
+  size_t lds = image > partial ? image : partial;
+  lds = (lds + 255) & ~(size_t)255;
+  const size_t coef_off = lds;
+  lds += 512;
+  if (lds > 160 * 1024) return false;
+  ConvSmallArgs a;
+  a.in0 = x0; a.in1 = x1; a.c0 = c0; a.c1 = c1; a.coef = nullptr; a.act = 0;
+  a.wpk = (const u32x4*)w1_f16x2; a.CTtot = 1; a.bias = b1; a.out = out; a.cout = 32; a.ch_part = nullptr;
+  a.D = dims.d; a.H = dims.h; a.W = dims.w; a.VB = VB; a.status = status;
+  a.defer = GnDefer(); a.coef_lds_off = (int)coef_off; a.in_absmax = nullptr;
+  a.gn_gamma = gn2_gamma; a.gn_beta = gn2_beta; a.gn_cpg = 32 / groups; a.res0 = res0; a.res1 = res1; a.res_c0 = res_c0;
+  a.part_out = part_out;
+  a.wpk2 = (const u32x4*)w2_f16x2; a.bias2 = b2; a.gn1_gamma = gn1_gamma; a.gn1_beta = gn1_beta; a.emb = emb; a.emb_ld = emb_ld;
+  a.h1 = h1;
+  char cat[96];
+  std::snprintf(cat, sizeof cat, "resblock_small C%d->32 @%dx%dx%d", cin, dims.d, dims.h, dims.w);
+  prof::Scope scope(cat, s, 2.0 * 27 * (cin + 32) * 32 * (double)vox * batch, 4.0 * batch * (double)vox * (cin + 64));
+  const dim3 grid((unsigned)batch, 1u);
+  switch (NT) {
+    case 1: launch_small_inst<1>(a, grid, lds, s); break;
+    case 2: launch_small_inst<2>(a, grid, lds, s); break;
+    case 3: launch_small_inst<3>(a, grid, lds, s); break;
+    default: launch_small_inst<4>(a, grid, lds, s); break;
+  }
   return true;
 }
 

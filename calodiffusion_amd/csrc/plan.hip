@@ -485,7 +485,11 @@ float* res_block(Run& r, const ResP& w, const float* x0, int c0, const float* x1
   int u1 = 0, u2 = 0;
   static const bool defer_gn = getenv("CD_NO_GNDEFER") == nullptr;  // consumers fold the GroupNorm coefficients (gn_defer.h)
   float* h1 = ws->get<float>((size_t)r.B * vox * w.cout);
-  float* p1 = conv3_with_stats(r, x0, c0, x1, c1, w.c1w, w.c1w3, w.c1b, h1, w.cout, dims, nullptr, &u1);
+  // a 32-channel block on a grid of <= 128 voxels is ONE launch (kernels_conv_small.hip): decided below, once the shortcut exists
+  const bool whole = vox <= 128 && w.cout == 32 && defer_gn && conv_precision() == PREC_F16X2 && w.c1w3 && w.c2w3;
+  float* p1 = nullptr;
+  if (!whole) p1 = conv3_with_stats(r, x0, c0, x1, c1, w.c1w, w.c1w3, w.c1b, h1, w.cout, dims, nullptr, &u1);
+  else p1 = ws->get<float>((size_t)r.B * ((vox + 31) / 32) * w.cout * 2);  // (same block as conv3_with_stats would take)
   float* coef1 = ws->get<float>((size_t)r.B * w.cout * 4);
   GnDefer d1;
   d1.part = p1; d1.units = u1; d1.gamma = w.n1g; d1.beta = w.n1b; d1.add = w.emb; d1.add_ld = w.emb_ld; d1.C = w.cout; d1.groups = G;
@@ -513,14 +517,26 @@ float* res_block(Run& r, const ResP& w, const float* x0, int c0, const float* x1
   };
   if (small && w.has_res) shortcut_conv();
   int fused = 0;
+  if (whole && !r.dry()) {
+    const float* sc0 = w.has_res ? res : x0;
+    const float* sc1 = w.has_res ? nullptr : (c1 ? x1 : nullptr);
+    if (try_launch_res_block_small(x0, c0, x1, c1, (const char*)w.c1w3 + packed_bf16x3_bytes(c0 + c1, 32, 27), w.c1b, w.n1g, w.n1b,
+                                   w.emb, w.emb_ld, (const char*)w.c2w3 + packed_bf16x3_bytes(32, 32, 27), w.c2b, w.n2g, w.n2b, G, sc0,
+                                   sc1, w.has_res ? 0 : c0, h1, h2, po, r.B, w.cout, dims, r.status, r.s))
+      fused = 2;
+    else
+      p1 = (ws->release(p1), conv3_with_stats(r, x0, c0, x1, c1, w.c1w, w.c1w3, w.c1b, h1, w.cout, dims, nullptr, &u1));
+  }
   ConvFusion::GnOut go;
-  if (small && defer_gn) {
+  if (small && defer_gn && fused != 2) {
     go.gamma = w.n2g; go.beta = w.n2b; go.groups = G; go.part_out = po; go.done = &fused;
     if (w.has_res) { go.res0 = res; }
     else { go.res0 = x0; go.res1 = c1 ? x1 : nullptr; go.res_c0 = c0; }
   }
-  float* p2 = conv3_with_stats(r, h1, w.cout, nullptr, 0, w.c2w, w.c2w3, w.c2b, h2, w.cout, dims, coef1, &u2, defer_gn ? &d1 : nullptr,
-                               coef1, go.gamma ? &go : nullptr);
+  float* p2 = nullptr;
+  if (fused == 2) p2 = ws->get<float>((size_t)r.B * ((vox + 31) / 32) * w.cout * 2);  // (conv2 ran inside the block launch)
+  else p2 = conv3_with_stats(r, h1, w.cout, nullptr, 0, w.c2w, w.c2w3, w.c2b, h2, w.cout, dims, coef1, &u2, defer_gn ? &d1 : nullptr,
+                             coef1, go.gamma ? &go : nullptr);
   ws->release(p1);
   ws->release(h1);
   ws->release(coef1);
