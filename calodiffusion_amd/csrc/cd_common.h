@@ -349,6 +349,10 @@ struct HeadArgs {
   float* out = nullptr;       // (B, vox): F (raw) or x0
   int batch = 0;
   int64_t vox = 0;
+  // The closing GroupNorm + SiLU + identity shortcut of the final ResnetBlock applied on the fly (defer.part != null): h is then
+  // that block's second conv output and `res` its input; saves the block's own elementwise pass over the level-0 tensor.
+  GnDefer defer;
+  const float* res = nullptr;
 };
 void launch_head(const HeadArgs& a, hipStream_t s);
 

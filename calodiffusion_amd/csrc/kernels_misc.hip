@@ -1,6 +1,7 @@
 // Small kernels around the U-Net: conditioning MLPs, EDM pre-conditioning head, sampler update, Philox noise,
 // loss reduction and layout transposes.
 #include "cd_common.h"
+#include "gn_defer.h"
 
 #include <cmath>
 
@@ -194,7 +195,58 @@ __global__ void __launch_bounds__(256) head_kernel(HeadArgs a) {
   }
 }
 
+// the same with the final ResnetBlock's GroupNorm(8) + SiLU + shortcut folded in: workgroups belong to one sample (blockIdx.y)
+__global__ void __launch_bounds__(256) head_gn_kernel(HeadArgs a) {
+  __shared__ __attribute__((aligned(16))) float sCoef[32 * 4];
+  __shared__ __attribute__((aligned(16))) char sDefer[32 * 16 + 64 * 8];
+  const int b = blockIdx.y;
+  gn_defer_to_lds(a.defer, b, sCoef, sDefer);
+  const int sub = threadIdx.x & 7;
+  const f32x4 w = *(const f32x4*)(a.w + sub * 4);
+  const float bias = a.bias[0];
+  f32x4 cf[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) cf[e] = *(const f32x4*)(sCoef + (sub * 4 + e) * 4);
+  const int64_t per = (a.vox + gridDim.x - 1) / gridDim.x;
+  const int64_t v0 = (int64_t)blockIdx.x * per, v1 = v0 + per < a.vox ? v0 + per : a.vox;
+  for (int64_t v = v0 + (threadIdx.x >> 3); v < v1; v += 32) {
+    const int64_t i = (int64_t)b * a.vox + v;
+    f32x4 h = *(const f32x4*)(a.h + (size_t)i * 32 + sub * 4);
+    const f32x4 r = *(const f32x4*)(a.res + (size_t)i * 32 + sub * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float u = cf[e][0] * h[e] + cf[e][1];
+      u = u * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(u * -1.4426950408889634f));  // (gn_apply's SiLU)
+      h[e] = u + cf[e][2] + r[e];
+    }
+    float p = (h[0] * w[0] + h[1] * w[1]) + (h[2] * w[2] + h[3] * w[3]);
+    p += __shfl_xor(p, 1, 64);
+    p += __shfl_xor(p, 2, 64);
+    p += __shfl_xor(p, 4, 64);
+    if (sub == 0) {
+      float pred = p + bias;
+      if (a.scal) {
+        const float xv = a.x[i];
+        if (a.objective == 0) pred = a.scal[b * 4 + 1] * xv + a.scal[b * 4 + 2] * pred;
+        else if (a.objective == 1) pred = xv - a.scal[b * 4 + 3] * pred;
+      }
+      a.out[i] = pred;
+    }
+  }
+}
+
 void launch_head(const HeadArgs& a, hipStream_t s) {
+  if (a.defer.part) {
+    CD_REQUIRE(a.defer.C == 32 && a.res, "head: the fused final block is 32 channels wide with an identity shortcut");
+    prof::Scope scope("head_gn", s, 64.0 * a.batch * a.vox, 4.0 * a.batch * a.vox * 66);
+    int per_sample = (int)((1024 + a.batch - 1) / a.batch);  // one round of ~1024 workgroups, each folds the GroupNorm once
+    const int cap = (int)((a.vox + 255) / 256);
+    if (per_sample > cap) per_sample = cap;
+    if (per_sample < 1) per_sample = 1;
+    hipLaunchKernelGGL(head_gn_kernel, dim3((unsigned)per_sample, (unsigned)a.batch), dim3(256), 0, s, a);
+    CD_HIP(hipGetLastError());
+    return;
+  }
   const int64_t total = (int64_t)a.batch * a.vox;
   int64_t blocks = (total * 8 + 255) / 256;
   if (blocks > 4096) blocks = 4096;

@@ -476,8 +476,16 @@ float* conv3_with_stats(Run& r, const float* x0, int c0, const float* x1, int c1
 //   conv1 (stats epilogue) -> finalize -> conv2 normalises h1 while staging it (stats epilogue) -> finalize ->
 //   one elementwise pass: silu(gn(h2)) + shortcut.  `part_out`/`units_out` (optional): channel partials of the block
 //   output for a following PreNorm.
+// `lazy` (optional): leave the closing GroupNorm + SiLU + identity shortcut to the consumer (the head kernel).  If the block
+// qualifies it returns its second conv's raw output, lazy->gn describes the normalisation, lazy->part (to be released by the
+// caller) holds its partials and the shortcut is x0.
+struct LazyClose {
+  GnDefer gn;
+  float* part = nullptr;
+  bool on = false;
+};
 float* res_block(Run& r, const ResP& w, const float* x0, int c0, const float* x1, int c1, Dims3 dims,
-                 float** part_out = nullptr, int* units_out = nullptr) {
+                 float** part_out = nullptr, int* units_out = nullptr, LazyClose* lazy = nullptr) {
   Arena* ws = r.ws;
   CD_REQUIRE(c0 + c1 == w.cin, "internal: resnet block input width mismatch");
   const int64_t vox = dims.vox();
@@ -550,6 +558,12 @@ float* res_block(Run& r, const ResP& w, const float* x0, int c0, const float* x1
     if (!res) shortcut_conv();
     if (!r.dry() && !fused) launch_gn_apply(h2, h2, coef2, r.B, w.cout, vox, 1, res, nullptr, 0, po, r.s, dp2);
     ws->release(res);
+  } else if (lazy && !small && defer_gn && c1 == 0 && w.cout == 32 && !part_out) {
+    lazy->gn = d2;
+    lazy->part = p2;
+    lazy->on = true;
+    ws->release(coef2);
+    return h2;
   } else {
     // identity shortcut; for a concatenated input it is read from the two sources (models.py:200,741)
     if (!r.dry() && !fused) launch_gn_apply(h2, h2, coef2, r.B, w.cout, vox, 1, x0, c1 ? x1 : nullptr, c0, po, r.s, dp2);
@@ -766,7 +780,8 @@ void conv_transpose_backward(Run& r, const float* x, const float* w_raw, const f
 }
 
 // CondUnet.forward after init_conv / embeddings (models.py:713-748). Takes ownership of h (a workspace block).
-float* unet_body(CdPlan* p, Run& r, const float* emb, float* h) {
+// `lazy`: see res_block -- when set on return, the result is the final block's raw conv output, *xin its (still allocated) input.
+float* unet_body(CdPlan* p, Run& r, const float* emb, float* h, LazyClose* lazy = nullptr, float** xin = nullptr) {
   const CdUnetDesc& d = p->desc;
   const int nres = p->nres;
   const int zs = d.compress_z ? 2 : 1;
@@ -851,8 +866,9 @@ float* unet_body(CdPlan* p, Run& r, const float* emb, float* h) {
       x = y;
     }
   }
-  t = res_block(r, resolve(p, p->fin, nullptr), x, cx, nullptr, 0, p->shapes[0]);
-  r.ws->release(x);
+  t = res_block(r, resolve(p, p->fin, nullptr), x, cx, nullptr, 0, p->shapes[0], nullptr, nullptr, lazy);
+  if (lazy && lazy->on) *xin = x;  // (the head reads it as the shortcut; released by the caller)
+  else r.ws->release(x);
   return t;
 }
 
@@ -925,12 +941,20 @@ void forward_impl(CdPlan* p, int B, const float* x, const float* cond, const flo
     }
     launch_init_conv(a, s);
   }
-  float* hf = unet_body(p, r, emb, h);
+  LazyClose lazy;
+  float* xin = nullptr;
+  static const bool head_fused = getenv("CD_NO_HEAD_GN") == nullptr;
+  float* hf = unet_body(p, r, emb, h, head_fused ? &lazy : nullptr, &xin);
   if (!r.dry()) {
     HeadArgs ha;
     ha.h = hf; ha.w = p->raw(p->head_w); ha.bias = p->raw(p->head_b); ha.out = out; ha.batch = B; ha.vox = dims.vox();
     if (!raw) { ha.x = x; ha.scal = scal; ha.objective = d.objective; }
+    if (lazy.on) { ha.defer = lazy.gn; ha.res = xin; }
     launch_head(ha, s);
+  }
+  if (lazy.on) {
+    r.ws->release(lazy.part);
+    r.ws->release(xin);
   }
   r.ws->release(hf);
   r.ws->release(scal);
