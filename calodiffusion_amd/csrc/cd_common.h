@@ -168,6 +168,20 @@ inline void launch_pack_weights_split16(const float* w_torch, void* wpk, int cou
 void launch_pack_weights(const float* w_torch, float* wpk, int cout, int cin, int taps, bool transposed, hipStream_t s,
                          bool flip = false);
 void launch_pack_init_weights(const float* w_torch, float* wpk, int cout, int cin, hipStream_t s);
+// All weights of a plan in two launches (cd_plan_set_weights: the re-pack after every optimizer step was ~400 launches and 3 ms
+// of host time per training step).  One job per tensor; null images are skipped.
+struct PackJob {
+  const float* src;  // the caller's tensor (device)
+  float* raw;        // copy in the plan arena
+  float* pk;         // f32 MFMA image (kind 1, 2) or the init conv's [tap][ci][cout] image (kind 3), or null
+  void* bf3;         // bf16x3 image or null
+  void* f16;         // f16x2 image or null
+  int cout, cin, taps;
+  int kind;          // 0 = raw only, 1 = conv, 2 = transposed conv (images in transposed channel order), 3 = init conv
+  unsigned long long numel, n_pk, n_bf3, n_f16;  // work items of the four phases
+};
+void launch_pack_jobs(const PackJob* d_jobs, int njobs, hipStream_t s);        // raw copy, f32 / init and bf16x3 images (kernels_conv.hip)
+void launch_pack_jobs_f16x2(const PackJob* d_jobs, int njobs, hipStream_t s);  // f16x2 images (kernels_conv_zs.hip)
 
 void launch_conv_mfma(const float* in0, int c0, const float* in1, int c1, const float* wpk, const float* bias, float* out,
                       int batch, int cout, const ConvGeom& g, hipStream_t s, const ConvFusion& fu = ConvFusion());

@@ -39,10 +39,8 @@ static constexpr int LDS_VOX_PAD = 4;  // floats of padding per LDS voxel: strid
 // ------------------------------------------------------------------------------------------------------------
 // weight packing (see cd_common.h for the layout)
 // ------------------------------------------------------------------------------------------------------------
-__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wpk, int cout, int cin, int taps,
-                                    int transposed, size_t total, int flip) {
-  size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (idx >= total) return;
+__device__ __forceinline__ void pack_weights_elem(size_t idx, const float* __restrict__ w, float* __restrict__ wpk, int cout, int cin,
+                                                  int taps, int transposed, int flip) {
   const int e = idx & 3, lane = (idx >> 2) & 63, q = (idx >> 8) & 3;
   size_t rest = idx >> 10;
   const int CT = (cout + 31) / 32;
@@ -58,6 +56,12 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
     v = transposed ? w[((size_t)ci * cout + co) * taps + st] : w[((size_t)co * cin + ci) * taps + st];
   wpk[idx] = v;
 }
+__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wpk, int cout, int cin, int taps,
+                                    int transposed, size_t total, int flip) {
+  size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  pack_weights_elem(idx, w, wpk, cout, cin, taps, transposed, flip);
+}
 
 void launch_pack_weights(const float* w_torch, float* wpk, int cout, int cin, int taps, bool transposed, hipStream_t s, bool flip) {
   CD_REQUIRE(cin % 32 == 0, "MFMA convolutions need input channels in multiples of 32");
@@ -68,13 +72,16 @@ void launch_pack_weights(const float* w_torch, float* wpk, int cout, int cin, in
 }
 
 // init conv weights: [tap][ci][cout] so that the 32 output-channel weights of one (tap, ci) are contiguous (scalar loads)
-__global__ void pack_init_weights_kernel(const float* __restrict__ w, float* __restrict__ wpk, int cout, int cin) {
-  int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= cout * cin * 27) return;
+__device__ __forceinline__ void pack_init_weights_elem(int idx, const float* __restrict__ w, float* __restrict__ wpk, int cout, int cin) {
   const int co = idx % cout;
   const int ci = (idx / cout) % cin;
   const int tap = idx / (cout * cin);
   wpk[idx] = w[((size_t)co * cin + ci) * 27 + tap];
+}
+__global__ void pack_init_weights_kernel(const float* __restrict__ w, float* __restrict__ wpk, int cout, int cin) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= cout * cin * 27) return;
+  pack_init_weights_elem(idx, w, wpk, cout, cin);
 }
 void launch_pack_init_weights(const float* w_torch, float* wpk, int cout, int cin, hipStream_t s) {
   int total = cout * cin * 27;
@@ -641,10 +648,8 @@ __device__ __forceinline__ void split3(const f32x4 x, u32x2& t1, u32x2& t2, u32x
 }
 
 // packed bf16x3 weights: [sub-chunk = ci/16][tap][ct][term][lane = h*32+j][8 bf16] = W_term[co = ct*32+j][ci = sc*16+8h+0..7]
-__global__ void pack_weights_bf16x3_kernel(const float* __restrict__ w, u32x4* __restrict__ wpk, int cout, int cin, int taps,
-                                           size_t total, int transposed, int flip) {
-  const size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x;  // one thread per (sc, tap, ct, lane)
-  if (idx >= total) return;
+__device__ __forceinline__ void pack_weights_bf16x3_elem(size_t idx, const float* __restrict__ w, u32x4* __restrict__ wpk, int cout,
+                                                         int cin, int taps, int transposed, int flip) {
   const int lane = idx & 63;
   size_t rest = idx >> 6;
   const int CT = (cout + 31) / 32;
@@ -669,6 +674,34 @@ __global__ void pack_weights_bf16x3_kernel(const float* __restrict__ w, u32x4* _
   dst[0] = u32x4{a1[0], a1[1], b1[0], b1[1]};
   dst[64] = u32x4{a2[0], a2[1], b2[0], b2[1]};
   dst[128] = u32x4{a3[0], a3[1], b3[0], b3[1]};
+}
+__global__ void pack_weights_bf16x3_kernel(const float* __restrict__ w, u32x4* __restrict__ wpk, int cout, int cin, int taps,
+                                           size_t total, int transposed, int flip) {
+  const size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x;  // one thread per (sc, tap, ct, lane)
+  if (idx >= total) return;
+  pack_weights_bf16x3_elem(idx, w, wpk, cout, cin, taps, transposed, flip);
+}
+
+// every tensor of a plan in one launch: blockIdx.y = job; raw copy, then the f32 (or init) image, then the bf16x3 image, each read
+// from the caller's tensor
+__global__ void __launch_bounds__(256) pack_jobs_kernel(const PackJob* __restrict__ jobs) {
+  const PackJob j = jobs[blockIdx.y];
+  const size_t t0 = blockIdx.x * (size_t)256 + threadIdx.x, stride = gridDim.x * (size_t)256;
+  for (size_t i = t0; i < j.numel; i += stride) j.raw[i] = j.src[i];
+  if (j.pk) {
+    if (j.kind == 3) {
+      for (size_t i = t0; i < j.n_pk; i += stride) pack_init_weights_elem((int)i, j.src, j.pk, j.cout, j.cin);
+    } else {
+      for (size_t i = t0; i < j.n_pk; i += stride) pack_weights_elem(i, j.src, j.pk, j.cout, j.cin, j.taps, j.kind == 2, 0);
+    }
+  }
+  if (j.bf3)
+    for (size_t i = t0; i < j.n_bf3; i += stride) pack_weights_bf16x3_elem(i, j.src, (u32x4*)j.bf3, j.cout, j.cin, j.taps, j.kind == 2, 0);
+}
+void launch_pack_jobs(const PackJob* d_jobs, int njobs, hipStream_t s) {
+  if (njobs <= 0) return;
+  hipLaunchKernelGGL(pack_jobs_kernel, dim3(48, (unsigned)njobs), dim3(256), 0, s, d_jobs);
+  CD_HIP(hipGetLastError());
 }
 
 void launch_pack_weights_bf16x3(const float* w_torch, void* wpk, int cout, int cin, int taps, hipStream_t s, bool transposed,

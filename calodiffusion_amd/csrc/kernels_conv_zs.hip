@@ -30,10 +30,8 @@
 namespace cd {
 
 // packed f16x2 weights: [k-step = ci/16][tap][ct = co/32][term][lane = h*32+j][8 fp16] = W_term[co = ct*32+j][ci = ks*16+8h+0..7]
-__global__ void pack_weights_f16x2_kernel(const float* __restrict__ w, u32x4* __restrict__ wpk, int cout, int cin, int taps,
-                                          size_t total, int transposed, int flip) {
-  const size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x;  // one thread per (ks, tap, ct, lane)
-  if (idx >= total) return;
+__device__ __forceinline__ void pack_weights_f16x2_elem(size_t idx, const float* __restrict__ w, u32x4* __restrict__ wpk, int cout,
+                                                        int cin, int taps, int transposed, int flip) {
   const int lane = idx & 63;
   size_t rest = idx >> 6;
   const int CT = (cout + 31) / 32;
@@ -57,6 +55,24 @@ __global__ void pack_weights_f16x2_kernel(const float* __restrict__ w, u32x4* __
   u32x4* dst = wpk + (((size_t)(ks * taps + tap) * CT + ct) * 2) * 64 + lane;
   dst[0] = u32x4{a1[0], a1[1], b1[0], b1[1]};
   dst[64] = u32x4{a2[0], a2[1], b2[0], b2[1]};
+}
+__global__ void pack_weights_f16x2_kernel(const float* __restrict__ w, u32x4* __restrict__ wpk, int cout, int cin, int taps,
+                                          size_t total, int transposed, int flip) {
+  const size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x;  // one thread per (ks, tap, ct, lane)
+  if (idx >= total) return;
+  pack_weights_f16x2_elem(idx, w, wpk, cout, cin, taps, transposed, flip);
+}
+// the f16x2 images of every tensor of a plan in one launch (PackJob, cd_common.h): blockIdx.y = job
+__global__ void __launch_bounds__(256) pack_jobs_f16x2_kernel(const PackJob* __restrict__ jobs) {
+  const PackJob j = jobs[blockIdx.y];
+  if (!j.f16) return;
+  const size_t t0 = blockIdx.x * (size_t)256 + threadIdx.x, stride = gridDim.x * (size_t)256;
+  for (size_t i = t0; i < j.n_f16; i += stride) pack_weights_f16x2_elem(i, j.src, (u32x4*)j.f16, j.cout, j.cin, j.taps, j.kind == 2, 0);
+}
+void launch_pack_jobs_f16x2(const PackJob* d_jobs, int njobs, hipStream_t s) {
+  if (njobs <= 0) return;
+  hipLaunchKernelGGL(pack_jobs_f16x2_kernel, dim3(48, (unsigned)njobs), dim3(256), 0, s, d_jobs);
+  CD_HIP(hipGetLastError());
 }
 
 void launch_pack_weights_f16x2(const float* w_torch, void* wpk, int cout, int cin, int taps, hipStream_t s, bool transposed,

@@ -149,6 +149,9 @@ struct CdPlan {
 
   // cached step graph; captured on a private stream (the caller's may be the legacy null stream, which cannot capture)
   hipStream_t cap_stream = nullptr;
+  // job list of cd_plan_set_weights: host copy (with the callers' pointers of the last call) and device copy
+  std::vector<PackJob> pack_jobs;
+  PackJob* d_pack_jobs = nullptr;
   hipGraphExec_t graph_exec = nullptr;
   struct GraphKey {
     int batch = 0; const void* ws = nullptr; const void* cond = nullptr; const void* x = nullptr; int noisy = 0; uint64_t seed = 0, offset = 0;
@@ -1055,6 +1058,7 @@ int cd_plan_destroy(CdPlan* plan) {
     destroy_graph(plan);
     destroy_prog_graph(plan);
     if (plan->cap_stream) hipStreamDestroy(plan->cap_stream);
+    if (plan->d_pack_jobs) hipFree(plan->d_pack_jobs);
     if (plan->arena) hipFree(plan->arena);
     if (plan->d_embed_layers) hipFree(plan->d_embed_layers);
     if (plan->d_coords) hipFree(plan->d_coords);
@@ -1102,6 +1106,56 @@ int cd_plan_set_weight(CdPlan* plan, const char* name, const float* dev_ptr, int
     else if (w.pack == PK_INIT) launch_pack_init_weights(plan->arena + w.raw_off, plan->arena + w.pk_off, w.cout, w.cin, s);
     w.set = true;
     if (it->second == plan->init_w || it->second == plan->init_b) refresh_init_table(plan, s);
+  });
+}
+
+int cd_plan_set_weights(CdPlan* plan, int n, const float* const* dev_ptrs, void* stream) {
+  return guarded([&] {
+    CD_REQUIRE(plan && dev_ptrs, "null argument");
+    if (n != (int)plan->weights.size())
+      throw Fail{CD_EWEIGHTS, "cd_plan_set_weights: " + std::to_string(n) + " tensors given, the plan has " +
+                                  std::to_string(plan->weights.size())};
+    hipStream_t s = (hipStream_t)stream;
+    bool changed = plan->pack_jobs.size() != plan->weights.size();
+    if (changed) plan->pack_jobs.assign(plan->weights.size(), PackJob{});
+    for (int i = 0; i < n; ++i) {
+      CD_REQUIRE(dev_ptrs[i], "cd_plan_set_weights: null tensor pointer");
+      const WeightEntry& w = plan->weights[i];
+      PackJob& j = plan->pack_jobs[i];
+      if (j.src != dev_ptrs[i]) changed = true;
+      j.src = dev_ptrs[i];
+      j.raw = plan->arena + w.raw_off;
+      j.cout = w.cout; j.cin = w.cin; j.taps = w.taps; j.kind = (int)w.pack;
+      j.numel = (unsigned long long)w.numel;
+      j.pk = nullptr; j.bf3 = nullptr; j.f16 = nullptr; j.n_pk = j.n_bf3 = j.n_f16 = 0;
+      const unsigned long long n16 = w.pack == PK_CONV || w.pack == PK_CONVT
+                                         ? (unsigned long long)(w.cin / 16) * w.taps * ((w.cout + 31) / 32) * 64 : 0ull;
+      if (w.pack == PK_CONV || w.pack == PK_CONVT) {
+        j.pk = plan->arena + w.pk_off;
+        j.n_pk = packed_weight_floats(w.cin, w.cout, w.taps);
+      } else if (w.pack == PK_INIT) {
+        j.pk = plan->arena + w.pk_off;
+        j.n_pk = (unsigned long long)w.cout * w.cin * 27;
+      }
+      if (w.pack == PK_CONVT) {  // (f16x2 image only, in transposed channel order)
+        j.f16 = plan->arena + w.pk3_off;
+        j.n_f16 = n16;
+      } else if (w.pack == PK_CONV && w.pk3_off) {
+        j.bf3 = plan->arena + w.pk3_off;
+        j.f16 = (char*)(plan->arena + w.pk3_off) + packed_bf16x3_bytes(w.cin, w.cout, w.taps);
+        j.n_bf3 = j.n_f16 = n16;
+      }
+    }
+    if (!plan->d_pack_jobs) CD_HIP(hipMalloc((void**)&plan->d_pack_jobs, sizeof(PackJob) * plan->weights.size()));
+    if (changed) {
+      // (rare: torch keeps a parameter's storage across optimizer steps) the kernels of the previous call may still read the list
+      CD_HIP(hipStreamSynchronize(s));
+      CD_HIP(hipMemcpy(plan->d_pack_jobs, plan->pack_jobs.data(), sizeof(PackJob) * plan->pack_jobs.size(), hipMemcpyHostToDevice));
+    }
+    launch_pack_jobs(plan->d_pack_jobs, n, s);
+    launch_pack_jobs_f16x2(plan->d_pack_jobs, n, s);
+    for (auto& w : plan->weights) w.set = true;
+    refresh_init_table(plan, s);
   });
 }
 

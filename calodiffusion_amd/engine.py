@@ -68,6 +68,7 @@ _SIGNATURES = {
     "cd_plan_num_weights": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "cd_plan_weight_name": (C.c_int, [_P, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int64)]),
     "cd_plan_set_weight": (C.c_int, [_P, C.c_char_p, _P, C.c_int64, _P]),
+    "cd_plan_set_weights": (C.c_int, [_P, C.c_int, C.POINTER(_P), _P]),
     "cd_plan_set_coords": (C.c_int, [_P, _P, _P, _P, _P]),
     "cd_plan_workspace_bytes": (C.c_int, [_P, C.c_int, C.POINTER(C.c_size_t)]),
     "cd_unet_forward": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, C.c_size_t, _P]),
@@ -205,6 +206,9 @@ class UnetEngine:
         _check(self.lib.cd_plan_create(C.byref(d), C.byref(handle)))
         self.plan = handle
         self._weights_version = None
+        self._weight_order = None  # [(state_dict name, tensor)] in the plan's order
+        self._weight_ids = None
+        self._held_weights = []
         self._ws: Dict[int, torch.Tensor] = {}
         self.device = next(unet.parameters()).device
         if self.device.type != "cuda":
@@ -230,32 +234,40 @@ class UnetEngine:
 
     # ------------------------------------------------------------------ weights
     def _version(self):
-        return tuple(p._version for p in self.unet.parameters()) + tuple(p.data_ptr() for p in self.unet.parameters())
+        ps = list(self.unet.parameters())
+        return tuple(p._version for p in ps) + tuple(p.data_ptr() for p in ps) + (tuple(id(p) for p in ps),)
 
     def sync_weights(self, force=False):
-        """(Re-)pack the parameters into the plan's arena; cheap no-op when nothing changed."""
+        """(Re-)pack the parameters into the plan's arena; cheap no-op when nothing changed.  All tensors go in ONE C-ABI call
+        (cd_plan_set_weights: two launches); the plan's tensor order and the Parameter objects behind it are looked up once (and
+        again whenever a Parameter object of the module is replaced)."""
         ver = self._version()
         if not force and ver == self._weights_version:
             return
-        sd = self.unet.state_dict()
-        n = C.c_int()
-        _check(self.lib.cd_plan_num_weights(self.plan, C.byref(n)))
-        buf = C.create_string_buffer(256)
-        numel = C.c_int64()
-        seen = set()
-        for i in range(n.value):
-            _check(self.lib.cd_plan_weight_name(self.plan, i, buf, 256, C.byref(numel)))
-            name = buf.value.decode()
-            if name not in sd:
-                raise RuntimeError(f"state_dict has no tensor named {name!r}")
-            t = _dev32(sd[name].detach(), name)
-            if t.numel() != numel.value:
-                raise RuntimeError(f"{name}: {t.numel()} elements, HIP plan expects {numel.value}")
-            _check(self.lib.cd_plan_set_weight(self.plan, name.encode(), t.data_ptr(), t.numel(), _stream()))
-            seen.add(name)
-        missing = set(sd) - seen
-        if missing:
-            raise RuntimeError(f"HIP plan does not consume these state_dict tensors: {sorted(missing)[:5]} ...")
+        ids = ver[-1]
+        if self._weight_order is None or self._weight_ids != ids:
+            sd = self.unet.state_dict(keep_vars=True)
+            n = C.c_int()
+            _check(self.lib.cd_plan_num_weights(self.plan, C.byref(n)))
+            buf = C.create_string_buffer(256)
+            numel = C.c_int64()
+            order = []
+            for i in range(n.value):
+                _check(self.lib.cd_plan_weight_name(self.plan, i, buf, 256, C.byref(numel)))
+                name = buf.value.decode()
+                if name not in sd:
+                    raise RuntimeError(f"state_dict has no tensor named {name!r}")
+                if sd[name].numel() != numel.value:
+                    raise RuntimeError(f"{name}: {sd[name].numel()} elements, HIP plan expects {numel.value}")
+                order.append((name, sd[name]))
+            missing = set(sd) - {name for name, _ in order}
+            if missing:
+                raise RuntimeError(f"HIP plan does not consume these state_dict tensors: {sorted(missing)[:5]} ...")
+            self._weight_order, self._weight_ids = order, ids
+        tensors = [_dev32(t.detach(), name) for name, t in self._weight_order]
+        ptrs = (_P * len(tensors))(*[t.data_ptr() for t in tensors])
+        _check(self.lib.cd_plan_set_weights(self.plan, len(tensors), ptrs, _stream()))
+        self._held_weights = tensors  # (conversions made by _dev32 must outlive the launches)
         self._weights_version = ver
 
     def workspace(self, batch: int) -> torch.Tensor:

@@ -95,6 +95,10 @@ int cd_plan_weight_name(const CdPlan* plan, int idx, char* name, int cap, int64_
 /* Copies/re-packs one state_dict tensor (device pointer, torch layout) into the plan's arena on `stream`.
  * Replaces nn.Module.load_state_dict for this path (calodiffusion.py:31-37). Call again after an optimizer step. */
 int cd_plan_set_weight(CdPlan* plan, const char* name, const float* dev_ptr, int64_t numel, void* stream);
+/* The same for every tensor at once: dev_ptrs[i] is the tensor cd_plan_weight_name(plan, i, ...) names (n = cd_plan_num_weights),
+ * all copied and re-packed by two launches.  This is the call for the training loop -- after optimizer.step() every parameter
+ * has changed (train/train.py:144-170); one tensor at a time that was ~400 launches and 3 ms of host time per step. */
+int cd_plan_set_weights(CdPlan* plan, int n, const float* const* dev_ptrs, void* stream);
 /* Host arrays: the 1-D profiles of the constant R (len W), Z (len D) and phi (len H) input images
  * (utils/utils.py:33-150, calodiffusion.py:17-20). */
 int cd_plan_set_coords(CdPlan* plan, const float* r_w, const float* z_d, const float* phi_h, void* stream);
