@@ -334,3 +334,28 @@ def test_generate_refuses_to_skip_the_inverse_preprocessing():
     assert raw.shape == (2, 1, 8, 8, 8)
     phys, _ = m.generate(loader, sample_steps=2, reverse_norm=lambda gen_, en, lay, cfg: (gen_ * 2.0, en))
     assert phys.shape == raw.shape
+
+
+def test_all_weights_in_one_call_equals_one_tensor_at_a_time():
+    """cd_plan_set_weights (every tensor by two launches from a job list) leaves the plan exactly as a cd_plan_set_weight per
+    tensor does: the same denoise output, bit for bit, for the level shapes of Dataset-2 (all pack kinds: stride-1 / strided /
+    transposed / 1x1 / init convs, raw tensors)."""
+    import ctypes as C
+    from calodiffusion_amd import engine as E_
+    m = _model("dataset2")
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn((2, 1, 45, 16, 9), generator=gen).cuda()
+    En, layers = torch.rand((2, 1), generator=gen).cuda(), torch.randn((2, 46), generator=gen).cuda()
+    sig = torch.tensor([0.7, 3.0], device="cuda")
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(1.0 + 0.01 * torch.randn(p.shape, generator=gen).to(p.device))  # (changes every tensor: bumps the versions)
+    y_batch = m.denoise(x, E=En, sigma=sig, layers=layers).clone()  # sync_weights -> cd_plan_set_weights
+    eng = m.engine()
+    sd = m.model.state_dict() if hasattr(m, "model") else eng.unet.state_dict()
+    for name, tns in eng._weight_order:
+        tt = tns.detach().float().contiguous()
+        E_._check(eng.lib.cd_plan_set_weight(eng.plan, name.encode(), tt.data_ptr(), tt.numel(), E_._stream()))
+    assert len(sd) == len(eng._weight_order)
+    y_one = m.denoise(x, E=En, sigma=sig, layers=layers)
+    assert torch.equal(y_batch, y_one)
