@@ -173,9 +173,12 @@ __device__ __forceinline__ void attn_pass1(const AttnArgs& a, int b, int split, 
   const int64_t tlast = t1 - 1;
   float m = -3.0e38f;  // (sentinel: never enters an exponential)
   bool any = false;
-  f32x16 ctx;
+  // The context product itself runs on the fp16 pipe with the convs' two-term split (split16.h): e in (0, 1] and v as f16x2, the
+  // registers 8s .. 8s+7 of a lane being the 8 k-slots of k-step s (the same voxels in e and in v), 3 MFMAs per k-step into two
+  // accumulators -- 6 x 32 cycles per tile against 16 x 64 for v_mfma_f32_32x32x2_f32, for ~110 more vector instructions.
+  f32x16 ctx, ctxB;  // ctx += e1 v1;  ctxB += e1 v2' + e2' v1;  context = ctx + ctxB / 2048
 #pragma unroll
-  for (int r = 0; r < 16; ++r) ctx[r] = 0.f;
+  for (int r = 0; r < 16; ++r) ctx[r] = ctxB[r] = 0.f;
   float ssum = 0.f;
   auto scale_rows = [&](float fac) {  // ctx[d][:] *= fac[d], fac given in lane d
     sFac[wave][col] = fac;  // (both halves write the same value)
@@ -184,8 +187,18 @@ __device__ __forceinline__ void attn_pass1(const AttnArgs& a, int b, int split, 
     for (int q = 0; q < 4; ++q) {
       const f32x4 f4 = *(const f32x4*)&sFac[wave][8 * q + 4 * half];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) ctx[4 * q + e] *= f4[e];
+      for (int e = 0; e < 4; ++e) {
+        ctx[4 * q + e] *= f4[e];
+        ctxB[4 * q + e] *= f4[e];
+      }
     }
+  };
+  auto split8 = [](const float (&x)[16], int s8, u32x4& hi, u32x4& lo) {  // registers 8 s8 .. 8 s8 + 7 -> one f16x2 operand pair
+    u32x2 h0, l0, h1, l1;
+    split2(f32x4{x[8 * s8], x[8 * s8 + 1], x[8 * s8 + 2], x[8 * s8 + 3]}, h0, l0);
+    split2(f32x4{x[8 * s8 + 4], x[8 * s8 + 5], x[8 * s8 + 6], x[8 * s8 + 7]}, h1, l1);
+    hi = u32x4{h0[0], h0[1], h1[0], h1[1]};
+    lo = u32x4{l0[0], l0[1], l1[0], l1[1]};
   };
   for (int64_t tt = t0 + wave; tt < t1; tt += 8) {
     u32x4 x1[NKS], x2[NKS];
@@ -211,12 +224,22 @@ __device__ __forceinline__ void attn_pass1(const AttnArgs& a, int b, int split, 
       scale_rows(fac);
       m = mn;
     }
+    float ex[16], vv[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-      const float ex = (full || tt * 32 + row < a.vox) ? attn_exp(k[r] - m) : 0.f;
-      ssum += ex;
-      ctx = MFMA32(ex, v[r], ctx);
+      ex[r] = (full || tt * 32 + row < a.vox) ? attn_exp(k[r] - m) : 0.f;
+      ssum += ex[r];
+      vv[r] = v[r];
+    }
+#pragma unroll
+    for (int s8 = 0; s8 < 2; ++s8) {
+      u32x4 e1, e2, v1, v2;
+      split8(ex, s8, e1, e2);
+      split8(vv, s8, v1, v2);
+      ctx = MFMA_F16(e1, v1, ctx);
+      ctxB = MFMA_F16(e1, v2, ctxB);
+      ctxB = MFMA_F16(e2, v1, ctxB);
     }
   }
   // merge the waves: common maximum, every wave's sums and context rescaled to it
@@ -235,7 +258,7 @@ __device__ __forceinline__ void attn_pass1(const AttnArgs& a, int b, int split, 
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int d = (r & 3) + 8 * (r >> 2) + 4 * half;  // row = channel d; column = e
-    sCtx[wave][d * 32 + col] = ctx[r];
+    sCtx[wave][d * 32 + col] = ctx[r] + ctxB[r] * (1.f / 2048.f);
   }
   __syncthreads();
   float* out = a.partials + ((size_t)b * a.nsplit + split) * (64 + 1024);
@@ -331,6 +354,19 @@ __device__ __forceinline__ void attn_pass2(const AttnArgs& a, int b, int unit, i
 #pragma unroll
       for (int q = 0; q < 4; ++q) wt[ch][q] = ((const f32x4*)sW)[(ch * 4 + q) * 64 + lane];
   }
+  // the folded weights as f16x2 B operands of the output product (fp16 pipe, as the context product of pass 1): k-step s = the
+  // registers 8s .. 8s+7 of wt (the d-slots of q's registers 8s .. 8s+7)
+  u32x4 wb1[NCH][2], wb2[NCH][2];
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+    for (int s8 = 0; s8 < 2; ++s8) {
+      u32x2 h0, l0, h1, l1;
+      split2(wt[ch][2 * s8], h0, l0);
+      split2(wt[ch][2 * s8 + 1], h1, l1);
+      wb1[ch][s8] = u32x4{h0[0], h0[1], h1[0], h1[1]};
+      wb2[ch][s8] = u32x4{l0[0], l0[1], l1[0], l1[1]};
+    }
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float bv[NCH], s1[NCH], s2[NCH];
 #pragma unroll
@@ -378,14 +414,27 @@ __device__ __forceinline__ void attn_pass2(const AttnArgs& a, int b, int unit, i
     }
     ss += __shfl_xor(ss, 32, 64);
     const float inv = 1.f / ss;
-    // y[n][co] = sum_d softmax(q)[n][d] W'[co][d]: A = q^T registers (row n = col, k-slot = half <-> d = row(r, half))
+    // y[n][co] = sum_d softmax(q)[n][d] W'[co][d]: A = q^T registers (row n = col, k-slots = the lane's registers <-> d = row(r, half))
+    u32x4 p1[2], p2[2];
+#pragma unroll
+    for (int s8 = 0; s8 < 2; ++s8) {
+      u32x2 h0, l0, h1, l1;
+      split2(f32x4{q[8 * s8] * inv, q[8 * s8 + 1] * inv, q[8 * s8 + 2] * inv, q[8 * s8 + 3] * inv}, h0, l0);
+      split2(f32x4{q[8 * s8 + 4] * inv, q[8 * s8 + 5] * inv, q[8 * s8 + 6] * inv, q[8 * s8 + 7] * inv}, h1, l1);
+      p1[s8] = u32x4{h0[0], h0[1], h1[0], h1[1]};
+      p2[s8] = u32x4{l0[0], l0[1], l1[0], l1[1]};
+    }
 #pragma unroll
     for (int ct = 0; ct < NCH; ++ct) {
-      f32x16 o;
+      f32x16 o = zero16, ob = zero16;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[r] = 0.f;
+      for (int s8 = 0; s8 < 2; ++s8) {
+        o = MFMA_F16(p1[s8], wb1[ct][s8], o);
+        ob = MFMA_F16(p1[s8], wb2[ct][s8], ob);
+        ob = MFMA_F16(p2[s8], wb1[ct][s8], ob);
+      }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o = MFMA32(q[r] * inv, wt[ct][r >> 2][r & 3], o);
+      for (int r = 0; r < 16; ++r) o[r] += ob[r] * (1.f / 2048.f);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t n = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
