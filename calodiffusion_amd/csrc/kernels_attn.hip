@@ -297,12 +297,18 @@ template <int NCH>
 __device__ __forceinline__ void attn_fold_weights(const AttnArgs& a, int b, float* sW) {
   __shared__ float sM[32], sInv[32];
   __shared__ float sCtx[1024];
+  __shared__ float sWout[NCH * 32 * 33];  // W_out rows padded to 33 floats: the 32 lanes of a half-wave read 32 different rows
   const int tid = threadIdx.x;
   const float* p = a.partials + (size_t)b * a.nsplit * (64 + 1024);
+  // (this prologue is pure latency for every workgroup of pass 2: independent loads are issued together, W_out is staged while
+  // the maxima are merged)
+  for (int i = tid; i < NCH * 1024; i += 512) sWout[(i >> 5) * 33 + (i & 31)] = a.fold_wout[i];
   if (tid < 32) {
     float M = -3.0e38f;
+#pragma unroll 4
     for (int i = 0; i < a.nsplit; ++i) M = fmaxf(M, p[(size_t)i * 1088 + tid]);
     float S = 0.f;
+#pragma unroll 4
     for (int i = 0; i < a.nsplit; ++i) S += p[(size_t)i * 1088 + 32 + tid] * expf(p[(size_t)i * 1088 + tid] - M);
     sM[tid] = M;
     sInv[tid] = a.fold_scale / S;
@@ -311,6 +317,7 @@ __device__ __forceinline__ void attn_fold_weights(const AttnArgs& a, int b, floa
   for (int i = tid; i < 1024; i += 512) {
     const int d = i >> 5;
     float c = 0.f;
+#pragma unroll 4
     for (int k = 0; k < a.nsplit; ++k) c += p[(size_t)k * 1088 + 64 + i] * expf(p[(size_t)k * 1088 + d] - sM[d]);
     sCtx[i] = c * sInv[d];
   }
@@ -320,7 +327,8 @@ __device__ __forceinline__ void attn_fold_weights(const AttnArgs& a, int b, floa
     const int c = ct * 32 + (lane & 31);
     const int d = e4 + 8 * q + 4 * (lane >> 5);
     float acc = 0.f;
-    for (int e = 0; e < 32; ++e) acc = fmaf(a.fold_wout[c * 32 + e], sCtx[d * 32 + e], acc);
+#pragma unroll
+    for (int e = 0; e < 32; ++e) acc = fmaf(sWout[c * 33 + e], sCtx[d * 32 + e], acc);
     sW[i] = acc;
   }
   __syncthreads();
