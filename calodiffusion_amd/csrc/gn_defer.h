@@ -20,14 +20,31 @@ __device__ __forceinline__ void gn_defer_to_lds(const GnDefer& g, int b, float* 
   float* sMR = (float*)((char*)scratch + g.C * 16);       // [G][2]
   const int tid = threadIdx.x, nthreads = blockDim.x;
   const int C = g.C, G = g.groups;
+  // the affine parameters do not depend on the statistics: their loads go out first and land under the reduction (every consumer
+  // kernel starts with this fold, so a global-load latency here is a latency of the whole launch)
+  float pg = 0.f, pb = 0.f, pa = 0.f;
+  if (tid < C) {
+    pg = g.gamma[tid];
+    pb = g.beta[tid];
+    pa = g.add ? g.add[(size_t)b * g.add_ld + tid] : 0.f;
+  }
   for (int i = tid; i < C * 8; i += nthreads) {
     const int c = i >> 3, j = i & 7;
     const float* p = g.part + ((size_t)b * g.units * C + c) * 2;
     double a1 = 0.0, a2 = 0.0;
-    for (int u = j; u < g.units; u += 8) {
-      const float2 v = *(const float2*)(p + (size_t)u * C * 2);
-      a1 += (double)v.x;
-      a2 += (double)v.y;
+    // four partials per trip, their loads issued together (one L2 latency per trip instead of one per partial); same order of
+    // additions as a plain loop
+    for (int u = j; u < g.units; u += 32) {
+      float2 v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = u + 8 * k < g.units ? *(const float2*)(p + (size_t)(u + 8 * k) * C * 2) : float2{0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (u + 8 * k < g.units) {
+          a1 += (double)v[k].x;
+          a2 += (double)v[k].y;
+        }
+      }
     }
 #pragma unroll
     for (int m = 1; m < 8; m <<= 1) {
@@ -57,11 +74,12 @@ __device__ __forceinline__ void gn_defer_to_lds(const GnDefer& g, int b, float* 
   __syncthreads();
   for (int c = tid; c < C; c += nthreads) {
     const int gi = c / cpg;
-    const float sc = sMR[gi * 2 + 1] * g.gamma[c];
+    const bool pre = c == tid;  // (C <= blockDim.x in every caller: the preloaded registers; otherwise read here)
+    const float sc = sMR[gi * 2 + 1] * (pre ? pg : g.gamma[c]);
     f32x4 o;
     o[0] = sc;
-    o[1] = g.beta[c] - sMR[gi * 2] * sc;
-    o[2] = g.add ? g.add[(size_t)b * g.add_ld + c] : 0.f;
+    o[1] = (pre ? pb : g.beta[c]) - sMR[gi * 2] * sc;
+    o[2] = pre ? pa : (g.add ? g.add[(size_t)b * g.add_ld + c] : 0.f);
     o[3] = 0.f;
     *(f32x4*)(coef_lds + c * 4) = o;
   }
