@@ -554,6 +554,11 @@ __global__ void __launch_bounds__(512, 1) conv_zslide_f16x2_kernel(ConvZsArgs a)
 // LDS: [zeros 512][coef, bias, flag 1024][ring NR planes][exchange 2 x 24 KB]  (Dataset-2: 130.5 KB)
 // ============================================================================================================
 typedef float f32x2 __attribute__((ext_vector_type(2)));  // pairs: v_pk_add_f32 / v_pk_fma_f32
+#ifndef Z3_PAD
+#define Z3_PAD 0  // 1: plane images with a zero record per row (no per-lane select for the r +- 1 taps of the edge columns, but
+                  // the shifted records break the conflict-free ds_read_b128 pattern: PMC showed 190 k bank-conflict cycles per
+                  // shader engine and launch against 16 k for the linear image, whose edge lanes are redirected into the zero area)
+#endif
 constexpr int Z3_PD = 3;                  // fragment pairs requested ahead of their MFMAs
 constexpr int Z3_COEF = 1024;             // [32][4] floats: the GroupNorm coefficients of this launch's 32 input channels;
                                           // +512: bias[32]; +640: range flag word
@@ -584,8 +589,10 @@ __device__ __forceinline__ Z3Geo z3_geo(const ConvZsArgs& a) {
   (ZsGeo&)g = zs_geo(a);
   // plane image with one zero record before every row and one after the last: the kw = 0 / kw = 2 taps of the first / last column
   // read a pad instead of selecting the zero area per lane
-  g.pitch = a.W + 1;
-  g.PLB = ((g.rows * g.pitch + 1) * ZS_VB + 255) & ~255;
+  if (Z3_PAD) {
+    g.pitch = a.W + 1;
+    g.PLB = ((g.rows * g.pitch + 1) * ZS_VB + 255) & ~255;
+  }
   g.RB = ZS_ZERO + Z3_COEF;
   g.XCH = g.RB + a.NR * g.PLB;
   g.ZPART = g.XCH;  // (prologue scratch of gn_defer_to_lds: the exchange region is still unused then)
@@ -645,7 +652,7 @@ __device__ __forceinline__ void z3_wave(const ConvZsArgs& a, char* lds) {
     int v = pi + src_off;
     v = v < 0 ? v + PV : (v >= PV ? v - PV : v);
     srco[k] = (v * a.ldc + q * 4) * 4;
-    dsto[k] = (pi + pi / W + 1) * ZS_VB + (q >> 2) * 64 + (q & 3) * 8 + G.RB;
+    dsto[k] = (Z3_PAD ? pi + pi / W + 1 : pi) * ZS_VB + (q >> 2) * 64 + (q & 3) * 8 + G.RB;
   }
   f32x4 ld[ZS_NSL];
   static_assert(ZS_NSL == 5, "Z3_LANDED names the five staging registers");
@@ -737,7 +744,8 @@ __device__ __forceinline__ void z3_wave(const ConvZsArgs& a, char* lds) {
 
   // ---- prologue: zero area, GroupNorm table, bias, the planes of step 0 (3 or 4) ------------------------------------
   if (tid < ZS_ZERO / 4) ((float*)lds)[tid] = 0.f;
-  for (int i = tid * 16; i < a.NR * G.PLB; i += 256 * 16) *z3_lds<f32x4>(G.RB + i) = f32x4{0.f, 0.f, 0.f, 0.f};  // (the pad records)
+  if (Z3_PAD)
+    for (int i = tid * 16; i < a.NR * G.PLB; i += 256 * 16) *z3_lds<f32x4>(G.RB + i) = f32x4{0.f, 0.f, 0.f, 0.f};  // (the pad records)
   if (tid < 32) bias_lds[tid] = a.bias ? a.bias[ct * 32 + tid] : 0.f;
   if (tid == 32) *flag_lds = 0;
   const int zstaged0 = need(0);
@@ -786,7 +794,7 @@ __device__ __forceinline__ void z3_wave(const ConvZsArgs& a, char* lds) {
     gh = p / W;
     gw = p - gh * W;
     // (record of (row, column) = row * pitch + column + 1; the kw = 0 tap is one record back)
-    po = ((gh + (HALO ? 1 : 0)) * G.pitch + gw) * ZS_VB + G.RB + KSTEP * 64 + half * 16;
+    po = ((gh + (HALO ? 1 : 0)) * G.pitch + gw) * ZS_VB + G.RB + KSTEP * 64 + half * 16 - (Z3_PAD ? 0 : ZS_VB);
     sb = ((gz + a.NR - 1) % a.NR) * G.PLB;
   }
   const int adv_h = 32 / W, adv_w = 32 - adv_h * W;
@@ -805,9 +813,13 @@ __device__ __forceinline__ void z3_wave(const ConvZsArgs& a, char* lds) {
   };
   // tap addresses of the two tiles of the step: fragment of tap (kz, kh, kw) = bz[t][kz] + {ro0, 0, ro2}[kh] + kw * ZS_VB
   int bz[ZS_TILES][3], ro0[ZS_TILES], ro2[ZS_TILES];
+  bool eL[ZS_TILES], eR[ZS_TILES];  // (linear image) first / last column: the kw = 0 / kw = 2 taps read the zero area
+  const int W1 = W - 1;
   auto prepare = [&]() {
 #pragma unroll
     for (int t = 0; t < ZS_TILES; ++t) {
+      eL[t] = gw == 0;
+      eR[t] = gw == W1;
       if (HALO) {  // strips carry their phi neighbours as halo rows
         ro0[t] = -RWB;
         ro2[t] = RWB;
@@ -847,6 +859,8 @@ __device__ __forceinline__ void z3_wave(const ConvZsArgs& a, char* lds) {
       int base = bz[t][kz] + kw * ZS_VB;
       if (kh == 0) base += ro0[t];
       if (kh == 2) base += ro2[t];
+      if (!Z3_PAD && kw == 0) base = eL[t] ? (base & 255) : base;  // into the zero area, same bank quad
+      if (!Z3_PAD && kw == 2) base = eR[t] ? (base & 255) : base;
       fa[i % (PD + 1)][0] = *z3_lds<const u32x4>(base);
       fa[i % (PD + 1)][1] = *z3_lds<const u32x4>(base + 32);
     };
@@ -1067,7 +1081,7 @@ bool try_launch_conv_zslide(const float* in0, int c0, const float* in1, int c1, 
   auto lds_for = [&](int hs) {
     const int rows = hs + (hs < H ? 2 : 0);
     const size_t ring = (size_t)ring_for(hs) * (((size_t)rows * W * ZS_VB + 255) & ~(size_t)255);
-    const size_t ring3 = (size_t)ring_for(hs) * ((((size_t)rows * (W + 1) + 1) * ZS_VB + 255) & ~(size_t)255);  // padded rows
+    const size_t ring3 = Z3_PAD ? (size_t)ring_for(hs) * ((((size_t)rows * (W + 1) + 1) * ZS_VB + 255) & ~(size_t)255) : ring;
     return v1 ? (size_t)ZS_ZERO + ring + ZS_PART : (size_t)ZS_ZERO + Z3_COEF + ring3 + 2 * Z3_XCH;
   };
   int HS = 0;
