@@ -22,7 +22,7 @@ LIB = os.path.join(LIBDIR, f"libcalodiff_hip{'_' + TAG if TAG else ''}.so")
 SOURCES = ["kernels_conv.hip", "kernels_conv_zs.hip", "kernels_attn.hip", "kernels_conv_small.hip", "kernels_wgrad16.hip", "kernels_norm_attn.hip", "kernels_misc.hip", "kernels_mlp.hip", "kernels_mlp_train.hip", "kernels_bwd.hip", "profiler.hip", "plan.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
-FLAGS += os.environ.get("CD_EXTRA_HIPCC_FLAGS", "").split()  # e.g. -DCD_ZS_EXPERIMENTS (tools/zs_phases.sh)
+FLAGS += os.environ.get("CD_EXTRA_HIPCC_FLAGS", "").split()  # e.g. -DCD_ZS_EXPERIMENTS (tools/zs_stamps.sh, tools/zs_power.sh)
 # per-file flags.  kernels_conv_zs.hip: MFMA results in vector registers (the one-wave-per-SIMD kernel keeps its weights in the
 # accumulation file and sums its partial tiles straight from the MFMA destinations; the default AGPR form costs a
 # v_accvgpr_read per accumulator register and step)

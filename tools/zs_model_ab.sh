@@ -1,3 +1,5 @@
+#!/bin/bash
+# same-box A/B of the two z-slide forms inside the sampling loop: one-wave-per-SIMD (default) vs matrix/helper-wave (CD_ZS_V1=1)
 mkdir -p gpurun_out/ab1
 for v in sw v1 sw v1; do
   if [ $v = v1 ]; then export CD_ZS_V1=1; else unset CD_ZS_V1; fi
