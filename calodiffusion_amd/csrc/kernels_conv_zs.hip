@@ -903,24 +903,50 @@ __device__ __forceinline__ void z3_wave(const ConvZsArgs& a, char* lds) {
   // ---- reduction of step s: this wave's 16 rows of tile TH ------------------------------------------------------------
   f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
   float* const out_sb = a.out + ((size_t)b * G.vox + (size_t)G.h0 * W) * a.cout + ct * 32;  // wave-uniform
-  const float inv_spv = 1.f / (float)SPV;
-  auto gvox = [&](int v) {  // exact: (v + 0.5) / SPV is never within float error of an integer
-    const int z = (int)(((float)v + 0.5f) * inv_spv);
-    return z * PV + (v - z * SPV);
-  };
   // accumulator register r of this wave's half tile = row (r & 3) + 8 (r >> 2) + 4 half + 16 RH; byte offsets of its 8 rows from
   // the tile's first output row (whole planes: output row = strip voxel, so the tile base is a scalar)
   int rowo[8];
 #pragma unroll
   for (int r = 0; r < 8; ++r) rowo[r] = (((r & 3) + 8 * (r >> 2) + 4 * half + 16 * RH) * a.cout + col) * 4;
+  // strips: a tile's rows are strip voxels vt + row = (plane rz, in-plane rp + row); called for s = 0, 1, 2, ... in order, so (rz, rp)
+  // of the wave's tile advance by one step per call (scalar; a strip-plane holds at least one step)
+  int rz = 0, rp = 0;
+  if (HALO) {
+    const int vt0 = G.v0 + TH * 32;
+    rz = vt0 / SPV;
+    rp = vt0 - rz * SPV;
+  }
+  int rrow8[8];  // row of accumulator register r in the tile
+#pragma unroll
+  for (int r = 0; r < 8; ++r) rrow8[r] = (r & 3) + 8 * (r >> 2) + 4 * half + 16 * RH;
   auto reduce_store = [&](int s) {
     const int xch = G.XCH + (s & 1) * Z3_XCH;
     const int vt = G.v0 + s * ZS_STEP + TH * 32;
-    f32x2 prev[4];
-    if (ACC && !HALO && vt + 32 <= G.cend) {
-      const char* const tb = (const char*)uniform_ptr(out_sb + (size_t)vt * a.cout);
+    const bool full = vt + 32 <= G.cend;  // whole tile inside the chunk (all but the last step)
+    // byte offsets of the 8 rows from a scalar base: whole planes -- output row = strip voxel, base = the tile's first row; strips --
+    // base = the strip's first row of plane 0, a row's plane found from (rz, rp)
+    int off[8];
+    const float* tb;
+    if (!HALO) {
+      tb = uniform_ptr(out_sb + (size_t)vt * a.cout);
 #pragma unroll
-      for (int r = 0; r < 8; ++r) prev[r >> 1][r & 1] = *(const float*)(tb + rowo[r]);
+      for (int r = 0; r < 8; ++r) off[r] = rowo[r];
+    } else {
+      tb = uniform_ptr(out_sb);
+      const int gbase = rz * PV + rp;  // (scalar) strip-relative output voxel of the tile's first row
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int pr = rp + rrow8[r];
+        const int gv = gbase + rrow8[r] + (pr >= SPV ? PV - SPV : 0);  // rows past the plane's end continue in the next plane
+        off[r] = (gv * a.cout + col) * 4;
+      }
+      rp += ZS_STEP;
+      if (rp >= SPV) { rp -= SPV; rz += 1; }
+    }
+    f32x2 prev[4];
+    if (ACC && full) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) prev[r >> 1][r & 1] = *(const float*)((const char*)tb + (unsigned)off[r]);
     }
     f32x2 sum[4];
 #pragma unroll
@@ -946,8 +972,7 @@ __device__ __forceinline__ void z3_wave(const ConvZsArgs& a, char* lds) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) sum[r] = sum[r] * gi;
     }
-    if (!HALO && vt + 32 <= G.cend) {
-      // whole planes, whole tile inside the chunk (all but the last step): scalar tile base + the row offsets
+    if (full) {
       if (ACC) {  // continuation launch of a wider-K conv: add to what the previous launch stored
 #pragma unroll
         for (int r = 0; r < 4; ++r) sum[r] = sum[r] + prev[r];
@@ -958,16 +983,14 @@ __device__ __forceinline__ void z3_wave(const ConvZsArgs& a, char* lds) {
         s1 = s1 + sum[r];
         s2 = s2 + sum[r] * sum[r];
       }
-      const float* const tb = uniform_ptr(out_sb + (size_t)vt * a.cout);
 #pragma unroll
       for (int r = 0; r < 8; ++r)
-        asm volatile("global_store_dword %0, %1, %2" ::"v"(rowo[r]), "v"(sum[r >> 1][r & 1]), "s"(tb) : "memory");
+        asm volatile("global_store_dword %0, %1, %2" ::"v"(off[r]), "v"(sum[r >> 1][r & 1]), "s"(tb) : "memory");
     } else {
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
-        const int row = (r & 3) + 8 * ((r >> 2) + 2 * RH) + 4 * half;
-        if (vt + row < G.cend) {  // (chunk tail)
-          float* dst = out_sb + (size_t)gvox(vt + row) * a.cout + col;
+        if (vt + rrow8[r] < G.cend) {  // (chunk tail)
+          float* dst = (float*)((char*)tb + (unsigned)off[r]);
           float v = sum[r >> 1][r & 1];
           if (ACC) v += *dst;  // continuation launch of a wider-K conv: add to what the previous launch stored
           v += bv1;
