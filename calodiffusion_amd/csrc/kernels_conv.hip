@@ -1288,10 +1288,16 @@ void launch_flat3_inst(const ConvFlatArgs& a, dim3 grid, int threads, size_t lds
 struct ConvTiled3Args {
   ConvKArgs k;       // geometry / tiling / pointers (wpk = packed bf16x3 weights)
   float* ch_part;    // optional channel statistics of the output: [B][nTZ*nTH][cout][2]
+  int* status;       // f16x2: bit 0 <- a staged value exceeded the fp16 range
 };
 
-template <int VT, int CT>
-__global__ void __launch_bounds__(512, (VT * CT <= 2 ? 3 : 2)) conv_tiled_bf16x3_kernel(ConvTiled3Args args) {
+// NTERM = 3: bf16x3; NTERM = 2: f16x2 (split16.h: 64 B + 16 B pad per voxel and sub-chunk, two accumulators per tile folded after
+// the K loop, fp16 range flag) -- the arithmetic of the other f16x2 kernels for the convs only this tiling fits (Dataset-3's
+// down-sampling conv out of 50x18 planes: 370 us per launch as bf16x3).
+template <int VT, int CT, int NTERM>
+__global__ void __launch_bounds__(512, (VT * CT * (NTERM == 2 ? 2 : 1) <= 2 ? 3 : 2)) conv_tiled_bf16x3_kernel(ConvTiled3Args args) {
+  constexpr int VB = NTERM == 3 ? 96 : 80;  // bytes per staged voxel
+  constexpr int WS = 64 * NTERM;            // u32x4 per (tap, ct) in the packed weights
   extern __shared__ __attribute__((aligned(16))) float lds[];
   char* ldsb = (char*)lds;
   const ConvKArgs& a = args.k;
@@ -1304,7 +1310,7 @@ __global__ void __launch_bounds__(512, (VT * CT <= 2 ? 3 : 2)) conv_tiled_bf16x3
   const int ct0 = blockIdx.y * CT;
   const int oz0 = tzi * a.TZ, oh0 = thi * a.TH;
   const int tileVox = a.IZ * a.IH * a.Win;
-  const int ZERO = tileVox * 96;  // byte offset of the all-zero voxel
+  const int ZERO = tileVox * VB;  // byte offset of the all-zero voxel
   const int half = lane >> 5, col = lane & 31;
   if (tid < 24) ((float*)(ldsb + ZERO))[tid] = 0.f;
 
@@ -1318,7 +1324,7 @@ __global__ void __launch_bounds__(512, (VT * CT <= 2 ? 3 : 2)) conv_tiled_bf16x3
     const int t = v / a.Wo;
     const int oh = t % a.TH, oz = t / a.TH;
     const bool valid = (oz < a.TZ) && (oz0 + oz < a.Do) && (oh0 + oh < a.Ho);
-    abase[vt] = ((oz * a.SZ * a.IH + oh * a.SH) * a.Win + ow * a.SW - 1) * 96 + half * 16;
+    abase[vt] = ((oz * a.SZ * a.IH + oh * a.SH) * a.Win + ow * a.SW - 1) * VB + half * 16;
     unsigned m = 0;
     for (int kw = 0; kw < a.KW; ++kw) {
       const int iw = ow * a.SW + kw - 1;
@@ -1330,13 +1336,17 @@ __global__ void __launch_bounds__(512, (VT * CT <= 2 ? 3 : 2)) conv_tiled_bf16x3
   }
   const bool wave_active = __any(any_valid);
 
-  f32x16 acc[VT][CT];
+  f32x16 acc[VT][CT], accB[NTERM == 2 ? VT : 1][NTERM == 2 ? CT : 1];
 #pragma unroll
   for (int vt = 0; vt < VT; ++vt)
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[vt][ct][r] = 0.f;
+      for (int r = 0; r < 16; ++r) {
+        acc[vt][ct][r] = 0.f;
+        if (NTERM == 2) accB[vt][ct][r] = 0.f;
+      }
+  float amax = 0.f;
 
   const int nsub = (a.c0 + a.c1) >> 4;
   const int T = a.KD * a.KH * a.KW;
@@ -1391,45 +1401,59 @@ __global__ void __launch_bounds__(512, (VT * CT <= 2 ? 3 : 2)) conv_tiled_bf16x3
       for (int k = 0; k < 4; ++k) {
         const int idx = i0 + k * nthreads;
         if (idx < items) {
-          u32x2 t1, t2, t3;
-          split3(val[k], t1, t2, t3);
-          char* d = ldsb + (size_t)(idx >> 2) * 96 + pq * 8;
-          *(u32x2*)d = t1;
-          *(u32x2*)(d + 32) = t2;
-          *(u32x2*)(d + 64) = t3;
+          char* d = ldsb + (size_t)(idx >> 2) * VB + pq * 8;
+          if (NTERM == 3) {
+            u32x2 t1, t2, t3;
+            split3(val[k], t1, t2, t3);
+            *(u32x2*)d = t1;
+            *(u32x2*)(d + 32) = t2;
+            *(u32x2*)(d + 64) = t3;
+          } else {
+            amax = fmaxf(amax, fmaxf(fmaxf(fabsf(val[k][0]), fabsf(val[k][1])), fmaxf(fabsf(val[k][2]), fabsf(val[k][3]))));
+            u32x2 t1, t2;
+            split2(val[k], t1, t2);
+            *(u32x2*)d = t1;
+            *(u32x2*)(d + 32) = t2;
+          }
         }
       }
     }
     __syncthreads();
     if (!wave_active) continue;
 
-    const u32x4* wq = (const u32x4*)a.wpk + ((size_t)sc * T * a.CTtot + ct0) * 192 + lane;
+    const u32x4* wq = (const u32x4*)a.wpk + ((size_t)sc * T * a.CTtot + ct0) * WS + lane;
     for (int kd = 0; kd < a.KD; ++kd) {
       for (int kh = 0; kh < a.KH; ++kh) {
-        const int rowoff = (kd * a.IH + kh) * a.Win * 96;
+        const int rowoff = (kd * a.IH + kh) * a.Win * VB;
         for (int kw = 0; kw < a.KW; ++kw) {
           const int tap = (kd * a.KH + kh) * a.KW + kw;
-          u32x4 bw[CT][3];
+          u32x4 bw[CT][NTERM];
 #pragma unroll
           for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-            for (int t = 0; t < 3; ++t) bw[ct][t] = wq[((size_t)tap * a.CTtot + ct) * 192 + t * 64];
+            for (int t = 0; t < NTERM; ++t) bw[ct][t] = wq[((size_t)tap * a.CTtot + ct) * WS + t * 64];
 #pragma unroll
           for (int vt = 0; vt < VT; ++vt) {
-            const int off = ((wmask[vt] >> kw) & 1u) ? abase[vt] + rowoff + kw * 96 : ZERO + half * 16;
-            u32x4 av[3];
+            const int off = ((wmask[vt] >> kw) & 1u) ? abase[vt] + rowoff + kw * VB : ZERO + half * 16;
+            u32x4 av[NTERM];
 #pragma unroll
-            for (int t = 0; t < 3; ++t) av[t] = *(const u32x4*)(ldsb + off + t * 32);
+            for (int t = 0; t < NTERM; ++t) av[t] = *(const u32x4*)(ldsb + off + t * 32);
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
-              f32x16 c = acc[vt][ct];
-              c = MFMA_BF16(av[2], bw[ct][0], c);
-              c = MFMA_BF16(av[1], bw[ct][1], c);
-              c = MFMA_BF16(av[0], bw[ct][2], c);
-              c = MFMA_BF16(av[1], bw[ct][0], c);
-              c = MFMA_BF16(av[0], bw[ct][1], c);
-              c = MFMA_BF16(av[0], bw[ct][0], c);
-              acc[vt][ct] = c;
+              if (NTERM == 3) {
+                f32x16 c = acc[vt][ct];
+                c = MFMA_BF16(av[2], bw[ct][0], c);
+                c = MFMA_BF16(av[NTERM - 2], bw[ct][NTERM - 2], c);
+                c = MFMA_BF16(av[0], bw[ct][NTERM - 1], c);
+                c = MFMA_BF16(av[NTERM - 2], bw[ct][0], c);
+                c = MFMA_BF16(av[0], bw[ct][NTERM - 2], c);
+                c = MFMA_BF16(av[0], bw[ct][0], c);
+                acc[vt][ct] = c;
+              } else {
+                acc[vt][ct] = MFMA_F16(av[0], bw[ct][0], acc[vt][ct]);
+                accB[vt][ct] = MFMA_F16(av[0], bw[ct][NTERM - 1], accB[vt][ct]);
+                accB[vt][ct] = MFMA_F16(av[NTERM - 1], bw[ct][0], accB[vt][ct]);
+              }
             }
           }
         }
@@ -1437,6 +1461,15 @@ __global__ void __launch_bounds__(512, (VT * CT <= 2 ? 3 : 2)) conv_tiled_bf16x3
     }
   }
 
+  if (NTERM == 2) {
+#pragma unroll
+    for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[vt][ct][r] += accB[vt][ct][r] * (1.f / 2048.f);
+    if (args.status && amax > 65504.f) atomicOr(args.status, 1);
+  }
   float* outb = a.out + (size_t)b * a.Do * a.Ho * a.Wo * a.cout;
   float bv[CT], s1[CT], s2[CT];
 #pragma unroll
@@ -1488,14 +1521,14 @@ __global__ void __launch_bounds__(512, (VT * CT <= 2 ? 3 : 2)) conv_tiled_bf16x3
 }
 
 namespace {
-template <int VT, int CT>
+template <int VT, int CT, int NTERM = 3>
 void launch_tiled3_inst(const ConvTiled3Args& a, dim3 grid, int threads, size_t lds, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    CD_HIP(hipFuncSetAttribute((const void*)conv_tiled_bf16x3_kernel<VT, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CD_HIP(hipFuncSetAttribute((const void*)conv_tiled_bf16x3_kernel<VT, CT, NTERM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_tiled_bf16x3_kernel<VT, CT>), grid, dim3(threads), lds, s, a);
+  hipLaunchKernelGGL((conv_tiled_bf16x3_kernel<VT, CT, NTERM>), grid, dim3(threads), lds, s, a);
   CD_HIP(hipGetLastError());
 }
 }  // namespace
@@ -1671,11 +1704,19 @@ void launch_conv_mfma(const float* in0, int c0, const float* in1, int c1, const 
   {
     const bool want_f32 = conv_precision() == PREC_F32;
     if (fu.wpk_bf16x3 && !want_f32) {
-      const std::vector<ConvTile> cand3 = conv_tile_candidates(g, batch, CT, 14, 96);
+      // f16x2 arm of the tiled kernel first (two accumulators per tile: at most two tiles per wave) unless the exact split is asked
+      // for; bf16x3 if no such tiling fits
+      const bool f16_ok = conv_precision() == PREC_F16X2 && !fu.in_absmax;
+      for (int pass = f16_ok ? 0 : 1; pass < 2; ++pass) {
+      const bool f16 = pass == 0;
+      const std::vector<ConvTile> cand3 = conv_tile_candidates(g, batch, CT, 14, f16 ? 80 : 96);
       auto launch3 = [&](const ConvTile& t) {
         ConvTiled3Args a3;
         ConvKArgs& a = a3.k;
-        a.in0 = in0; a.in1 = in1; a.c0 = c0; a.c1 = c1; a.wpk = (const float*)fu.wpk_bf16x3; a.bias = bias; a.out = out;
+        a3.status = fu.status;
+        a.in0 = in0; a.in1 = in1; a.c0 = c0; a.c1 = c1; a.bias = bias; a.out = out;
+        a.wpk = f16 ? (const float*)((const char*)fu.wpk_bf16x3 + packed_bf16x3_bytes(c0 + c1, cout, g.kd * g.kh * g.kw))
+                    : (const float*)fu.wpk_bf16x3;
         a.Din = g.in.d; a.Hin = g.in.h; a.Win = g.in.w; a.Do = g.out.d; a.Ho = g.out.h; a.Wo = g.out.w;
         a.KD = g.kd; a.KH = g.kh; a.KW = g.kw; a.SZ = g.sz; a.SH = g.sh; a.SW = g.sw;
         a.TZ = t.TZ; a.TH = t.TH; a.nTZ = (g.out.d + t.TZ - 1) / t.TZ; a.nTH = (g.out.h + t.TH - 1) / t.TH;
@@ -1689,6 +1730,12 @@ void launch_conv_mfma(const float* in0, int c0, const float* in1, int c1, const 
         size_t lds = t.lds;
         const size_t red = (size_t)t.NW * CT * 32 * 2 * 4;
         if (lds < red) lds = red;
+        if (f16) {
+          if (t.VT == 1 && CT == 1) { launch_tiled3_inst<1, 1, 2>(a3, grid, t.NW * 64, lds, s); return; }
+          if (t.VT == 2 && CT == 1) { launch_tiled3_inst<2, 1, 2>(a3, grid, t.NW * 64, lds, s); return; }
+          if (t.VT == 1 && CT == 2) { launch_tiled3_inst<1, 2, 2>(a3, grid, t.NW * 64, lds, s); return; }
+          CD_REQUIRE(false, "conv: no f16x2 tiled kernel instance for the chosen tiling");
+        }
 #define CD_T3_CASE(V, C)                                              \
   if (t.VT == V && CT == C) {                                         \
     launch_tiled3_inst<V, C>(a3, grid, t.NW * 64, lds, s);            \
@@ -1702,13 +1749,14 @@ void launch_conv_mfma(const float* in0, int c0, const float* in1, int c1, const 
       };
       std::vector<ConvTile> ok;
       for (auto& t : cand3)
-        if (t.VT <= 4 && !(CT == 3 && t.VT > 2)) ok.push_back(t);
+        if (f16 ? (t.VT * CT <= 2) : (t.VT <= 4 && !(CT == 3 && t.VT > 2))) ok.push_back(t);
       if (!ok.empty()) {
         char key3[192];
-        std::snprintf(key3, sizeof key3, "tiled_bf16x3 %s b%d", cat, batch);
+        std::snprintf(key3, sizeof key3, "tiled_%s %s b%d", f16 ? "f16x2" : "bf16x3", cat, batch);
         const int pick3 = autotune(key3, (int)ok.size(), [&](int i) { launch3(ok[i]); }, s);
         launch3(ok[pick3 < 0 ? 0 : pick3]);
         return;
+      }
       }
     }
   }
