@@ -57,9 +57,13 @@ struct ConvSmallArgs {
 };
 
 constexpr int CS_PD = 6;  // weight fragments requested this many pairs ahead
+#ifndef CS_NW
+#define CS_NW 4           // waves per workgroup (8 was measured: same step time, twice the partial exchange): the (tap, k-step) pairs of a conv are dealt round-robin to them (K split)
+#endif
+constexpr int CS_THREADS = CS_NW * 64;
 
 template <int NT>  // row tiles (32 voxels each) of the sample: ceil(vox / 32) <= 4
-__global__ void __launch_bounds__(256, 1) conv_small_f16x2_kernel(ConvSmallArgs a) {
+__global__ void __launch_bounds__(CS_THREADS, 1) conv_small_f16x2_kernel(ConvSmallArgs a) {
   extern __shared__ __attribute__((aligned(16))) char cs_lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
   const int b = blockIdx.x, ct = blockIdx.y;
@@ -101,14 +105,14 @@ __global__ void __launch_bounds__(256, 1) conv_small_f16x2_kernel(ConvSmallArgs 
     const int nq = cn >> 2;               // channel quads per voxel
     __syncthreads();                      // previous block's MFMAs have finished reading the image
     // ---- zero the image, then stage the sample (interior records; phi halo rows are copies) ----------------------
-    for (int i = tid; i < nrec * VB / 16; i += 256) ((u32x4*)cs_lds)[i] = u32x4{0u, 0u, 0u, 0u};
+    for (int i = tid; i < nrec * VB / 16; i += CS_THREADS) ((u32x4*)cs_lds)[i] = u32x4{0u, 0u, 0u, 0u};
     __syncthreads();
     // this wave's first weight fragments are requested now: their L2 latency hides behind the staging
     const int npairs = 27 * (cn >> 4);
-    const int mine = (npairs - wave + 3) >> 2;
+    const int mine = (npairs - wave + CS_NW - 1) / CS_NW;
     const u32x4* wbase = wpk_pass + lane;
     auto wptr = [&](int i) {  // pair index i of this wave -> weight fragment pointer
-      const int p = wave + 4 * i;
+      const int p = wave + CS_NW * i;
       const int ks = p / 27, tap = p - ks * 27;
       return wbase + ((size_t)(((cb >> 4) + ks) * 27 + tap) * a.CTtot + ct) * 128;
     };
@@ -121,11 +125,11 @@ __global__ void __launch_bounds__(256, 1) conv_small_f16x2_kernel(ConvSmallArgs 
         wr[i][1] = wp[64];
       }
     // staging: all of a thread's global loads are issued before the first conversion (4 items per batch)
-    for (int i0 = tid; i0 < vox * nq; i0 += 4 * 256) {
+    for (int i0 = tid; i0 < vox * nq; i0 += 4 * CS_THREADS) {
       f32x4 xs[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const int i = min(i0 + k * 256, vox * nq - 1);
+        const int i = min(i0 + k * CS_THREADS, vox * nq - 1);
         const int v = i / nq, q = i - v * nq;
         const int c = cb + q * 4;
         const float* src = c < c0 ? in0 + ((size_t)b * vox + v) * c0 + c : in1 + ((size_t)b * vox + v) * c1 + (c - c0);
@@ -133,7 +137,7 @@ __global__ void __launch_bounds__(256, 1) conv_small_f16x2_kernel(ConvSmallArgs 
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const int i = i0 + k * 256;
+        const int i = i0 + k * CS_THREADS;
         if (i >= vox * nq) break;
         const int v = i / nq, q = i - v * nq;
         const int c = cb + q * 4;
@@ -177,7 +181,7 @@ __global__ void __launch_bounds__(256, 1) conv_small_f16x2_kernel(ConvSmallArgs 
       for (int k = 0; k < CS_PD; ++k) {
         const int i = i0 + k;
         if (i < mine) {
-          const int p = wave + 4 * i;
+          const int p = wave + CS_NW * i;
           const int ks = p / 27, tap = p - ks * 27;
           const int kz = tap / 9, kh = (tap - kz * 9) / 3, kw = tap - kz * 9 - kh * 3;
           const int toff = ((kz - 1) * prow + (kh - 1) * pitch + (kw - 1)) * VB + ks * 64;
@@ -207,7 +211,7 @@ __global__ void __launch_bounds__(256, 1) conv_small_f16x2_kernel(ConvSmallArgs 
   __syncthreads();
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    char* d = part + ((t * 4 + wave) * 4) * 1024 + lane * 16;
+    char* d = part + ((t * CS_NW + wave) * 4) * 1024 + lane * 16;
 #pragma unroll
     for (int g = 0; g < 4; ++g)
       *(f32x4*)(d + g * 1024) = f32x4{accA[t][4 * g] + accB[t][4 * g] * (1.f / 2048.f), accA[t][4 * g + 1] + accB[t][4 * g + 1] * (1.f / 2048.f),
@@ -219,8 +223,8 @@ __global__ void __launch_bounds__(256, 1) conv_small_f16x2_kernel(ConvSmallArgs 
     const float bv = bias_pass ? bias_pass[ct * 32 + col] : 0.f;
     f32x16 sum;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const char* d = part + ((wave * 4 + w) * 4) * 1024 + lane * 16;
+    for (int w = 0; w < CS_NW; ++w) {
+      const char* d = part + ((wave * CS_NW + w) * 4) * 1024 + lane * 16;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const f32x4 x = *(const f32x4*)(d + g * 1024);
@@ -264,7 +268,7 @@ __global__ void __launch_bounds__(256, 1) conv_small_f16x2_kernel(ConvSmallArgs 
     if (tid < 32) {
       float t1 = 0.f, t2 = 0.f;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) {
+      for (int w = 0; w < CS_NW; ++w) {
         t1 += red[(w * 32 + tid) * 2];
         t2 += red[(w * 32 + tid) * 2 + 1];
       }
@@ -293,7 +297,7 @@ __global__ void __launch_bounds__(256, 1) conv_small_f16x2_kernel(ConvSmallArgs 
   // one pass = one convolution; a whole ResnetBlock (wpk2) is two, conv1's GroupNorm + SiLU + embedding being folded into the staging
   // of conv2 through the coefficient table in LDS.  (One loop body instead of two call sites of the lambdas: each is inlined once.)
   float s1 = 0.f, s2 = 0.f;
-  float* const red = (float*)cs_lds;                        // [4][32][2] per-wave channel sums (head of the image region)
+  float* const red = (float*)cs_lds;                        // [CS_NW][32][2] per-wave channel sums (head of the image region)
   float* const table = (float*)(cs_lds + a.coef_lds_off);   // [32][4] {scale, shift, add, 0} of the GroupNorm this workgroup computes
   const int npass = a.wpk2 ? 2 : 1;
   for (int pass = 0; pass < npass; ++pass) {
@@ -353,7 +357,7 @@ __global__ void __launch_bounds__(256, 1) conv_small_f16x2_kernel(ConvSmallArgs 
       if (tid < 32) {
         float t1 = 0.f, t2 = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < CS_NW; ++w) {
           t1 += red[(w * 32 + tid) * 2];
           t2 += red[(w * 32 + tid) * 2 + 1];
         }
@@ -377,7 +381,7 @@ __global__ void __launch_bounds__(256, 1) conv_small_f16x2_kernel(ConvSmallArgs 
     if (tid < 32) {
       float t1 = 0.f, t2 = 0.f;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) {
+      for (int w = 0; w < CS_NW; ++w) {
         t1 += red[(w * 32 + tid) * 2];
         t2 += red[(w * 32 + tid) * 2 + 1];
       }
@@ -395,7 +399,7 @@ void launch_small_inst(const ConvSmallArgs& a, dim3 grid, size_t lds, hipStream_
     CD_HIP(hipFuncSetAttribute((const void*)conv_small_f16x2_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL(conv_small_f16x2_kernel<NT>, grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL(conv_small_f16x2_kernel<NT>, grid, dim3(CS_THREADS), lds, s, a);
   CD_HIP(hipGetLastError());
 }
 
@@ -414,7 +418,7 @@ bool try_launch_conv_small(const float* in0, int c0, const float* in1, int c1, c
   const int VB = (cin < 64 ? cin : 64) * 4 + 16;
   const int NT = (int)((vox + 31) / 32);
   const size_t image = (size_t)(g.in.d + 2) * (g.in.h + 2) * (g.in.w + 1) * VB;
-  const size_t partial = (size_t)NT * 4 * 4096;
+  const size_t partial = (size_t)NT * CS_NW * 4096;
   size_t lds = image > partial ? image : partial;
   lds = (lds + 255) & ~(size_t)255;
   const size_t coef_off = lds;
@@ -460,7 +464,7 @@ bool try_launch_res_block_small(const float* x0, int c0, const float* x1, int c1
   const int VB = (cin < 64 ? cin : 64) * 4 + 16;  // (conv2's 32 input channels need no more)
   const int NT = (int)((vox + 31) / 32);
   const size_t image = (size_t)(dims.d + 2) * (dims.h + 2) * (dims.w + 1) * VB;
-  const size_t partial = (size_t)NT * 4 * 4096;
+  const size_t partial = (size_t)NT * CS_NW * 4096;
   size_t lds = image > partial ? image : partial;
   lds = (lds + 255) & ~(size_t)255;
   const size_t coef_off = lds;
