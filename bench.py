@@ -56,6 +56,49 @@ def dist_info():
     return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 
 
+# per-configuration defaults = the cases BASELINE.json names (configs[1], [3], [4]; [2] is --mode train)
+CONFIG_DEFAULTS = {
+    "dataset2": {"batch": 64, "sample_steps": 400, "sampler": "DDim"},   # the headline: 400-step DDIM, batch 64 per GPU
+    "dataset3": {"batch": 32, "sample_steps": 400, "sampler": None},     # config's own sampler (DDim)
+    "hgcal": {"batch": 16, "sample_steps": 200, "sampler": None},        # config's own sampler (DDPM): 128 showers over 8 GPUs
+}
+TRAIN_BATCH = 32  # BASELINE configs[2]: global batch 256 over 8 GPUs
+
+
+def launcher_command(argv, gpus: int, port: int):
+    """The command a bare `python bench.py --gpus N ...` (no WORLD_SIZE in the environment) re-launches itself as: N fresh
+    ranks, one per GPU, under torch.distributed.run.  Built and started BEFORE this process touches the GPU (a process that
+    has initialised HIP must neither fork ranks nor exec)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def launch_ranks(argv, gpus: int) -> int:
+    """Parent of a multi-GPU run started without a launcher: start the ranks as a child process group, relay rank 0's JSON
+    line, exit with the child's code.  Fails loudly if the node has fewer GPUs than asked for (device_count does not
+    initialise the GPU on this stack)."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < gpus:
+        raise SystemExit(f"bench.py --gpus {gpus}: this node exposes {have} GPU(s); refusing to report a {gpus}-GPU number")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = launcher_command(argv, gpus, port)
+    print("[bench] launching " + " ".join(cmd), file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def collective_info():
+    """What the timing barrier / max-over-ranks (and, in --mode train, the gradient all-reduce) actually ran on."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return {"backend": dist.get_backend(), "ranks": dist.get_world_size()}
+    return {"backend": None, "ranks": 1}
+
+
 def max_over_ranks(value: float) -> float:
     """Slowest rank's time (MAX all-reduce); identity in a single-process run."""
     import torch.distributed as dist
@@ -177,6 +220,7 @@ def train_bench(args, model, cfg, E, layers, rank, world):
     """Training throughput (BASELINE configs[2]): zero_grad -> compute_loss -> backward -> Adam.step per iteration, as
     TrainDiffusion.training_loop does; data-parallel replicas with one flat gradient all-reduce per step."""
     B = args.batch
+    from calodiffusion_amd import utils as cd_utils
     g = torch.Generator().manual_seed(4321 + rank)
     shape = [B] + list(cfg["SHAPE_PAD"][1:])
     data = torch.randn(shape, generator=g).cuda()
@@ -196,18 +240,24 @@ def train_bench(args, model, cfg, E, layers, rank, world):
         step()
     barrier()
     torch.cuda.synchronize()
+    cd_utils.ALLREDUCE_EVENTS = []  # (start, end) device events around every gradient all-reduce of the timed steps
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     torch.cuda.synchronize()
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
+    events, cd_utils.ALLREDUCE_EVENTS = cd_utils.ALLREDUCE_EVENTS, None
+    ar_ms = max_over_ranks(sum(a.elapsed_time(b) for a, b in events) / max(1, args.steps))
+    nbytes = model.engine().grad_layout()[1] * 4
     result = {"metric": f"training samples/sec ({args.config}, hybrid_weight l2, Adam)", "value": world * args.steps * B / dt,
               "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
               "config": {"workload": f"{args.config} training step, batch {B} per GPU", "global_batch": B * world,
                          "parallelism": f"data-parallel x{world}, one flat fp32 gradient all-reduce per step",
-                         "final_loss": float(loss)}}
+                         "final_loss": float(loss)},
+              "collective": dict(collective_info(), allreduce_bytes=nbytes, allreduces_per_step=len(events) / max(1, args.steps),
+                                 allreduce_ms=ar_ms, allreduce_share_of_step=ar_ms / (1e3 * dt / args.steps))}
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
@@ -221,8 +271,10 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="dataset2")
-    ap.add_argument("--batch", type=int, default=64, help="showers per GPU (weak scaling)")
-    ap.add_argument("--sample-steps", type=int, default=400)
+    ap.add_argument("--batch", type=int, default=None,
+                    help="showers per GPU (weak scaling); default: BASELINE's case of the config (64 / 32 / 16; 32 for --mode train)")
+    ap.add_argument("--sample-steps", type=int, default=None, help="default: BASELINE's case of the config (400; hgcal 200)")
+    ap.add_argument("--sampler", default=None, help="sampler class name; default: DDim for dataset2, else the config's own")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the roofline and cpu_baseline legs")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel breakdown to stderr")
@@ -230,10 +282,18 @@ def main():
     ap.add_argument("--mode", default="sample", choices=["sample", "train"],
                     help="train: BASELINE configs[2], a step = one training iteration (fwd + bwd + grad all-reduce + Adam)")
     args = ap.parse_args()
+    dflt = CONFIG_DEFAULTS.get(args.config, {"batch": 64, "sample_steps": 400, "sampler": None})
+    if args.batch is None:
+        args.batch = TRAIN_BATCH if args.mode == "train" else dflt["batch"]
+    if args.sample_steps is None:
+        args.sample_steps = dflt["sample_steps"]
 
     rank, local_rank, world = dist_info()
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started without a launcher: become the parent of N fresh ranks (nothing has touched the GPU yet)
+        raise SystemExit(launch_ranks(sys.argv[1:], args.gpus))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a number for another GPU count")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -246,8 +306,10 @@ def main():
     from calodiffusion_amd.configs import load_config
     cfg = dict(load_config(args.config))
     cfg["_name"] = args.config
-    cfg["SAMPLER"] = "DDim"
-    cfg["SAMPLER_OPTIONS"] = {"HIP_GRAPH": not args.no_graph}
+    if args.sampler or dflt["sampler"]:
+        cfg["SAMPLER"] = args.sampler or dflt["sampler"]
+    sampler_name = cfg["SAMPLER"]
+    cfg["SAMPLER_OPTIONS"] = dict(cfg.get("SAMPLER_OPTIONS") or {}, HIP_GRAPH=not args.no_graph)
     torch.manual_seed(1234)  # identical random-init weights on every rank
     model = CaloDiffusion(cfg, n_steps=cfg["NSTEPS"], loss_type=cfg["LOSS_TYPE"])
     B = args.batch
@@ -275,8 +337,9 @@ def main():
     assert np.isfinite(out).all()
 
     result = {
-        "metric": "sampled showers/sec (Dataset-2, 400-step DDIM)" if args.config == "dataset2" and args.sample_steps == 400
-        else f"sampled showers/sec ({args.config}, {args.sample_steps}-step DDIM)",
+        "metric": "sampled showers/sec (Dataset-2, 400-step DDIM)"
+        if args.config == "dataset2" and args.sample_steps == 400 and sampler_name == "DDim"
+        else f"sampled showers/sec ({args.config}, {args.sample_steps}-step {sampler_name})",
         "value": world * args.steps * B / dt,
         "unit": "showers/s",
         "n_gpus": world,
@@ -290,9 +353,10 @@ def main():
         if engine_mod.get_conv_precision() == "f16x2" else f"f32 (convs: {engine_mod.get_conv_precision()})",
         "data": "synthetic",
         "config": {"workload": f"{args.config}: {'x'.join(str(v) for v in cfg['SHAPE_PAD'][2:])} voxels, "
-                               f"{args.sample_steps}-step DDIM, batch {B} per GPU, random-init weights (seed 1234)",
+                               f"{args.sample_steps}-step {sampler_name}, batch {B} per GPU, random-init weights (seed 1234)",
                    "global_batch": B * world, "parallelism": f"batch-sharded x{world}, no collective",
                    "hip_graph": not args.no_graph, "denoise_ms": 1e3 * dt / args.steps / args.sample_steps},
+        "collective": collective_info(),  # timing barrier + max-over-ranks only: the sampling path has no data-path collective
     }
     if rank == 0 and world == 1 and not args.no_extra:
         roof, breakdown = roofline_leg(model, cfg, B, E, layers)

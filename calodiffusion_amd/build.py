@@ -29,14 +29,27 @@ FLAGS += os.environ.get("CD_EXTRA_HIPCC_FLAGS", "").split()  # e.g. -DCD_ZS_EXPE
 FILE_FLAGS = {"kernels_conv_zs.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
-def _stale(target: str, deps) -> bool:
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+def _file_digest(paths, extra: str = "") -> str:
+    import hashlib
+    h = hashlib.sha256(extra.encode())
+    for f in paths:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+def _read(path: str):
+    try:
+        return open(path).read().strip()
+    except OSError:
+        return None
 
 
 def build_all(force: bool = False, verbose: bool = True) -> str:
+    """Compile what changed and link.  Staleness is decided by CONTENT, not mtimes: every object carries `<obj>.hash` = sha256
+    of its source, every header / include fragment and its flags, and the library's `.srchash` stamp is (re)written only when
+    the link step ran -- after an rsync or a stash that preserves mtimes the stamp can therefore never vouch for a library
+    that was not built from the hashed sources (engine.load_library compares it with source_hash())."""
     os.makedirs(LIBDIR, exist_ok=True)
     objdir = os.path.join(LIBDIR, "obj" + ("_" + TAG if TAG else ""))
     os.makedirs(objdir, exist_ok=True)
@@ -51,8 +64,10 @@ def build_all(force: bool = False, verbose: bool = True) -> str:
         sp = os.path.join(CSRC, src)
         op = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(op)
-        if force or _stale(op, [sp] + headers):
-            jobs.append([HIPCC, *FLAGS, *FILE_FLAGS.get(os.path.basename(sp), []), "-c", sp, "-o", op])
+        flags = [*FLAGS, *FILE_FLAGS.get(os.path.basename(sp), [])]
+        key = _file_digest([sp] + headers, " ".join(flags))
+        if force or not os.path.exists(op) or _read(op + ".hash") != key:
+            jobs.append(([HIPCC, *flags, "-c", sp, "-o", op], op, key))
 
     def run(cmd):
         if verbose:
@@ -63,12 +78,23 @@ def build_all(force: bool = False, verbose: bool = True) -> str:
         if verbose and r.stderr.strip():
             print(r.stderr, file=sys.stderr)
 
+    def compile_one(job):
+        cmd, op, key = job
+        if os.path.exists(op + ".hash"):
+            os.remove(op + ".hash")
+        run(cmd)
+        with open(op + ".hash", "w") as fh:
+            fh.write(key + "\n")
+
     with ThreadPoolExecutor(max_workers=4) as ex:
-        list(ex.map(run, jobs))
-    if force or jobs or _stale(LIB, objs):
+        list(ex.map(compile_one, jobs))
+    want = source_hash()
+    if force or jobs or not os.path.exists(LIB) or _read(LIB + ".srchash") != want:
+        if os.path.exists(LIB + ".srchash"):
+            os.remove(LIB + ".srchash")
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
-    with open(LIB + ".srchash", "w") as fh:  # which sources the library next to it was built from
-        fh.write(source_hash() + "\n")
+        with open(LIB + ".srchash", "w") as fh:  # which sources the library next to it was built from
+            fh.write(want + "\n")
     return LIB
 
 

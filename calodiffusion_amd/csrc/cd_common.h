@@ -46,6 +46,9 @@ struct Scope {
 enum ConvPrecision { PREC_F16X2 = 0, PREC_BF16X3 = 1, PREC_F32 = 2 };
 int conv_precision();
 void set_conv_precision(int p);
+// this thread's override of the process-wide setting (-1 = none): the bf16x3 re-run of a range fallback must not switch the
+// kernels of other plans / threads / ranks of the process in mid-call
+void set_conv_precision_override(int p);
 
 // ---- channels-last tensor view ------------------------------------------------------------------------
 // Internal activation layout: (B, D, H, W, C) fp32, C a multiple of 32 => every voxel is a whole number of 128-B lines.
@@ -316,14 +319,14 @@ bool try_launch_res_block_small(const float* x0, int c0, const float* x1, int c1
 bool attn_small_eligible(int64_t vox);
 void launch_attn_small(const float* x, int C, const float* coef, const void* wqkv_f16x2, float* partials, const float* w_out,
                        float scale, const float* bias, const float* out_gamma, const float* out_beta, float* y, float* ch_part,
-                       int batch, int64_t vox, hipStream_t s, const GnDefer* defer);
+                       int batch, int64_t vox, hipStream_t s, const GnDefer* defer, int* status = nullptr);
 void launch_attn_kv_context(const float* x, int C, const float* coef, const void* wqkv_f16x2, float* partials, int batch,
-                            int64_t vox, int nsplit, hipStream_t s, const GnDefer* defer = nullptr);
+                            int64_t vox, int nsplit, hipStream_t s, const GnDefer* defer = nullptr, int* status = nullptr);
 void launch_attn_out(const float* x, int C, const float* coef, const void* wqkv_f16x2, const float* wT_b, const float* bias,
                      float* y, float* ch_part /* [B][nsplit][C][2] */, int batch, int64_t vox, int nsplit, hipStream_t s,
                      const GnDefer* defer = nullptr,
                      // wT_b == null: every workgroup merges the pass-1 partials and folds W_out itself (no combine launch)
-                     const float* partials = nullptr, const float* w_out = nullptr, float scale = 0.f);
+                     const float* partials = nullptr, const float* w_out = nullptr, float scale = 0.f, int* status = nullptr);
 
 struct EmbedLayer {
   const float* w;  // (cout, 128) torch layout
@@ -385,6 +388,7 @@ void launch_randn_step(float* out, int64_t n, const uint64_t* seed_offset_stride
                        int per_step = 1, int index = 0);
 // generic sampler programs (cd_sampler_run): per-step scalars are columns of row (*step_counter - 1) of a device table
 void launch_step_advance(int* counter, hipStream_t s);  // (*counter)++
+void launch_or_word(int* word, int bits, hipStream_t s);  // *word |= bits
 void launch_fill_from_table(float* dst, int count, const float* table, int ncol, int col, const int* step_counter, hipStream_t s);
 // out[i] = sum_k table[row][col + k] * src[k][i]   (nsrc <= 6; out may alias a source)
 void launch_lincomb(float* out, const float* const* src, int nsrc, const float* table, int ncol, int col, const int* step_counter,

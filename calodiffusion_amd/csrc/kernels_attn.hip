@@ -47,6 +47,7 @@ struct AttnArgs {
   float* ch_part;     // [B][units][C][2]
   GnDefer defer;      // PreNorm coefficients folded in the prologue instead of read from `coef`
   const float *out_gamma, *out_beta;  // attn_small_kernel: affine parameters of the closing GroupNorm(1, C)
+  int* status;        // bit 0: an operand of the fp16-pipe products (normalised x, v, the folded output weights) left the fp16 range
 };
 
 // A fragments of one 32-voxel tile for v_mfma_f32_32x32x16_f16: lane (voxel n0 + col, half) holds, per 16-channel k-step ks,
@@ -69,7 +70,7 @@ __device__ __forceinline__ void load_raw(const AttnArgs& a, int b, int64_t t, in
 }
 template <int NCH>
 __device__ __forceinline__ void norm_split(const AttnArgs& a, int64_t n0, int col, const f32x4 (&cf)[NCH][8], const RawTile<NCH>& raw,
-                                           u32x4 (&x1)[NCH * 2], u32x4 (&x2)[NCH * 2]) {
+                                           u32x4 (&x1)[NCH * 2], u32x4 (&x2)[NCH * 2], float& amax) {
   const bool valid = n0 + col < a.vox;
 #pragma unroll
   for (int ks = 0; ks < NCH * 2; ++ks) {
@@ -83,6 +84,7 @@ __device__ __forceinline__ void norm_split(const AttnArgs& a, int64_t n0, int co
         const f32x4 c2 = cf[ks >> 1][(ks & 1) * 4 + j * 2 + (e >> 1)];
         v[e] = valid ? c2[(e & 1) * 2] * v[e] + c2[(e & 1) * 2 + 1] : 0.f;
       }
+      amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
       split2(v, t1[j], t2[j]);
     }
     x1[ks] = u32x4{t1[0][0], t1[0][1], t1[1][0], t1[1][1]};
@@ -173,6 +175,7 @@ __device__ __forceinline__ void attn_pass1(const AttnArgs& a, int b, int split, 
   const int64_t tlast = t1 - 1;
   float m = -3.0e38f;  // (sentinel: never enters an exponential)
   bool any = false;
+  float amax = 0.f;  // largest |operand| of the fp16-pipe products of this thread (normalised x, v)
   // The context product itself runs on the fp16 pipe with the convs' two-term split (split16.h): e in (0, 1] and v as f16x2, the
   // registers 8s .. 8s+7 of a lane being the 8 k-slots of k-step s (the same voxels in e and in v), 3 MFMAs per k-step into two
   // accumulators -- 6 x 32 cycles per tile against 16 x 64 for v_mfma_f32_32x32x2_f32, for ~110 more vector instructions.
@@ -203,7 +206,7 @@ __device__ __forceinline__ void attn_pass1(const AttnArgs& a, int b, int split, 
   for (int64_t tt = t0 + wave; tt < t1; tt += 8) {
     u32x4 x1[NKS], x2[NKS];
     load_raw<NCH>(a, b, tt, tlast, col, half, raw);
-    norm_split<NCH>(a, tt * 32, col, cf, raw, x1, x2);
+    norm_split<NCH>(a, tt * 32, col, cf, raw, x1, x2, amax);
     const f32x16 k = project(x1, x2, wk1, wk2);
     const f32x16 v = project(x1, x2, wv1, wv2);
     const bool full = tt * 32 + 32 <= a.vox;  // (only a sample's last tile can be partial)
@@ -231,6 +234,7 @@ __device__ __forceinline__ void attn_pass1(const AttnArgs& a, int b, int split, 
       ex[r] = (full || tt * 32 + row < a.vox) ? attn_exp(k[r] - m) : 0.f;
       ssum += ex[r];
       vv[r] = v[r];
+      amax = fmaxf(amax, fabsf(v[r]));
     }
 #pragma unroll
     for (int s8 = 0; s8 < 2; ++s8) {
@@ -242,6 +246,7 @@ __device__ __forceinline__ void attn_pass1(const AttnArgs& a, int b, int split, 
       ctxB = MFMA_F16(e2, v1, ctxB);
     }
   }
+  if (a.status && !(amax <= 65504.f)) atomicOr(a.status, 1);  // (also catches NaN)
   // merge the waves: common maximum, every wave's sums and context rescaled to it
   if (half == 0) sMax[wave][col] = m;
   attn_barrier_lds();
@@ -365,6 +370,12 @@ __device__ __forceinline__ void attn_pass2(const AttnArgs& a, int b, int unit, i
   // the folded weights as f16x2 B operands of the output product (fp16 pipe, as the context product of pass 1): k-step s = the
   // registers 8s .. 8s+7 of wt (the d-slots of q's registers 8s .. 8s+7)
   u32x4 wb1[NCH][2], wb2[NCH][2];
+  float amax = 0.f;
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      amax = fmaxf(amax, fmaxf(fmaxf(fabsf(wt[ch][q][0]), fabsf(wt[ch][q][1])), fmaxf(fabsf(wt[ch][q][2]), fabsf(wt[ch][q][3]))));
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
@@ -398,7 +409,7 @@ __device__ __forceinline__ void attn_pass2(const AttnArgs& a, int b, int unit, i
     if (t >= t1) break;
     u32x4 x1[NKS], x2[NKS];
     if (!PRE) load_raw<NCH>(a, b, t, tlast, col, half, raw[d]);
-    norm_split<NCH>(a, t * 32, col, cf, raw[d], x1, x2);
+    norm_split<NCH>(a, t * 32, col, cf, raw[d], x1, x2, amax);
     if (PRE && t + 8 * DEPTH < t1) load_raw<NCH>(a, b, t + 8 * DEPTH, tlast, col, half, raw[d]);
     // q^T[d][n]: A = W_q (row d), B = xn^T (column n); the registers of a lane are 16 channels d of its voxel n = col
     f32x16 q = zero16, qb = zero16;
@@ -456,6 +467,7 @@ __device__ __forceinline__ void attn_pass2(const AttnArgs& a, int b, int unit, i
     }
   }
   }
+  if (a.status && !(amax <= 65504.f)) atomicOr(a.status, 1);
   if (a.ch_part) {
 #pragma unroll
     for (int ct = 0; ct < NCH; ++ct) {
@@ -574,9 +586,10 @@ int attn_fused_nsplit_for(int64_t vox, int batch) {
 }
 
 void launch_attn_kv_context(const float* x, int C, const float* coef, const void* wqkv_f16x2, float* partials, int batch,
-                            int64_t vox, int nsplit, hipStream_t s, const GnDefer* defer) {
+                            int64_t vox, int nsplit, hipStream_t s, const GnDefer* defer, int* status) {
   CD_REQUIRE(C == 32 || C == 64 || C == 96 || C == 128, "fused attention: 32..128 input channels");
   AttnArgs a{};
+  a.status = status;
   a.x = x; a.coef = coef; a.wqkv = (const u32x4*)wqkv_f16x2; a.C = C; a.vox = vox; a.tiles_per_wg = tiles_per_wg_for(vox, nsplit);
   a.partials = partials; a.nsplit = nsplit;
   if (defer) a.defer = *defer;
@@ -595,9 +608,10 @@ void launch_attn_kv_context(const float* x, int C, const float* coef, const void
 
 void launch_attn_out(const float* x, int C, const float* coef, const void* wqkv_f16x2, const float* wT_b, const float* bias,
                      float* y, float* ch_part, int batch, int64_t vox, int nsplit, hipStream_t s, const GnDefer* defer,
-                     const float* partials, const float* w_out, float scale) {
+                     const float* partials, const float* w_out, float scale, int* status) {
   CD_REQUIRE(C == 32 || C == 64 || C == 96 || C == 128, "fused attention: 32..128 channels");
   AttnArgs a{};
+  a.status = status;
   a.x = x; a.coef = coef; a.wqkv = (const u32x4*)wqkv_f16x2; a.C = C; a.vox = vox; a.tiles_per_wg = tiles_per_wg_for(vox, nsplit);
   a.wT = wT_b; a.bias = bias; a.y = y; a.ch_part = ch_part;
   CD_REQUIRE(wT_b || (partials && w_out), "attn_out: folded weights or the pass-1 partials to fold them from");
@@ -624,10 +638,11 @@ bool attn_small_eligible(int64_t vox) {
 }
 void launch_attn_small(const float* x, int C, const float* coef, const void* wqkv_f16x2, float* partials, const float* w_out,
                        float scale, const float* bias, const float* out_gamma, const float* out_beta, float* y, float* ch_part,
-                       int batch, int64_t vox, hipStream_t s, const GnDefer* defer) {
+                       int batch, int64_t vox, hipStream_t s, const GnDefer* defer, int* status) {
   CD_REQUIRE(C == 32 || C == 64 || C == 96 || C == 128, "fused attention: 32..128 channels");
   CD_REQUIRE((vox * C) % 4 == 0, "fused attention: whole float4 rows");
   AttnArgs a{};
+  a.status = status;
   a.x = x; a.coef = coef; a.wqkv = (const u32x4*)wqkv_f16x2; a.C = C; a.vox = vox; a.tiles_per_wg = tiles_per_wg_for(vox, 1);
   a.partials = partials; a.nsplit = 1; a.wT = nullptr; a.fold_wout = w_out; a.fold_scale = scale; a.bias = bias;
   a.y = y; a.ch_part = ch_part; a.out_gamma = out_gamma; a.out_beta = out_beta;

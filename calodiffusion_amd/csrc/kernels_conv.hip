@@ -23,7 +23,10 @@ namespace cd {
 // process-wide arithmetic of the convolutions (cd_common.h); the plan flips it to bf16x3 for the re-run of a trajectory
 // whose f16x2 pass left the fp16 range
 static int g_conv_precision = -1;
+static thread_local int tl_conv_precision_override = -1;
+void set_conv_precision_override(int p) { tl_conv_precision_override = p; }
 int conv_precision() {
+  if (tl_conv_precision_override >= 0) return tl_conv_precision_override;
   if (g_conv_precision < 0) {
     const char* e = getenv("CD_CONV_PRECISION");
     g_conv_precision = !e ? PREC_F16X2 : (!strcmp(e, "f32") ? PREC_F32 : (!strcmp(e, "bf16x3") ? PREC_BF16X3 : PREC_F16X2));

@@ -408,7 +408,8 @@ void launch_small_inst(const ConvSmallArgs& a, dim3 grid, size_t lds, hipStream_
 // Eligible: 3x3x3 stride 1, whole sample <= 128 voxels.  Returns false otherwise.
 bool try_launch_conv_small(const float* in0, int c0, const float* in1, int c1, const void* wpk_f16x2, const float* bias, float* out,
                            int batch, int cout, const ConvGeom& g, hipStream_t s, const ConvFusion& fu) {
-  if (getenv("CD_NO_CONV_SMALL")) return false;
+  static const bool off = getenv("CD_NO_CONV_SMALL") != nullptr;
+  if (off) return false;
   if (!(g.kd == 3 && g.kh == 3 && g.kw == 3 && g.sz == 1 && g.sh == 1 && g.sw == 1)) return false;
   const int64_t vox = g.in.vox();
   if (vox > 128 || vox < 1) return false;
@@ -457,7 +458,8 @@ bool try_launch_res_block_small(const float* x0, int c0, const float* x1, int c1
                                 const float* b2, const float* gn2_gamma, const float* gn2_beta, int groups, const float* res0,
                                 const float* res1, int res_c0, float* h1, float* out, float* part_out, int batch, int cout,
                                 Dims3 dims, int* status, hipStream_t s) {
-  if (getenv("CD_NO_CONV_SMALL") || getenv("CD_NO_BLOCK_SMALL")) return false;
+  static const bool off = getenv("CD_NO_CONV_SMALL") != nullptr || getenv("CD_NO_BLOCK_SMALL") != nullptr;
+  if (off) return false;
   const int64_t vox = dims.vox();
   const int cin = c0 + c1;
   if (vox > 128 || vox < 1 || cout != 32 || cin % 16 || c0 % 4 || c1 % 4 || groups <= 0 || 32 % groups || !res0) return false;

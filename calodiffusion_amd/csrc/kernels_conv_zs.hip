@@ -1091,7 +1091,11 @@ void z3_launch(const ConvZsArgs& a, bool acc, dim3 grid, size_t lds, hipStream_t
 // 12x21 in 3 strips of 4.  Returns false otherwise.
 bool try_launch_conv_zslide(const float* in0, int c0, const float* in1, int c1, const void* wpk_f16x2, const float* bias, float* out,
                             int batch, int cout, const ConvGeom& g, hipStream_t s, const ConvFusion& fu) {
-  if (getenv("CD_NO_ZSLIDE")) return false;
+  // (environment switches of this launcher are read once: it sits on the eager hot path, one call per K-block)
+  static const bool no_zslide = getenv("CD_NO_ZSLIDE") != nullptr;
+  static const int strip_env = getenv("CD_ZS_STRIP") ? atoi(getenv("CD_ZS_STRIP")) : 0;  // testing: force a strip height
+  static const int dbg_env = getenv("CD_ZS_DBG") ? atoi(getenv("CD_ZS_DBG")) : 0;
+  if (no_zslide) return false;
   if (!(g.kd == 3 && g.kh == 3 && g.kw == 3 && g.sz == 1 && g.sh == 1 && g.sw == 1)) return false;
   if (cout % 32 || c0 % 32 || c1 % 32) return false;
   const int H = g.in.h, W = g.in.w;
@@ -1116,8 +1120,8 @@ bool try_launch_conv_zslide(const float* in0, int c0, const float* in1, int c1, 
     break;
   }
   if (!HS) return false;
-  if (getenv("CD_ZS_STRIP")) {  // testing: force a strip height
-    const int hs = atoi(getenv("CD_ZS_STRIP"));
+  if (strip_env) {
+    const int hs = strip_env;
     const int rows = hs + (hs < H ? 2 : 0);
     if (hs >= 1 && H % hs == 0 && hs * W >= ZS_STEP && rows * W <= ZS_NSL * 32 && lds_for(hs) <= 160 * 1024) HS = hs;
   }
@@ -1173,7 +1177,7 @@ bool try_launch_conv_zslide(const float* in0, int c0, const float* in1, int c1, 
     a.D = g.in.d; a.H = g.in.h; a.W = g.in.w; a.HS = HS; a.NR = ring_for(HS);
     a.nchunk = nchunk; a.CV = CV;
     a.status = fu.status;
-    a.dbg = getenv("CD_ZS_DBG") ? atoi(getenv("CD_ZS_DBG")) : 0;
+    a.dbg = dbg_env;
     const dim3 grid((unsigned)(nstrip * nchunk), (unsigned)batch, (unsigned)CTtot);
 #ifdef CD_ZS_EXPERIMENTS
     if (kb == 0 && a.dbg == 2048 && !v1) {  // stamps: print the per-wave cycle sums of one launch

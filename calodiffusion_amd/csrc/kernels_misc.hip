@@ -396,6 +396,11 @@ void launch_randn_step(float* out, int64_t n, const uint64_t* seed_offset_stride
 // Generic sampler programs (cd_sampler_run): every per-step scalar is a column of row (*counter - 1) of a device table, so a
 // step whose op list does not change is one captured graph replayed for the whole trajectory.
 // ------------------------------------------------------------------------------------------------------------
+__global__ void or_word_kernel(int* word, int bits) { atomicOr(word, bits); }
+void launch_or_word(int* word, int bits, hipStream_t s) {
+  hipLaunchKernelGGL(or_word_kernel, dim3(1), dim3(1), 0, s, word, bits);
+  CD_HIP(hipGetLastError());
+}
 __global__ void step_advance_kernel(int* counter) { *counter = *counter + 1; }
 void launch_step_advance(int* counter, hipStream_t s) {
   hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, counter);

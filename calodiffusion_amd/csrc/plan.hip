@@ -146,6 +146,9 @@ struct CdPlan {
   float* d_table = nullptr;
   int* d_counter = nullptr;
   float* d_stepvals = nullptr;
+  // device word the f16x2 kernels of the current call OR their range flag into: d_counter + 2 (the sticky word cd_plan_status
+  // reports) or, inside an entry point with its own bf16x3 fallback, d_counter + 3 (that call's private word)
+  int* status_word = nullptr;
 
   // cached step graph; captured on a private stream (the caller's may be the legacy null stream, which cannot capture)
   hipStream_t cap_stream = nullptr;
@@ -385,6 +388,7 @@ void build_plan(CdPlan* p) {
   CD_HIP(hipMalloc((void**)&p->d_table, sizeof(float) * 4 * CdPlan::kMaxSteps));
   CD_HIP(hipMalloc((void**)&p->d_counter, sizeof(int) * 4));  // [0] sampler step counter, [2] range flags
   CD_HIP(hipMemset(p->d_counter, 0, sizeof(int) * 4));
+  p->status_word = p->d_counter + 2;
   CD_HIP(hipMalloc((void**)&p->d_stepvals, sizeof(float) * 8));
 }
 
@@ -587,8 +591,12 @@ float* attn_block(Run& r, const AttnP& w, const float* x, Dims3 dims, float* xpa
     own = stats_pass(r, x, C, vox, &xunits);
     xpart = own;
   }
-  static const bool no_fused = getenv("CD_NO_FUSED_ATTN") != nullptr;
-  static const bool defer_gn = getenv("CD_NO_GNDEFER") == nullptr && !no_fused;  // consumers fold the coefficients (gn_defer.h)
+  // The fused kernels run every product on the fp16 pipe (f16x2 splits: fp16 RANGE); the full-range precisions (bf16x3 / f32,
+  // and with them the re-run of a range fallback) take the unfused form on the f32-input MFMA instead.
+  static const bool no_fused_env = getenv("CD_NO_FUSED_ATTN") != nullptr;
+  static const bool defer_env = getenv("CD_NO_GNDEFER") == nullptr;
+  const bool no_fused = no_fused_env || conv_precision() != PREC_F16X2;
+  const bool defer_gn = defer_env && !no_fused;  // consumers fold the coefficients (gn_defer.h)
   float* coefn = ws->get<float>((size_t)r.B * C * 4);
   GnDefer dn;
   dn.part = xpart; dn.units = xunits; dn.gamma = w.ng; dn.beta = w.nb; dn.C = C; dn.groups = 1; dn.vox = vox;
@@ -610,15 +618,16 @@ float* attn_block(Run& r, const AttnP& w, const float* x, Dims3 dims, float* xpa
     ypart = ws->get<float>((size_t)r.B * yu * C * 2);
     if (!r.dry() && single) {
       launch_attn_small(x, C, coefn, w.qkv16, part, w.ow, 0.17677669529663689f /* 32^-1/2 */, w.ob, w.gg, w.gb, y, ypart, r.B, vox,
-                        r.s, dnp);
+                        r.s, dnp, r.status);
     } else if (!r.dry()) {
-      launch_attn_kv_context(x, C, coefn, w.qkv16, part, r.B, vox, nsp, r.s, dnp);
+      launch_attn_kv_context(x, C, coefn, w.qkv16, part, r.B, vox, nsp, r.s, dnp, r.status);
       static const bool sep_combine = getenv("CD_ATTN_COMBINE_LAUNCH") != nullptr;  // A/B: the separate combine launch
       if (sep_combine) {
         launch_attn_combine(part, nsp, w.ow, C, wpb, r.B, 0.17677669529663689f /* 32^-1/2 */, r.s, nullptr, nullptr, true);
-        launch_attn_out(x, C, coefn, w.qkv16, wpb, w.ob, y, ypart, r.B, vox, nsp, r.s, dnp);
+        launch_attn_out(x, C, coefn, w.qkv16, wpb, w.ob, y, ypart, r.B, vox, nsp, r.s, dnp, nullptr, nullptr, 0.f, r.status);
       } else {
-        launch_attn_out(x, C, coefn, w.qkv16, nullptr, w.ob, y, ypart, r.B, vox, nsp, r.s, dnp, part, w.ow, 0.17677669529663689f);
+        launch_attn_out(x, C, coefn, w.qkv16, nullptr, w.ob, y, ypart, r.B, vox, nsp, r.s, dnp, part, w.ow, 0.17677669529663689f,
+                        r.status);
       }
     }
     if (own) ws->release(own);
@@ -925,7 +934,7 @@ void forward_impl(CdPlan* p, int B, const float* x, const float* cond, const flo
   const CdUnetDesc& d = p->desc;
   const Dims3 dims = p->shapes[0];
   Run r{&p->ws, s, B, d.groups};
-  r.status = p->d_counter + 2;
+  r.status = p->status_word;
   float* emb = p->ws.get<float>((size_t)B * p->emb_ld);
   float* scal = p->ws.get<float>((size_t)B * 4);
   float* h = p->ws.get<float>((size_t)B * dims.vox() * d.layer_sizes[0]);
@@ -993,28 +1002,52 @@ void destroy_prog_graph(CdPlan* p) {
   }
 }
 
-// Range fallback of the sampler entry points: `run(eager)` enqueues the whole trajectory.  If the f16x2 convolutions left the
-// fp16 range on the way (sticky flag bit 0), the trajectory is run again with the exact bf16x3 convolutions (full fp32 range;
-// eagerly, the cached step graph holds the f16x2 kernels) and bit 1 replaces bit 0.
+// High-water mark of a dry run of the forward's allocation sequence (after `front`, the caller's own blocks).  The sequence
+// depends on the convolution precision (whole-block launches, fused / unfused attention), and a range fallback re-runs a call
+// in bf16x3 on the SAME workspace: the answer is the larger of the precision in force and the fallback's.
 template <typename F>
-void run_with_range_fallback(CdPlan* plan, hipStream_t s, F&& run) {
-  run(false);
-  if (conv_precision() != PREC_F16X2) return;
-  int flags = 0;
-  CD_HIP(hipMemcpyAsync(&flags, plan->d_counter + 2, sizeof(int), hipMemcpyDeviceToHost, s));
-  CD_HIP(hipStreamSynchronize(s));
-  if (!(flags & 1)) return;
-  set_conv_precision(PREC_BF16X3);
-  try {
-    run(true);
-  } catch (...) {
-    set_conv_precision(PREC_F16X2);
-    throw;
+size_t dry_forward_bytes(CdPlan* plan, int batch, F&& front) {
+  struct Restore {
+    ~Restore() { set_conv_precision_override(-1); }
+  } restore;
+  size_t need = 0;
+  for (int mode : {-1, (int)PREC_BF16X3}) {
+    set_conv_precision_override(mode);
+    plan->ws.reset(nullptr, 0, true);
+    front();
+    forward_impl(plan, batch, nullptr, nullptr, nullptr, nullptr, false, nullptr);
+    need = plan->ws.high() > need ? plan->ws.high() : need;
   }
-  set_conv_precision(PREC_F16X2);
-  flags = (flags & ~1) | 2;
-  CD_HIP(hipMemcpyAsync(plan->d_counter + 2, &flags, sizeof(int), hipMemcpyHostToDevice, s));
-  CD_HIP(hipStreamSynchronize(s));  // `flags` lives on this stack frame
+  return need;
+}
+
+// Range fallback of the entry points that promise finite results (the samplers, cd_denoise_safe): `run(eager)` enqueues the
+// whole call.  The f16x2 kernels of THIS call raise bit 0 of a private word (d_counter + 3, cleared first), so a flag left in
+// the sticky word by an earlier, un-queried cd_denoise / cd_unet_forward / cd_train_step is neither mistaken for this call's
+// overflow nor lost.  If the call left the fp16 range it is run again with the exact bf16x3 convolutions (full fp32 range;
+// eagerly, a cached step graph holds the f16x2 kernels) -- the precision is overridden for THIS THREAD only, other plans /
+// threads of the process keep their kernels -- and bit 1 is OR-ed into the sticky word.  Returns whether the fallback ran.
+template <typename F>
+bool run_with_range_fallback(CdPlan* plan, hipStream_t s, F&& run) {
+  struct Restore {
+    CdPlan* p;
+    ~Restore() {
+      p->status_word = p->d_counter + 2;
+      set_conv_precision_override(-1);
+    }
+  } restore{plan};
+  plan->status_word = plan->d_counter + 3;
+  CD_HIP(hipMemsetAsync(plan->d_counter + 3, 0, sizeof(int), s));
+  run(false);
+  if (conv_precision() != PREC_F16X2) return false;
+  int flags = 0;
+  CD_HIP(hipMemcpyAsync(&flags, plan->d_counter + 3, sizeof(int), hipMemcpyDeviceToHost, s));
+  CD_HIP(hipStreamSynchronize(s));
+  if (!(flags & 1)) return false;
+  set_conv_precision_override(PREC_BF16X3);
+  run(true);
+  launch_or_word(plan->d_counter + 2, 2, s);
+  return true;
 }
 
 }  // namespace
@@ -1025,6 +1058,7 @@ void run_with_range_fallback(CdPlan* plan, hipStream_t s, F&& run) {
 extern "C" {
 
 const char* cd_last_error(void) { return g_last_error.c_str(); }
+int cd_abi_version(void) { return CD_ABI_VERSION; }
 
 int cd_device_check(char* name, int cap) {
   return guarded([&] {
@@ -1045,6 +1079,10 @@ int cd_device_check(char* name, int cap) {
 int cd_plan_create(const CdUnetDesc* desc, CdPlan** plan) {
   return guarded([&] {
     CD_REQUIRE(desc && plan, "null argument");
+    if (desc->struct_size != sizeof(CdUnetDesc))
+      throw Fail{CD_EINVAL, "CdUnetDesc.struct_size is " + std::to_string(desc->struct_size) + ", this library expects " +
+                                std::to_string(sizeof(CdUnetDesc)) + " (ABI version " + std::to_string(CD_ABI_VERSION) +
+                                "): the binding was written against another calodiff.h"};
     std::unique_ptr<CdPlan> p(new CdPlan());
     p->desc = *desc;
     build_plan(p.get());
@@ -1177,15 +1215,13 @@ int cd_plan_workspace_bytes(CdPlan* plan, int batch, size_t* bytes) {
   return guarded([&] {
     CD_REQUIRE(plan && bytes && batch > 0, "bad argument");
     const int64_t n = (int64_t)batch * plan->shapes[0].vox();
-    plan->ws.reset(nullptr, 0, true);
-    // superset of what any entry point allocates around forward_impl: x0 / noise / x_noisy, sigma, partials
-    float* a = plan->ws.get<float>((size_t)n);
-    float* b = plan->ws.get<float>((size_t)n);
-    float* c = plan->ws.get<float>((size_t)batch + 64);
-    double* dd = plan->ws.get<double>((size_t)batch + 8);
-    forward_impl(plan, batch, nullptr, nullptr, nullptr, nullptr, false, nullptr);
-    (void)a; (void)b; (void)c; (void)dd;
-    *bytes = plan->ws.high() + 4096;
+    *bytes = dry_forward_bytes(plan, batch, [&] {
+      // superset of what any entry point allocates around forward_impl: x0 / noise / x_noisy, sigma, partials
+      plan->ws.get<float>((size_t)n);
+      plan->ws.get<float>((size_t)n);
+      plan->ws.get<float>((size_t)batch + 64);
+      plan->ws.get<double>((size_t)batch + 8);
+    }) + 4096;
   });
 }
 
@@ -1206,6 +1242,19 @@ int cd_denoise(CdPlan* plan, int batch, const float* x, const float* sigma, cons
     check_ready(plan, true);
     plan->ws.reset((char*)workspace, workspace_bytes, false);
     forward_impl(plan, batch, x, cond, sigma, out, false, (hipStream_t)stream);
+  });
+}
+
+int cd_denoise_safe(CdPlan* plan, int batch, const float* x, const float* sigma, const float* cond, float* out,
+                    void* workspace, size_t workspace_bytes, int* fell_back, void* stream) {
+  return guarded([&] {
+    CD_REQUIRE(plan && x && sigma && cond && out && workspace && batch > 0, "bad argument");
+    check_ready(plan, true);
+    const bool fb = run_with_range_fallback(plan, (hipStream_t)stream, [&](bool) {
+      plan->ws.reset((char*)workspace, workspace_bytes, false);
+      forward_impl(plan, batch, x, cond, sigma, out, false, (hipStream_t)stream);
+    });
+    if (fell_back) *fell_back = fb ? 1 : 0;
   });
 }
 
@@ -1244,6 +1293,7 @@ static void layer_mlp_call(const CdLayerMlpDesc* d, const float* const* weights,
                            const float* x, const float* cond, const float* tsig, const float* table, int n_steps,
                            const float* noise, float* out, float* xs, float* x0s, void* stream) {
   CD_REQUIRE(d && weights && x && cond && out && batch > 0, "bad argument");
+  CD_REQUIRE(d->struct_size == sizeof(CdLayerMlpDesc), "CdLayerMlpDesc.struct_size does not match this library's calodiff.h");
   CD_REQUIRE(d->n_res >= 0 && d->n_res <= 8 && n_weights == 2 * (8 + 3 * d->n_res),
              "layer MLP: n_weights must be 2*(8 + 3*n_res) (time_mlp, cond_mlp, in_lay, blocks, out_lay)");
   CD_REQUIRE(d->time_embed_kind >= 0 && d->time_embed_kind <= 2 && d->objective >= 0 && d->objective <= 2, "bad descriptor");
@@ -1285,6 +1335,7 @@ int cd_layer_sample(const CdLayerMlpDesc* desc, const float* const* weights, int
 
 static LayerMlpTrainArgs layer_train_args(const CdLayerMlpDesc* d, int batch) {
   CD_REQUIRE(d && batch > 0, "bad argument");
+  CD_REQUIRE(d->struct_size == sizeof(CdLayerMlpDesc), "CdLayerMlpDesc.struct_size does not match this library's calodiff.h");
   CD_REQUIRE(d->n_res >= 0 && d->n_res <= 8 && d->time_embed_kind >= 0 && d->time_embed_kind <= 2, "bad descriptor");
   LayerMlpTrainArgs a{};
   a.dim_in = d->dim_in; a.hidden = d->hidden; a.cond_emb = d->cond_emb; a.cond_size = d->cond_size; a.n_res = d->n_res;
@@ -1464,9 +1515,7 @@ int cd_plan_sampler_workspace_bytes(CdPlan* plan, int batch, int n_bufs, int n_s
     CD_REQUIRE(plan && bytes && batch > 0 && n_bufs >= 2 && n_bufs <= 16 && n_steps >= 1 && n_coef >= 1, "bad argument");
     plan->ws.reset(nullptr, 0, true);
     const size_t front = sampler_front_bytes(plan, batch, n_bufs, (size_t)n_steps * n_coef, nullptr, nullptr, nullptr, nullptr);
-    plan->ws.reset(nullptr, 0, true);
-    forward_impl(plan, batch, nullptr, nullptr, nullptr, nullptr, false, nullptr);
-    *bytes = front + plan->ws.high() + 8192;
+    *bytes = front + dry_forward_bytes(plan, batch, [] {}) + 8192;
   });
 }
 

@@ -91,7 +91,7 @@ class Diffusion(torch.nn.Module, ABC):
             start = self.noise_generation(shape)
         x, xs, x0s = self.sampler_algorithm(self, start, energy, layers, num_steps, sample_offset, debug)
         # every noise tensor the sampler drew took one (global) tensor's worth of normals behind the start tensor's own
-        self.noise_offset += self._shard_geometry(shape)[2] * getattr(self.sampler_algorithm, "noise_tensors_drawn", num_steps)
+        self.noise_offset += self._shard_geometry(shape)[2] * getattr(self.sampler_algorithm, "noise_tensors_drawn", 0)
         if debug:
             return x.detach().cpu().numpy(), xs, x0s
         return x.detach().cpu().numpy()
@@ -111,6 +111,7 @@ class Diffusion(torch.nn.Module, ABC):
         (e.g. the reference's own function for the geometry-converted datasets); ``reverse_norm=False`` returns the
         normalised-space showers.
         """
+        self._physical_form(reverse_norm)  # raises NOW, not after minutes of sampling, if there is no inverse pre-processing
         generated, energies, layers = [], [], []
         for E, layers_, d_batch in data_loader:
             E = E.to(device=self.device)
@@ -124,12 +125,30 @@ class Diffusion(torch.nn.Module, ABC):
         layers = np.concatenate(layers) if layers else None
         return self._to_physical(generated, energies, layers, reverse_norm, debug)
 
+    def _physical_form(self, reverse_norm) -> str:
+        """Which inverse pre-processing generate() will apply: 'callable', 'device', or 'none' (reverse_norm=False).  Raises for
+        configs the device form does not cover -- called at the top of generate() (and of LayerDiffusion.generate), before the
+        sampling loop."""
+        cfg = self.config
+        if callable(reverse_norm):
+            return "callable"
+        if reverse_norm is False:
+            return "none"
+        if (reverse_norm is None and cfg.get("DATASET_NUM", 2) in (2, 3)
+                and cfg.get("SHOWERMAP") in ("layer-logit-norm", "logit-norm")
+                and all(k in cfg for k in ("EMAX", "EMIN", "logE", "MAXDEP", "ECUT"))):
+            return "device"
+        # the reference always applies utils.ReverseNorm (diffusion.py:171-195): never hand back normalised-space showers
+        # silently.  HGCal / Dataset-1 need geometry files outside this package: pass the reference's function.
+        raise ValueError(
+            "generate(): no inverse pre-processing for this config on the device path (needs DATASET_NUM 2/3 with a "
+            "[layer-]logit-norm SHOWERMAP and the EMAX/EMIN/logE/MAXDEP/ECUT keys); pass reverse_norm=<callable "
+            "(generated, energies, layers, config)> or reverse_norm=False for normalised-space showers")
+
     def _to_physical(self, generated, energies, layers, reverse_norm, debug=False):
         """Inverse pre-processing of generated showers (shared with LayerDiffusion.generate)."""
         cfg = self.config
-        device_form = (reverse_norm is None and cfg.get("DATASET_NUM", 2) in (2, 3)
-                       and cfg.get("SHOWERMAP") in ("layer-logit-norm", "logit-norm")
-                       and all(k in cfg for k in ("EMAX", "EMIN", "logE", "MAXDEP", "ECUT")))
+        device_form = self._physical_form(reverse_norm) == "device"
         if callable(reverse_norm):
             generated, energies = reverse_norm(generated, energies, layers, cfg)
         elif device_form:
@@ -139,11 +158,4 @@ class Diffusion(torch.nn.Module, ABC):
                                               showerMap=cfg["SHOWERMAP"], dataset_num=cfg.get("DATASET_NUM", 2),
                                               ecut=float(cfg["ECUT"]))
             generated = generated.reshape(cfg["SHAPE_ORIG"])
-        elif reverse_norm is not False:
-            # the reference always applies utils.ReverseNorm (diffusion.py:171-195): never hand back normalised-space showers
-            # silently.  HGCal / Dataset-1 need geometry files outside this package: pass the reference's function.
-            raise ValueError(
-                "generate(): no inverse pre-processing for this config on the device path (needs DATASET_NUM 2/3 with a "
-                "[layer-]logit-norm SHOWERMAP and the EMAX/EMIN/logE/MAXDEP/ECUT keys); pass reverse_norm=<callable "
-                "(generated, energies, layers, config)> or reverse_norm=False for normalised-space showers")
         return generated, np.reshape(energies, (energies.shape[0], -1))

@@ -16,12 +16,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CALODIFF_LIB") or os.path.join(_HERE, "lib", "libcalodiff_hip.so")  # override: A/B builds
 
 CD_MAX_SIZES = 8
+CD_ABI_VERSION = 3  # include/calodiff.h; load_library refuses a library that reports another one
 TIME_KINDS = {"log": 0, "sigma": 1, "raw": 2}
 OBJECTIVES = {"hybrid": 0, "noise_pred": 1, "mean_pred": 2}
 
 
 class CdUnetDesc(C.Structure):
     _fields_ = [
+        ("struct_size", C.c_uint32),
         ("grid", C.c_int32 * 3),
         ("in_channels", C.c_int32),
         ("n_sizes", C.c_int32),
@@ -50,7 +52,7 @@ class CdSamplerOp(C.Structure):
 
 
 class CdLayerMlpDesc(C.Structure):
-    _fields_ = [("dim_in", C.c_int32), ("hidden", C.c_int32), ("cond_emb", C.c_int32), ("cond_size", C.c_int32),
+    _fields_ = [("struct_size", C.c_uint32), ("dim_in", C.c_int32), ("hidden", C.c_int32), ("cond_emb", C.c_int32), ("cond_size", C.c_int32),
                 ("n_res", C.c_int32), ("time_embed_kind", C.c_int32), ("objective", C.c_int32), ("sigma_data", C.c_float)]
 
 
@@ -62,6 +64,7 @@ class CdStep(C.Structure):
 _P = C.c_void_p
 _SIGNATURES = {
     "cd_last_error": (C.c_char_p, []),
+    "cd_abi_version": (C.c_int, []),
     "cd_device_check": (C.c_int, [C.c_char_p, C.c_int]),
     "cd_plan_create": (C.c_int, [C.POINTER(CdUnetDesc), C.POINTER(_P)]),
     "cd_plan_destroy": (C.c_int, [_P]),
@@ -73,6 +76,7 @@ _SIGNATURES = {
     "cd_plan_workspace_bytes": (C.c_int, [_P, C.c_int, C.POINTER(C.c_size_t)]),
     "cd_unet_forward": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "cd_denoise": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "cd_denoise_safe": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, C.c_size_t, C.POINTER(C.c_int), _P]),
     "cd_ddim_sample": (C.c_int, [_P, C.c_int, _P, _P, C.POINTER(CdStep), C.c_int, _P, C.c_uint64, C.c_uint64, C.c_uint64, _P, _P, _P,
                                  C.c_int, _P, C.c_size_t, _P]),
     "cd_plan_sampler_workspace_bytes": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
@@ -130,12 +134,31 @@ def load_library() -> C.CDLL:
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python -m calodiffusion_amd.build` (hipcc, --offload-arch=gfx950). "
             "calodiffusion_amd has no CPU or PyTorch fallback.")
+    _check_built_from_these_sources()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export it
         fn.restype, fn.argtypes = res, args
+    if lib.cd_abi_version() != CD_ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH} reports ABI version {lib.cd_abi_version()}, this binding is written against "
+                           f"{CD_ABI_VERSION} (include/calodiff.h): rebuild with `python -m calodiffusion_amd.build`")
     _lib = lib
     return lib
+
+
+def _check_built_from_these_sources():
+    """The library is git-ignored and travels between boxes as a built file: refuse one that was not built from the sources
+    next to it (a stale .so with an older argument list shifts every pointer argument).  build.py writes `<lib>.srchash`
+    after every link; CALODIFF_LIB (an explicit A/B build) and CD_SKIP_SRCHASH=1 bypass the check."""
+    if os.environ.get("CALODIFF_LIB") or os.environ.get("CD_SKIP_SRCHASH"):
+        return
+    from . import build
+    stamp = LIB_PATH + ".srchash"
+    have = open(stamp).read().strip() if os.path.exists(stamp) else None
+    want = build.source_hash()
+    if have != want:
+        raise RuntimeError(f"{LIB_PATH} was not built from the sources in {build.CSRC} (stamp {str(have)[:12]}, sources "
+                           f"{want[:12]}): run `python -m calodiffusion_amd.build`")
 
 
 def _check(code: int):
@@ -184,6 +207,7 @@ class UnetEngine:
         self.device_name = require_gpu()
         self.unet = unet
         d = CdUnetDesc()
+        d.struct_size = C.sizeof(CdUnetDesc)
         d.grid = _i32x3(unet.grid)
         d.in_channels = unet.channels
         d.n_sizes = len(unet.layer_sizes)
@@ -276,7 +300,10 @@ class UnetEngine:
             nbytes = C.c_size_t()
             _check(self.lib.cd_plan_workspace_bytes(self.plan, batch, C.byref(nbytes)))
             ws = torch.empty(nbytes.value, dtype=torch.uint8, device=self.device)
-            self._ws = {batch: ws}  # keep one (and the sampler-program workspace of sampler_run): workspaces are large
+            # keep ONE network workspace (they are large) -- and the sampler-program workspaces cached by sampler_run under
+            # ("sampler", B), which alternating denoise / sampler calls would otherwise reallocate (~1 GB) every time
+            self._ws = {k: v for k, v in self._ws.items() if isinstance(k, tuple)}
+            self._ws[batch] = ws
         return ws
 
     # ------------------------------------------------------------------ compute
@@ -299,6 +326,11 @@ class UnetEngine:
                                         ws.data_ptr(), ws.numel(), _stream()))
         return out
 
+    # denoise() recovers from an fp16-range overflow by itself (cd_denoise_safe: one stream synchronisation per call to read the
+    # flag, then a full-range re-run if it was raised) so that samplers calling the model back from Python never die
+    # mid-trajectory; set False for the asynchronous, graph-capturable cd_denoise, whose overflow only shows in check_status().
+    safe_denoise = True
+
     def denoise(self, x, sigma, cond):
         x, cond = _dev32(x, "x"), _dev32(cond, "cond")
         B = x.shape[0]
@@ -310,8 +342,15 @@ class UnetEngine:
         self.sync_weights()
         ws = self.workspace(B)
         out = torch.empty_like(x)
-        _check(self.lib.cd_denoise(self.plan, B, x.data_ptr(), sigma.data_ptr(), cond.data_ptr(), out.data_ptr(),
-                                   ws.data_ptr(), ws.numel(), _stream()))
+        if self.safe_denoise:
+            fell = C.c_int(0)
+            _check(self.lib.cd_denoise_safe(self.plan, B, x.data_ptr(), sigma.data_ptr(), cond.data_ptr(), out.data_ptr(),
+                                            ws.data_ptr(), ws.numel(), C.byref(fell), _stream()))
+            if fell.value:
+                self.range_fallbacks = getattr(self, "range_fallbacks", 0) + 1
+        else:
+            _check(self.lib.cd_denoise(self.plan, B, x.data_ptr(), sigma.data_ptr(), cond.data_ptr(), out.data_ptr(),
+                                       ws.data_ptr(), ws.numel(), _stream()))
         return out
 
     def ddim_sample(self, start, cond, steps: np.ndarray, step_noise=None, seed=0, offset=0, debug=False, use_graph=True,
@@ -463,6 +502,7 @@ class LayerMlpEngine:
         self.device_name = require_gpu()
         self.net = resnet
         d = CdLayerMlpDesc()
+        d.struct_size = C.sizeof(CdLayerMlpDesc)
         d.dim_in, d.hidden, d.cond_emb, d.cond_size = resnet.dim_in, resnet.hidden_dim, resnet.cond_emb_dim, resnet.cond_size
         d.n_res = len(resnet.hidden_layers)
         d.time_embed_kind, d.objective, d.sigma_data = TIME_KINDS[time_kind], OBJECTIVES[objective], float(sigma_data)

@@ -154,6 +154,7 @@ class LayerDiffusion(CaloDiffusion):
     def generate(self, data_loader, sample_steps: int, debug: bool = False, sample_offset: Optional[int] = 0,
                  sparse_decoding: Optional[bool] = False, sparse_per_batch: Optional[bool] = False, reverse_norm=None):
         """layerdiffusion.py:171-235: no layer energies are taken from the loader, the layer model generates them."""
+        self._physical_form(reverse_norm)  # raise before sampling if this config has no inverse pre-processing here
         generated, energies, layers = [], [], []
         for E, _, _d in data_loader:
             E = E.to(device=self.device)

@@ -84,6 +84,10 @@ def shard_batch(n: int, world_size: int, rank: int) -> slice:
     return slice(lo, lo + base + (1 if rank < rem else 0))
 
 
+# measurement hook (bench.py --mode train): a list to which every device-side all-reduce appends its (start, end) events
+ALLREDUCE_EVENTS = None
+
+
 def allreduce_mean_(flat: torch.Tensor) -> torch.Tensor:
     """Data-parallel gradient exchange: ONE sum all-reduce of the flat fp32 gradient buffer (8.85 MB for Dataset-2) over
     the default process group (RCCL over xGMI on GPUs, gloo in the CPU tests), then the mean.  No-op outside a
@@ -95,6 +99,12 @@ def allreduce_mean_(flat: torch.Tensor) -> torch.Tensor:
             host = flat.detach().cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM)
             flat.copy_(host)
+        elif flat.is_cuda and ALLREDUCE_EVENTS is not None:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            b.record()
+            ALLREDUCE_EVENTS.append((a, b))
         else:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         flat.div_(dist.get_world_size())

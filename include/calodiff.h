@@ -39,6 +39,12 @@ extern "C" {
 
 #define CD_MAX_SIZES 8
 
+/* Bumped whenever a struct layout or an argument list of this header changes.  cd_abi_version() returns the value the
+ * library was built with: a binder compares it with the CD_ABI_VERSION it was written against before any other call, and
+ * every descriptor struct starts with its own sizeof (struct_size), which the library checks -- a binder written against an
+ * older header gets CD_EINVAL from cd_plan_create instead of the library reading past its struct. */
+#define CD_ABI_VERSION 3
+
 #define CD_TIME_LOG 0      /* t_emb = 0.5*ln(sigma)         (calodiffusion.py:150) */
 #define CD_TIME_SIGMA 1    /* t_emb = sigma/sqrt(1+sigma^2) (calodiffusion.py:149) */
 #define CD_TIME_RAW 2      /* t_emb = the value passed (CondUnet.forward's `time` argument) */
@@ -52,6 +58,7 @@ typedef struct CdPlan CdPlan;
 /* Mirrors the arguments of CondUnet.__init__ (models/models.py:525-543) as CaloDiffusion.init_model
  * derives them from the config (models/calodiffusion.py:39-81). */
 typedef struct CdUnetDesc {
+  uint32_t struct_size;            /* = sizeof(CdUnetDesc) of the header the caller was built against */
   int32_t grid[3];                 /* D, H, W of SHAPE_FINAL */
   int32_t in_channels;             /* `channels`: 1 (+2 if R_Z_INPUT) (+1 if PHI_INPUT) */
   int32_t n_sizes;                 /* len(LAYER_SIZE_UNET) */
@@ -81,6 +88,7 @@ typedef struct CdStep {
 } CdStep;
 
 const char* cd_last_error(void);
+int cd_abi_version(void);  /* CD_ABI_VERSION of the build */
 /* 0 if a gfx950 device is usable by this process, CD_ENOGPU otherwise. Fills name (may be NULL). */
 int cd_device_check(char* name, int cap);
 
@@ -114,6 +122,13 @@ int cd_unet_forward(CdPlan* plan, int batch, const float* x, const float* cond, 
  * x: (B,1,D,H,W); sigma: (B,); cond: (B, cond_size) = cat(E, layers); out: (B,1,D,H,W). */
 int cd_denoise(CdPlan* plan, int batch, const float* x, const float* sigma, const float* cond, float* out,
                void* workspace, size_t workspace_bytes, void* stream);
+/* cd_denoise with the range fallback of the sampler entry points (below): if an operand of the fp16-pipe kernels left the fp16
+ * range during the call, the call is run again with the full-range kernels (bf16x3 convolutions, f32-MFMA attention) before it
+ * returns, *fell_back (may be NULL) is set to 1 and cd_plan_status reports bit 1.  Unlike cd_denoise it SYNCHRONISES `stream`
+ * (to read the flag) and is therefore not graph-capturable: it is the entry point for samplers that call the model back from
+ * host code (models/sample.py: `model(x, sigma=, E=, layers=)`, e.g. DPMAdaptive :188-309), which must not die mid-trajectory. */
+int cd_denoise_safe(CdPlan* plan, int batch, const float* x, const float* sigma, const float* cond, float* out,
+                    void* workspace, size_t workspace_bytes, int* fell_back, void* stream);
 /* DDim.__call__ / DDPM (models/sample.py:41-121) with Diffusion.sample's start tensor (diffusion.py:77-104).
  * start: (B,1,D,H,W) unit normal; steps: host array of n_steps rows; x_out: (B,1,D,H,W).
  * step_noise: NULL (DDIM, eta = 0: the reference draws and discards it) or device (n_steps, B,1,D,H,W);
@@ -127,10 +142,12 @@ int cd_ddim_sample(CdPlan* plan, int batch, const float* start, const float* con
  * 0 = this call's own tensor size.  A rank holding rows [lo, hi) of a global batch passes offset + lo * voxels and
  * noise_stride = global_batch * voxels: the union of the shards then IS the single-GPU result of the same seed.
  *
- * Range fallback (both sampler entry points): the f16x2 convolutions cover the fp16 range only.  If a trajectory leaves it
- * (sticky flag, cd_plan_status bit 0) the call re-runs the whole trajectory with the exact bf16x3 convolutions (full fp32
- * range) before it returns, synchronising `stream` for the check; cd_plan_status then reports bit 1 (fallback taken)
- * instead of bit 0. */
+ * Range fallback (both sampler entry points, cd_denoise_safe): the default arithmetic (f16x2 convolutions, the fused
+ * attention's fp16-pipe products) covers the fp16 range only.  If an operand leaves it during the call (a flag private to the
+ * call: a bit 0 left in the sticky word by an earlier cd_denoise is neither consumed nor lost) the call re-runs the whole
+ * trajectory with the full-range kernels -- exact bf16x3 convolutions, attention on the f32-input MFMA -- before it returns,
+ * synchronising `stream` for the check; cd_plan_status then reports bit 1 (fallback taken).  The switch of arithmetic is local
+ * to the calling thread: other plans / threads of the process keep their kernels. */
 
 /* ---- every other sampler of models/sample.py on the same device loop ------------------------------------------------
  * A sampler is a "step program": per step a short list of ops over a few (B,1,D,H,W) buffers, whose scalars are columns of
@@ -177,10 +194,11 @@ int cd_plan_grad_layout(const CdPlan* plan, int idx, int64_t* offset, int64_t* t
 int cd_plan_train_workspace_bytes(CdPlan* plan, int batch, size_t* bytes);
 
 /* Sticky range flags of the compute calls issued on this plan since the last query (synchronises `stream`, then clears):
- *   bit 0: an activation fed to an f16x2 convolution exceeded the fp16 range (|x| > 65504): the outputs of that call
+ *   bit 0: an operand of an fp16-pipe kernel (an activation staged for an f16x2 convolution; the normalised input, v or the
+ *          folded output weights of the fused attention) exceeded the fp16 range (|x| > 65504): the outputs of that call
  *          contain inf/NaN.  The reference computes in fp32 throughout; rerun with CD_CONV_PRECISION=bf16x3 (full fp32 range).
- *          (cd_denoise / cd_unet_forward / cd_train_step; the sampler entry points recover by themselves, see above)
- *   bit 1: a sampler call took the bf16x3 fallback (its result is valid). */
+ *          (cd_denoise / cd_unet_forward / cd_train_step; cd_denoise_safe and the sampler entry points recover by themselves)
+ *   bit 1: a sampler / cd_denoise_safe call took the full-range fallback (its result is valid). */
 int cd_plan_status(CdPlan* plan, int* flags, void* stream);
 int cd_train_step(CdPlan* plan, int batch, const float* data, const float* noise, const float* sigma, const float* cond,
                   double* loss_out, float* grads, void* workspace, size_t workspace_bytes, void* stream);
@@ -208,6 +226,7 @@ int cd_reverse_norm(const float* voxels, const float* energy, const float* layer
  * module's state_dict order: time_mlp.{1,3,5}, cond_mlp.{0,2,4}, in_lay, hidden_layers.i.{embeder.1, dense1.0, dense2.0},
  * out_lay; torch (out, in) row-major fp32. */
 typedef struct CdLayerMlpDesc {
+  uint32_t struct_size;     /* = sizeof(CdLayerMlpDesc) */
   int32_t dim_in;           /* SHAPE_FINAL[2] + 1 */
   int32_t hidden;           /* 256 */
   int32_t cond_emb;         /* 128: cat(cond_mlp, time_mlp) */
@@ -241,9 +260,11 @@ int cd_layer_train_step(const CdLayerMlpDesc* desc, const float* const* weights,
                         const float* noise, const float* sigma, const float* cond, double* loss_out, float* grads,
                         void* workspace, size_t workspace_bytes, void* stream);
 
-/* Arithmetic of the 3x3x3 / strided / transposed convolutions, process-wide: "f16x2" (default; fp32 operands as two-term fp16
- * splits, 3 MFMAs per block, fp16 range), "bf16x3" (exact three-term bf16 split, 6 MFMAs, full fp32 range) or "f32" (f32-input
- * MFMA).  Initial value: environment variable CD_CONV_PRECISION.  Cached step graphs are dropped by the next sampler call. */
+/* Arithmetic of the matrix-core kernels, process-wide: "f16x2" (default; fp32 operands as two-term fp16 splits, 3 MFMAs per
+ * block, fp16 RANGE -- the 3x3x3 / strided / transposed convolutions and the fused attention's projections and products),
+ * "bf16x3" (convolutions on an exact three-term bf16 split, 6 MFMAs; attention unfused on the f32-input MFMA: full fp32 range)
+ * or "f32" (everything on the f32-input MFMA).  Initial value: environment variable CD_CONV_PRECISION.  Cached step graphs are
+ * dropped by the next sampler call. */
 int cd_set_conv_precision(const char* mode);
 const char* cd_get_conv_precision(void);
 

@@ -570,6 +570,60 @@ def gold_grads():
         print("grads", name, float(loss), float(sum(float((v.double() ** 2).sum()) for v in grads.values()) ** 0.5))
 
 
+def gold_grads_round3():
+    """Round 3: (a) HGCal .grad tensors of the reference's compute_loss(...).backward() (the round-2 fixtures cover Dataset-2 and
+    Dataset-3 only), with their inputs; (b) the other LOSS_TYPEs of Loss._loss (models/loss.py:97-116: 'l1', 'mse', 'huber' --
+    the reference's CI fixture trains with 'huber', tests/test_execution.py:94) on the tiny config: loss value and gradients."""
+    cfg = my_configs.load_config("hgcal")
+    m = build_ref(cfg)
+    m.train()
+    data, E, layers = synth_inputs(cfg, 2, SEED + 90)
+    g = torch.Generator().manual_seed(SEED + 91)
+    noise = torch.randn(data.shape, generator=g)
+    rnd = torch.randn((2,), generator=g)
+    m.zero_grad()
+    loss = m.compute_loss(data, E, noise=noise, layers=layers, rnd_normal=rnd)
+    loss.backward()
+    grads = {k: p.grad for k, p in m.model.named_parameters()}
+    keys, cks = checksums(grads)
+    out = {"ck_keys": keys, "ck_vals": cks, "loss": np.array(float(loss), dtype=np.float64), "data": npf(data), "E": npf(E),
+           "layers": npf(layers), "noise": npf(noise), "rnd_normal": npf(rnd)}
+    for k in ("init_conv.conv.weight", "mid_attn.fn.fn.to_qkv.conv.weight", "downs.0.2.conv.weight",
+              "ups.2.0.block1.proj.conv.weight", "ups_attn.0.fn.fn.to_out.0.conv.weight", "cond_mlp.0.weight",
+              "final_conv.0.block2.norm.weight"):
+        out["grad." + k] = npf(grads[k])
+    save("grads_hgcal", **out)
+    print("grads hgcal", float(loss), float(sum(float((v.double() ** 2).sum()) for v in grads.values()) ** 0.5))
+    del m
+
+    cfg = my_configs.load_config("tiny")
+    data, E, layers = synth_inputs(cfg, 4, SEED + 92)
+    g = torch.Generator().manual_seed(SEED + 93)
+    noise = torch.randn(data.shape, generator=g)
+    rnd = torch.randn((4,), generator=g)
+    out = {"data": npf(data), "E": npf(E), "layers": npf(layers), "noise": npf(noise), "rnd_normal": npf(rnd)}
+    for lt in ("l1", "mse", "huber", "l2"):
+        c = copy.deepcopy(cfg)
+        c["LOSS_TYPE"] = lt
+        m = build_ref(c)
+        m.train()
+        m.zero_grad()
+        loss = m.compute_loss(data, E, noise=noise, layers=layers, rnd_normal=rnd)
+        loss.backward()
+        grads = {k: p.grad for k, p in m.model.named_parameters()}
+        keys, cks = checksums(grads)
+        out[f"{lt}.ck_keys"], out[f"{lt}.ck_vals"], out[f"{lt}.loss"] = keys, cks, np.array(float(loss), dtype=np.float64)
+        for k in ("init_conv.conv.weight", "mid_block1.block1.proj.conv.weight", "final_conv.1.conv.weight", "time_mlp.1.weight"):
+            out[f"{lt}.grad.{k}"] = npf(grads[k])
+        # how the residuals of this case straddle the huber knee (|d| = 1): both branches must be exercised
+        with torch.no_grad():
+            sigma = (rnd * m.loss_function.P_std + m.loss_function.P_mean).exp().reshape(-1, 1, 1, 1, 1)
+            d = m.denoise(data + sigma * noise, E=E, sigma=sigma, layers=layers) - data
+        out[f"{lt}.frac_abs_d_below_1"] = np.array(float((d.abs() < 1).float().mean()))
+        print("loss type", lt, float(loss), float((d.abs() < 1).float().mean()))
+    save("losstypes_tiny", **out)
+
+
 def gold_trajectories():
     """Dataset-3 DDIM (10 and 50 steps, batch 1) and HGCal DDPM (200 steps, batch 2, seeded noise stream) end points."""
     cfg3 = my_configs.load_config("dataset3")
@@ -621,3 +675,5 @@ if __name__ == "__main__":
         gold_grads()
     if "traj" in which:
         gold_trajectories()
+    if "grads3" in which:
+        gold_grads_round3()

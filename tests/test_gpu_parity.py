@@ -118,7 +118,7 @@ def _conv_case(ops, gen, B, c0, c1, cout, shape, nb=3):
     cin = c0 + c1
     x = torch.randn((B, cin) + shape, generator=gen)
     w, bias = torch.randn((cout, cin, 3, 3, 3), generator=gen) * 0.05, torch.randn(cout, generator=gen)
-    nb = min(B, nb)
+    nb = B if nb is None else min(B, nb)
     want = O.cyl_conv3d(x[:nb], w, bias, padding=(1, 1, 1)).numpy()
     if c1:
         y = ops.cyl_conv(cl(ops, x[:, :c0].contiguous().numpy()), w.cuda(), bias.cuda(), x1_cl=cl(ops, x[:, c0:].contiguous().numpy()))
@@ -133,7 +133,7 @@ def test_full_resolution_conv_kernel(ops):
     gen = torch.Generator().manual_seed(11)
     for B, c0, c1, cout, shape in ((1, 32, 0, 32, (45, 16, 9)), (3, 32, 0, 32, (45, 16, 9)), (2, 32, 32, 32, (10, 16, 9)),
                                    (2, 32, 0, 64, (7, 16, 8)), (5, 64, 0, 32, (3, 16, 9)), (64, 32, 0, 32, (45, 16, 9))):
-        err = _conv_case(ops, gen, B, c0, c1, cout, shape)
+        err = _conv_case(ops, gen, B, c0, c1, cout, shape, nb=None)  # every sample, the 64 of the headline shape included
         assert err < 2e-6, (B, c0, c1, cout, shape, err)
     # wider planes run as phi strips with halo rows and a 5-plane ring: Dataset-3 (50x18 -> 10 strips of 5 rows), HGCal
     # (12x21 -> 3 strips of 4 rows), a two-strip grid with a concatenated input
@@ -199,25 +199,89 @@ def test_conv_precision_modes_agree(ops, monkeypatch):
         assert max(errs[mode]) < 3e-6, (mode, errs[mode])
 
 
-def test_fp16_range_flag():
-    """f16x2 convs need |activation| <= 65504; leaving that range poisons the output with inf/NaN AND raises the plan's sticky
-    flag, which the sampler turns into an exception (the reference would have produced finite fp32 numbers)."""
+def test_fp16_range_flag_and_fallback_of_plain_denoise():
+    """The default arithmetic (f16x2 convs, fp16-pipe attention products) needs |operand| <= 65504.  Leaving that range
+    poisons the raw cd_denoise output with inf/NaN AND raises the plan's sticky flag; denoise() as the samplers' callback
+    (cd_denoise_safe) recovers instead: the call is re-run with the full-range kernels and equals the bf16x3 result."""
+    from calodiffusion_amd import engine
     m = _model("dataset2")
     cfg = m.config
-    B = 1
+    B = 2
     shape = [B] + list(cfg["SHAPE_PAD"][1:])
     x = torch.randn(shape, device="cuda")
     E = torch.rand((B, 1), device="cuda")
     layers = torch.randn((B, cfg["SHAPE_PAD"][2] + 1), device="cuda")
     sig = torch.full((B,), 1.0, device="cuda")
+    eng = m.engine()
+    eng.safe_denoise = False  # the raw, asynchronous entry point
     m.denoise(x, E=E, sigma=sig, layers=layers)
-    m.engine().check_status()  # in range: no exception
+    eng.check_status()  # in range: no exception
     with torch.no_grad():
         m.model.init_conv.conv.bias.fill_(1.0e6)  # drives the first block's conv input out of range
-    m.denoise(x, E=E, sigma=sig, layers=layers)
+    bad = m.denoise(x, E=E, sigma=sig, layers=layers)
+    assert not torch.isfinite(bad).all()
     with pytest.raises(FloatingPointError):
-        m.engine().check_status()
-    m.engine().check_status()  # the flag was cleared by the query
+        eng.check_status()
+    eng.check_status()  # the flag was cleared by the query
+    # a flag left behind by an un-queried raw call is neither consumed by the next safe call nor mistaken for its own
+    m.denoise(x, E=E, sigma=sig, layers=layers)
+    eng.safe_denoise = True
+    before = getattr(eng, "range_fallbacks", 0)
+    got = m.denoise(x, E=E, sigma=sig, layers=layers)
+    assert torch.isfinite(got).all() and eng.range_fallbacks == before + 1
+    with pytest.raises(FloatingPointError):
+        eng.check_status()  # bit 0 of the EARLIER raw call is still reported (together with bit 1 of the fallback)
+    engine.set_conv_precision("bf16x3")
+    try:
+        want = m.denoise(x, E=E, sigma=sig, layers=layers)
+        assert eng.range_fallbacks == before + 1  # full-range arithmetic up front: nothing to fall back from
+    finally:
+        engine.set_conv_precision("f16x2")
+    assert torch.equal(got, want)
+    # in range again: the safe call takes no fallback
+    with torch.no_grad():
+        m.model.init_conv.conv.bias.fill_(0.0)
+    ok = m.denoise(x, E=E, sigma=sig, layers=layers)
+    assert torch.isfinite(ok).all() and eng.range_fallbacks == before + 1
+    eng.check_status()
+
+
+def test_trained_scale_residual_stream_needs_no_fallback():
+    """Random-init weights keep the un-normalised residual stream at O(1); trained checkpoints do not.  The level-0 convs'
+    biases and weights are scaled so that the stream reaches ~1e3-1e4 (GroupNorm renormalises inside the blocks; the stream
+    itself -- shortcut sums, attention inputs, the f16x2-staged conv inputs -- carries the magnitude): denoise must still
+    equal the fp32 oracle to 1e-5 without leaving the fp16 range."""
+    from oracle import torch_oracle as O
+    m = _model("dataset2")
+    with torch.no_grad():
+        sd = m.model.state_dict()
+        sd["init_conv.conv.weight"].mul_(3.0e3)
+        sd["init_conv.conv.bias"].mul_(3.0e3)
+        for k in sd:  # the blocks' own outputs follow the stream's scale through their closing norms' affine parameters
+            if k.endswith("block2.norm.weight") or k.endswith("block2.norm.bias") or k.endswith("to_out.1.weight"):
+                sd[k].mul_(1.0e3)
+    g = torch.Generator().manual_seed(21)
+    B = 2
+    x = torch.randn([B] + list(m.config["SHAPE_PAD"][1:]), generator=g)
+    E, layers = torch.rand((B, 1), generator=g), torch.randn((B, m.config["SHAPE_PAD"][2] + 1), generator=g)
+    sig = torch.tensor([1.0, 30.0])
+    om = O.OracleModel(m.config, {k: v.detach().cpu() for k, v in m.state_dict().items()})
+    seen, orig = [], O.resnet_block
+    try:  # max |input| of every ResnetBlock of the oracle's forward = the residual stream
+        O.resnet_block = lambda sd_, p, xx, *a: (seen.append(float(xx.abs().max())), orig(sd_, p, xx, *a))[1]
+        with torch.no_grad():
+            want = om.denoise(x, E, sig, layers)
+    finally:
+        O.resnet_block = orig
+    stream = max(seen)
+    assert len(seen) == 15 and min(seen) > 1e3 and stream < 6e4, seen
+    eng = m.engine()
+    before = getattr(eng, "range_fallbacks", 0)
+    got = m.denoise(x.cuda(), E=E.cuda(), sigma=sig.cuda(), layers=layers.cuda()).cpu()
+    assert getattr(eng, "range_fallbacks", 0) == before
+    err = float((got - want).norm() / want.norm())
+    print(f"trained-scale stream (block inputs {min(seen):.0f} .. {stream:.0f}): denoise rel L2 {err:.2e}")
+    assert err < 1e-5
 
 
 def test_group_norm(ops):
@@ -410,7 +474,7 @@ def test_ddpm_tiny_with_reference_noise_stream():
     out, xs, x0s = m.sample(E, layers, num_steps=50, start=start, debug=True)
     assert rel_l2(xs[10].cpu().numpy(), g["x_step10"]) < TOL_TRAJ
     assert rel_l2(x0s[10].cpu().numpy(), g["x0_step10"]) < TOL_TRAJ
-    assert rel_l2(out, g["ddpm_50"]) < 5e-4  # 50 stochastic steps
+    assert rel_l2(out, g["ddpm_50"]) < TOL_TRAJ  # 50 stochastic steps, the reference's noise stream: north_star's 1e-4
     # device Philox noise: runs, finite, and differs from the fixed-noise result
     m.sampler_algorithm.step_noise = None
     out2 = m.sample(E, layers, num_steps=50, start=start)

@@ -55,9 +55,28 @@ def test_sampler_programs_match_reference_trajectories(tag):
     to_np = lambda seq: None if seq is None or isinstance(seq, list) and not seq else [v.cpu().numpy() for v in seq]  # noqa: E731
     if name == "Consistency":
         x0s = None  # (the reference returns the last denoised tensor there, not a list)
-    # dpm_2 is ONE second-order step from sigma = 142 down to sigma = 1: the update cancels terms of order sigma_max against each
-    # other (|x| ~ 142 -> |result| ~ 2), so every fp32 realisation of it -- the reference's own included -- carries ~1e-4
-    tol = 5e-4 if tag == "dpm_2" else TOL_TRAJ
+    tol = TOL_TRAJ
+    if tag == "dpm_2":
+        # dpm_2 is ONE second-order step from sigma = 142 down to sigma = 1: x_next = x - 141 eps_r1 cancels terms of order
+        # sigma_max against each other (|x| ~ 142 -> |result| ~ 2).  Two measured numbers bound what a correct device run can
+        # show here (both printed): the SAME step program interpreted on the CPU with the exact oracle denoiser already differs
+        # from the reference by `reassoc` (fp32 re-association of the update alone: 4.0e-5), and a denoiser error comes out
+        # `amp` times larger (9.8x for white noise, tests/test_oracle_golden.py).  The device is held to
+        # reassoc + amp x (its denoise bound 1e-5), doubled for the fused-multiply-add order of the device's linear
+        # combinations: ~2.8e-4 (observed on MI355X: 1.4e-4); every other case keeps north_star's 1e-4.
+        from oracle import torch_oracle as O
+        from test_host import _interpret_program
+        from test_oracle_golden import denoise_error_amplification
+        om = O.OracleModel(m.config, {k: v.cpu() for k, v in m.state_dict().items()})
+        den = lambda xx, ss: om.denoise(xx, E.cpu(), ss.float().expand(rows), layers.cpu())  # noqa: E731
+        with torch.no_grad():
+            xc = _interpret_program(prog, den, start.cpu(), [])[0]
+        reassoc = rel_l2(np.asarray(xc), g[f"{tag}.x"])
+        amp = denoise_error_amplification("dpm_2")
+        tol = 2 * (reassoc + amp * TOL_OP)
+        print(f"dpm_2: device {rel_l2(np.asarray(x), g[f'{tag}.x']):.2e}; CPU-interpreted program {reassoc:.2e}, "
+              f"denoise-error amplification {amp:.1f}x -> bound {tol:.2e}")
+        assert tol < 5e-4
     check_sampler_case(tag, g, x, to_np(xs), to_np(x0s), tol)
 
 
@@ -148,14 +167,16 @@ def test_sampler_recovers_from_fp16_range_overflow():
 
 
 # ---------------------------------------------------------------------------------------------- gradients
-@pytest.mark.parametrize("name", ["dataset2", "dataset3"])
+@pytest.mark.parametrize("name", ["dataset2", "dataset3", "hgcal"])
 def test_gradients_match_the_reference(name):
-    """cd_train_step against .grad of the reference's own compute_loss(...).backward() (fixtures: oracle/gen_golden.py grads)."""
-    g, gl = gold(f"grads_{name}"), gold(f"loss_{name}")
+    """cd_train_step against .grad of the reference's own compute_loss(...).backward() (fixtures: oracle/gen_golden.py grads /
+    grads3; the HGCal fixture carries its own inputs)."""
+    g = gold(f"grads_{name}")
+    gl = g if name == "hgcal" else gold(f"loss_{name}")
     m = _model(name)
     data, E, noise = t(gl["data"]).cuda(), t(gl["E"]).cuda(), t(gl["noise"]).cuda()
     layers = t(gl["layers"]).cuda() if "layers" in gl.files else None
-    if name == "dataset2":
+    if name in ("dataset2", "hgcal"):
         sigma = m.loss_function.draw_sigma(data, rnd_normal=t(gl["rnd_normal"]).cuda())
     else:
         sigma = m.loss_function.draw_sigma(data, time=torch.from_numpy(gl["time"]).cuda())
