@@ -19,7 +19,7 @@ LIBDIR = os.path.join(HERE, "lib")
 # its own object directory; load it with CALODIFF_LIB=.../libcalodiff_hip_<tag>.so
 TAG = os.environ.get("CD_BUILD_TAG", "")
 LIB = os.path.join(LIBDIR, f"libcalodiff_hip{'_' + TAG if TAG else ''}.so")
-SOURCES = ["kernels_conv.hip", "kernels_conv_zs.hip", "kernels_attn.hip", "kernels_conv_small.hip", "kernels_wgrad16.hip", "kernels_norm_attn.hip", "kernels_misc.hip", "kernels_mlp.hip", "kernels_mlp_train.hip", "kernels_bwd.hip", "profiler.hip", "plan.hip"]
+SOURCES = ["kernels_conv.hip", "kernels_conv_zs.hip", "kernels_attn.hip", "kernels_conv_small.hip", "kernels_deep.hip", "kernels_wgrad16.hip", "kernels_norm_attn.hip", "kernels_misc.hip", "kernels_mlp.hip", "kernels_mlp_train.hip", "kernels_bwd.hip", "profiler.hip", "plan.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
 FLAGS += os.environ.get("CD_EXTRA_HIPCC_FLAGS", "").split()  # e.g. -DCD_ZS_EXPERIMENTS (tools/zs_stamps.sh, tools/zs_power.sh)

@@ -315,6 +315,30 @@ bool try_launch_res_block_small(const float* x0, int c0, const float* x1, int c1
                                 const float* b2, const float* gn2_gamma, const float* gn2_beta, int groups, const float* res0,
                                 const float* res1, int res_c0, float* h1, float* out, float* part_out, int batch, int cout,
                                 Dims3 dims, int* status, hipStream_t s);
+// The whole deepest level -- downs[-1], mid blocks, ups[0]: six ResnetBlocks and up to three attention blocks -- in ONE launch,
+// one workgroup per sample with the activations resident in LDS (kernels_deep.hip).  Block order: downs r1, downs r2, mid1, mid2,
+// ups r1 (input = cat(x, skip)), ups r2; attention after downs r2, mid1 and ups r2.
+struct DeepLevelDesc {
+  Dims3 dims{};
+  int Ca = 0, Cb = 0, groups = 0;  // channels entering / leaving the level (layer_sizes[-2]) and inside it (layer_sizes[-1])
+  struct Res {
+    int c0 = 0, c1 = 0, cout = 0;
+    const void *w1 = nullptr, *w2 = nullptr;  // f16x2 images of the two 3x3x3 convs
+    const float *b1 = nullptr, *b2 = nullptr, *g1 = nullptr, *be1 = nullptr, *g2 = nullptr, *be2 = nullptr;
+    const float* emb = nullptr;               // (B, emb_ld) slice or null
+    int emb_ld = 0;
+    const void* wres = nullptr;               // f16x2 image of the 1x1 shortcut conv or null (identity)
+    const float* bres = nullptr;
+  } res[6];
+  struct Attn {
+    int C = 0;
+    const float *ng = nullptr, *nb = nullptr, *wout = nullptr, *bout = nullptr, *gg = nullptr, *gb = nullptr;
+    const void* wqkv = nullptr;               // f16x2 image of to_qkv
+  } attn[3];
+  int has_attn[3] = {0, 0, 0};
+};
+bool deep_level_eligible(const DeepLevelDesc& d);
+void launch_deep_level(const DeepLevelDesc& d, const float* x_in, float* x_out, int batch, int* status, hipStream_t s);
 // whole attention block in one launch for small grids (kernels_attn.hip: attn_small_kernel)
 bool attn_small_eligible(int64_t vox);
 void launch_attn_small(const float* x, int C, const float* coef, const void* wqkv_f16x2, float* partials, const float* w_out,

@@ -1,0 +1,936 @@
+// The deepest U-Net level as ONE launch: everything CondUnet.forward (calodiffusion/models/models.py:713-743) does on the
+// coarsest grid -- downs[-1] (ResnetBlock, ResnetBlock, Residual(PreNorm(LinearAttention))), mid_block1, mid_attn, mid_block2,
+// ups[0] (ResnetBlock on cat(x, skip), ResnetBlock, attention) -- for grids where a whole sample is at most 128 voxels
+// (Dataset-2: 12 x 4 x 2 = 96 voxels, 32 / 64 channels).
+//
+// As separate launches that level was 13 kernels per denoise step, 0.33 of the 2.0 ms, for ~1.5 % of the arithmetic: every
+// launch paid a launch gap, a GroupNorm fold from global partials, an L2 round trip of its input and output and its own
+// prologue / epilogue around 1-4 us of MFMA work.  Here ONE workgroup (4 waves, one per SIMD, 512 registers each: the
+// accumulators of all row tiles, a deep weight-fragment ring and the block's shortcut tile live in registers together) owns one
+// sample from the strided conv's output to the transposed conv's input and the activations never leave the CU:
+//
+//  * state in LDS as fp32 rows [voxel][channel]: X (the running tensor, also every block's shortcut), SKIP (the level's skip
+//    connection), H1 (a block's first conv output).  GroupNorm statistics are workgroup-local sums.
+//  * a 3x3x3 conv = conv_small's scheme (kernels_conv_small.hip) on those rows: the input -- normalised on the fly where it is
+//    a block's second conv -- is split to f16x2 (split16.h) into a zero / phi-halo padded record image, every tap is
+//    "record + constant"; the (tap, k-step) pairs are dealt round-robin over the waves of an output-channel tile (K split:
+//    each weight fragment is fetched from L2 once per workgroup and applied to all row tiles), the K slices are summed through
+//    LDS (the exchange re-uses the image), slice s of a channel tile ends up owning row tiles s, s + KS, ... in registers: bias,
+//    statistics, GroupNorm + SiLU (+ embedding) and the shortcut are applied there.
+//  * the 1x1 shortcut conv of a block that changes width runs on the block's own conv1 image (centre tap), each owner wave
+//    computing its own tile (K = cin is small: no K split, no exchange).
+//  * linear attention = the arithmetic of kernels_attn.hip's single-launch form with x read from / written to LDS.
+//
+// The reference ops: ResnetBlock models.py:172-200, Block :147-169, LinearAttention / PreNorm / Residual :281-329, 111-117.
+#include "cd_common.h"
+#include "split16.h"
+
+#include <cstdio>
+#include <cstdlib>
+
+namespace cd {
+
+namespace {
+
+constexpr int DC_THREADS = 256;
+constexpr int DC_NW = 4;    // one wave per SIMD
+template <int NT>
+struct DcRing {  // weight fragments requested this many pairs ahead (4 row tiles leave fewer registers)
+  static constexpr int PD = NT >= 4 ? 4 : 6;
+};
+constexpr int DC_VB = 272;  // bytes per image record: 64 channels x (2 + 2) B + 16 B pad (conflict-free ds_read_b128)
+
+struct DcRes {
+  int c0, c1, cout;                // input = cat(X[:, :c0], SKIP[:, :c1]) (c1 = 0: X only)
+  const u32x4 *w1, *w2;            // f16x2 images [k-step][tap][ct][term][lane] of the two 3x3x3 convs
+  const float *b1, *b2;
+  const float *g1, *be1, *g2, *be2;  // GroupNorm affine parameters
+  const float* emb;                // (B, emb_ld) slice of this block's projected conditioning, or null
+  int emb_ld;
+  const u32x4* wres;               // f16x2 image of the 1x1 shortcut conv (cin != cout), or null: identity
+  const float* bres;
+};
+struct DcAttn {
+  int C;
+  const float *ng, *nb;            // PreNorm GroupNorm(1, C)
+  const u32x4* wqkv;               // f16x2 image of to_qkv [k-step][ct (q, k, v)][term][lane]
+  const float *wout, *bout;        // to_out conv: torch (C, 32), (C)
+  const float *gg, *gb;            // closing GroupNorm(1, C)
+};
+struct DeepArgs {
+  const float* x_in;   // (B, vox, Ca) channels-last: output of the strided conv into this level
+  float* x_out;        // (B, vox, Ca): input of the transposed conv out of it
+  int D, H, W, groups, Ca, Cb;
+  int CXP;             // floats per LDS state row (>= max(Ca, Cb) + 8: the +8 de-phases the two half-waves' rows)
+  int offSkip, offH1, offImg, offTab, offRed, offGeo;  // byte offsets into the dynamic LDS block (X at 0)
+  DcRes r[6];          // downs.r1, downs.r2, mid1, mid2, ups.r1, ups.r2
+  DcAttn a[3];         // downs attention, mid attention, ups attention
+  int has_attn[3];
+  int* status;         // bit 0: an operand of the fp16-pipe products left the fp16 range
+  int dbg;             // (-DCD_DEEP_STAMPS builds, CD_DEEP_ABL) ablations of the MFMA loop: 1 = no ring refills, 2 = no MFMAs, 4 = no fragment reads
+};
+
+struct Ctx {
+  int tid, lane, wave, half, col;
+  int D, H, W, PV, vox, pitch, prow;
+  int CXP, groups, dbg;
+  char* lds;
+  float *X, *SKIP, *H1, *tab, *red;
+  char* img;  // record 0 of the image (one zeroed lead record in front of it)
+  // geometry tables in LDS, built once per launch (integer divisions by run-time extents cost ~40 instructions each, and a single
+  // wave issues one instruction per 4 cycles: the per-item index arithmetic was a fifth of the launch):
+  const int* vrec;   // [vox] byte offset of voxel v's record | 1 if phi row 0 | 2 if phi row H-1
+  const int* tapo;   // [4 * 27] byte offset of pair p = ks * 27 + tap from a voxel's own record: tap displacement + ks * 64
+  const unsigned char* zrec;  // [(D+2)*prow + 1] 1 = record i - 1 must read as zero (planes in front / behind, r pads, lead record)
+
+#ifdef CD_DEEP_STAMPS
+  mutable unsigned long long t_last;
+#endif
+};
+
+
+__device__ __forceinline__ void dc_barrier() { __syncthreads(); }
+
+// diagnostic build only (-DCD_DEEP_STAMPS, CD_DEEP_DBG=1): s_memtime sums of the phases of the launch, wave 0 of workgroup 0
+#ifdef CD_DEEP_STAMPS
+__device__ unsigned long long dc_stamp_buf[16];
+#define DC_T(i)                                                                          \
+  do {                                                                                   \
+    unsigned long long _t;                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");           \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+    if (blockIdx.x == 0 && threadIdx.x == 0) dc_stamp_buf[i] += _t - k.t_last;            \
+    k.t_last = _t;                                                                       \
+  } while (0)
+#define DC_T0()                                                                          \
+  do {                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(k.t_last)::"memory");     \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+  } while (0)
+#else
+#define DC_T(i) do { } while (0)
+#define DC_T0() do { } while (0)
+#endif
+
+// Tiles a wave can own: slice s of the KS slices of its channel tile owns row tiles s, s + KS, ... (KS = 4 or 2)
+template <int NT>
+struct DcOwn {
+  static constexpr int N = (NT + 1) / 2;
+};
+
+// ---- one 3x3x3 convolution of the sample: src (LDS rows) -> hold[j]: rows of tile slice + j KS, channel ctw*32 + col.
+// normed: the input is y = silu(tab[c][0] x + tab[c][1]) + tab[c][2] (a block's second conv).  wres (optional): the block's 1x1
+// shortcut conv of the SAME (un-normalised) input -> hsc (same tiles, without its bias).
+template <int NT>
+__device__ __forceinline__ void conv_stage(const Ctx& k, const float* src0, int c0, const float* src1, int c1, bool normed,
+                                           const u32x4* __restrict__ wimg, int cout, const float* __restrict__ bias,
+                                           const u32x4* __restrict__ wres, float (&hold)[DcOwn<NT>::N][16],
+                                           float (&hsc)[DcOwn<NT>::N][16], float& amax) {
+  constexpr int NO = DcOwn<NT>::N, DC_PD = DcRing<NT>::PD;
+  const int CT = cout >> 5, KS = DC_NW / CT;  // channel tiles (1 or 2); K slices per tile (4 or 2)
+  const int ctw = k.wave / KS, slice = k.wave - ctw * KS;
+  const int cin = c0 + c1;
+  const int vox = k.vox, H = k.H;
+  auto rec_of = [&](int t) {  // record (kz = kh = kw = 1 tap) of this lane's voxel in row tile t
+    const int v = t * 32 + k.col;
+    return (k.vrec[v < vox ? v : 0] & ~3) + k.half * 16;
+  };
+  int rec[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) rec[t] = rec_of(t);
+  f32x16 accA[NT], accB[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accA[t][r] = accB[t][r] = 0.f;
+
+  for (int cb = 0; cb < cin; cb += 64) {  // input channels in blocks of <= 64
+    const int cn = min(64, cin - cb);
+    const int nq = cn >> 2, nks = cn >> 4;
+    dc_barrier();  // whoever read the image region before (MFMAs of the previous block, exchange reads, attention scratch) is done
+    DC_T(8);
+    // This wave's (tap, k-step) pairs of the block: p = slice, slice + KS, ... -- NP of them for every slice (the last one may not
+    // exist for the higher slices: its loads are clamped, its MFMAs skipped).  Weight fragments come from L2 through a register
+    // ring DC_PD pairs deep, the first DC_PD requested now: their latency hides behind the staging.
+    const int npairs = 27 * nks;
+    const int NP = (npairs + KS - 1) / KS;
+    const int ilast = (npairs - 1 - slice) / KS;  // this slice's last pair; indices past it are clamped to it (loads) or skipped (MFMAs)
+    // fragment of pair p = ks * 27 + tap: wimg + (((cb/16 + ks) * 27 + tap) * CT + ctw) * 128 + term * 64 + lane -- linear in p
+    const u32x4* const wb0 = wimg + ((size_t)((cb >> 4) * 27 + slice) * CT + ctw) * 128 + k.lane;
+    const int wstep = KS * CT * 128;
+    auto wptr = [&](int i) { return wb0 + (unsigned)(min(i, ilast) * wstep); };  // (< 2^31 bytes: 32-bit scalar arithmetic)
+    u32x4 wr[DC_PD][2];
+#pragma unroll
+    for (int i = 0; i < DC_PD; ++i) {
+      const u32x4* wp = wptr(i);
+      wr[i][0] = wp[0];
+      wr[i][1] = wp[64];
+    }
+    // ---- the records no voxel is staged into must read as zero: the planes in front and behind, the record closing every r row,
+    // the lead record.  The region was last used by an exchange or the attention scratch, so they are cleared for every image.
+    for (int i = k.tid; i <= (k.D + 2) * k.prow; i += DC_THREADS) {
+      if (k.zrec[i]) {
+        u32x4* d = (u32x4*)(k.img + (i - 1) * DC_VB);  // record i - 1 (-1 = the lead record)
+#pragma unroll
+        for (int e = 0; e < DC_VB / 16; ++e) d[e] = u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+    DC_T(9);
+    // ---- stage the rows into the record image (interior records; the phi halo rows are copies).  Item i = (voxel i >> qsh,
+    // channel quad i & (nq - 1)), i = tid + 256 j: a thread's quad is the same for all its items (256 is a multiple of nq), so its
+    // four coefficient vectors are read once; all rows and record offsets of its (<= 8) items are requested together -- one LDS
+    // latency for the lot instead of three per item (a single wave per SIMD has nobody to hide them behind).
+    const int qsh = nq == 16 ? 4 : 3;  // cn is 64 or 32: 16 or 8 channel quads per voxel
+    {
+      constexpr int NI = 8;  // 128 voxels x 16 quads / 256 threads
+      const int q = k.tid & (nq - 1), c = cb + q * 4;
+      const int v0 = k.tid >> qsh, vstep = DC_THREADS >> qsh;
+      const float* sp = c < c0 ? src0 + c : src1 + (c - c0);
+      f32x4 xs[NI];
+      int vr[NI];
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int v = v0 + j * vstep;
+        if (v < vox) {
+          xs[j] = *(const f32x4*)(sp + v * k.CXP);
+          vr[j] = k.vrec[v];
+        }
+      }
+      f32x4 cf[4];
+      if (normed) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cf[e] = *(const f32x4*)(k.tab + (c + e) * 4);
+      }
+      const int qoff = (q >> 2) * 64 + (q & 3) * 8;  // record layout: [k-step][term][16 ch]
+      const int hrow = H * k.pitch * DC_VB;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int v = v0 + j * vstep;
+        if (v < vox) {
+          f32x4 x = xs[j];
+          if (normed) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = cd_fast_silu(cf[e][0] * x[e] + cf[e][1]) + cf[e][2];
+          }
+          amax = fmaxf(amax, fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3]))));
+          u32x2 t1, t2;
+          split2(x, t1, t2);
+          char* d = k.img + (vr[j] & ~3) + qoff;
+          *(u32x2*)d = t1;
+          *(u32x2*)(d + 32) = t2;
+          if (vr[j] & 1) {  // phi row 0: copy into the halo row H
+            *(u32x2*)(d + hrow) = t1;
+            *(u32x2*)(d + hrow + 32) = t2;
+          }
+          if (vr[j] & 2) {  // phi row H-1: copy into the halo row -1
+            *(u32x2*)(d - hrow) = t1;
+            *(u32x2*)(d - hrow + 32) = t2;
+          }
+        }
+      }
+    }
+    DC_T(10);
+    dc_barrier();
+    DC_T(0);
+    // ---- the block's 1x1 shortcut on this image (centre tap): every wave computes the tiles it will own, no K split -----------
+    if (wres) {
+#pragma unroll
+      for (int j = 0; j < NO; ++j) {
+        const int t = slice + j * KS;
+        if (t < NT) {
+          const int rt = rec_of(t);
+          f32x16 sA, sB;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sA[r] = sB[r] = 0.f;
+          for (int ks = 0; ks < nks; ++ks) {
+            const char* ap = k.img + rt + ks * 64;
+            const u32x4 a1 = *(const u32x4*)ap, a2 = *(const u32x4*)(ap + 32);
+            const u32x4* wp = wres + ((size_t)((cb >> 4) + ks) * CT + ctw) * 128 + k.lane;
+            const u32x4 w1 = wp[0], w2 = wp[64];
+            sA = MFMA_F16(a1, w1, sA);
+            sB = MFMA_F16(a1, w2, sB);
+            sB = MFMA_F16(a2, w1, sB);
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) hsc[j][r] += sA[r] + sB[r] * (1.f / 2048.f);
+        }
+      }
+    }
+    DC_T(1);
+    // ---- the MFMAs.  Software pipeline, written so that the compiler's own wait counts come out right: the A fragments of
+    // pair i + 1 are requested (LDS) before the MFMAs of pair i, a ring slot is refilled AFTER the MFMAs that read it (the old
+    // value is dead by then, so the load lands in the loop-carried register: no copy, no wait), every load is unconditional.
+    // tap displacement of pair i: lane i of `tv` (i <= ilast <= 53), read with one v_readlane instead of an LDS round trip
+    const int tv = k.tapo[slice + KS * min(k.lane, ilast)];
+    auto frag_off = [&](int i) { return __builtin_amdgcn_readlane(tv, min(i, ilast)); };
+    u32x4 fa[2][NT][2];
+    auto load_frags = [&](u32x4 (&f)[NT][2], int i) {
+      const int toff = frag_off(i);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const char* ap = k.img + rec[t] + toff;
+        f[t][0] = *(const u32x4*)ap;
+        f[t][1] = *(const u32x4*)(ap + 32);
+      }
+    };
+    load_frags(fa[0], 0);
+    static_assert(DC_PD % 2 == 0, "the fragment double buffer alternates inside one unrolled ring round");
+    (void)NP;
+    for (int i0 = 0; i0 <= ilast; i0 += DC_PD) {
+#pragma unroll
+      for (int kk = 0; kk < DC_PD; ++kk) {
+        const int i = i0 + kk;
+#ifdef CD_DEEP_ABL
+        if (!(k.dbg & 4))
+#endif
+        load_frags(fa[(kk + 1) & 1], i + 1);
+        const u32x4 w1 = wr[kk][0], w2 = wr[kk][1];
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef CD_DEEP_ABL
+        if (!(k.dbg & 2))
+#endif
+        if (i <= ilast) {  // (wave-uniform)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            accA[t] = MFMA_F16(fa[kk & 1][t][0], w1, accA[t]);
+            accB[t] = MFMA_F16(fa[kk & 1][t][0], w2, accB[t]);
+            accB[t] = MFMA_F16(fa[kk & 1][t][1], w1, accB[t]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef CD_DEEP_ABL
+        if (!(k.dbg & 1))
+#endif
+        {
+          const u32x4* wp = wptr(i + DC_PD);
+          wr[kk][0] = wp[0];
+          wr[kk][1] = wp[64];
+        }
+      }
+    }
+    DC_T(2);
+  }
+  // ---- sum the K slices of every tile through LDS (the exchange re-uses the image): every wave hands over all its tiles,
+  // slice s then sums the KS partials of the tiles it owns
+  float* const ex = (float*)k.img;  // [wave][tile][4][64 lanes][4 floats]
+  dc_barrier();                     // every MFMA has read its fragments
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    float* d = ex + (size_t)(k.wave * NT + t) * 1024 + k.lane * 4;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *(f32x4*)(d + g * 256) = f32x4{accA[t][4 * g] + accB[t][4 * g] * (1.f / 2048.f), accA[t][4 * g + 1] + accB[t][4 * g + 1] * (1.f / 2048.f),
+                                     accA[t][4 * g + 2] + accB[t][4 * g + 2] * (1.f / 2048.f),
+                                     accA[t][4 * g + 3] + accB[t][4 * g + 3] * (1.f / 2048.f)};
+  }
+  dc_barrier();
+  const float bv = bias ? bias[ctw * 32 + k.col] : 0.f;
+#pragma unroll
+  for (int j = 0; j < NO; ++j) {
+    const int t = slice + j * KS;
+    if (t < NT) {
+      f32x16 sum;
+      for (int s2 = 0; s2 < KS; ++s2) {
+        const float* d = ex + (size_t)((ctw * KS + s2) * NT + t) * 1024 + k.lane * 4;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 x = *(const f32x4*)(d + g * 256);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sum[4 * g + e] = s2 == 0 ? x[e] : sum[4 * g + e] + x[e];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hold[j][r] = sum[r] + bv;
+    }
+  }
+  DC_T(3);
+}
+
+// GroupNorm coefficients of the tensor whose tiles the waves hold: tab[c] = {scale, shift, add, 0}, c < cout.  The arithmetic of
+// gn_defer.h (fp64 group sums of per-channel float sums).  Ends with a barrier: tab is ready.
+template <int NT>
+__device__ __forceinline__ void gn_table(const Ctx& k, const float (&hold)[DcOwn<NT>::N][16], int cout, const float* __restrict__ gamma,
+                                         const float* __restrict__ beta, int groups, const float* __restrict__ add) {
+  constexpr int NO = DcOwn<NT>::N;
+  const int CT = cout >> 5, KS = DC_NW / CT;
+  const int ctw = k.wave / KS, slice = k.wave - ctw * KS;
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < NO; ++j) {
+    const int t = slice + j * KS;
+    if (t < NT) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * k.half;
+        if (t * 32 + row < k.vox) {
+          s1 += hold[j][r];
+          s2 += hold[j][r] * hold[j][r];
+        }
+      }
+    }
+  }
+  s1 += __shfl_xor(s1, 32, 64);
+  s2 += __shfl_xor(s2, 32, 64);
+  if (k.half == 0) {  // per wave: the sums of its channel tile's 32 channels over the row tiles it owns
+    k.red[(k.wave * 32 + k.col) * 2] = s1;
+    k.red[(k.wave * 32 + k.col) * 2 + 1] = s2;
+  }
+  dc_barrier();
+  if (k.tid < cout) {  // (cout <= 64: wave 0)
+    const int c = k.tid;
+    const int cpg = cout / groups;
+    const int g0 = c - c % cpg;
+    double a1 = 0.0, a2 = 0.0;  // fp64 group sums of the per-channel float sums (gn_defer.h), read straight from the waves' slots
+    for (int i = 0; i < cpg; ++i) {
+      const int cc = g0 + i, ct = cc >> 5;
+      float t1 = 0.f, t2 = 0.f;
+      for (int s = 0; s < KS; ++s) {
+        const f32x2v v = *(const f32x2v*)(k.red + ((ct * KS + s) * 32 + (cc & 31)) * 2);
+        t1 += v[0];
+        t2 += v[1];
+      }
+      a1 += (double)t1;
+      a2 += (double)t2;
+    }
+    const double inv = 1.0 / ((double)k.vox * cpg);
+    const double mu = a1 * inv;
+    double var = a2 * inv - mu * mu;
+    var = var < 0.0 ? 0.0 : var;
+    // 1 / sqrt(var + eps): the hardware estimate refined by one Newton step in fp64 (an fp64 sqrt + divide cost hundreds of
+    // instructions on the one wave everybody is waiting for)
+    const double vx = var + 1e-5;
+    double y = (double)__builtin_amdgcn_rsqf((float)vx);
+    y = y * (1.5 - 0.5 * vx * y * y);
+    const float sc = (float)y * gamma[c];
+    *(f32x4*)(k.tab + c * 4) = f32x4{sc, beta[c] - (float)mu * sc, add ? add[c] : 0.f, 0.f};
+  }
+  dc_barrier();
+}
+
+// ResnetBlock.forward (models.py:191-200) on the LDS state: X <- silu(gn2(conv2(silu(gn1(conv1(in))) + emb))) + shortcut(in),
+// in = cat(X[:, :c0], SKIP[:, :c1]).
+template <int NT>
+__device__ __forceinline__ void res_block(const Ctx& k, const DcRes& R, int b, float& amax) {
+  constexpr int NO = DcOwn<NT>::N;
+  const int CT = R.cout >> 5, KS = DC_NW / CT;
+  const int ctw = k.wave / KS, slice = k.wave - ctw * KS;
+  const int c = ctw * 32 + k.col;
+  float hold[NO][16], hsc[NO][16];
+#pragma unroll
+  for (int j = 0; j < NO; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hsc[j][r] = 0.f;
+  // (one loop body for both convs: two inlined copies of conv_stage in one function crash this compiler's SimplifyCFG, and
+  // the code is half the size)
+  for (int pass = 0; pass < 2; ++pass) {
+    const bool second = pass == 1;
+    conv_stage<NT>(k, second ? k.H1 : k.X, second ? R.cout : R.c0, second ? nullptr : k.SKIP, second ? 0 : R.c1, second,
+                   second ? R.w2 : R.w1, R.cout, second ? R.b2 : R.b1, second ? nullptr : R.wres, hold, hsc, amax);
+    gn_table<NT>(k, hold, R.cout, second ? R.g2 : R.g1, second ? R.be2 : R.be1, k.groups,
+                 (!second && R.emb) ? R.emb + (size_t)b * R.emb_ld : nullptr);
+    DC_T(4);
+    if (!second) {  // conv1's raw output: the rows conv2 stages (its staging starts behind a barrier)
+#pragma unroll
+      for (int j = 0; j < NO; ++j) {
+        const int t = slice + j * KS;
+        if (t < NT) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * k.half;
+            if (row < k.vox) k.H1[row * k.CXP + c] = hold[j][r];
+          }
+        }
+      }
+    }
+  }
+  {
+    const float sc = k.tab[c * 4], sh = k.tab[c * 4 + 1];
+    const float rb = R.wres ? R.bres[c] : 0.f;
+    const float* sp = (R.wres || c < R.c0) ? k.X + c : k.SKIP + (c - R.c0);
+#pragma unroll
+    for (int j = 0; j < NO; ++j) {
+      const int t = slice + j * KS;
+      if (t < NT) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * k.half;
+          if (row < k.vox) {
+            const float u = cd_fast_silu(sc * hold[j][r] + sh);
+            const float sv = R.wres ? hsc[j][r] + rb : sp[row * k.CXP];
+            k.X[row * k.CXP + c] = u + sv;  // (the element this lane reads as the shortcut, if any, is the one it overwrites)
+          }
+        }
+      }
+    }
+  }
+  dc_barrier();
+  DC_T(5);
+}
+
+// e^x for x <= 0 on the transcendental unit with a first-order correction of the product's rounding (kernels_attn.hip)
+__device__ __forceinline__ float dc_exp(float x) {
+  const float L2E = 1.4426950408889634f, L2E_LO = 1.925963033500519e-8f;
+  const float t = x * L2E;
+  const float lo = __builtin_fmaf(x, L2E, -t) + x * L2E_LO;
+  const float e = __builtin_amdgcn_exp2f(t);
+  return __builtin_fmaf(e, lo * 0.6931471805599453f, e);
+}
+
+// mean and 1/sqrt(var + eps) of NCH*32 x vox values given per-thread partial sums (GroupNorm(1, C)); all threads call
+__device__ __forceinline__ void block_mean_rstd(const Ctx& k, double a1, double a2, double cnt, float& mean, float& rstd) {
+  double* rd = (double*)k.red;  // [8 waves][2] + result
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    a1 += __shfl_xor(a1, o, 64);
+    a2 += __shfl_xor(a2, o, 64);
+  }
+  dc_barrier();
+  if (k.lane == 0) {
+    rd[k.wave * 2] = a1;
+    rd[k.wave * 2 + 1] = a2;
+  }
+  dc_barrier();
+  double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+  for (int w = 0; w < DC_NW; ++w) {
+    t1 += rd[w * 2];
+    t2 += rd[w * 2 + 1];
+  }
+  const double mu = t1 / cnt;
+  double var = t2 / cnt - mu * mu;
+  var = var < 0.0 ? 0.0 : var;
+  mean = (float)mu;
+  rstd = (float)(1.0 / sqrt(var + 1e-5));
+}
+
+// Residual(PreNorm(LinearAttention)) (models.py:111-117, 281-329) on the LDS state: X <- GroupNorm(to_out(attention(GroupNorm(X)))) + X.
+// Wave t < NT owns the 32-voxel tile t in both passes (the arithmetic of kernels_attn.hip's attn_pass1 / attn_fold_weights /
+// attn_pass2: projections, context and output products on the fp16 pipe as f16x2 splits).
+template <int NCH, int NT>
+__device__ __forceinline__ void attn_stage(const Ctx& k, const DcAttn& A, float& amax) {
+  constexpr int C = NCH * 32, NKS = NCH * 2;
+  // scratch in the image region (no conv is in flight): sCtx [NT][1024], sM [NT][32], sS [NT*2][32], sFac [NT][32], pM [32], pInv [32],
+  // pCtx [1024], sWout [C*33], sW [NCH*1024]
+  float* const sc = (float*)k.img;
+  float* const sCtx = sc;
+  float* const sM = sCtx + NT * 1024;
+  float* const sS = sM + NT * 32;
+  float* const sFac = sS + NT * 64;
+  float* const pInv = sFac + NT * 32;
+  float* const pCtx = pInv + 32;
+  float* const sWout = pCtx + 1024;
+  float* const sW = sWout + C * 33;
+  const int vox = k.vox;
+  const bool mine = k.wave < NT;
+  const int n = k.wave * 32 + k.col;  // this lane's voxel (A operand row) in both passes
+  const bool valid = mine && n < vox;
+
+  // ---- PreNorm: GroupNorm(1, C) statistics of X --------------------------------------------------------------------------
+  double a1 = 0.0, a2 = 0.0;
+  for (int i = k.tid; i < vox * (C / 4); i += DC_THREADS) {
+    const int v = i / (C / 4), q = i - v * (C / 4);
+    const f32x4 x = *(const f32x4*)(k.X + v * k.CXP + q * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      a1 += (double)x[e];
+      a2 += (double)x[e] * (double)x[e];
+    }
+  }
+  float mean, rstd;
+  block_mean_rstd(k, a1, a2, (double)vox * C, mean, rstd);  // (its barriers also fence the image region's previous users)
+  for (int i = k.tid; i < C * 32; i += DC_THREADS) sWout[(i >> 5) * 33 + (i & 31)] = A.wout[i];  // staged for the fold below
+  // the lane's normalised input as f16x2 A fragments: k-step ks = channels ks*16 + half*8 + 0..7
+  u32x4 x1[NKS], x2[NKS];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    u32x2 t1[2], t2[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c0 = ks * 16 + k.half * 8 + j * 4;
+      f32x4 v = valid ? *(const f32x4*)(k.X + n * k.CXP + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float s = A.ng[c0 + e] * rstd;
+        v[e] = valid ? s * v[e] + (A.nb[c0 + e] - mean * s) : 0.f;
+      }
+      amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+      split2(v, t1[j], t2[j]);
+    }
+    x1[ks] = u32x4{t1[0][0], t1[0][1], t1[1][0], t1[1][1]};
+    x2[ks] = u32x4{t2[0][0], t2[0][1], t2[1][0], t2[1][1]};
+  }
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  auto split8 = [](const float (&x)[16], int s8, u32x4& hi, u32x4& lo) {  // registers 8 s8 .. 8 s8 + 7 -> one f16x2 operand pair
+    u32x2 h0, l0, h1, l1;
+    split2(f32x4{x[8 * s8], x[8 * s8 + 1], x[8 * s8 + 2], x[8 * s8 + 3]}, h0, l0);
+    split2(f32x4{x[8 * s8 + 4], x[8 * s8 + 5], x[8 * s8 + 6], x[8 * s8 + 7]}, h1, l1);
+    hi = u32x4{h0[0], h0[1], h1[0], h1[1]};
+    lo = u32x4{l0[0], l0[1], l1[0], l1[1]};
+  };
+
+  // ---- pass 1: k, v of the tile; e = exp(k - max over the tile's voxels); ctx[d][e'] = sum_n e[n][d] v[n][e'] ---------------------
+  if (mine) {
+    f32x16 kk, vv16;
+    {
+      f32x16 pa = zero16, pb = zero16, qa = zero16, qb = zero16;
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        const u32x4 wk1 = A.wqkv[(size_t)(ks * 3 + 1) * 128 + k.lane], wk2 = A.wqkv[(size_t)(ks * 3 + 1) * 128 + 64 + k.lane];
+        const u32x4 wv1 = A.wqkv[(size_t)(ks * 3 + 2) * 128 + k.lane], wv2 = A.wqkv[(size_t)(ks * 3 + 2) * 128 + 64 + k.lane];
+        pa = MFMA_F16(x1[ks], wk1, pa);
+        pb = MFMA_F16(x1[ks], wk2, pb);
+        pb = MFMA_F16(x2[ks], wk1, pb);
+        qa = MFMA_F16(x1[ks], wv1, qa);
+        qb = MFMA_F16(x1[ks], wv2, qb);
+        qb = MFMA_F16(x2[ks], wv1, qb);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        kk[r] = pa[r] + pb[r] * (1.f / 2048.f);
+        vv16[r] = qa[r] + qb[r] * (1.f / 2048.f);
+      }
+    }
+    // rows of kk / vv16 = voxels (r, half), columns = channel d = col
+    float tm = -3.0e38f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * k.half;
+      if (k.wave * 32 + row < vox) tm = fmaxf(tm, kk[r]);
+    }
+    tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+    float ex[16], vv[16], ssum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * k.half;
+      ex[r] = (k.wave * 32 + row < vox) ? dc_exp(kk[r] - tm) : 0.f;
+      ssum += ex[r];
+      vv[r] = vv16[r];
+      amax = fmaxf(amax, fabsf(vv16[r]));
+    }
+    f32x16 ctx = zero16, ctxB = zero16;
+#pragma unroll
+    for (int s8 = 0; s8 < 2; ++s8) {
+      u32x4 e1, e2, v1, v2;
+      split8(ex, s8, e1, e2);
+      split8(vv, s8, v1, v2);
+      ctx = MFMA_F16(e1, v1, ctx);
+      ctxB = MFMA_F16(e1, v2, ctxB);
+      ctxB = MFMA_F16(e2, v1, ctxB);
+    }
+    if (k.half == 0) sM[k.wave * 32 + k.col] = tm;
+    sS[(k.wave * 2 + k.half) * 32 + k.col] = ssum;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int d = (r & 3) + 8 * (r >> 2) + 4 * k.half;  // row = channel d; column = e'
+      sCtx[k.wave * 1024 + d * 32 + k.col] = ctx[r] + ctxB[r] * (1.f / 2048.f);
+    }
+  }
+  dc_barrier();
+  // ---- merge the tiles (log-sum-exp) and normalise: pCtx[d][e'] = scale * ctx[d][e'] / sum[d] ------------------------------
+  if (k.tid < 32) {
+    float M = sM[k.tid];
+    for (int t = 1; t < NT; ++t) M = fmaxf(M, sM[t * 32 + k.tid]);
+    float S = 0.f;
+    for (int t = 0; t < NT; ++t) {
+      const float f = dc_exp(sM[t * 32 + k.tid] - M);
+      sFac[t * 32 + k.tid] = f;
+      S += (sS[(t * 2) * 32 + k.tid] + sS[(t * 2 + 1) * 32 + k.tid]) * f;
+    }
+    pInv[k.tid] = 0.17677669529663689f /* 32^-1/2 */ / S;
+  }
+  dc_barrier();
+  for (int i = k.tid; i < 1024; i += DC_THREADS) {
+    const int d = i >> 5;
+    float c = 0.f;
+    for (int t = 0; t < NT; ++t) c += sCtx[t * 1024 + i] * sFac[t * 32 + d];
+    pCtx[i] = c * pInv[d];
+  }
+  dc_barrier();
+  // folded output weights W'[c][d] = sum_e W_out[c][e] pCtx[d][e] in the k-slot order of an accumulator-register A operand
+  for (int i = k.tid; i < NCH * 1024; i += DC_THREADS) {
+    const int e4 = i & 3, ln = (i >> 2) & 63, q = (i >> 8) & 3, ct = i >> 10;
+    const int c = ct * 32 + (ln & 31);
+    const int d = e4 + 8 * q + 4 * (ln >> 5);
+    float acc = 0.f;
+#pragma unroll
+    for (int e = 0; e < 32; ++e) acc = fmaf(sWout[c * 33 + e], pCtx[d * 32 + e], acc);
+    sW[i] = acc;
+  }
+  dc_barrier();
+
+  // ---- pass 2: q^T = W_q xn^T, softmax over the 32 channels (lane-local), y = softmax(q) W'^T + b --------------------------------
+  float y[NCH][16];
+  double y1 = 0.0, y2 = 0.0;
+  if (mine) {
+    f32x16 q = zero16, qb = zero16;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const u32x4 wq1 = A.wqkv[(size_t)(ks * 3 + 0) * 128 + k.lane], wq2 = A.wqkv[(size_t)(ks * 3 + 0) * 128 + 64 + k.lane];
+      q = MFMA_F16(wq1, x1[ks], q);
+      qb = MFMA_F16(wq2, x1[ks], qb);
+      qb = MFMA_F16(wq1, x2[ks], qb);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) q[r] += qb[r] * (1.f / 2048.f);
+    float mx = q[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, q[r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float ss = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      q[r] = dc_exp(q[r] - mx);
+      ss += q[r];
+    }
+    ss += __shfl_xor(ss, 32, 64);
+    const float inv = 1.f / ss;
+    u32x4 p1[2], p2[2];
+#pragma unroll
+    for (int s8 = 0; s8 < 2; ++s8) {
+      u32x2 h0, l0, h1, l1;
+      split2(f32x4{q[8 * s8] * inv, q[8 * s8 + 1] * inv, q[8 * s8 + 2] * inv, q[8 * s8 + 3] * inv}, h0, l0);
+      split2(f32x4{q[8 * s8 + 4] * inv, q[8 * s8 + 5] * inv, q[8 * s8 + 6] * inv, q[8 * s8 + 7] * inv}, h1, l1);
+      p1[s8] = u32x4{h0[0], h0[1], h1[0], h1[1]};
+      p2[s8] = u32x4{l0[0], l0[1], l1[0], l1[1]};
+    }
+#pragma unroll
+    for (int ct = 0; ct < NCH; ++ct) {
+      f32x16 o = zero16, ob = zero16;
+#pragma unroll
+      for (int s8 = 0; s8 < 2; ++s8) {
+        const f32x4 wa = ((const f32x4*)sW)[(ct * 4 + 2 * s8) * 64 + k.lane], wb = ((const f32x4*)sW)[(ct * 4 + 2 * s8 + 1) * 64 + k.lane];
+        amax = fmaxf(amax, fmaxf(fmaxf(fmaxf(fabsf(wa[0]), fabsf(wa[1])), fmaxf(fabsf(wa[2]), fabsf(wa[3]))),
+                                 fmaxf(fmaxf(fabsf(wb[0]), fabsf(wb[1])), fmaxf(fabsf(wb[2]), fabsf(wb[3])))));
+        u32x2 h0, l0, h1, l1;
+        split2(wa, h0, l0);
+        split2(wb, h1, l1);
+        const u32x4 wb1 = u32x4{h0[0], h0[1], h1[0], h1[1]}, wb2 = u32x4{l0[0], l0[1], l1[0], l1[1]};
+        o = MFMA_F16(p1[s8], wb1, o);
+        ob = MFMA_F16(p1[s8], wb2, ob);
+        ob = MFMA_F16(p2[s8], wb1, ob);
+      }
+      const float bv = A.bout[ct * 32 + k.col];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = k.wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * k.half;
+        const float v = o[r] + ob[r] * (1.f / 2048.f) + bv;
+        y[ct][r] = v;
+        if (row < vox) {
+          y1 += (double)v;
+          y2 += (double)v * (double)v;
+        }
+      }
+    }
+  }
+  // ---- closing GroupNorm(1, C) of y and the residual: X <- gn(y) + X ------------------------------------------------------
+  block_mean_rstd(k, y1, y2, (double)vox * C, mean, rstd);
+  if (mine) {
+#pragma unroll
+    for (int ct = 0; ct < NCH; ++ct) {
+      const int c = ct * 32 + k.col;
+      const float s = A.gg[c] * rstd, sh = A.gb[c] - mean * s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = k.wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * k.half;
+        if (row < vox) k.X[row * k.CXP + c] = s * y[ct][r] + sh + k.X[row * k.CXP + c];
+      }
+    }
+  }
+  dc_barrier();
+}
+
+template <int NT>
+__global__ void __launch_bounds__(DC_THREADS) deep_level_kernel(DeepArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char dc_lds[];
+  Ctx k;
+  k.tid = threadIdx.x; k.lane = k.tid & 63; k.half = k.lane >> 5; k.col = k.lane & 31;
+  k.wave = __builtin_amdgcn_readfirstlane(k.tid >> 6);  // a scalar: the K-slice bookkeeping (pairs, taps, weight addresses) runs on the SALU
+  k.D = a.D; k.H = a.H; k.W = a.W; k.PV = a.H * a.W; k.vox = a.D * k.PV; k.pitch = a.W + 1; k.prow = (a.H + 2) * k.pitch;
+  k.CXP = a.CXP; k.groups = a.groups; k.dbg = a.dbg;
+  k.lds = dc_lds;
+  k.X = (float*)dc_lds; k.SKIP = (float*)(dc_lds + a.offSkip); k.H1 = (float*)(dc_lds + a.offH1);
+  k.tab = (float*)(dc_lds + a.offTab); k.red = (float*)(dc_lds + a.offRed);
+  k.img = dc_lds + a.offImg + DC_VB;  // (record -1, the kw = 0 tap of the image's very first voxel, is the zeroed lead record)
+  {
+    // geometry tables (see Ctx): voxel -> record, pair -> tap displacement, which records must read as zero
+    int* vrec = (int*)(dc_lds + a.offGeo);
+    int* tapo = vrec + 128;
+    unsigned char* zrec = (unsigned char*)(tapo + 128);
+    for (int v = k.tid; v < k.vox; v += DC_THREADS) {
+      const int z = v / k.PV, p = v - z * k.PV, h = p / a.W, w = p - h * a.W;
+      vrec[v] = ((((z + 1) * (a.H + 2) + (h + 1)) * k.pitch + w) * DC_VB) | (h == 0 ? 1 : 0) | (h == a.H - 1 ? 2 : 0);
+    }
+    for (int p = k.tid; p < 4 * 27; p += DC_THREADS) {
+      const int ks = p / 27, tap = p - ks * 27;
+      const int kz = tap / 9, kh = (tap - kz * 9) / 3, kw = tap - kz * 9 - kh * 3;
+      tapo[p] = ((kz - 1) * k.prow + (kh - 1) * k.pitch + (kw - 1)) * DC_VB + ks * 64;
+    }
+    for (int i = k.tid; i <= (a.D + 2) * k.prow; i += DC_THREADS) {
+      const int ri = i - 1;
+      const int z = ri / k.prow, w = (ri - z * k.prow) % k.pitch;
+      zrec[i] = (ri < 0 || z == 0 || z == a.D + 1 || w == a.W) ? 1 : 0;
+    }
+    k.vrec = vrec; k.tapo = tapo; k.zrec = zrec;
+  }
+  const int b = blockIdx.x;
+  const int vox = k.vox;
+  float amax = 0.f;
+  DC_T0();
+
+  // X <- x_in
+  {
+    const int nq = a.Ca >> 2;
+    const float* src = a.x_in + (size_t)b * vox * a.Ca;
+    for (int i = k.tid; i < vox * nq; i += DC_THREADS) {
+      const int v = i / nq, q = i - v * nq;
+      *(f32x4*)(k.X + v * k.CXP + q * 4) = *(const f32x4*)(src + (size_t)v * a.Ca + q * 4);
+    }
+  }
+  // (the first conv_stage starts with a barrier)
+  DC_T(7);
+  for (int bi = 0; bi < 6; ++bi) {
+    res_block<NT>(k, a.r[bi], b, amax);
+    const int ai = bi == 1 ? 0 : (bi == 2 ? 1 : (bi == 5 ? 2 : -1));
+    if (ai >= 0 && a.has_attn[ai]) {
+      if (a.a[ai].C == 32) attn_stage<1, NT>(k, a.a[ai], amax);
+      else attn_stage<2, NT>(k, a.a[ai], amax);
+      DC_T(6);
+    }
+    if (bi == 1) {  // the level's skip connection (models.py:719): SKIP <- X  (after the attention)
+      const int nq = a.Cb >> 2;
+      for (int i = k.tid; i < vox * nq; i += DC_THREADS) {
+        const int v = i / nq, q = i - v * nq;
+        *(f32x4*)(k.SKIP + v * k.CXP + q * 4) = *(const f32x4*)(k.X + v * k.CXP + q * 4);
+      }
+      dc_barrier();
+      DC_T(7);
+    }
+  }
+  {
+    const int nq = a.Ca >> 2;
+    float* dst = a.x_out + (size_t)b * vox * a.Ca;
+    for (int i = k.tid; i < vox * nq; i += DC_THREADS) {
+      const int v = i / nq, q = i - v * nq;
+      *(f32x4*)(dst + (size_t)v * a.Ca + q * 4) = *(const f32x4*)(k.X + v * k.CXP + q * 4);
+    }
+  }
+  DC_T(7);
+  if (a.status && !(amax <= 65504.f)) atomicOr(a.status, 1);
+}
+
+template <int NT>
+void launch_deep_inst(const DeepArgs& a, int batch, size_t lds, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    CD_HIP(hipFuncSetAttribute((const void*)deep_level_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(deep_level_kernel<NT>, dim3((unsigned)batch), dim3(DC_THREADS), lds, s, a);
+  CD_HIP(hipGetLastError());
+}
+
+}  // namespace
+
+// LDS plan of the launch, or 0 if the level does not qualify: <= 128 voxels, 32 or 64 channels on both sides, f16x2 images present.
+static size_t deep_level_layout(const DeepLevelDesc& d, DeepArgs* a) {
+  const int64_t vox = d.dims.vox();
+  if (vox < 1 || vox > 128) return 0;
+  if (!((d.Ca == 32 || d.Ca == 64) && (d.Cb == 32 || d.Cb == 64))) return 0;
+  if (d.groups <= 0 || d.Ca % d.groups || d.Cb % d.groups || 32 % (d.Ca / d.groups) || 32 % (d.Cb / d.groups)) return 0;
+  const int NT = (int)((vox + 31) / 32);
+  const int cmax = d.Ca > d.Cb ? d.Ca : d.Cb;
+  const int CXP = cmax + 8;
+  const size_t rows = (size_t)vox * CXP * 4;
+  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t image = (size_t)((d.dims.d + 2) * (d.dims.h + 2) * (d.dims.w + 1) + 1) * DC_VB + DC_VB;
+  const size_t exch = (size_t)DC_NW * NT * 4096;  // every wave's partial of every row tile, 4 KB each
+  const size_t attn = (size_t)(NT * 1024 + NT * 32 + NT * 64 + NT * 32 + 32 + 1024 + 64 * 33 + 2 * 1024) * 4;
+  size_t img = image > exch + DC_VB ? image : exch + DC_VB;  // (the exchange and the scratch start at record 0, behind the lead record)
+  img = img > attn + DC_VB ? img : attn + DC_VB;
+  size_t off = 0;
+  const size_t offX = off; off += up(rows);
+  const size_t offSkip = off; off += up(rows);
+  const size_t offH1 = off; off += up(rows);
+  const size_t offImg = off; off += up(img);
+  const size_t offTab = off; off += up(64 * 16);
+  const size_t offRed = off; off += up(DC_NW * 32 * 2 * 4 + 256);
+  const size_t offGeo = off; off += up(128 * 4 + 128 * 4 + (size_t)(d.dims.d + 2) * (d.dims.h + 2) * (d.dims.w + 1) + 1);
+  (void)offX;
+  if (off > 160 * 1024) return 0;
+  if (a) {
+    a->CXP = CXP; a->offSkip = (int)offSkip; a->offH1 = (int)offH1; a->offImg = (int)offImg; a->offTab = (int)offTab; a->offRed = (int)offRed; a->offGeo = (int)offGeo;
+  }
+  return off;
+}
+
+bool deep_level_eligible(const DeepLevelDesc& d) {
+  // (read on every call, once per forward: the parity tests switch between this launch and the per-op kernels in one process;
+  // a captured step graph replays whatever was decided at capture time)
+  if (getenv("CD_NO_DEEP_LEVEL")) return false;
+  for (int i = 0; i < 6; ++i)
+    if (!d.res[i].w1 || !d.res[i].w2) return false;
+  return deep_level_layout(d, nullptr) != 0;
+}
+
+void launch_deep_level(const DeepLevelDesc& d, const float* x_in, float* x_out, int batch, int* status, hipStream_t s) {
+  DeepArgs a{};
+  const size_t lds = deep_level_layout(d, &a);
+  CD_REQUIRE(lds != 0, "internal: deep level launched on an ineligible geometry");
+  a.x_in = x_in; a.x_out = x_out; a.D = d.dims.d; a.H = d.dims.h; a.W = d.dims.w; a.groups = d.groups; a.Ca = d.Ca; a.Cb = d.Cb;
+  a.status = status;
+  double flops = 0.0;
+  const double vox = (double)d.dims.vox();
+  for (int i = 0; i < 6; ++i) {
+    const DeepLevelDesc::Res& r = d.res[i];
+    DcRes& o = a.r[i];
+    o.c0 = r.c0; o.c1 = r.c1; o.cout = r.cout;
+    o.w1 = (const u32x4*)r.w1; o.w2 = (const u32x4*)r.w2; o.b1 = r.b1; o.b2 = r.b2;
+    o.g1 = r.g1; o.be1 = r.be1; o.g2 = r.g2; o.be2 = r.be2; o.emb = r.emb; o.emb_ld = r.emb_ld;
+    o.wres = (const u32x4*)r.wres; o.bres = r.bres;
+    CD_REQUIRE((r.c0 + r.c1) % 16 == 0 && (r.cout == 32 || r.cout == 64) && r.c0 % 4 == 0, "internal: deep level block widths");
+    CD_REQUIRE(r.wres || r.c0 + r.c1 == r.cout, "internal: deep level block without a shortcut conv must keep its width");
+    flops += 2.0 * 27 * ((double)(r.c0 + r.c1) + r.cout) * r.cout * vox + (r.wres ? 2.0 * (r.c0 + r.c1) * r.cout * vox : 0.0);
+  }
+  for (int i = 0; i < 3; ++i) {
+    a.has_attn[i] = d.has_attn[i];
+    if (!d.has_attn[i]) continue;
+    const DeepLevelDesc::Attn& t = d.attn[i];
+    CD_REQUIRE(t.C == 32 || t.C == 64, "internal: deep level attention width");
+    a.a[i].C = t.C; a.a[i].ng = t.ng; a.a[i].nb = t.nb; a.a[i].wqkv = (const u32x4*)t.wqkv; a.a[i].wout = t.wout; a.a[i].bout = t.bout;
+    a.a[i].gg = t.gg; a.a[i].gb = t.gb;
+    flops += 2.0 * (4.0 * t.C + 32) * 32 * vox;
+  }
+  char cat[96];
+  std::snprintf(cat, sizeof cat, "deep_level C%d/%d @%dx%dx%d", d.Ca, d.Cb, d.dims.d, d.dims.h, d.dims.w);
+  prof::Scope scope(cat, s, flops * batch, 8.0 * batch * vox * d.Ca);
+  const int NT = (int)((d.dims.vox() + 31) / 32);
+#ifdef CD_DEEP_STAMPS
+  a.dbg = getenv("CD_DEEP_ABL") ? atoi(getenv("CD_DEEP_ABL")) : 0;
+  static const bool dbg = getenv("CD_DEEP_DBG") != nullptr;
+  unsigned long long zero[16] = {0};
+  if (dbg) CD_HIP(hipMemcpyToSymbol(HIP_SYMBOL(dc_stamp_buf), zero, sizeof zero));
+#endif
+  switch (NT) {
+    case 1: launch_deep_inst<1>(a, batch, lds, s); break;
+    case 2: launch_deep_inst<2>(a, batch, lds, s); break;
+    case 3: launch_deep_inst<3>(a, batch, lds, s); break;
+    default: launch_deep_inst<4>(a, batch, lds, s); break;
+  }
+#ifdef CD_DEEP_STAMPS
+  if (dbg) {
+    unsigned long long st[16];
+    CD_HIP(hipStreamSynchronize(s));
+    CD_HIP(hipMemcpyFromSymbol(st, HIP_SYMBOL(dc_stamp_buf), sizeof st));
+    unsigned long long tot = 0;
+    for (int i = 0; i < 8; ++i) tot += st[i];
+    std::fprintf(stderr, "[deep stamps] stage: top barrier %llu prefetch+zero %llu rows %llu barrier %llu\n", st[8], st[9], st[10], st[0]);
+    st[0] += st[8] + st[9] + st[10];
+    std::fprintf(stderr, "[deep stamps] stage %llu shortcut %llu mfma %llu exchange %llu gn %llu close %llu attn %llu io %llu  total %llu (s_memtime ticks)\n",
+                 st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7], tot);
+  }
+#endif
+}
+
+}  // namespace cd

@@ -350,7 +350,8 @@ void build_plan(CdPlan* p) {
     w.raw_off = bump((size_t)w.numel);
     if (w.pack == PK_CONV || w.pack == PK_CONVT) w.pk_off = bump(packed_weight_floats(w.cin, w.cout, w.taps));
     // 16-bit split images: the 3x3x3 / strided convs and the attention's to_qkv (cout = 96)
-    if (w.pack == PK_CONV && (w.taps == 27 || w.taps == 48 || (w.taps == 1 && w.cout == 96)))
+    // (1x1: the attention's to_qkv and the ResnetBlocks' res_conv, which the deep-level kernel runs on the fp16 pipe)
+    if (w.pack == PK_CONV && (w.taps == 27 || w.taps == 48 || w.taps == 1))
       w.pk3_off = bump(packed_split16_bytes(w.cin, w.cout, w.taps) / 4);
     else if (w.pack == PK_CONVT) w.pk3_off = bump(packed_f16x2_bytes(w.cin, w.cout, w.taps) / 4);  // f16x2 image only
     else if (w.pack == PK_INIT) w.pk_off = bump((size_t)w.numel);
@@ -791,6 +792,48 @@ void conv_transpose_backward(Run& r, const float* x, const float* w_raw, const f
   if (folded) ws->release(folded);
 }
 
+// Descriptor of the deepest level for the one-launch form (kernels_deep.hip); false if the level does not qualify.
+bool deep_level_desc(const CdPlan* p, const float* emb, DeepLevelDesc* out) {
+  const CdUnetDesc& d = p->desc;
+  const int nres = p->nres;
+  if (conv_precision() != PREC_F16X2) return false;  // (the full-range precisions keep the per-op kernels)
+  DeepLevelDesc L;
+  L.dims = p->shapes[nres - 1];
+  L.Ca = d.layer_sizes[nres - 1]; L.Cb = d.layer_sizes[nres]; L.groups = d.groups;
+  const ResW* rw[6] = {&p->downs[nres - 1].r1, &p->downs[nres - 1].r2, &p->mid1, &p->mid2, &p->ups[0].r1, &p->ups[0].r2};
+  for (int i = 0; i < 6; ++i) {
+    const ResW& w = *rw[i];
+    DeepLevelDesc::Res& r = L.res[i];
+    const bool cat = i == 4;  // ups r1 reads cat(x, skip): two Cb-wide halves
+    r.c0 = cat ? L.Cb : w.cin; r.c1 = cat ? w.cin - L.Cb : 0; r.cout = w.cout;
+    if (!p->packed3(w.c1w) || !p->packed3(w.c2w)) return false;
+    r.w1 = (const char*)p->packed3(w.c1w) + packed_bf16x3_bytes(w.cin, w.cout, 27);
+    r.w2 = (const char*)p->packed3(w.c2w) + packed_bf16x3_bytes(w.cout, w.cout, 27);
+    r.b1 = p->raw(w.c1b); r.b2 = p->raw(w.c2b); r.g1 = p->raw(w.n1g); r.be1 = p->raw(w.n1b); r.g2 = p->raw(w.n2g); r.be2 = p->raw(w.n2b);
+    if (w.has_mlp && emb) { r.emb = emb + w.emb_off; r.emb_ld = p->emb_ld; }
+    if (w.has_res) {
+      if (!p->packed3(w.rw)) return false;
+      r.wres = (const char*)p->packed3(w.rw) + packed_bf16x3_bytes(w.cin, w.cout, 1);
+      r.bres = p->raw(w.rb);
+    }
+  }
+  const AttnW* aw[3] = {&p->downs[nres - 1].attn, &p->mid_attn, &p->ups[0].attn};
+  const bool on[3] = {d.block_attn != 0, d.mid_attn != 0, d.block_attn != 0};
+  for (int i = 0; i < 3; ++i) {
+    L.has_attn[i] = on[i] ? 1 : 0;
+    if (!on[i]) continue;
+    const AttnW& w = *aw[i];
+    DeepLevelDesc::Attn& a = L.attn[i];
+    a.C = w.c; a.ng = p->raw(w.ng); a.nb = p->raw(w.nb); a.wout = p->raw(w.ow); a.bout = p->raw(w.ob); a.gg = p->raw(w.gg); a.gb = p->raw(w.gb);
+    if (!p->packed3(w.qkv)) return false;
+    a.wqkv = (const char*)p->packed3(w.qkv) + packed_bf16x3_bytes(w.c, 96, 1);
+  }
+  if (L.res[0].c0 != L.Ca || L.res[0].cout != L.Cb || L.res[4].cout != L.Ca || L.res[4].c1 != L.Cb || L.res[5].cout != L.Ca) return false;
+  if (!deep_level_eligible(L)) return false;
+  *out = L;
+  return true;
+}
+
 // CondUnet.forward after init_conv / embeddings (models.py:713-748). Takes ownership of h (a workspace block).
 // `lazy`: see res_block -- when set on return, the result is the final block's raw conv output, *xin its (still allocated) input.
 float* unet_body(CdPlan* p, Run& r, const float* emb, float* h, LazyClose* lazy = nullptr, float** xin = nullptr) {
@@ -800,8 +843,18 @@ float* unet_body(CdPlan* p, Run& r, const float* emb, float* h, LazyClose* lazy 
   std::vector<float*> skips(nres, nullptr);
   float* x = h;
   int cx = d.layer_sizes[0];
+  // The deepest level (downs[-1], the mid blocks, ups[0] up to its transposed conv) as ONE launch where a sample is <= 128 voxels
+  DeepLevelDesc deep;
+  const bool deep_on = deep_level_desc(p, emb, &deep);
   for (int i = 0; i < nres; ++i) {
     const Dims3 dims = p->shapes[i];
+    if (deep_on && i == nres - 1) {
+      float* y = r.ws->get<float>((size_t)r.B * dims.vox() * cx);
+      if (!r.dry()) launch_deep_level(deep, x, y, r.B, r.status, r.s);
+      r.ws->release(x);
+      x = y;
+      break;
+    }
     float* t = res_block(r, resolve(p, p->downs[i].r1, emb), x, cx, nullptr, 0, dims);
     r.ws->release(x);
     x = t; cx = p->downs[i].r1.cout;
@@ -833,40 +886,45 @@ float* unet_body(CdPlan* p, Run& r, const float* emb, float* h, LazyClose* lazy 
     }
   }
   const Dims3 md = p->shapes[nres - 1];
-  float* mp = nullptr;
-  int mu = 0;
-  float* t = res_block(r, resolve(p, p->mid1, emb), x, cx, nullptr, 0, md, d.mid_attn ? &mp : nullptr, &mu);
-  // x aliases skips[nres-1]: keep it alive for the concat
-  x = t;
-  if (d.mid_attn) {
-    t = attn_block(r, resolve(p, p->mid_attn), x, md, mp, mu);
-    r.ws->release(mp);
+  float* t = nullptr;
+  if (!deep_on) {
+    float* mp = nullptr;
+    int mu = 0;
+    t = res_block(r, resolve(p, p->mid1, emb), x, cx, nullptr, 0, md, d.mid_attn ? &mp : nullptr, &mu);
+    // x aliases skips[nres-1]: keep it alive for the concat
+    x = t;
+    if (d.mid_attn) {
+      t = attn_block(r, resolve(p, p->mid_attn), x, md, mp, mu);
+      r.ws->release(mp);
+      r.ws->release(x);
+      x = t;
+    }
+    t = res_block(r, resolve(p, p->mid2, emb), x, cx, nullptr, 0, md);
     r.ws->release(x);
     x = t;
   }
-  t = res_block(r, resolve(p, p->mid2, emb), x, cx, nullptr, 0, md);
-  r.ws->release(x);
-  x = t;
 
   for (int i = 0; i < nres; ++i) {
     const int lv = nres - 1 - i;
     const Dims3 dims = p->shapes[lv];
     const int cs = d.layer_sizes[lv + 1];  // width of the skip (and of x after the previous stage)
-    CD_REQUIRE(cx == cs, "internal: up path width mismatch");
-    t = res_block(r, resolve(p, p->ups[i].r1, emb), x, cx, skips[lv], cs, dims);
-    r.ws->release(x);
-    r.ws->release(skips[lv]);
-    x = t; cx = p->ups[i].r1.cout;
-    float* up = nullptr;
-    int uu = 0;
-    t = res_block(r, resolve(p, p->ups[i].r2, emb), x, cx, nullptr, 0, dims, d.block_attn ? &up : nullptr, &uu);
-    r.ws->release(x);
-    x = t;
-    if (d.block_attn) {
-      t = attn_block(r, resolve(p, p->ups[i].attn), x, dims, up, uu);
-      r.ws->release(up);
+    if (!(deep_on && i == 0)) {  // (the deep-level launch already ran ups[0]'s blocks: x is their output, layer_sizes[lv] wide)
+      CD_REQUIRE(cx == cs, "internal: up path width mismatch");
+      t = res_block(r, resolve(p, p->ups[i].r1, emb), x, cx, skips[lv], cs, dims);
+      r.ws->release(x);
+      r.ws->release(skips[lv]);
+      x = t; cx = p->ups[i].r1.cout;
+      float* up = nullptr;
+      int uu = 0;
+      t = res_block(r, resolve(p, p->ups[i].r2, emb), x, cx, nullptr, 0, dims, d.block_attn ? &up : nullptr, &uu);
       r.ws->release(x);
       x = t;
+      if (d.block_attn) {
+        t = attn_block(r, resolve(p, p->ups[i].attn), x, dims, up, uu);
+        r.ws->release(up);
+        r.ws->release(x);
+        x = t;
+      }
     }
     if (i + 1 < nres) {
       const Dims3 od = p->up_out[i];
@@ -1028,7 +1086,7 @@ size_t dry_forward_bytes(CdPlan* plan, int batch, F&& front) {
 // eagerly, a cached step graph holds the f16x2 kernels) -- the precision is overridden for THIS THREAD only, other plans /
 // threads of the process keep their kernels -- and bit 1 is OR-ed into the sticky word.  Returns whether the fallback ran.
 template <typename F>
-bool run_with_range_fallback(CdPlan* plan, hipStream_t s, F&& run) {
+bool run_with_range_fallback(CdPlan* plan, hipStream_t s, F&& run, bool report_sticky = true) {
   struct Restore {
     CdPlan* p;
     ~Restore() {
@@ -1046,7 +1104,7 @@ bool run_with_range_fallback(CdPlan* plan, hipStream_t s, F&& run) {
   if (!(flags & 1)) return false;
   set_conv_precision_override(PREC_BF16X3);
   run(true);
-  launch_or_word(plan->d_counter + 2, 2, s);
+  if (report_sticky) launch_or_word(plan->d_counter + 2, 2, s);
   return true;
 }
 
@@ -1253,7 +1311,7 @@ int cd_denoise_safe(CdPlan* plan, int batch, const float* x, const float* sigma,
     const bool fb = run_with_range_fallback(plan, (hipStream_t)stream, [&](bool) {
       plan->ws.reset((char*)workspace, workspace_bytes, false);
       forward_impl(plan, batch, x, cond, sigma, out, false, (hipStream_t)stream);
-    });
+    }, /*report_sticky=*/fell_back == nullptr);
     if (fell_back) *fell_back = fb ? 1 : 0;
   });
 }

@@ -124,7 +124,7 @@ int cd_denoise(CdPlan* plan, int batch, const float* x, const float* sigma, cons
                void* workspace, size_t workspace_bytes, void* stream);
 /* cd_denoise with the range fallback of the sampler entry points (below): if an operand of the fp16-pipe kernels left the fp16
  * range during the call, the call is run again with the full-range kernels (bf16x3 convolutions, f32-MFMA attention) before it
- * returns, *fell_back (may be NULL) is set to 1 and cd_plan_status reports bit 1.  Unlike cd_denoise it SYNCHRONISES `stream`
+ * returns and *fell_back is set to 1 (fell_back == NULL: cd_plan_status reports bit 1 instead).  Unlike cd_denoise it SYNCHRONISES `stream`
  * (to read the flag) and is therefore not graph-capturable: it is the entry point for samplers that call the model back from
  * host code (models/sample.py: `model(x, sigma=, E=, layers=)`, e.g. DPMAdaptive :188-309), which must not die mid-trajectory. */
 int cd_denoise_safe(CdPlan* plan, int batch, const float* x, const float* sigma, const float* cond, float* out,
