@@ -375,6 +375,9 @@ struct EmbedArgs {
   // SinusoidalPositionEmbeddings(half/2) (models.py:132-144) in place of the first Linear+GELU of the time / cond branch
   // (CondUnet(time_embed=True / cond_embed=True), models.py:578-601): tw1/tb1 resp. cw1/cb1 are unused then, and cond is (B,)
   int time_sin = 0, cond_sin = 0;
+  // Several steps of one trajectory in one launch (the sampler loop's embeddings, a chunk of steps ahead): workgroup b embeds
+  // sample b % cond_rows at the time value time_or_sigma[(b / cond_rows) * time_stride].  cond_rows = 0: one step, as before.
+  int cond_rows = 0, time_stride = 0;
 };
 void launch_embed(const EmbedArgs& a, hipStream_t s);
 void launch_silu_linear(const float* cond, const float* w, const float* bias, float* out, int batch, int nin, int nout,
@@ -394,14 +397,33 @@ struct HeadArgs {
   // that block's second conv output and `res` its input; saves the block's own elementwise pass over the level-0 tensor.
   GnDefer defer;
   const float* res = nullptr;
+  // DDim.__call__'s update of the running sample (models/sample.py:88-107) in the same pass (needs x and scal): with
+  // stepvals = {sigma, sigma_prev*[t>0], ddim_sigma, denom}:  x_next = x0 + sigma_prev (x - x0) / sigma + ddim_sigma noise / denom
+  // -- the arithmetic of launch_ddim_update, whose launch and pass over x / x0 it saves.  upd_x_next may alias x.
+  const float* upd_stepvals = nullptr;  // null: no update
+  const float* upd_noise = nullptr;
+  float* upd_x_next = nullptr;
+  float* upd_xs = nullptr;
+  float* upd_x0s = nullptr;
 };
 void launch_head(const HeadArgs& a, hipStream_t s);
 
 // x_next = x0 + sigma_prev*((x - x0)/sigma) + ddim_sigma*noise/denom, scalars read from stepvals[0..3]
 void launch_ddim_update(const float* x, const float* x0, const float* noise, const float* stepvals, float* x_next,
                         float* xs_slot, float* x0s_slot, int64_t n, hipStream_t s);
-// stepvals <- table[*counter]; sigma_b[0..B) <- stepvals.sigma; (*counter)++
-void launch_load_step(const float* table, int* counter, float* stepvals, float* sigma_b, int batch, hipStream_t s);
+// stepvals <- table[*counter]; sigma_b[0..B) <- stepvals.sigma; (*counter)++.  chunk (optional): the step's slice of the
+// embeddings / scalings computed a chunk of steps ahead -- slot (*counter) % chunk_steps of emb_src / scal_src -> emb_dst / scal_dst
+struct StepChunk {
+  const float* emb_src = nullptr;  // [chunk_steps][emb_floats]
+  float* emb_dst = nullptr;
+  int emb_floats = 0;
+  const float* scal_src = nullptr;  // [chunk_steps][scal_floats]
+  float* scal_dst = nullptr;
+  int scal_floats = 0;
+  int chunk_steps = 0;
+};
+void launch_load_step(const float* table, int* counter, float* stepvals, float* sigma_b, int batch, hipStream_t s,
+                      const StepChunk* chunk = nullptr);
 void launch_scale(const float* x, float* y, const float* stepvals_sigma, int64_t n, hipStream_t s);
 void launch_scale_imm(const float* x, float* y, float scale, int64_t n, hipStream_t s);
 void launch_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, hipStream_t s);

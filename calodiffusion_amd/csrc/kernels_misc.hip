@@ -64,7 +64,8 @@ __global__ void __launch_bounds__(512) embed_kernel(EmbedArgs a) {
   __shared__ float bufA[256], bufB[256], cat[256];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-  const float tv = a.time_or_sigma[b];
+  const int bc = a.cond_rows ? b % a.cond_rows : b;  // row of `cond`
+  const float tv = a.cond_rows ? a.time_or_sigma[(size_t)(b / a.cond_rows) * a.time_stride] : a.time_or_sigma[b];
   float t_in = tv;
   if (a.time_kind == 0) t_in = 0.5f * logf(tv);
   else if (a.time_kind == 1) t_in = tv / sqrtf(1.f + tv * tv);
@@ -102,9 +103,9 @@ __global__ void __launch_bounds__(512) embed_kernel(EmbedArgs a) {
   // cond branch: Linear(cond_size, hidden) GELU | sinusoidal(half/2) of the scalar condition;  Linear(hidden, half) GELU
   // Linear(half, half)
   if (a.cond_sin) {
-    sinusoidal(a.cond[b], bufB);
+    sinusoidal(a.cond[bc], bufB);
   } else {
-    for (int i = tid; i < a.cond_size; i += blockDim.x) bufA[i] = a.cond[(size_t)b * a.cond_size + i];
+    for (int i = tid; i < a.cond_size; i += blockDim.x) bufA[i] = a.cond[(size_t)bc * a.cond_size + i];
     __syncthreads();
     dense(a.cw1, a.cb1, bufA, bufB, a.cond_size, a.cond_hidden, true);
   }
@@ -144,6 +145,7 @@ void launch_embed(const EmbedArgs& a, hipStream_t s) {
   CD_REQUIRE(a.half * 2 <= 256 && a.cond_hidden <= 256 && a.cond_size <= 256, "embedding widths above 256 unsupported");
   prof::Scope scope("embed", s, 0, 0);
   const int groups = a.n_layers >= 4 ? 4 : 1;
+  CD_REQUIRE(!a.cond_rows || a.batch % a.cond_rows == 0, "internal: embedding chunk must be whole steps");
   hipLaunchKernelGGL(embed_kernel, dim3(a.batch, groups), dim3(512), 0, s, a);
   CD_HIP(hipGetLastError());
 }
@@ -191,6 +193,15 @@ __global__ void __launch_bounds__(256) head_kernel(HeadArgs a) {
         else if (a.objective == 1) pred = xv - a.scal[b * 4 + 3] * pred;
       }
       a.out[i] = pred;
+      if (a.upd_stepvals) {  // (ddim_update_kernel's arithmetic)
+        const float sigma = a.upd_stepvals[0], sprev = a.upd_stepvals[1], dsig = a.upd_stepvals[2], denom = a.upd_stepvals[3];
+        const float eps = (a.x[i] - pred) / sigma;
+        float r = pred + sprev * eps;
+        if (a.upd_noise) r += dsig * a.upd_noise[i] / denom;
+        a.upd_x_next[i] = r;
+        if (a.upd_xs) a.upd_xs[i] = r;
+        if (a.upd_x0s) a.upd_x0s[i] = pred;
+      }
     }
   }
 }
@@ -231,11 +242,21 @@ __global__ void __launch_bounds__(256) head_gn_kernel(HeadArgs a) {
         else if (a.objective == 1) pred = xv - a.scal[b * 4 + 3] * pred;
       }
       a.out[i] = pred;
+      if (a.upd_stepvals) {  // (ddim_update_kernel's arithmetic)
+        const float sigma = a.upd_stepvals[0], sprev = a.upd_stepvals[1], dsig = a.upd_stepvals[2], denom = a.upd_stepvals[3];
+        const float eps = (a.x[i] - pred) / sigma;
+        float r = pred + sprev * eps;
+        if (a.upd_noise) r += dsig * a.upd_noise[i] / denom;
+        a.upd_x_next[i] = r;
+        if (a.upd_xs) a.upd_xs[i] = r;
+        if (a.upd_x0s) a.upd_x0s[i] = pred;
+      }
     }
   }
 }
 
 void launch_head(const HeadArgs& a, hipStream_t s) {
+  CD_REQUIRE(!a.upd_stepvals || (a.x && a.scal && a.upd_x_next), "head: the fused sampler update needs x, the scalings and x_next");
   if (a.defer.part) {
     CD_REQUIRE(a.defer.C == 32 && a.res, "head: the fused final block is 32 channels wide with an identity shortcut");
     prof::Scope scope("head_gn", s, 64.0 * a.batch * a.vox, 4.0 * a.batch * a.vox * 66);
@@ -260,18 +281,34 @@ void launch_head(const HeadArgs& a, hipStream_t s) {
 // captured step graph can be replayed for every iteration.
 //   stepvals = {sigma, sigma_prev*[t>0], ddim_sigma, denom}
 // ------------------------------------------------------------------------------------------------------------
-__global__ void load_step_kernel(const float* __restrict__ table, int* counter, float* stepvals, float* sigma_b, int batch) {
+__global__ void __launch_bounds__(1024) load_step_kernel(const float* __restrict__ table, int* counter, float* stepvals, float* sigma_b,
+                                                         int batch, StepChunk ch) {
   const int step = *counter;
   const float* row = table + (size_t)step * 4;
   const int tid = threadIdx.x;
   if (tid < 4) stepvals[tid] = row[tid];
   const float sg = row[0];
   for (int i = tid; i < batch; i += blockDim.x) sigma_b[i] = sg;
+  if (ch.chunk_steps) {  // this step's embeddings and scalings out of the chunk computed ahead (one workgroup: ~150 KB from L2)
+    const int slot = step % ch.chunk_steps;
+    const f32x4* es = (const f32x4*)(ch.emb_src + (size_t)slot * ch.emb_floats);
+    f32x4* ed = (f32x4*)ch.emb_dst;
+    for (int i = tid; i < ch.emb_floats / 4; i += blockDim.x) ed[i] = es[i];
+    const f32x4* ss = (const f32x4*)(ch.scal_src + (size_t)slot * ch.scal_floats);
+    f32x4* sd = (f32x4*)ch.scal_dst;
+    for (int i = tid; i < ch.scal_floats / 4; i += blockDim.x) sd[i] = ss[i];
+  }
   __syncthreads();
   if (tid == 0) *counter = step + 1;
 }
-void launch_load_step(const float* table, int* counter, float* stepvals, float* sigma_b, int batch, hipStream_t s) {
-  hipLaunchKernelGGL(load_step_kernel, dim3(1), dim3(256), 0, s, table, counter, stepvals, sigma_b, batch);
+void launch_load_step(const float* table, int* counter, float* stepvals, float* sigma_b, int batch, hipStream_t s,
+                      const StepChunk* chunk) {
+  StepChunk ch;
+  if (chunk) {
+    ch = *chunk;
+    CD_REQUIRE(ch.emb_floats % 4 == 0 && ch.scal_floats % 4 == 0, "internal: step chunk rows must be whole float4s");
+  }
+  hipLaunchKernelGGL(load_step_kernel, dim3(1), dim3(chunk ? 1024 : 256), 0, s, table, counter, stepvals, sigma_b, batch, ch);
   CD_HIP(hipGetLastError());
 }
 

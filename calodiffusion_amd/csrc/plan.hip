@@ -143,6 +143,7 @@ struct CdPlan {
 
   // sampler state (device): step table, counter, stepvals
   static constexpr int kMaxSteps = 4096;
+  static constexpr int kEmbedChunk = 16;  // sampler steps whose embeddings one launch computes ahead (cd_ddim_sample)
   float* d_table = nullptr;
   int* d_counter = nullptr;
   float* d_stepvals = nullptr;
@@ -988,17 +989,26 @@ static void refresh_init_table(CdPlan* p, hipStream_t s) {
 }
 
 // shared by cd_unet_forward (raw = true) and cd_denoise; workspace must have been reset by the caller
-void forward_impl(CdPlan* p, int B, const float* x, const float* cond, const float* t, float* out, bool raw, hipStream_t s) {
+// Options of the sampler loop (cd_ddim_sample): embeddings / scalings already in place (computed a chunk of steps ahead), and the
+// sampler's update of the running sample fused into the head kernel.
+struct FwdOpts {
+  float* emb_pre = nullptr;   // (B, emb_ld) ready-made: no embedding launch
+  float* scal_pre = nullptr;  // (B, 4)
+  const HeadArgs* upd = nullptr;  // only the upd_* fields are read
+};
+void forward_impl(CdPlan* p, int B, const float* x, const float* cond, const float* t, float* out, bool raw, hipStream_t s,
+                  const FwdOpts* opt = nullptr) {
   const CdUnetDesc& d = p->desc;
   const Dims3 dims = p->shapes[0];
   Run r{&p->ws, s, B, d.groups};
   r.status = p->status_word;
-  float* emb = p->ws.get<float>((size_t)B * p->emb_ld);
-  float* scal = p->ws.get<float>((size_t)B * 4);
+  const bool pre = opt && opt->emb_pre;
+  float* emb = pre ? opt->emb_pre : p->ws.get<float>((size_t)B * p->emb_ld);
+  float* scal = pre ? opt->scal_pre : p->ws.get<float>((size_t)B * 4);
   float* h = p->ws.get<float>((size_t)B * dims.vox() * d.layer_sizes[0]);
   if (!r.dry()) {
     // (running this launch beside the init conv on a second stream was measured: no gain inside the step graph)
-    launch_embed(embed_args(p, B, cond, t, raw ? CD_TIME_RAW : d.time_embed_kind, emb, raw ? nullptr : scal), s);
+    if (!pre) launch_embed(embed_args(p, B, cond, t, raw ? CD_TIME_RAW : d.time_embed_kind, emb, raw ? nullptr : scal), s);
     InitConvArgs a;
     a.x = x; a.cin = d.in_channels; a.wpk = p->packed(p->init_w); a.bias = p->raw(p->init_b); a.out = h; a.batch = B;
     a.cout = d.layer_sizes[0]; a.dims = dims;
@@ -1020,6 +1030,10 @@ void forward_impl(CdPlan* p, int B, const float* x, const float* cond, const flo
     ha.h = hf; ha.w = p->raw(p->head_w); ha.bias = p->raw(p->head_b); ha.out = out; ha.batch = B; ha.vox = dims.vox();
     if (!raw) { ha.x = x; ha.scal = scal; ha.objective = d.objective; }
     if (lazy.on) { ha.defer = lazy.gn; ha.res = xin; }
+    if (opt && opt->upd) {
+      ha.upd_stepvals = opt->upd->upd_stepvals; ha.upd_noise = opt->upd->upd_noise; ha.upd_x_next = opt->upd->upd_x_next;
+      ha.upd_xs = opt->upd->upd_xs; ha.upd_x0s = opt->upd->upd_x0s;
+    }
     launch_head(ha, s);
   }
   if (lazy.on) {
@@ -1027,8 +1041,10 @@ void forward_impl(CdPlan* p, int B, const float* x, const float* cond, const flo
     r.ws->release(xin);
   }
   r.ws->release(hf);
-  r.ws->release(scal);
-  r.ws->release(emb);
+  if (!pre) {
+    r.ws->release(scal);
+    r.ws->release(emb);
+  }
 }
 
 #include "train.inc"
@@ -1279,6 +1295,11 @@ int cd_plan_workspace_bytes(CdPlan* plan, int batch, size_t* bytes) {
       plan->ws.get<float>((size_t)n);
       plan->ws.get<float>((size_t)batch + 64);
       plan->ws.get<double>((size_t)batch + 8);
+      // cd_ddim_sample: this step's embeddings / scalings and the chunk computed ahead
+      plan->ws.get<float>((size_t)batch * plan->emb_ld);
+      plan->ws.get<float>((size_t)batch * 4);
+      plan->ws.get<float>((size_t)CdPlan::kEmbedChunk * batch * plan->emb_ld);
+      plan->ws.get<float>((size_t)CdPlan::kEmbedChunk * batch * 4);
     }) + 4096;
   });
 }
@@ -1476,6 +1497,22 @@ int cd_ddim_sample(CdPlan* plan, int batch, const float* start, const float* con
     float* noise_buf = plan->ws.get<float>((size_t)n);
     float* sigma_b = plan->ws.get<float>((size_t)batch + 64);
     uint64_t* noise_dev = (uint64_t*)plan->ws.get<double>(4);  // {seed, base offset, stride}
+    // Embeddings and EDM scalings depend on (sigma_step, cond) only -- not on x: one launch computes them for kEmbedChunk steps
+    // ahead (the per-step embedding kernel was 34 us of pure latency in every 2 ms step), load_step hands each step its slice.
+    const int K = CdPlan::kEmbedChunk;
+    float* emb_cur = plan->ws.get<float>((size_t)batch * plan->emb_ld);
+    float* scal_cur = plan->ws.get<float>((size_t)batch * 4);
+    float* emb_chunk = plan->ws.get<float>((size_t)K * batch * plan->emb_ld);
+    float* scal_chunk = plan->ws.get<float>((size_t)K * batch * 4);
+    StepChunk chunk;
+    chunk.emb_src = emb_chunk; chunk.emb_dst = emb_cur; chunk.emb_floats = batch * plan->emb_ld;
+    chunk.scal_src = scal_chunk; chunk.scal_dst = scal_cur; chunk.scal_floats = batch * 4; chunk.chunk_steps = K;
+    auto embed_ahead = [&](hipStream_t st, int i0) {  // steps i0 .. i0 + K - 1 (slot = step % K; i0 is a multiple of K)
+      const int nst = n_steps - i0 < K ? n_steps - i0 : K;
+      EmbedArgs e = embed_args(plan, nst * batch, cond, plan->d_table + (size_t)i0 * 4, plan->desc.time_embed_kind, emb_chunk, scal_chunk);
+      e.cond_rows = batch; e.time_stride = 4;
+      launch_embed(e, st);
+    };
     if (noisy && !step_noise) {
       const uint64_t so[3] = {seed, offset, noise_stride ? noise_stride : (uint64_t)n};
       CD_HIP(hipMemcpyAsync(noise_dev, so, sizeof(so), hipMemcpyHostToDevice, s));
@@ -1487,9 +1524,7 @@ int cd_ddim_sample(CdPlan* plan, int batch, const float* start, const float* con
     const size_t sub_bytes = workspace_bytes > used ? workspace_bytes - used : 0;
 
     auto one_step = [&](hipStream_t st, int i, const float* noise_i, float* xs_i, float* x0s_i) {
-      launch_load_step(plan->d_table, plan->d_counter, plan->d_stepvals, sigma_b, batch, st);
-      plan->ws.reset(sub, sub_bytes, false);
-      forward_impl(plan, batch, x_out, cond, sigma_b, x0, false, st);
+      launch_load_step(plan->d_table, plan->d_counter, plan->d_stepvals, sigma_b, batch, st, &chunk);
       const float* nz = noise_i;
       if (!nz && noisy) {
         // stream position = offset + i * stride, read from device memory (the step counter is i + 1 after load_step): the same
@@ -1497,7 +1532,13 @@ int cd_ddim_sample(CdPlan* plan, int batch, const float* start, const float* con
         launch_randn_step(noise_buf, n, noise_dev, plan->d_counter, st);
         nz = noise_buf;
       }
-      launch_ddim_update(x_out, x0, nz, plan->d_stepvals, x_out, xs_i, x0s_i, n, st);
+      // the update of the running sample (x_out, in place) happens in the network's head kernel
+      HeadArgs upd;
+      upd.upd_stepvals = plan->d_stepvals; upd.upd_noise = nz; upd.upd_x_next = x_out; upd.upd_xs = xs_i; upd.upd_x0s = x0s_i;
+      FwdOpts fo;
+      fo.emb_pre = emb_cur; fo.scal_pre = scal_cur; fo.upd = &upd;
+      plan->ws.reset(sub, sub_bytes, false);
+      forward_impl(plan, batch, x_out, cond, sigma_b, x0, false, st, &fo);
     };
 
     run_with_range_fallback(plan, s, [&](bool eager) {
@@ -1541,11 +1582,16 @@ int cd_ddim_sample(CdPlan* plan, int batch, const float* start, const float* con
           }
           plan->graph_key = key;
         }
-        for (int i = 0; i < n_steps; ++i) CD_HIP(hipGraphLaunch(plan->graph_exec, s));
+        for (int i = 0; i < n_steps; ++i) {
+          if (i % K == 0) embed_ahead(s, i);
+          CD_HIP(hipGraphLaunch(plan->graph_exec, s));
+        }
       } else {
-        for (int i = 0; i < n_steps; ++i)
+        for (int i = 0; i < n_steps; ++i) {
+          if (i % K == 0) embed_ahead(s, i);
           one_step(s, i, step_noise ? step_noise + (size_t)i * n : nullptr, xs ? xs + (size_t)i * n : nullptr,
                    x0s ? x0s + (size_t)i * n : nullptr);
+        }
       }
     });
   });
