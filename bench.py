@@ -279,6 +279,7 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the roofline and cpu_baseline legs")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel breakdown to stderr")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg only")
+    ap.add_argument("--no-clocks", action="store_true", help="do not sample the GPU's clocks / power during the timed region")
     ap.add_argument("--mode", default="sample", choices=["sample", "train"],
                     help="train: BASELINE configs[2], a step = one training iteration (fwd + bwd + grad all-reduce + Adam)")
     args = ap.parse_args()
@@ -326,6 +327,20 @@ def main():
 
     for _ in range(args.warmup):
         one_pass()
+    # shader clock / socket power of this rank's GPU during the timed region (amdsmi gpu_metrics, sampled every 10 ms by a thread
+    # that sleeps in between): the boxes of the pool differ by a few per cent at the same code, and the chip's power management
+    # decides how fast the MFMA-heavy kernels run -- the line says under which conditions its number was measured
+    smp = None
+    if rank == 0 and not args.no_clocks:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import clock_trace
+            smp = clock_trace.Sampler(0.010)
+            smp.phase = "timed"
+            smp.th.start()
+        except Exception as e:  # noqa: BLE001 -- measurement garnish only
+            print(f"[bench] clock sampling unavailable: {e!r}", file=sys.stderr)
+            smp = None
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -334,6 +349,11 @@ def main():
     torch.cuda.synchronize()
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
+    gpu_state = None
+    if smp is not None:
+        smp.stop = True
+        smp.th.join()
+        gpu_state = dict(clock_trace.phase_summary(smp, "timed", drop_head=0.1), source=smp.source)
     assert np.isfinite(out).all()
 
     result = {
@@ -358,6 +378,8 @@ def main():
                    "hip_graph": not args.no_graph, "denoise_ms": 1e3 * dt / args.steps / args.sample_steps},
         "collective": collective_info(),  # timing barrier + max-over-ranks only: the sampling path has no data-path collective
     }
+    if gpu_state:
+        result["gpu_state"] = gpu_state
     if rank == 0 and world == 1 and not args.no_extra:
         roof, breakdown = roofline_leg(model, cfg, B, E, layers)
         result["roofline"] = roof

@@ -29,6 +29,7 @@ class Sampler:
     def __init__(self, period_s):
         self.period = period_s
         self.samples = []
+        self.extra = []
         self.phase = "idle0"
         self.stop = False
         self.source = None
@@ -47,6 +48,9 @@ class Sampler:
                                 "current_socket_power", "temperature_hotspot", "throttle_status", "indep_throttle_status") if k in m]
             self.source = f"amdsmi gpu_metrics {keys}"
 
+            def num(v):
+                return v if isinstance(v, (int, float)) and 0 < v < 60000 else None
+
             def rd():
                 m = amdsmi.amdsmi_get_gpu_metrics_info(h)
                 clk = m.get("current_gfxclks") or m.get("current_gfxclk") or m.get("average_gfxclk_frequency")
@@ -56,6 +60,11 @@ class Sampler:
                 pw = m.get("current_socket_power")
                 if not isinstance(pw, (int, float)) or pw <= 0 or pw > 5000:
                     pw = m.get("average_socket_power")
+                # the other clock domains and the throttle status, when the driver reports them (kept per sample in self.extra)
+                self.extra_last = {k: num(m.get(k)) for k in ("current_uclk", "average_uclk_frequency", "current_socclk",
+                                                              "average_socclk_frequency", "average_fclk_frequency",
+                                                              "temperature_hotspot", "temperature_mem")}
+                self.extra_last["throttle_status"] = m.get("throttle_status")
                 return clk, pw
             rd()
             return rd
@@ -90,9 +99,32 @@ class Sampler:
             except Exception:  # noqa: BLE001
                 clk, pw = None, None
             self.samples.append([round((t - self.t0) * 1e3, 2), clk, pw, self.phase])
+            if getattr(self, "extra_last", None):
+                self.extra.append(dict(self.extra_last, phase=self.phase))
             dt = self.period - (time.perf_counter() - t)
             if dt > 0:
                 time.sleep(dt)
+
+
+def phase_summary(smp, phase, drop_head=0.2):
+    """Means of one phase's samples (the first `drop_head` of it dropped as ramp): clocks in MHz, power in W."""
+    rows = [s for s in smp.samples if s[3] == phase]
+    rows = rows[int(len(rows) * drop_head):]
+    clk = [r[1] for r in rows if r[1]]
+    pw = [r[2] for r in rows if r[2]]
+    out = {"samples": len(rows), "sclk_mhz_mean": round(sum(clk) / len(clk), 1) if clk else None,
+           "sclk_mhz_min": min(clk) if clk else None, "power_w_mean": round(sum(pw) / len(pw), 1) if pw else None,
+           "power_w_max": max(pw) if pw else None}
+    ex = [e for e in smp.extra if e.get("phase") == phase]
+    ex = ex[int(len(ex) * drop_head):]
+    for k in ("current_uclk", "average_uclk_frequency", "current_socclk", "average_fclk_frequency", "temperature_hotspot", "temperature_mem"):
+        v = [e[k] for e in ex if e.get(k)]
+        if v:
+            out[k + "_mean"] = round(sum(v) / len(v), 1)
+    th = {str(e.get("throttle_status")) for e in ex}
+    if th - {"None"}:
+        out["throttle_status_seen"] = sorted(th)
+    return out
 
 
 def main():
