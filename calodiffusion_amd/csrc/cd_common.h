@@ -279,8 +279,9 @@ void launch_ksoftmax_bwd(const float* qkv, const float* dks, const float* kstat,
                          float* dqkv, int batch, int64_t vox, hipStream_t s);
 void launch_pack_sample32(const float* m, float* wpk, int batch, bool transpose, float scale, hipStream_t s);
 int head_bwd_blocks(int batch, int64_t vox);
+// loss_type (here and below): CD_LOSS_* of calodiff.h -- 0 l2 (hybrid weight), 1 l1, 2 mse, 3 huber (models/loss.py:97-116)
 void launch_head_loss_bwd(const float* x0, const float* data, const float* scal, const float* h, const float* wh, float* dh,
-                          float* part, float* dwh, float* dbh, int batch, int64_t vox, hipStream_t s);
+                          float* part, float* dwh, float* dbh, int batch, int64_t vox, hipStream_t s, int loss_type = 0);
 struct LinearWgradJob {
   const float* delta;  // (B, delta_ld) rows, nout used
   const float* in;     // (B, in_ld) rows, nin used
@@ -452,8 +453,9 @@ void launch_record_step(float* traj, const float* src, const int* step_counter, 
 void launch_axpy_sigma(const float* data, const float* noise, const float* sigma_b, float* out, int batch, int64_t per,
                        hipStream_t s);
 void launch_loss_partial(const float* x0, const float* data, const float* sigma_b, double* partial, int batch,
-                         int64_t per, hipStream_t s);
-void launch_loss_final(const double* partial, const float* sigma_b, double* loss, int batch, int64_t per, hipStream_t s);
+                         int64_t per, hipStream_t s, int loss_type = 0);
+void launch_loss_final(const double* partial, const float* sigma_b, double* loss, int batch, int64_t per, hipStream_t s,
+                       int loss_type = 0);
 void launch_transpose_to_cl(const float* ncdhw, float* ndhwc, int batch, int channels, int64_t vox, hipStream_t s);
 void launch_transpose_to_planar(const float* ndhwc, float* ncdhw, int batch, int channels, int64_t vox, hipStream_t s);
 
@@ -464,6 +466,11 @@ struct ReverseNormArgs {
   float* out;           // (B, D*H*W)
   int batch, D, H, W, layer_mode;
   float logit_mean, logit_std, totalE_mean, totalE_std, layers_mean, layers_std, max_deposit, ecut;
+  // 0: everything (CaloChallenge regular grids); 1: un-normalise + inverse logit only; 2: layer renormalisation + scaling of
+  // already-decoded showers (the two halves of ReverseNormHGCal around its geometry decode, utils/HGCal_utils.py:167-292)
+  int stage = 0;
+  float alpha = 1e-6f;      // reverse_logit's alpha (utils.py:233: 1e-6; HGCal_utils.py:13: 1e-8)
+  float layer_eps = 1e-6f;  // "essentially zero" layer (utils.py:539-547: 1e-6; HGCal_utils.py:262-268: 1e-8)
 };
 void launch_reverse_norm(const ReverseNormArgs& a, hipStream_t s);
 

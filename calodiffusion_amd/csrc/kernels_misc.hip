@@ -518,15 +518,19 @@ void launch_axpy_sigma(const float* data, const float* noise, const float* sigma
 }
 
 // partial[b] = sum_i (x0 - data)^2 over sample b (fp64), one block per sample
+// per-sample sum of the element loss of Loss._loss (models/loss.py:97-116): 0 'l2' and 2 'mse': d^2; 1 'l1': |d|;
+// 3 'huber' = torch smooth_l1_loss, beta 1: d^2 / 2 below |d| = 1, |d| - 1/2 above
 __global__ void __launch_bounds__(256) loss_partial_kernel(const float* __restrict__ x0, const float* __restrict__ data,
-                                                           double* __restrict__ partial, int64_t per) {
+                                                           double* __restrict__ partial, int64_t per, int loss_type) {
   __shared__ double sh[256];
   const int b = blockIdx.x, tid = threadIdx.x;
   const size_t base = (size_t)b * per;
   double acc = 0.0;
   for (int64_t i = tid; i < per; i += 256) {
     const float d = x0[base + i] - data[base + i];
-    acc += (double)(d * d);
+    const float ad = fabsf(d);
+    const float e = loss_type == 1 ? ad : (loss_type == 3 ? (ad < 1.f ? 0.5f * d * d : ad - 0.5f) : d * d);
+    acc += (double)e;
   }
   sh[tid] = acc;
   __syncthreads();
@@ -537,27 +541,29 @@ __global__ void __launch_bounds__(256) loss_partial_kernel(const float* __restri
   if (tid == 0) partial[b] = sh[0];
 }
 void launch_loss_partial(const float* x0, const float* data, const float* sigma_b, double* partial, int batch, int64_t per,
-                         hipStream_t s) {
+                         hipStream_t s, int loss_type) {
   (void)sigma_b;
-  hipLaunchKernelGGL(loss_partial_kernel, dim3(batch), dim3(256), 0, s, x0, data, partial, per);
+  hipLaunchKernelGGL(loss_partial_kernel, dim3(batch), dim3(256), 0, s, x0, data, partial, per, loss_type);
   CD_HIP(hipGetLastError());
 }
 // loss = sum_b w_b * partial[b] / (mean_b(w_b) * B * per),  w_b = 1 + 1/sigma_b^2
+// (only 'l2' carries the hybrid weight; the torch.nn.functional losses of the other types are plain means, loss.py:106-111)
 __global__ void loss_final_kernel(const double* __restrict__ partial, const float* __restrict__ sigma_b, double* loss,
-                                  int batch, int64_t per) {
+                                  int batch, int64_t per, int loss_type) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     double num = 0.0, wsum = 0.0;
     for (int b = 0; b < batch; ++b) {
       const float sg = sigma_b[b];
-      const float w = 1.0f + 1.0f / (sg * sg);
+      const float w = loss_type == 0 ? 1.0f + 1.0f / (sg * sg) : 1.0f;
       num += (double)w * partial[b];
       wsum += (double)w;
     }
     loss[0] = num / ((wsum / batch) * (double)batch * (double)per);
   }
 }
-void launch_loss_final(const double* partial, const float* sigma_b, double* loss, int batch, int64_t per, hipStream_t s) {
-  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, s, partial, sigma_b, loss, batch, per);
+void launch_loss_final(const double* partial, const float* sigma_b, double* loss, int batch, int64_t per, hipStream_t s,
+                       int loss_type) {
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, s, partial, sigma_b, loss, batch, per, loss_type);
   CD_HIP(hipGetLastError());
 }
 
@@ -641,10 +647,10 @@ void launch_adam(const AdamChunk& c, int ntensors, int64_t max_numel, double lr,
 // negatives and rescale every calorimeter layer to the layer energy given by the conditioning vector, scale to the incident
 // energy, apply the read-out threshold.  One workgroup per (sample, layer z): the layer sum is a workgroup reduction.
 // ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float rev_logit(float x) {  // utils.py:233-237
+__device__ __forceinline__ float rev_logit(float x, float alpha = 1e-6f) {  // utils.py:233-237 (HGCal_utils.py:13-17: alpha 1e-8)
   const float ex = expf(x);
   const float o = ex / (1.f + ex);
-  return (o - 1e-6f) / (1.f - 2.f * 1e-6f);
+  return (o - alpha) / (1.f - 2.f * alpha);
 }
 
 __global__ void __launch_bounds__(256) reverse_norm_kernel(ReverseNormArgs a) {
@@ -674,9 +680,14 @@ __global__ void __launch_bounds__(256) reverse_norm_kernel(ReverseNormArgs a) {
   }
   const float* v = a.voxels + ((size_t)b * a.D + z) * PV;
   float* out = a.out + ((size_t)b * a.D + z) * PV;
+  if (a.stage == 1) {  // un-normalise + inverse logit only: what the HGCal / Dataset-1 variants do BEFORE their geometry decode
+    for (int i = tid; i < PV; i += 256) out[i] = rev_logit(v[i] * a.logit_std + a.logit_mean, a.alpha);
+    return;
+  }
   float part = 0.f;
   for (int i = tid; i < PV; i += 256) {
-    float d = rev_logit(v[i] * a.logit_std + a.logit_mean);
+    // stage 2: the input is already in deposited-energy-fraction space (the decoded showers)
+    float d = a.stage == 2 ? v[i] : rev_logit(v[i] * a.logit_std + a.logit_mean, a.alpha);
     if (a.layer_mode) d = d < 0.f ? 0.f : d;
     out[i] = d;
     part += d;
@@ -691,7 +702,7 @@ __global__ void __launch_bounds__(256) reverse_norm_kernel(ReverseNormArgs a) {
     }
     const float prev = red[0];
     fac = layer_e / (prev + 1e-10f);
-    if (layer_e < 1e-6f || prev < 1e-6f) fac = 1.f;
+    if (layer_e < a.layer_eps || prev < a.layer_eps) fac = 1.f;
   }
   const float en = a.energy[b];
   for (int i = tid; i < PV; i += 256) {

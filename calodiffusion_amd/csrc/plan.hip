@@ -1437,6 +1437,22 @@ int cd_reverse_norm(const float* voxels, const float* energy, const float* layer
   });
 }
 
+int cd_reverse_norm_staged(const float* voxels, const float* energy, const float* layerE, float* out, int batch,
+                           const int32_t dims[3], const float consts[6], float max_deposit, float ecut, float alpha, float layer_eps,
+                           int stage, void* stream) {
+  return guarded([&] {
+    CD_REQUIRE(voxels && out && dims && consts && batch > 0 && stage >= 0 && stage <= 2, "bad argument");
+    CD_REQUIRE(stage == 1 || energy, "cd_reverse_norm_staged: stages 0 and 2 scale by the incident energies");
+    ReverseNormArgs a;
+    a.voxels = voxels; a.energy = energy; a.layerE = stage == 1 ? nullptr : layerE; a.out = out; a.batch = batch;
+    a.D = dims[0]; a.H = dims[1]; a.W = dims[2]; a.layer_mode = a.layerE ? 1 : 0;
+    a.logit_mean = consts[0]; a.logit_std = consts[1]; a.totalE_mean = consts[2]; a.totalE_std = consts[3];
+    a.layers_mean = consts[4]; a.layers_std = consts[5]; a.max_deposit = max_deposit; a.ecut = ecut;
+    a.stage = stage; a.alpha = alpha; a.layer_eps = layer_eps;
+    launch_reverse_norm(a, (hipStream_t)stream);
+  });
+}
+
 static void layer_mlp_call(const CdLayerMlpDesc* d, const float* const* weights, int n_weights, int batch, int mode,
                            const float* x, const float* cond, const float* tsig, const float* table, int n_steps,
                            const float* noise, float* out, float* xs, float* x0s, void* stream) {
@@ -1868,21 +1884,28 @@ int cd_plan_train_workspace_bytes(CdPlan* plan, int batch, size_t* bytes) {
 }
 
 int cd_train_step(CdPlan* plan, int batch, const float* data, const float* noise, const float* sigma, const float* cond,
-                  double* loss_out, float* grads, void* workspace, size_t workspace_bytes, void* stream) {
+                  int loss_type, double* loss_out, float* grads, void* workspace, size_t workspace_bytes, void* stream) {
   return guarded([&] {
     CD_REQUIRE(plan && data && noise && sigma && cond && loss_out && grads && workspace && batch > 0, "bad argument");
     CD_REQUIRE(plan->desc.objective == CD_OBJ_HYBRID, "cd_train_step implements the hybrid_weight objective");
+    CD_REQUIRE(loss_type >= CD_LOSS_L2 && loss_type <= CD_LOSS_HUBER, "loss_type must be one of CD_LOSS_L2 / L1 / MSE / HUBER");
     check_ready(plan, true);
     plan->ws.reset((char*)workspace, workspace_bytes, false);
-    train_step_impl(plan, batch, data, noise, sigma, cond, loss_out, grads, (hipStream_t)stream);
+    train_step_impl(plan, batch, data, noise, sigma, cond, loss_out, grads, (hipStream_t)stream, loss_type);
   });
 }
 
 int cd_loss_hybrid_l2(CdPlan* plan, int batch, const float* data, const float* noise, const float* sigma,
                       const float* cond, double* loss_out, void* workspace, size_t workspace_bytes, void* stream) {
+  return cd_loss_hybrid(plan, batch, data, noise, sigma, cond, CD_LOSS_L2, loss_out, workspace, workspace_bytes, stream);
+}
+
+int cd_loss_hybrid(CdPlan* plan, int batch, const float* data, const float* noise, const float* sigma, const float* cond,
+                   int loss_type, double* loss_out, void* workspace, size_t workspace_bytes, void* stream) {
   return guarded([&] {
     CD_REQUIRE(plan && data && noise && sigma && cond && loss_out && workspace && batch > 0, "bad argument");
-    CD_REQUIRE(plan->desc.objective == CD_OBJ_HYBRID, "cd_loss_hybrid_l2 needs a hybrid_weight plan");
+    CD_REQUIRE(plan->desc.objective == CD_OBJ_HYBRID, "cd_loss_hybrid needs a hybrid_weight plan");
+    CD_REQUIRE(loss_type >= CD_LOSS_L2 && loss_type <= CD_LOSS_HUBER, "loss_type must be one of CD_LOSS_L2 / L1 / MSE / HUBER");
     check_ready(plan, true);
     hipStream_t s = (hipStream_t)stream;
     const int64_t per = plan->shapes[0].vox();
@@ -1895,8 +1918,8 @@ int cd_loss_hybrid_l2(CdPlan* plan, int batch, const float* data, const float* n
     launch_axpy_sigma(data, noise, sigma, xn, batch, per, s);
     plan->ws.reset((char*)workspace + used, workspace_bytes > used ? workspace_bytes - used : 0, false);
     forward_impl(plan, batch, xn, cond, sigma, x0, false, s);
-    launch_loss_partial(x0, data, sigma, part, batch, per, s);
-    launch_loss_final(part, sigma, loss_out, batch, per, s);
+    launch_loss_partial(x0, data, sigma, part, batch, per, s, loss_type);
+    launch_loss_final(part, sigma, loss_out, batch, per, s, loss_type);
   });
 }
 

@@ -19,6 +19,7 @@ CD_MAX_SIZES = 8
 CD_ABI_VERSION = 3  # include/calodiff.h; load_library refuses a library that reports another one
 TIME_KINDS = {"log": 0, "sigma": 1, "raw": 2}
 OBJECTIVES = {"hybrid": 0, "noise_pred": 1, "mean_pred": 2}
+LOSS_TYPES = {"l2": 0, "l1": 1, "mse": 2, "huber": 3}  # CD_LOSS_* (Loss._loss, models/loss.py:97-116)
 
 
 class CdUnetDesc(C.Structure):
@@ -93,14 +94,17 @@ _SIGNATURES = {
     "cd_layer_train_workspace_bytes": (C.c_int, [_P, C.c_int, C.POINTER(C.c_size_t)]),
     "cd_layer_train_step": (C.c_int, [_P, C.POINTER(C.c_void_p), C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "cd_reverse_norm": (C.c_int, [_P, _P, _P, _P, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.c_float, C.c_float, _P]),
+    "cd_reverse_norm_staged": (C.c_int, [_P, _P, _P, _P, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.c_float, C.c_float,
+                                         C.c_float, C.c_float, C.c_int, _P]),
     "cd_adam_step": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                C.POINTER(C.c_int64), C.c_double, C.c_double, C.c_double, C.c_float, C.c_float, C.c_int, _P]),
-    "cd_train_step": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "cd_train_step": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_int, _P, _P, _P, C.c_size_t, _P]),
     "cd_set_conv_precision": (C.c_int, [C.c_char_p]),
     "cd_get_conv_precision": (C.c_char_p, []),
     "cd_profile_begin": (C.c_int, []),
     "cd_profile_end": (C.c_int, [C.c_char_p, C.c_int]),
     "cd_loss_hybrid_l2": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "cd_loss_hybrid": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_int, _P, _P, C.c_size_t, _P]),
     "cd_op_to_channels_last": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int64, _P]),
     "cd_op_to_ncdhw": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int64, _P]),
     "cd_op_cyl_conv": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.POINTER(C.c_int32),
@@ -458,8 +462,9 @@ class UnetEngine:
             self._tws = {batch: ws}
         return ws
 
-    def train_step(self, data, noise, sigma, cond):
-        """hybrid_weight/l2 loss and the gradient of every parameter (flat fp32 buffer, see grad_layout)."""
+    def train_step(self, data, noise, sigma, cond, loss_type="l2"):
+        """hybrid_weight loss (LOSS_TYPE l2 / l1 / mse / huber) and the gradient of every parameter (flat fp32 buffer, see
+        grad_layout)."""
         data, noise, cond = _dev32(data, "data"), _dev32(noise, "noise"), _dev32(cond, "cond")
         sigma = _dev32(sigma, "sigma").reshape(-1)
         B = data.shape[0]
@@ -469,7 +474,7 @@ class UnetEngine:
         flat = torch.empty(total, dtype=torch.float32, device=data.device)
         loss = torch.empty((), dtype=torch.float64, device=data.device)
         _check(self.lib.cd_train_step(self.plan, B, data.data_ptr(), noise.data_ptr(), sigma.data_ptr(), cond.data_ptr(),
-                                      loss.data_ptr(), flat.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+                                      LOSS_TYPES[loss_type], loss.data_ptr(), flat.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
         return loss, flat
 
     def param_grads(self, flat):
@@ -481,16 +486,19 @@ class UnetEngine:
             out.append(flat[off:off + numel].view(p.shape))
         return out
 
-    def loss_hybrid_l2(self, data, noise, sigma, cond):
+    def loss_hybrid(self, data, noise, sigma, cond, loss_type="l2"):
         data, noise, cond = _dev32(data, "data"), _dev32(noise, "noise"), _dev32(cond, "cond")
         sigma = _dev32(sigma, "sigma").reshape(-1)
         B = data.shape[0]
         self.sync_weights()
         ws = self.workspace(B)
         out = torch.empty((), dtype=torch.float64, device=data.device)
-        _check(self.lib.cd_loss_hybrid_l2(self.plan, B, data.data_ptr(), noise.data_ptr(), sigma.data_ptr(), cond.data_ptr(),
-                                          out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+        _check(self.lib.cd_loss_hybrid(self.plan, B, data.data_ptr(), noise.data_ptr(), sigma.data_ptr(), cond.data_ptr(),
+                                       LOSS_TYPES[loss_type], out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
         return out
+
+    def loss_hybrid_l2(self, data, noise, sigma, cond):
+        return self.loss_hybrid(data, noise, sigma, cond, "l2")
 
 
 class LayerMlpEngine:
@@ -560,8 +568,10 @@ class LayerMlpEngine:
             off += p.numel()
         return lay, off
 
-    def train_step(self, data, noise, sigma, cond):
+    def train_step(self, data, noise, sigma, cond, loss_type="l2"):
         """hybrid_weight / l2 loss and the gradient of every parameter of the layer model (cd_layer_train_step)."""
+        if loss_type != "l2":
+            raise NotImplementedError("the layer model's training step implements LOSS_TYPE 'l2' (cd_layer_train_step)")
         data, cond, B = self._io(data, cond)
         noise = _dev32(noise, "noise")
         sigma = _dev32(sigma, "sigma").reshape(-1)
@@ -585,8 +595,11 @@ class LayerMlpEngine:
         names = {id(p): k for k, p in self.net.named_parameters()}
         return [flat[lay[names[id(p)]][0]: lay[names[id(p)]][0] + p.numel()].view_as(p) for p in self.net.parameters()]
 
+    def loss_hybrid(self, data, noise, sigma, cond, loss_type="l2"):
+        return self.train_step(data, noise, sigma, cond, loss_type)[0].to(torch.float32)
+
     def loss_hybrid_l2(self, data, noise, sigma, cond):
-        return self.train_step(data, noise, sigma, cond)[0].to(torch.float32)
+        return self.loss_hybrid(data, noise, sigma, cond, "l2")
 
     def ddim_sample(self, start, cond, steps: np.ndarray, step_noise=None, seed=0, offset=0, debug=False, use_graph=True,
                     out=None, noise_stride=0):

@@ -8,7 +8,8 @@ from .utils import allreduce_mean_, subsample_alphas
 
 
 class Loss:
-    """EDM scalings + noise-level draw (models/loss.py:9-142).  Only the `l2` reduction runs on the HIP path."""
+    """EDM scalings + noise-level draw (models/loss.py:9-142); the reductions of Loss._loss (l2 / l1 / mse / huber) run in
+    cd_train_step / cd_loss_hybrid."""
 
     def __init__(self, config, n_steps, loss_type="l1") -> None:
         self.config = config
@@ -59,8 +60,8 @@ class _TrainStep(torch.autograd.Function):
     node whose backward hands the pre-computed gradients (scaled by the incoming gradient) to the parameters."""
 
     @staticmethod
-    def forward(ctx, engine, data, noise, sigma, cond, *params):
-        loss, flat = engine.train_step(data, noise, sigma, cond)
+    def forward(ctx, engine, loss_type, data, noise, sigma, cond, *params):
+        loss, flat = engine.train_step(data, noise, sigma, cond, loss_type)
         allreduce_mean_(flat)  # data parallel: identical replicas, one flat-buffer all-reduce per step
         ctx.engine, ctx.flat = engine, flat
         return loss.to(torch.float32)
@@ -69,21 +70,24 @@ class _TrainStep(torch.autograd.Function):
     def backward(ctx, grad_out):
         # one scaling of the flat buffer, then per-parameter views (no per-tensor kernels)
         grads = ctx.engine.param_grads(ctx.flat * grad_out.to(ctx.flat.dtype))
-        return (None, None, None, None, None) + tuple(grads)
+        return (None, None, None, None, None, None) + tuple(grads)
 
 
 class hybrid_weight(Loss):
-    """x0-prediction with weight 1 + sigma^-2 (models/loss.py:163-179); value computed by cd_loss_hybrid_l2."""
+    """x0-prediction with weight 1 + sigma^-2 (models/loss.py:163-179); value computed by cd_loss_hybrid, value and every
+    gradient by cd_train_step."""
 
     def __init__(self, config, n_steps, loss_type="l1") -> None:
         super().__init__(config, n_steps, loss_type)
 
+    LOSS_TYPES = ("l2", "l1", "mse", "huber")  # Loss._loss (models/loss.py:97-116)
+
     def loss_function(self, model, data, E, sigma=None, noise=None, layers=None):
-        if self.loss_type != "l2":
-            raise NotImplementedError("the HIP path implements LOSS_TYPE 'l2' (the only one the shipped configs use)")
+        if self.loss_type not in self.LOSS_TYPES:  # (the reference raises the same from Loss._loss at construction)
+            raise NotImplementedError("Loss type %s not implemented, pick from (%s)" % (self.loss_type, self.LOSS_TYPES))
         cond = model.cond_tensor(E, layers)
         params = list(model.model.parameters())
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
             # training: TrainDiffusion.training_loop calls loss.backward(); optimizer.step() on the result
-            return _TrainStep.apply(model.engine(), data, noise, sigma, cond, *params)
-        return model.engine().loss_hybrid_l2(data, noise, sigma, cond)
+            return _TrainStep.apply(model.engine(), self.loss_type, data, noise, sigma, cond, *params)
+        return model.engine().loss_hybrid(data, noise, sigma, cond, self.loss_type)

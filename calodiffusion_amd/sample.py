@@ -12,8 +12,9 @@ host<->device ``extract`` round trips) in between.  Here every sampler is ONE C-
   {x, denoised, noise, history} with coefficients that depend on the step only.  Uniform programs replay one captured step
   graph; the others (Restart's nested loops, DPM-Solver-fast's changing orders) run their steps eagerly.
 
-Not provided: ``DPMAdaptive`` (its step-size controller needs a host decision per step), ``DPMPPSDE`` / ``DPMPP2MSDE`` /
-``DPMPP3MSDE`` (``torchsde`` Brownian trees) and ``BespokeNonStationary`` (needs a trained theta file); asking for them raises.
+``DPMAdaptive`` decides every step on the host from a norm of the state: it is a host loop around ``denoise`` (one
+``cd_denoise_safe`` call per model evaluation), not a step program.  Not provided: ``DPMPPSDE`` / ``DPMPP2MSDE`` / ``DPMPP3MSDE``
+(``torchsde`` Brownian trees) and ``BespokeNonStationary`` (needs a trained theta file); asking for them raises.
 """
 from __future__ import annotations
 
@@ -573,7 +574,93 @@ def _unavailable(name, why):
     return _Missing
 
 
-DPMAdaptive = _unavailable("DPMAdaptive", "its PID step-size controller decides every step on the host from a norm of the state")
+class DPMAdaptive(DPM):
+    """DPM-Solver-12 / -23 with an error test per step (models/sample.py:188-309) as a host loop around the denoiser: every step
+    the host compares the lower- and the higher-order estimate and decides, so it cannot be a device step program.
+
+    The reference's own class cannot run: it hands the denoiser a (B,) sigma, which `x * c_in` only broadcasts for B = 1
+    (calodiffusion.py:159), and it unpacks `torch.randn_like(x)` into `lambda_0, lambda_s` (sample.py:255, 305), which needs
+    B = 2 -- every call raises.  There is therefore no reference trajectory to pin this class to; it implements what the
+    reference's code would compute with those two defects removed (the lambdas never influence the result), including its other
+    quirks:
+
+    * `PIDStepSizeControl.update_h` returns the new step size and the caller drops it (utils/sampling.py:1281-1290): the step
+      stays H_INIT for the whole trajectory, the controller only accepts or rejects;
+    * a rejected step would therefore repeat forever with the same step size: RuntimeError here;
+    * with ETA = 0 the ancestral noise has amplitude sqrt(sigma_t^2 - sigma_t'^2) = 0: the trajectory is deterministic.
+
+    Three denoiser calls per step at order 3 (two at order 2), each one cd_denoise_safe call.  Pinned by the same loop on the
+    CPU oracle (tests/test_host.py, tests/test_gpu_round3.py)."""
+
+    def __init__(self, config):
+        super().__init__(config)
+        sc = self.sample_config
+        self.order = sc.get("ORDER", 3)
+        self.r_tol, self.a_tol = sc.get("R_TOL", 0.05), sc.get("A_TOL", 0.0078)
+        self.h_init, self.t_err = sc.get("H_INIT", 0.05), sc.get("T_ERROR", 1e-5)
+        self.accept_safety = sc.get("ACCEPT_SAFETY", 0.81)
+
+    def build(self, model, num_steps, sample_offset):
+        raise NotImplementedError("DPMAdaptive decides its steps on the host: it has no device step program")
+
+    def _eps(self, model, x, t, energy, layers):
+        sigma = self.sigma_fn(t)
+        den = model.denoise(x, E=energy, sigma=(sigma * x.new_ones([x.shape[0]])), layers=layers)
+        self.denoise_calls += 1
+        return (x - den) / sigma
+
+    @torch.no_grad()
+    def __call__(self, model, start, energy, layers, num_steps, sample_offset=0, debug=False):
+        sig = self.setup_sigmas(model, num_steps)
+        x = start * sig[0]
+        sigma_min, sigma_max = sig[-1], sig[0]
+        if sigma_min <= 0 or sigma_max <= 0:
+            raise ValueError("sigma_min and sigma_max must not be 0")
+        if self.order not in {2, 3}:
+            raise ValueError("order should be 2 or 3")
+        if self.eta:
+            raise NotImplementedError("DPMAdaptive: ETA > 0 (ancestral noise) is not provided")
+        t_start, t_end = self.time_fn(sigma_max.clone()), self.time_fn(sigma_min.clone())
+        forward = bool(t_end > t_start)
+        h = torch.tensor(abs(self.h_init) * (1 if forward else -1))
+        atol, rtol = torch.tensor(self.a_tol, device=x.device), torch.tensor(self.r_tol, device=x.device)
+        s_fn = self.sigma_fn
+        self.denoise_calls = self.steps_taken = 0
+        s, x_prev = t_start, x
+        while (s < t_end - self.t_err) if forward else (s > self.t_err + self.t_err):
+            t = torch.minimum(t_end, s + h) if forward else torch.maximum(t_end, s + h)
+            tp = torch.minimum(t_end, t)  # eta = 0: sigma_down = sigma(t)
+            hh = tp - s
+            eps = self._eps(model, x, s, energy, layers)
+            if self.order == 2:
+                x_low = x - _f(s_fn(tp) * hh.expm1()) * eps
+                r1 = 1 / 2
+            else:
+                r1 = 1 / 3
+            s1 = s + r1 * hh
+            u1 = x - _f(s_fn(s1) * (r1 * hh).expm1()) * eps
+            eps_r1 = self._eps(model, u1, s1, energy, layers)
+            x_2 = x - _f(s_fn(tp) * hh.expm1()) * eps - _f(s_fn(tp) / (2 * r1) * hh.expm1()) * (eps_r1 - eps)
+            if self.order == 2:
+                x_high = x_2
+            else:
+                x_low, r2 = x_2, 2 / 3
+                s2 = s + r2 * hh
+                u2 = x - _f(s_fn(s2) * (r2 * hh).expm1()) * eps - _f(s_fn(s2) * (r2 / r1) * ((r2 * hh).expm1() / (r2 * hh) - 1)) * (eps_r1 - eps)
+                eps_r2 = self._eps(model, u2, s2, energy, layers)
+                x_high = x - _f(s_fn(tp) * hh.expm1()) * eps - _f(s_fn(tp) / r2 * (hh.expm1() / hh - 1)) * (eps_r2 - eps)
+            delta = torch.maximum(atol, rtol * torch.maximum(x_low.abs(), x_prev.abs()))
+            error = torch.linalg.norm((x_low - x_high) / delta) / x.numel() ** 0.5
+            if not bool(torch.all(error <= 1.0)):
+                raise RuntimeError(f"DPMAdaptive: the step at t = {float(s):.4f} (sigma {float(s_fn(s)):.4g}) is rejected (error "
+                                   f"{float(error):.3f} > 1) and the reference's controller never changes its step size "
+                                   f"(PIDStepSizeControl.update_h's result is dropped): the reference loops forever here; "
+                                   f"lower H_INIT or raise R_TOL / A_TOL")
+            x_prev, x, s = x_low, x_high, t
+            self.steps_taken += 1
+        return x, None, None
+
+
 DPMPPSDE = _unavailable("DPMPPSDE", "needs torchsde's Brownian tree")
 DPMPP2MSDE = _unavailable("DPMPP2MSDE", "needs torchsde's Brownian tree")
 DPMPP3MSDE = _unavailable("DPMPP3MSDE", "needs torchsde's Brownian tree")

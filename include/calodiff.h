@@ -183,10 +183,23 @@ int cd_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream
  * sigma: (B,) device. loss_out: 1 double on device. */
 int cd_loss_hybrid_l2(CdPlan* plan, int batch, const float* data, const float* noise, const float* sigma,
                       const float* cond, double* loss_out, void* workspace, size_t workspace_bytes, void* stream);
+/* The same for every LOSS_TYPE of Loss._loss (models/loss.py:97-116) under hybrid_weight.loss_function (:163-179), which passes
+ * (pred = x0, target = data, weight = 1 + sigma^-2):
+ *   CD_LOSS_L2    sum(w (x0-data)^2) / (mean(w) numel)          (the only one that uses the weight; the shipped configs)
+ *   CD_LOSS_L1    torch.nn.functional.l1_loss:        mean |x0 - data|
+ *   CD_LOSS_MSE   torch.nn.functional.mse_loss:       mean (x0 - data)^2
+ *   CD_LOSS_HUBER torch.nn.functional.smooth_l1_loss: mean of d^2/2 where |d| < 1, |d| - 1/2 elsewhere (the reference's CI
+ *                 fixture trains with it, tests/test_execution.py:94) */
+#define CD_LOSS_L2 0
+#define CD_LOSS_L1 1
+#define CD_LOSS_MSE 2
+#define CD_LOSS_HUBER 3
+int cd_loss_hybrid(CdPlan* plan, int batch, const float* data, const float* noise, const float* sigma, const float* cond,
+                   int loss_type, double* loss_out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- training step ----------------------------------------------------------------------------------------------- */
 /* Body of TrainDiffusion.training_loop (train/train_diffusion.py:52-63) up to loss.backward(): the hybrid_weight/l2 loss
- * (as cd_loss_hybrid_l2) AND the gradient of that loss with respect to every parameter, written to `grads`, a flat fp32
+ * (as cd_loss_hybrid, any CD_LOSS_* type) AND the gradient of that loss with respect to every parameter, written to `grads`, a flat fp32
  * buffer laid out as cd_plan_grad_layout reports (tensor idx of cd_plan_weight_name starts at *offset, torch layout;
  * *total_floats = size of the buffer).  Workspace: cd_plan_train_workspace_bytes (the forward's activations are kept
  * until the backward has consumed them). */
@@ -201,7 +214,8 @@ int cd_plan_train_workspace_bytes(CdPlan* plan, int batch, size_t* bytes);
  *   bit 1: a sampler / cd_denoise_safe call took the full-range fallback (its result is valid). */
 int cd_plan_status(CdPlan* plan, int* flags, void* stream);
 int cd_train_step(CdPlan* plan, int batch, const float* data, const float* noise, const float* sigma, const float* cond,
-                  double* loss_out, float* grads, void* workspace, size_t workspace_bytes, void* stream);
+                  int loss_type /* CD_LOSS_* */, double* loss_out, float* grads, void* workspace, size_t workspace_bytes,
+                  void* stream);
 
 /* torch.optim.Adam step (train/train.py:144: Adam(model.parameters(), lr); no amsgrad) over n tensors in ceil(n / 48)
  * launches: params / grads / exp_avg / exp_avg_sq are HOST arrays of n DEVICE pointers, numel their lengths.  step is the
@@ -218,6 +232,17 @@ int cd_adam_step(int n, float* const* params, const float* const* grads, float* 
  * totalE_std, layers_mean, layers_std} (utils/consts.py:82-116). */
 int cd_reverse_norm(const float* voxels, const float* energy, const float* layerE, float* out, int batch, const int32_t dims[3],
                     const float consts[6], float max_deposit, float ecut, void* stream);
+
+/* The HGCal variant, utils.ReverseNormHGCal (calodiffusion/utils/HGCal_utils.py:167-292), has a geometry decode in the middle
+ * (NN_embed.dec_batches: needs a geometry file that does not ship with the reference).  Its arithmetic either side of the decode:
+ *   stage 1  out = reverse_logit(voxels * logit_std + logit_mean, alpha)                     (any shape: dims only give the count)
+ *   stage 2  voxels = DECODED showers (B, L, cells) given as dims = {L, 1, cells}: negatives clamped, every layer rescaled to
+ *            the layer energy of layerE unless layer or sum < layer_eps, then x max_deposit x energy
+ *   stage 0  = cd_reverse_norm with explicit alpha / layer_eps.
+ * HGCal: alpha 1e-8, layer_eps 1e-8, energy = emin + (emax - emin) e[:, 0] (host), ecut 0 (the reference's cut is disabled). */
+int cd_reverse_norm_staged(const float* voxels, const float* energy, const float* layerE, float* out, int batch,
+                           const int32_t dims[3], const float consts[6], float max_deposit, float ecut, float alpha, float layer_eps,
+                           int stage, void* stream);
 
 /* ---- LayerDiffusion's layer-energy model --------------------------------------------------------------------------
  * The conditional residual MLP `ResNet` (calodiffusion/models/models.py:391-457) that LayerDiffusion

@@ -343,6 +343,37 @@ def gold_reverse_norm():
     save("reverse_norm", **out)
 
 
+class _ReshapeDecoder:
+    """Stand-in for HGCalConverter (needs a geometry pickle that does not ship): dec_batches flattens (phi, r) into cells, so
+    that the arithmetic AROUND the decode of utils.ReverseNormHGCal can be pinned."""
+
+    def dec_batches(self, data, sparse_decoding=False, sparse_per_batch=False):
+        d = np.squeeze(np.asarray(data), axis=1)
+        return d.reshape(d.shape[0], d.shape[1], -1)
+
+
+def gold_reverse_norm_hgcal():
+    """utils.ReverseNormHGCal of the reference (utils/HGCal_utils.py:167-292) on synthetic normalised HGCal-shaped showers:
+    dataset 111 (the shipped config) with layer energies, dataset 120 without, both through the stand-in decoder (the reference's
+    final scaling only broadcasts for decoded (B, L, cells) showers)."""
+    from calodiffusion.utils import HGCal_utils as ref_hg
+    g = torch.Generator().manual_seed(SEED + 41)
+    B, dims = 3, (28, 12, 21)
+    vox = (torch.randn((B, 1) + dims, generator=g) * 0.9 + 0.3).numpy().astype(np.float32)
+    vox[1, 0, 5] = -9.0  # an (almost) empty layer: the rescale factor falls back to 1
+    e = torch.rand((B, 3), generator=g).numpy().astype(np.float32)
+    layerE = torch.randn((B, dims[0] + 1), generator=g).numpy().astype(np.float32)
+    out = {"vox": vox, "e": e, "layerE": layerE}
+    data, gen = ref_hg.ReverseNormHGCal(vox.copy(), e.copy(), emax=1000., emin=1., max_deposit=2, logE=True, layerE=layerE.copy(),
+                                        showerMap="layer-logit-norm", dataset_num=111, embed=True, NN_embed=_ReshapeDecoder())
+    out["layer.data"], out["layer.gen"] = np.asarray(data, dtype=np.float32), np.asarray(gen, dtype=np.float32)
+    data, gen = ref_hg.ReverseNormHGCal(vox.copy(), e.copy(), emax=1000., emin=1., max_deposit=2, logE=True, layerE=None,
+                                        showerMap="logit-norm", dataset_num=120, embed=True, NN_embed=_ReshapeDecoder())
+    out["plain.data"], out["plain.gen"] = np.asarray(data, dtype=np.float32), np.asarray(gen, dtype=np.float32)
+    print("reverse_norm hgcal", out["layer.data"].shape, float(np.abs(out["layer.data"]).mean()), out["plain.data"].shape)
+    save("reverse_norm_hgcal", **out)
+
+
 def gold_layer():
     """LayerDiffusion (models/layerdiffusion.py): the ResNet layer model's forward / denoise, sample_layers trajectories and one
     two-stage sample() on Dataset-2, from the reference's own classes.  Parameters come from torch.manual_seed(SEED)."""
@@ -665,6 +696,8 @@ if __name__ == "__main__":
         gold_euler()
     if "renorm" in which:
         gold_reverse_norm()
+    if "renorm_hgcal" in which:
+        gold_reverse_norm_hgcal()
     if "layer" in which:
         gold_layer()
     if "samplers" in which:
@@ -677,3 +710,4 @@ if __name__ == "__main__":
         gold_trajectories()
     if "grads3" in which:
         gold_grads_round3()
+

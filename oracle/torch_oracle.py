@@ -434,8 +434,9 @@ class OracleModel:
 
     def hybrid_l2_loss(self, data: Tensor, E: Tensor, noise: Tensor, layers: Optional[Tensor],
                        rnd_normal: Optional[Tensor] = None, time: Optional[Tensor] = None,
-                       n_steps: int = 400) -> Tensor:
-        """Loss.__call__ + hybrid_weight + l2 (models/loss.py:103-104, 118-142, 163-179)."""
+                       n_steps: int = 400, loss_type: str = "l2") -> Tensor:
+        """Loss.__call__ + hybrid_weight + the reduction of Loss._loss (models/loss.py:97-116, 118-142, 163-179): 'l2' (weighted),
+        'l1', 'mse', 'huber' (= smooth_l1_loss, beta 1)."""
         shp = (data.shape[0], 1, 1, 1, 1)
         if "log" in self.cfg.get("NOISE_SCHED", "linear"):
             sigma = (rnd_normal * 1.2 + (-1.2)).exp().reshape(shp)
@@ -443,6 +444,12 @@ class OracleModel:
             tb = ddim_tables(n_steps)
             sigma = (tb.sqrt_one_minus_alphas_cumprod[time] / tb.sqrt_alphas_cumprod[time]).reshape(shp)
         x0 = self.denoise(data + sigma * noise, E, sigma, layers)
+        if loss_type == "l1":
+            return F.l1_loss(x0, data)
+        if loss_type == "mse":
+            return F.mse_loss(x0, data)
+        if loss_type == "huber":
+            return F.smooth_l1_loss(x0, data)
         w = (1.0 + 1.0 / sigma ** 2).reshape(shp)
         return (w * (x0 - data) ** 2).sum() / (torch.mean(w) * float(np.prod(data.shape)))
 
@@ -597,3 +604,34 @@ def reverse_norm_calochall(voxels, e, layerE, consts, emax=1000.0, emin=1.0, max
     if ecut > 0:
         data[data < ecut] = 0
     return data, energy
+
+
+def reverse_norm_hgcal(voxels, e, layerE, consts, emax=1000.0, emin=1.0, max_deposit=2, decode=None):
+    """utils.ReverseNormHGCal (utils/HGCal_utils.py:167-292) for the [layer-]logit-norm maps, numpy: energy linear in e,
+    reverse_logit with alpha 1e-8, `decode` (optional) = the geometry decode between the inverse logit and the layer
+    renormalisation, "essentially zero" = 1e-8, the energy cut disabled."""
+    def reverse_logit(x, alpha=1e-8):  # HGCal_utils.py:13-17
+        ex = np.exp(x)
+        o = ex / (1 + ex)
+        return (o - alpha) / (1 - 2 * alpha)
+
+    gen_out = np.array(emin) + (np.array(emax) - np.array(emin)) * e
+    energy = gen_out[:, 0]
+    data = reverse_logit((voxels * consts["logit_std"]) + consts["logit_mean"])
+    if decode is not None:
+        data = decode(data)
+    if layerE is not None:
+        totalE, layers = layerE[:, :1], layerE[:, 1:]
+        totalE = (totalE * consts["totalE_std"]) + consts["totalE_mean"]
+        layers = reverse_logit((layers * consts["layers_std"]) + consts["layers_mean"])
+        layers = layers / np.sum(layers, axis=1, keepdims=True) * totalE
+        data = np.squeeze(data).copy()
+        data[data < 0] = 0
+        prev = np.sum(data, (2), keepdims=True)
+        layers = layers.reshape((-1, data.shape[1], 1))
+        fac = layers / (prev + 1e-10)
+        fac[layers < 1e-8] = 1.0
+        fac[prev < 1e-8] = 1.0
+        data = data * fac
+        return data * max_deposit * energy.reshape(-1, 1, 1), gen_out
+    return data * max_deposit * energy.reshape((-1,) + (1,) * (data.ndim - 1)), gen_out

@@ -63,3 +63,74 @@ def test_ddim_with_chunked_embeddings_matches_the_reference_over_chunk_boundarie
     assert np.array_equal(outs[0], outs[1])
     xd, xs, x0s = m.sample(E, layers, num_steps=50, start=start, debug=True)
     assert np.array_equal(xd, outs[0]) and len(xs) == 50 and len(x0s) == 50
+
+
+@pytest.mark.parametrize("lt", ["l1", "mse", "huber", "l2"])
+def test_training_step_loss_types_match_the_reference(lt):
+    """cd_train_step with every LOSS_TYPE of Loss._loss: loss and gradients against .grad of the reference's own
+    compute_loss(...).backward() (tests/golden/losstypes_tiny.npz); the no-grad evaluation (cd_loss_hybrid) gives the same value."""
+    from test_gpu_round2 import _model
+    g = gold("losstypes_tiny")
+    m = _model("tiny", {"LOSS_TYPE": lt})
+    assert m.loss_function.loss_type == lt
+    data, E, noise, layers = (t(g[k]).cuda() for k in ("data", "E", "noise", "layers"))
+    rnd = t(g["rnd_normal"]).cuda()
+    m.zero_grad()
+    loss = m.compute_loss(data, E, noise=noise, layers=layers, rnd_normal=rnd)
+    loss.backward()
+    want = float(g[f"{lt}.loss"])
+    assert abs(float(loss) - want) <= 1e-5 * abs(want), (lt, float(loss), want)
+    with torch.no_grad():
+        assert abs(float(m.compute_loss(data, E, noise=noise, layers=layers, rnd_normal=rnd)) - want) <= 1e-5 * abs(want)
+    grads = dict(m.model.named_parameters())
+    worst = 0.0
+    for k in g.files:
+        if k.startswith(f"{lt}.grad."):
+            err = rel_l2(grads[k[len(lt) + 6:]].grad.cpu().numpy(), g[k])
+            worst = max(worst, err)
+            assert err < 1e-4, (lt, k, err)
+    for k, (s1, s2) in zip(g[f"{lt}.ck_keys"], g[f"{lt}.ck_vals"]):
+        gr = grads[str(k)].grad.double()
+        # (l1: the gradient is sign(d) / N -- an x0 within rounding of its target may flip one of 2048 signs)
+        assert abs(float((gr * gr).sum()) - s2) <= (2e-3 if lt == "l1" else 2e-4) * max(s2, 1e-30), (lt, k)
+    print(f"[{lt}] loss {float(loss):.6f} (reference {want:.6f}); worst whole-tensor gradient error {worst:.2e}")
+
+
+def test_dpm_adaptive_on_the_device_equals_the_same_loop_on_the_oracle():
+    """DPMAdaptive (host loop, one cd_denoise_safe call per model evaluation): the device against the CPU oracle running the
+    identical loop -- the reference's own class raises for every input (see the class docstring), so the oracle is the pin."""
+    from test_host import dpm_adaptive_on_oracle
+    from test_gpu_round2 import _model
+    opts = {"ORDER": 3, "H_INIT": 0.25, "R_TOL": 0.5}  # (large steps: ~30 of them, each three oracle evaluations on the CPU)
+    (start, E, layers), want, calls, steps = dpm_adaptive_on_oracle(opts, 8)
+    m = _model("tiny", {"SAMPLER": "DPMAdaptive", "SAMPLER_OPTIONS": opts})
+    assert type(m.sampler_algorithm).__name__ == "DPMAdaptive"
+    got = m.sample(E.cuda(), layers.cuda(), num_steps=8, start=start.cuda())
+    smp = m.sampler_algorithm
+    err = rel_l2(got, want.numpy())
+    print(f"DPMAdaptive: {smp.steps_taken} steps, {smp.denoise_calls} denoise calls; device vs oracle loop rel L2 {err:.2e}")
+    assert (smp.steps_taken, smp.denoise_calls) == (steps, calls) and err < 1e-4
+
+
+def test_reverse_norm_hgcal_on_device():
+    """postprocess.ReverseNormHGCal = two device stages around the caller's geometry decode, against the reference's own
+    utils.ReverseNormHGCal (fixture: oracle/gen_golden.py renorm_hgcal, stand-in decoder)."""
+    from calodiffusion_amd import postprocess
+
+    class Decoder:
+        def dec_batches(self, data, sparse_decoding=False, sparse_per_batch=False):
+            d = np.squeeze(np.asarray(data), axis=1)
+            return d.reshape(d.shape[0], d.shape[1], -1)
+
+    g = gold("reverse_norm_hgcal")
+    data, gen = postprocess.ReverseNorm(g["vox"], g["e"], hgcal=True, emax=1000., emin=1., max_deposit=2, logE=True, layerE=g["layerE"],
+                                        showerMap="layer-logit-norm", dataset_num=111, embed=True, NN_embed=Decoder())
+    assert data.shape == g["layer.data"].shape and np.allclose(gen, g["layer.gen"], rtol=1e-6)
+    # (HGCal's logit_mean is -17.3: sigmoid values of ~3e-8 minus alpha = 1e-8 in fp32, here with the device's expf -- the
+    # cancellation leaves ~1e-5 of relative difference to numpy's fp32 result; the CaloChallenge maps hold 1e-5)
+    assert rel_l2(data, g["layer.data"]) < 3e-5
+    data, gen = postprocess.ReverseNormHGCal(g["vox"], g["e"], emax=1000., emin=1., max_deposit=2, layerE=None, showerMap="logit-norm",
+                                             dataset_num=120, embed=True, NN_embed=Decoder())
+    assert data.shape == g["plain.data"].shape and rel_l2(data, g["plain.data"]) < 3e-5
+    with pytest.raises(NotImplementedError, match="geometry"):
+        postprocess.ReverseNormHGCal(g["vox"], g["e"], layerE=g["layerE"], showerMap="layer-logit-norm", dataset_num=111, embed=True)

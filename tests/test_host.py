@@ -265,3 +265,51 @@ def test_reference_module_paths_resolve_to_this_package():
     assert m_m.CondUnet is a_u.CondUnet
     assert m_u.load_attr("sampler", "Heun") is a_s.Heun and callable(m_u.ReverseNorm)
     assert A is not None
+
+
+class _OracleBackedModel:
+    """What a sampler sees of CaloDiffusion -- denoise, nsteps, loss_function -- with the CPU oracle as the denoiser."""
+
+    def __init__(self, cfg):
+        self.om = O.OracleModel(cfg, seeded_unet("tiny").state_dict())
+        self.host = CaloDiffusion(cfg, n_steps=cfg["NSTEPS"], loss_type=cfg["LOSS_TYPE"])
+        self.loss_function, self.nsteps = self.host.loss_function, self.host.nsteps
+
+    def denoise(self, x, E=None, sigma=None, layers=None):
+        with torch.no_grad():
+            return self.om.denoise(x, E, sigma.reshape(-1), layers)
+
+
+def dpm_adaptive_on_oracle(opts, n, rows=3, seed=41):
+    """(inputs, final x, denoise calls, steps) of calodiffusion_amd.sample.DPMAdaptive run on the CPU oracle."""
+    import copy
+    from calodiffusion_amd import sample
+    cfg = copy.deepcopy(load_config("tiny"))
+    cfg["SAMPLER_OPTIONS"] = opts
+    gen = torch.Generator().manual_seed(seed)
+    start = torch.randn((rows, 1, 8, 8, 8), generator=gen)
+    E, layers = torch.rand((rows, 3), generator=gen), torch.randn((rows, 9), generator=gen)
+    smp = sample.DPMAdaptive(cfg)
+    x, _, _ = smp(_OracleBackedModel(cfg), start, E, layers, n)
+    return (start, E, layers), x, smp.denoise_calls, smp.steps_taken
+
+
+def test_dpm_adaptive_host_loop():
+    """The host-decision sampler on the oracle: step count = the t-range over H_INIT (the reference's controller never changes
+    the step), 3 / 2 model evaluations per step at order 3 / 2, a halved step lands within the error estimate's scale of the
+    full one, and a rejected step raises instead of looping forever."""
+    import math
+    _, x3, calls3, steps3 = dpm_adaptive_on_oracle({"ORDER": 3}, 8)
+    m = _OracleBackedModel(load_config("tiny"))
+    from calodiffusion_amd import sample
+    sig = sample.DPMAdaptive(load_config("tiny")).setup_sigmas(m, 8)
+    span = float(torch.log(sig[0] / sig[-1]))
+    assert steps3 == math.ceil((span - 1e-5) / 0.05) and calls3 == 3 * steps3 and torch.isfinite(x3).all()
+    _, x3h, _, steps3h = dpm_adaptive_on_oracle({"ORDER": 3, "H_INIT": 0.1}, 8)
+    assert steps3h == math.ceil((span - 1e-5) / 0.1) and rel_l2(x3h.numpy(), x3.numpy()) < 5e-3
+    _, x2, calls2, steps2 = dpm_adaptive_on_oracle({"ORDER": 2}, 8)
+    assert calls2 == 2 * steps2 and rel_l2(x2.numpy(), x3.numpy()) < 2e-2
+    with pytest.raises(RuntimeError, match="rejected"):
+        dpm_adaptive_on_oracle({"ORDER": 2, "H_INIT": 3.0, "R_TOL": 1e-6, "A_TOL": 1e-8}, 8)
+    with pytest.raises(ValueError):
+        dpm_adaptive_on_oracle({"ORDER": 4}, 8)

@@ -110,6 +110,18 @@ def test_reverse_norm():
         assert ((np.asarray(data) == 0) == (g[f"{tag}.data"] == 0)).mean() > 0.9999  # same voxels under the read-out threshold
 
 
+def test_reverse_norm_hgcal():
+    """utils.ReverseNormHGCal: numpy restatement against the reference's outputs (stand-in decoder: (phi, r) flattened to cells)."""
+    from calodiffusion_amd.postprocess import DATASET_PARAMS
+    g = gold("reverse_norm_hgcal")
+    dec = lambda d: np.squeeze(d, axis=1).reshape(d.shape[0], d.shape[2], -1)  # noqa: E731
+    data, gen = O.reverse_norm_hgcal(g["vox"], g["e"], g["layerE"], DATASET_PARAMS[111], decode=dec)
+    assert np.allclose(np.asarray(gen, dtype=np.float32), g["layer.gen"], rtol=1e-6) and data.shape == g["layer.data"].shape
+    assert rel_l2(np.asarray(data, dtype=np.float32), g["layer.data"]) < 2e-6
+    data, gen = O.reverse_norm_hgcal(g["vox"], g["e"], None, DATASET_PARAMS[120], decode=dec)
+    assert data.shape == g["plain.data"].shape and rel_l2(np.asarray(data, dtype=np.float32), g["plain.data"]) < 2e-6
+
+
 def test_edm_euler_trajectories():
     """EDM Euler sampler (reference models/sample.py:577-727, 771-789): the Karras time steps bit for bit, the oracle's loop
     against the reference's trajectories, and the host step table that maps it onto the device sampler loop."""
@@ -355,6 +367,27 @@ def test_reference_gradients():
         for k, (s1, s2) in zip(g["ck_keys"], g["ck_vals"]):
             gr = m.sd[str(k)].grad.double()
             assert abs(float((gr * gr).sum()) - s2) <= 1e-4 * max(s2, 1e-30), (name, k)
+
+
+def test_loss_types_against_the_reference():
+    """LOSS_TYPE l1 / mse / huber / l2 under hybrid_weight (models/loss.py:97-116, 163-179): loss value and .grad of the reference's
+    own compute_loss(...).backward() on the tiny config (fixture: oracle/gen_golden.py grads3).  The huber case has residuals on
+    both sides of its knee."""
+    g = gold("losstypes_tiny")
+    cfg = load_config("tiny")
+    assert 0.5 < float(g["huber.frac_abs_d_below_1"]) < 0.999
+    for lt in ("l1", "mse", "huber", "l2"):
+        sd = {k: v.detach().clone().requires_grad_(True) for k, v in seeded_unet("tiny").state_dict().items()}
+        m = O.OracleModel(cfg, sd)
+        loss = m.hybrid_l2_loss(t(g["data"]), t(g["E"]), t(g["noise"]), t(g["layers"]), rnd_normal=t(g["rnd_normal"]), loss_type=lt)
+        loss.backward()
+        assert abs(float(loss) - float(g[f"{lt}.loss"])) <= 2e-6 * abs(float(g[f"{lt}.loss"])), lt
+        for k in g.files:
+            if k.startswith(f"{lt}.grad."):
+                assert rel_l2(m.sd[k[len(lt) + 6:]].grad.numpy(), g[k]) < 2e-5, (lt, k)
+        for k, (s1, s2) in zip(g[f"{lt}.ck_keys"], g[f"{lt}.ck_vals"]):
+            gr = m.sd[str(k)].grad.double()
+            assert abs(float((gr * gr).sum()) - s2) <= 1e-4 * max(s2, 1e-30), (lt, k)
 
 
 def test_dataset3_and_hgcal_trajectories():
