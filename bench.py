@@ -38,15 +38,21 @@ def measured_traffic(kernel: str, batch: int):
     profiles/zslide_traffic.json: FETCH_SIZE x 2 on gfx950 + WRITE_SIZE).  PMC counters cannot be collected inside this
     process, so the committed figure is attached -- only while the kernel source is the one that was measured (sha256 stamp),
     and only for the profiled kernel and batch; otherwise None."""
+    import glob
     import hashlib
     try:
-        rec = json.load(open(os.path.join(ROOT, "profiles", "zslide_traffic.json")))
         src = open(os.path.join(ROOT, "calodiffusion_amd", "csrc", "kernels_conv_zs.hip"), "rb").read()
     except OSError:
         return None
-    if rec.get("kernel") != kernel or rec.get("batch") != batch or rec.get("kernel_source_sha256") != hashlib.sha256(src).hexdigest():
-        return None
-    return rec["traffic_bytes"]
+    stamp = hashlib.sha256(src).hexdigest()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "zslide_traffic*.json"))):  # one record per configuration
+        try:
+            rec = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if rec.get("kernel") == kernel and rec.get("batch") == batch and rec.get("kernel_source_sha256") == stamp:
+            return rec["traffic_bytes"]
+    return None
 
 BF16X3_TERMS = 6                # bf16 MFMAs per fp32 product in the split-bf16 convolution (DESIGN.md section 4)
 PEAK_HBM_GBS = 8000.0

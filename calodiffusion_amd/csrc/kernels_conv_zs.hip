@@ -91,7 +91,8 @@ constexpr int ZS_VB = 144;     // bytes per voxel record: 2 k-steps x 2 terms x 
 // planes in the LDS ring (ConvZsArgs::NR): a 64-voxel step reads 3-4 planes and one more is staged for the next step.
 // With planes of >= 128 voxels two consecutive steps cross at most one plane boundary and 4 slots suffice; smaller
 // (strip-)planes need 5.
-constexpr int ZS_ZERO = 512;   // zero area in front of the ring (r - 1 / r + 1 neighbours of the edge columns read it)
+constexpr int ZS_ZERO = 1024;  // zero area in front of the ring: the r - 1 / r + 1 neighbours of the edge columns read it, at the lane's own
+                               // offset mod 256 plus the tap's constant (<= 2 records + 48 B): 255 + 288 + 48 < 1024
 constexpr int ZS_NSL = 5;      // staging slots per helper thread per plane (plane <= 160 voxels)
 constexpr int ZS_TILES = 2;    // 32-voxel row tiles per step
 constexpr int ZS_STEP = 32 * ZS_TILES;
@@ -566,7 +567,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));  // pairs: v_pk_add_f32
 constexpr int Z3_PD = 3;                  // fragment pairs requested ahead of their MFMAs
 constexpr int Z3_COEF = 1024;             // [32][4] floats: the GroupNorm coefficients of this launch's 32 input channels;
                                           // +512: bias[32]; +640: range flag word
-constexpr int Z3_XCH = 4 * 3 * 2048;      // exchange buffer of one step: 4 reducers x 3 foreign K-slices x (8 rows x 64 lanes x 4 B)
+constexpr int Z3_XCH = 4 * 2048;          // exchange buffer of one step: 4 reducers x the partner's K-slice (8 rows x 64 lanes x 4 B)
 
 // LDS access by byte address: an address_space(3) pointer made from the integer -- through the generic `lds + offset` form
 // every access pays a `v_add_u32 addr, 0, offset` for the (zero) base of the dynamic LDS symbol
@@ -611,9 +612,13 @@ template <int WV, bool ACC, int MODE, int DBG = 0>
 __device__ __forceinline__ void z3_wave(const ConvZsArgs& a, char* lds) {
   constexpr bool NORMED = (MODE & 1) != 0, HALO = (MODE & 2) != 0, SCALED = (MODE & 4) != 0, CLOSE = (MODE & 8) != 0;
   static_assert(!CLOSE || (NORMED && !SCALED), "the fused block close normalises its input");
-  constexpr int KSTEP = WV >> 1, ODD = WV & 1, T0 = ODD ? 13 : 0;  // K-slice: k-step and taps T0 .. T0+13 (as zs_matrix_wave)
+  // matrix role: all 27 taps of row tile TILE of the step, for the 16 input channels of k-step KSTEP.  (The K split used to be
+  // four ways -- k-step x half the taps, both tiles per wave: every wave then prepared the addresses of two tiles, handed three
+  // quarters of two partial tiles to the other waves and summed three foreign slices per row, ~350 vector / LDS instructions per
+  // step that are additive to the wave's 81 MFMAs.  Two ways: one tile's addresses, half a tile handed over, one foreign slice.)
+  constexpr int KSTEP = WV & 1, TILE = WV >> 1;
   constexpr int TH = WV >> 1, RH = WV & 1;  // reduction role: rows 16*RH .. 16*RH+15 (accumulator registers 8*RH..8*RH+7) of tile TH
-  static_assert(ZS_TILES == 2, "the tap split alternates over the two tiles of a step");
+  static_assert(ZS_TILES == 2 && TH == TILE, "a wave reduces half of the tile it multiplies; its partner (the other k-step) the other half");
   const int lane = threadIdx.x & 63, half = lane >> 5, col = lane & 31;
   const int tid = threadIdx.x;  // 256 threads: staging and reduction roles
   const int b = blockIdx.y, ct = blockIdx.z;
@@ -629,18 +634,18 @@ __device__ __forceinline__ void z3_wave(const ConvZsArgs& a, char* lds) {
   int* const flag_lds = (int*)(lds + ZS_ZERO + 640);
 
   // ---- weights of this wave's K-slice: registers for the whole chunk --------------------------------------------
-  u32x4 w1[14], w2[14];
+  u32x4 w1[27], w2[27];
   {
-    const u32x4* wq = a.wpk + ((size_t)(KSTEP * 27 + T0) * a.CTtot + ct) * 128 + lane;
+    const u32x4* wq = a.wpk + ((size_t)(KSTEP * 27) * a.CTtot + ct) * 128 + lane;
 #pragma unroll
-    for (int j = 0; j < 14; ++j) {
+    for (int j = 0; j < 27; ++j) {
       w1[j] = wq[(size_t)j * a.CTtot * 128];
       w2[j] = wq[(size_t)j * a.CTtot * 128 + 64];
     }
-    // in accumulation registers (MFMA reads its A/B operands from either file): the 112 of them leave the vector registers to
+    // in accumulation registers (MFMA reads its A/B operands from either file): the 216 of them leave the vector registers to
     // the accumulators, whose hand-over then needs no v_accvgpr_read
 #pragma unroll
-    for (int j = 0; j < 14; ++j) asm volatile("" : "+a"(w1[j]), "+a"(w2[j]));
+    for (int j = 0; j < 27; ++j) asm volatile("" : "+a"(w1[j]), "+a"(w2[j]));
   }
 
   // ---- staging role (thread = channel quad q = tid & 7 of image voxels p0 + 32k, p0 = tid >> 3, k < 5) -------------
@@ -838,7 +843,7 @@ __device__ __forceinline__ void z3_wave(const ConvZsArgs& a, char* lds) {
   const int RWB = G.pitch * ZS_VB;  // bytes per image row (with its pad record)
   const int ring_bytes = a.NR * G.PLB;
   {
-    const int v = G.v0 + col;
+    const int v = G.v0 + TILE * 32 + col;
     const int gz = v / SPV;
     const int p = v - gz * SPV;
     gh = p / W;
@@ -847,9 +852,10 @@ __device__ __forceinline__ void z3_wave(const ConvZsArgs& a, char* lds) {
     po = ((gh + (HALO ? 1 : 0)) * G.pitch + gw) * ZS_VB + G.RB + KSTEP * 64 + half * 16 - (Z3_PAD ? 0 : ZS_VB);
     sb = ((gz + a.NR - 1) % a.NR) * G.PLB;
   }
-  const int adv_h = 32 / W, adv_w = 32 - adv_h * W;
+  // one step on: 64 voxels (a strip-plane holds at least one step, so at most one plane boundary is crossed)
+  const int adv_h = ZS_STEP / W, adv_w = ZS_STEP - adv_h * W;
   const int adv_po = (adv_h * G.pitch + adv_w) * ZS_VB, plane_po = H * RWB;
-  auto advance32 = [&]() {
+  auto advance_step = [&]() {
     gw += adv_w;
     gh += adv_h;
     po += adv_po;
@@ -861,93 +867,87 @@ __device__ __forceinline__ void z3_wave(const ConvZsArgs& a, char* lds) {
       sb = sb == ring_bytes ? 0 : sb;
     }
   };
-  // tap addresses of the two tiles of the step: fragment of tap (kz, kh, kw) = bz[t][kz] + {ro0, 0, ro2}[kh] + kw * ZS_VB
-  int bz[ZS_TILES][3], ro0[ZS_TILES], ro2[ZS_TILES];
-  bool eL[ZS_TILES], eR[ZS_TILES];  // (linear image) first / last column: the kw = 0 / kw = 2 taps read the zero area
+  // tap addresses of the wave's tile: fragment of tap (kz, kh, kw) = (row base of (kz, kh)) + kw * ZS_VB, the constant folded into
+  // the ds_read's offset field.  Per (kz, kh): rb = the row base; aL / aR = the base the kw = 0 / kw = 2 tap reads from -- rb, or
+  // for the lanes of the first / last column the zero area at rb's offset mod 256 (the lane keeps its bank quad): ~45 vector
+  // instructions per step here instead of ~3.5 per fragment pair in the MFMA loop (where every instruction of the wave's own
+  // stream costs ~4 cycles next to the MFMAs).
+  int rb[1][3][3], aL[1][3][3], aR[1][3][3];
   const int W1 = W - 1;
   auto prepare = [&]() {
-#pragma unroll
-    for (int t = 0; t < ZS_TILES; ++t) {
-      eL[t] = gw == 0;
-      eR[t] = gw == W1;
+    {
+      constexpr int t = 0;
+      const bool eL = gw == 0, eR = gw == W1;
+      int ro0, ro2;
       if (HALO) {  // strips carry their phi neighbours as halo rows
-        ro0[t] = -RWB;
-        ro2[t] = RWB;
+        ro0 = -RWB;
+        ro2 = RWB;
       } else {     // whole planes wrap around
-        ro0[t] = gh > 0 ? -RWB : (H - 1) * RWB;
-        ro2[t] = gh < H - 1 ? RWB : -(H - 1) * RWB;
+        ro0 = gh > 0 ? -RWB : (H - 1) * RWB;
+        ro2 = gh < H - 1 ? RWB : -(H - 1) * RWB;
       }
-      bz[t][0] = sb + po;
+      int bz[3];
+      bz[0] = sb + po;
 #pragma unroll
       for (int kz = 1; kz < 3; ++kz) {
         const unsigned x = (unsigned)(sb + kz * G.PLB);
-        bz[t][kz] = (int)min(x, x - (unsigned)ring_bytes) + po;  // slot wrap: x < ring ? x : x - ring
+        bz[kz] = (int)min(x, x - (unsigned)ring_bytes) + po;  // slot wrap: x < ring ? x : x - ring
       }
-      advance32();
+#pragma unroll
+      for (int kz = 0; kz < 3; ++kz)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          const int r = bz[kz] + (kh == 0 ? ro0 : (kh == 2 ? ro2 : 0));
+          rb[t][kz][kh] = r;
+          if (Z3_PAD) {
+            aL[t][kz][kh] = aR[t][kz][kh] = r;
+          } else {
+            const int zl = r & 255;
+            aL[t][kz][kh] = eL ? zl : r;
+            aR[t][kz][kh] = eR ? zl : r;
+          }
+        }
+      advance_step();
     }
   };
 
-  constexpr int N0 = ODD ? 13 : 14;  // pairs of tile 0: even wave taps [0,14), odd wave [14,27); tile 1: [0,13) / [13,27)
   constexpr int NI = 27;
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   f32x2 own[4];  // this wave's own K-slice of the rows it reduces: stays in registers until the next step's reduction
 
-  // ---- the 81 MFMAs of step s; partial tiles to the exchange buffer of parity s & 1 ---------------------------------
+  // ---- the 81 MFMAs of step s; the partner's half of the partial tile to the exchange buffer of parity s & 1 ---------------
   auto matrix = [&](int s) {
     constexpr int PD = Z3_PD;
     const int xch = G.XCH + (s & 1) * Z3_XCH;
     u32x4 fa[PD + 1][2];
-    auto pair_tile = [](int i) { return i < N0 ? 0 : 1; };
-    auto pair_tap = [](int i) {
-      if (i < N0) return ODD ? 14 + i : i;
-      const int j = i - N0;
-      return ODD ? 13 + j : j;
-    };
-    auto load_frag = [&](int i) {
-      const int t = pair_tile(i), tap = pair_tap(i);
+    auto load_frag = [&](int tap) {
       const int kz = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-      int base = bz[t][kz] + kw * ZS_VB;
-      if (kh == 0) base += ro0[t];
-      if (kh == 2) base += ro2[t];
-      if (!Z3_PAD && kw == 0) base = eL[t] ? (base & 255) : base;  // into the zero area, same bank quad
-      if (!Z3_PAD && kw == 2) base = eR[t] ? (base & 255) : base;
-      fa[i % (PD + 1)][0] = *z3_lds<const u32x4>(base);
-      fa[i % (PD + 1)][1] = *z3_lds<const u32x4>(base + 32);
+      const int base = (kw == 0 ? aL[0][kz][kh] : (kw == 2 ? aR[0][kz][kh] : rb[0][kz][kh])) + kw * ZS_VB;
+      fa[tap % (PD + 1)][0] = *z3_lds<const u32x4>(base);
+      fa[tap % (PD + 1)][1] = *z3_lds<const u32x4>(base + 32);
     };
-    // K-slice partial of tile t: rows 8*rh .. of reducer (t, rh) go to its region of the exchange buffer -- or stay here
-    auto hand_over = [&](int t, const f32x16& A, const f32x16& B) {
-      f32x2 pt[8];
-      const f32x2 lo = {1.f / 2048.f, 1.f / 2048.f};
-#pragma unroll
-      for (int r = 0; r < 8; ++r) pt[r] = f32x2{A[2 * r], A[2 * r + 1]} + f32x2{B[2 * r], B[2 * r + 1]} * lo;
-#pragma unroll
-      for (int rh = 0; rh < 2; ++rh) {
-        const int R = 2 * t + rh;  // reducer wave
-        if (R == WV) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) own[r] = pt[4 * rh + r];
-        } else {
-          const int d = xch + (R * 3 + (WV < R ? WV : WV - 1)) * 2048 + lane * 16;
-          *z3_lds<f32x4>(d) = f32x4{pt[4 * rh][0], pt[4 * rh][1], pt[4 * rh + 1][0], pt[4 * rh + 1][1]};
-          *z3_lds<f32x4>(d + 1024) = f32x4{pt[4 * rh + 2][0], pt[4 * rh + 2][1], pt[4 * rh + 3][0], pt[4 * rh + 3][1]};
-        }
-      }
-    };
-    f32x16 accA[2], accB[2];
+    f32x16 accA, accB;
 #pragma unroll
     for (int i = 0; i < PD; ++i) load_frag(i);
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const int t = pair_tile(i), j = pair_tap(i) - T0;
-      const bool first = i == 0 || i == N0;
       if (i + PD < NI) load_frag(i + PD);
       __builtin_amdgcn_sched_barrier(0);
-      accA[t] = MFMA_F16(fa[i % (PD + 1)][0], w1[j], first ? zero16 : accA[t]);
-      accB[t] = MFMA_F16(fa[i % (PD + 1)][0], w2[j], first ? zero16 : accB[t]);
-      accB[t] = MFMA_F16(fa[i % (PD + 1)][1], w1[j], accB[t]);
-      if (i == N0 + 3) hand_over(0, accA[0], accB[0]);
+      accA = MFMA_F16(fa[i % (PD + 1)][0], w1[i], i == 0 ? zero16 : accA);
+      accB = MFMA_F16(fa[i % (PD + 1)][0], w2[i], i == 0 ? zero16 : accB);
+      accB = MFMA_F16(fa[i % (PD + 1)][1], w1[i], accB);
     }
-    hand_over(1, accA[1], accB[1]);
+    // K-slice partial of the tile: the rows this wave reduces stay in registers, the partner's go to its exchange region
+    f32x2 pt[8];
+    const f32x2 lo = {1.f / 2048.f, 1.f / 2048.f};
+#pragma unroll
+    for (int r = 0; r < 8; ++r) pt[r] = f32x2{accA[2 * r], accA[2 * r + 1]} + f32x2{accB[2 * r], accB[2 * r + 1]} * lo;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) own[r] = pt[4 * RH + r];
+    constexpr int PH = 1 - RH;  // the partner's row half
+    const int d = xch + (WV ^ 1) * 2048 + lane * 16;
+    *z3_lds<f32x4>(d) = f32x4{pt[4 * PH][0], pt[4 * PH][1], pt[4 * PH + 1][0], pt[4 * PH + 1][1]};
+    *z3_lds<f32x4>(d + 1024) = f32x4{pt[4 * PH + 2][0], pt[4 * PH + 2][1], pt[4 * PH + 3][0], pt[4 * PH + 3][1]};
   };
 
   // ---- reduction of step s: this wave's 16 rows of tile TH ------------------------------------------------------------
@@ -998,21 +998,14 @@ __device__ __forceinline__ void z3_wave(const ConvZsArgs& a, char* lds) {
 #pragma unroll
       for (int r = 0; r < 8; ++r) prev[r >> 1][r & 1] = *(const float*)((const char*)tb + (unsigned)off[r]);
     }
-    f32x2 sum[4];
+    f32x2 sum[4];  // k-step 0's slice + k-step 1's (fp32 addition commutes: the same sum whichever wave reduces)
+    {
+      const int d = xch + WV * 2048 + lane * 16;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {  // K-slices in fixed order: deterministic, and the same sum whichever wave reduces
-      if (w == WV) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sum[r] = w == 0 ? own[r] : sum[r] + own[r];
-      } else {
-        const int d = xch + (WV * 3 + (w < WV ? w : w - 1)) * 2048 + lane * 16;
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          const f32x4 x = *z3_lds<const f32x4>(d + g * 1024);
-          const f32x2 x0 = {x[0], x[1]}, x1 = {x[2], x[3]};
-          sum[2 * g] = w == 0 ? x0 : sum[2 * g] + x0;
-          sum[2 * g + 1] = w == 0 ? x1 : sum[2 * g + 1] + x1;
-        }
+      for (int g = 0; g < 2; ++g) {
+        const f32x4 x = *z3_lds<const f32x4>(d + g * 1024);
+        sum[2 * g] = own[2 * g] + f32x2{x[0], x[1]};
+        sum[2 * g + 1] = own[2 * g + 1] + f32x2{x[2], x[3]};
       }
     }
     const float bv1 = *z3_lds<const float>(ZS_ZERO + 512 + col * 4);

@@ -48,7 +48,21 @@ def read_pass(root, pattern):
     return {k: sum(v) / len(v) for k, v in vals.items()}, len(durs), (sum(durs) / max(1, len(durs)))
 
 
+CASES = {  # BASELINE.json's sampling configurations: level-0 grid, batch per GPU, output file
+    "dataset2": ((45, 16, 9), 64, "zslide_traffic.json"),           # whole planes
+    "dataset3": ((45, 50, 18), 32, "zslide_traffic_dataset3.json"),  # 10 phi strips of 5 rows (+ halo rows)
+    "hgcal": ((28, 12, 21), 16, "zslide_traffic_hgcal.json"),        # 3 phi strips of 4 rows
+}
+
+
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="dataset2", choices=sorted(CASES))
+    a = ap.parse_args()
+    dims, batch, fname = CASES[a.config]
+    global OUT
+    OUT = os.path.join(ROOT, "profiles", fname)
     os.makedirs(SCRATCH, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")
     res = {}
@@ -56,7 +70,7 @@ def main():
         d = os.path.join(SCRATCH, counter)
         subprocess.run(["rm", "-rf", d])
         cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "-d", d, "-o", "pmc", "--", "python3", os.path.join(ROOT, "tools", "conv_bench.py"),
-               "--iters", "5"]
+               "--iters", "5", "--dims", ",".join(str(v) for v in dims), "--batch", str(batch)]
         r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=400)
         if r.returncode != 0:
             print(r.stdout[-2000:], r.stderr[-2000:], file=sys.stderr)
@@ -67,12 +81,13 @@ def main():
     fetch_kib, write_kib = res["FETCH_SIZE"]["mean_per_dispatch"], res["WRITE_SIZE"]["mean_per_dispatch"]
     fetch_b = fetch_kib * 1024.0 * 2.0  # gfx950: doubled for 16-B/lane coalesced reads (MI355X_MICROARCH.md)
     write_b = write_kib * 1024.0
-    out = {"kernel": "conv3x3x3_s1 C32->32 @45x16x9", "batch": 64, "kernel_source_sha256": kernel_source_hash(),
+    vox = dims[0] * dims[1] * dims[2]
+    out = {"kernel": "conv3x3x3_s1 C32->32 @%dx%dx%d" % dims, "batch": batch, "kernel_source_sha256": kernel_source_hash(),
            "fetch_bytes": fetch_b, "write_bytes": write_b, "traffic_bytes": fetch_b + write_b,
-           "algorithmic_bytes": 2.0 * 64 * 6480 * 32 * 4, "raw": res,
-           "method": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (one pass each) --kernel-trace -- python3 tools/conv_bench.py --iters 5; "
-                     "KiB per dispatch; FETCH_SIZE x2 on gfx950"}
-    for path in (OUT, os.path.join(ROOT, "gpurun_out", "zslide_traffic.json")):  # (gpurun merges gpurun_out/ back, not profiles/)
+           "algorithmic_bytes": 2.0 * batch * vox * 32 * 4, "raw": res,
+           "method": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (one pass each) --kernel-trace -- python3 tools/conv_bench.py --iters 5 "
+                     "--dims ... --batch ...; KiB per dispatch; FETCH_SIZE x2 on gfx950"}
+    for path in (OUT, os.path.join(ROOT, "gpurun_out", fname)):  # (gpurun merges gpurun_out/ back, not profiles/)
         with open(path, "w") as fh:
             json.dump(out, fh, indent=1)
     print("wrote", OUT, f"traffic {out['traffic_bytes'] / 1e6:.1f} MB vs algorithmic {out['algorithmic_bytes'] / 1e6:.1f} MB")
