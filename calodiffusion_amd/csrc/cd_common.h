@@ -129,12 +129,6 @@ struct ConvFusion {
     float* part_out = nullptr;     // [B][1][cout][2] channel partials of `out` (for a following PreNorm), or null
     int* done = nullptr;
   } gn_out;
-  // Input side of a ResnetBlock's FIRST conv whose input is the previous block's un-closed output (z-slide f16x2 kernel, one
-  // 32-channel input): the conv's input is  silu(gn(in0)) + close_res  -- the normalisation given by `defer` / `coef` with act = 1,
-  // close_res the previous block's shortcut -- and the kernel writes that tensor, the previous block's output, to close_out as it
-  // stages it.  Saves that block's own elementwise pass (gn_apply: a launch and three passes over the level-0 tensor).
-  const float* close_res = nullptr;  // (B, vox, 32)
-  float* close_out = nullptr;        // (B, vox, 32)
 };
 // device word holding max |x| (bit pattern) of the tensor last passed to launch_absmax_bits; valid in stream order
 const unsigned* launch_absmax_bits(const float* x, size_t n, hipStream_t s);
@@ -195,9 +189,8 @@ void launch_pack_jobs_f16x2(const PackJob* d_jobs, int njobs, hipStream_t s);  /
 void launch_conv_mfma(const float* in0, int c0, const float* in1, int c1, const float* wpk, const float* bias, float* out,
                       int batch, int cout, const ConvGeom& g, hipStream_t s, const ConvFusion& fu = ConvFusion());
 // z-slide f16x2 kernel for the full-resolution 3x3x3 convs (kernels_conv_zs.hip); false = geometry not eligible
-// query_only: answer whether this call WOULD be taken (geometry, precision form, fused-close request) without launching
 bool try_launch_conv_zslide(const float* in0, int c0, const float* in1, int c1, const void* wpk_f16x2, const float* bias, float* out,
-                            int batch, int cout, const ConvGeom& g, hipStream_t s, const ConvFusion& fu, bool query_only = false);
+                            int batch, int cout, const ConvGeom& g, hipStream_t s, const ConvFusion& fu);
 // whole-sample-in-LDS f16x2 kernel for the deepest levels (kernels_conv_small.hip); false = geometry not eligible
 bool try_launch_conv_small(const float* in0, int c0, const float* in1, int c1, const void* wpk_f16x2, const float* bias, float* out,
                            int batch, int cout, const ConvGeom& g, hipStream_t s, const ConvFusion& fu);
@@ -443,7 +436,6 @@ void launch_randn_step(float* out, int64_t n, const uint64_t* seed_offset_stride
 // generic sampler programs (cd_sampler_run): per-step scalars are columns of row (*step_counter - 1) of a device table
 void launch_step_advance(int* counter, hipStream_t s);  // (*counter)++
 void launch_or_word(int* word, int bits, hipStream_t s);  // *word |= bits
-void launch_delay(int us, hipStream_t s);  // (experiment) an idle gap of ~us microseconds on the stream
 void launch_fill_from_table(float* dst, int count, const float* table, int ncol, int col, const int* step_counter, hipStream_t s);
 // out[i] = sum_k table[row][col + k] * src[k][i]   (nsrc <= 6; out may alias a source)
 void launch_lincomb(float* out, const float* const* src, int nsrc, const float* table, int ncol, int col, const int* step_counter,

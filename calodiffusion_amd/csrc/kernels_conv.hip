@@ -1691,7 +1691,6 @@ void launch_conv_mfma(const float* in0, int c0, const float* in1, int c1, const 
         try_launch_conv_zslide(in0, c0, in1, c1, (const char*)fu.wpk_bf16x3 + packed_bf16x3_bytes(c0 + c1, cout, g.kd * g.kh * g.kw),
                                bias, out, batch, cout, g, s, fu))
       return;
-    CD_REQUIRE(!fu.close_out, "conv: a fused block close was requested but the z-slide kernel did not take the conv (zslide_close_ok?)");
     if (fu.wpk_bf16x3 && !want_f32 && !want_bf16x3 &&
         try_launch_conv_small(in0, c0, in1, c1, (const char*)fu.wpk_bf16x3 + packed_bf16x3_bytes(c0 + c1, cout, g.kd * g.kh * g.kw),
                               bias, out, batch, cout, g, s, fu))

@@ -119,10 +119,6 @@ struct ConvZsArgs {
   const unsigned* in_absmax;  // input rescaling by a power of two (ConvFusion::in_absmax) or null
   int dbg;           // timing experiments (builds with -DCD_ZS_EXPERIMENTS, CD_ZS_DBG): 2 = no plane loads / conversion,
                      // 4 = no reduce/store, 16 = no MFMAs or fragment reads, 32 = no fragment reads, 64 = no MFMAs
-  // (one-wave-per-SIMD form, MODE bit 8) the input is the previous ResnetBlock's un-closed output: in = silu(gn(in)) + close_res,
-  // written to close_out as it is staged -- that block's own elementwise pass (gn_apply) never runs.  Both (B, vox, 32).
-  const float* close_res;
-  float* close_out;
 };
 
 // LDS image: [512 B of zeros][ring: NR planes][partials].  A plane is H rows of W records, planes 256-byte aligned: the
@@ -606,12 +602,10 @@ __device__ __forceinline__ Z3Geo z3_geo(const ConvZsArgs& a) {
 
 // MODE (compile-time specialisation: every run-time switch costs select / branch instructions in all 256 threads):
 //   1 = NORMED (input = GroupNorm + SiLU + embedding of the tensor read), 2 = HALO (phi strips with halo rows instead of whole
-//   planes), 4 = SCALED (input rescaled by a power of two from its max: the training gradients), 8 = CLOSE (with NORMED: the
-//   previous ResnetBlock's shortcut is added to the normalised input and the sum written out: see ConvZsArgs::close_res)
+//   planes), 4 = SCALED (input rescaled by a power of two from its max: the training gradients)
 template <int WV, bool ACC, int MODE, int DBG = 0>
 __device__ __forceinline__ void z3_wave(const ConvZsArgs& a, char* lds) {
-  constexpr bool NORMED = (MODE & 1) != 0, HALO = (MODE & 2) != 0, SCALED = (MODE & 4) != 0, CLOSE = (MODE & 8) != 0;
-  static_assert(!CLOSE || (NORMED && !SCALED), "the fused block close normalises its input");
+  constexpr bool NORMED = (MODE & 1) != 0, HALO = (MODE & 2) != 0, SCALED = (MODE & 4) != 0;
   // matrix role: all 27 taps of row tile TILE of the step, for the 16 input channels of k-step KSTEP.  (The K split used to be
   // four ways -- k-step x half the taps, both tiles per wave: every wave then prepared the addresses of two tiles, handed three
   // quarters of two partial tiles to the other waves and summed three foreign slices per row, ~350 vector / LDS instructions per
@@ -666,9 +660,6 @@ __device__ __forceinline__ void z3_wave(const ConvZsArgs& a, char* lds) {
     dsto[k] = (Z3_PAD ? pi + pi / W + 1 : pi) * ZS_VB + (q >> 2) * 64 + (q & 3) * 8 + G.RB;
   }
   f32x4 ld[ZS_NSL];
-  f32x4 ldr[CLOSE ? ZS_NSL : 1];  // (CLOSE) the shortcut's pieces of the same plane
-  const float* const res_b = CLOSE ? a.close_res + (size_t)b * G.vox * 32 : nullptr;
-  float* const yout_b = CLOSE ? a.close_out + (size_t)b * G.vox * 32 : nullptr;
   static_assert(ZS_NSL == 5, "Z3_LANDED names the five staging registers");
   // Plane loads are issued and awaited by hand, but -- unlike zs_helper_wave -- with nothing to count: they are the LAST
   // vector-memory operations of a step (after the reduction's row stores), so the wait one step later is a plain vmcnt(0); the
@@ -685,12 +676,6 @@ __device__ __forceinline__ void z3_wave(const ConvZsArgs& a, char* lds) {
 #pragma unroll
     for (int k = 0; k < ZS_NSL; ++k)
       asm volatile("global_load_dwordx4 %0, %1, %2 ; zs_plane_load" : "=v"(ld[k]) : "v"(srco[k]), "s"(src) : "memory");
-    if (CLOSE) {  // (ldc == 32 in this mode: the shortcut's quads sit at the same offsets)
-      const float* rsrc = uniform_ptr(res_b + (size_t)zc * PV * 32);
-#pragma unroll
-      for (int k = 0; k < ZS_NSL; ++k)
-        asm volatile("global_load_dwordx4 %0, %1, %2 ; zs_plane_load" : "=v"(ldr[CLOSE ? k : 0]) : "v"(srco[k]), "s"(rsrc) : "memory");
-    }
   };
 #define Z3_LANDED(younger)                                                                                   \
   do {                                                                                                       \
@@ -698,13 +683,9 @@ __device__ __forceinline__ void z3_wave(const ConvZsArgs& a, char* lds) {
                  : "+v"(ld[0]), "+v"(ld[1]), "+v"(ld[2]), "+v"(ld[3]), "+v"(ld[4])                           \
                  : "n"(younger)                                                                              \
                  : "memory");                                                                                \
-    if (CLOSE)                                                                                               \
-      asm volatile("; zs_landed (shortcut pieces)"                                                          \
-                   : "+v"(ldr[0]), "+v"(ldr[CLOSE ? 1 : 0]), "+v"(ldr[CLOSE ? 2 : 0]), "+v"(ldr[CLOSE ? 3 : 0]), \
-                     "+v"(ldr[CLOSE ? 4 : 0])::"memory");                                                    \
   } while (0)
   // normalise + split the five pieces in v[] (this thread's quad of image voxels p0 + 32k) into the ring slot of plane z
-  auto convert = [&](f32x4 (&v)[ZS_NSL], f32x4 (&vr)[CLOSE ? ZS_NSL : 1], int z) {
+  auto convert = [&](f32x4 (&v)[ZS_NSL], int z) {
     float amax = 0.f;
     const int zz = z + a.NR;  // ring slot (z + NR) mod NR, z >= -1, NR = 4 or 5, without a division
     const int slot = a.NR == 4 ? (zz & 3) : zz - 5 * ((zz * 205) >> 10);
@@ -719,36 +700,38 @@ __device__ __forceinline__ void z3_wave(const ConvZsArgs& a, char* lds) {
         cn[e][1] = cf[e][1] * -1.4426950408889634f;
       }
     }
+    if (zero) {  // a plane outside the volume (wave-uniform: one branch, not one per piece)
+#pragma unroll
+      for (int k = 0; k < ZS_NSL; ++k) {
+        int d = dsto[k] + sbase;
+        asm volatile("" : "+v"(d));  // (one address register, the second write through the offset field)
+        *z3_lds<u32x2>(d) = u32x2{0u, 0u};
+        *z3_lds<u32x2>(d + 32) = u32x2{0u, 0u};
+      }
+      return;
+    }
 #pragma unroll
     for (int k = 0; k < ZS_NSL; ++k) {
-      u32x2 t1 = {0u, 0u}, t2 = {0u, 0u};
-      if (!zero) {
-        f32x4 x = v[k];
-        if (SCALED) x = x * gscale;  // (training: input gradients rescaled by a power of two)
-        if (NORMED) {
+      u32x2 t1, t2;
+      f32x4 x = v[k];
+      if (SCALED) x = x * gscale;  // (training: input gradients rescaled by a power of two)
+      if (NORMED) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            // SiLU(t) + add, t = scale x + shift: t / (1 + 2^(-t log2 e)) + add on the transcendental unit -- fma, exp, add,
-            // rcp, fma, fma
-            const float t = cf[e][0] * x[e] + cf[e][1];
-            const float ex = __builtin_amdgcn_exp2f(cn[e][0] * x[e] + cn[e][1]);
-            x[e] = t * __builtin_amdgcn_rcpf(1.f + ex) + cf[e][2];
-          }
+        for (int e = 0; e < 4; ++e) {
+          // SiLU(t) + add, t = scale x + shift: t / (1 + 2^(-t log2 e)) + add on the transcendental unit -- fma, exp, add,
+          // rcp, fma, fma
+          const float t = cf[e][0] * x[e] + cf[e][1];
+          const float ex = __builtin_amdgcn_exp2f(cn[e][0] * x[e] + cn[e][1]);
+          x[e] = t * __builtin_amdgcn_rcpf(1.f + ex) + cf[e][2];
         }
-        if (CLOSE) {  // + shortcut = the previous block's output: this conv's input, and written out for everybody after it
-          x = x + vr[CLOSE ? k : 0];
-          // (an ordinary store, not an asm statement: the registers of x are reused a few instructions later, and only for stores it
-          // knows about does the compiler keep them intact until the 16-byte store has read all its lanes' data -- an asm store
-          // here delivered the NEXT values of those registers in half the lanes)
-          char* ydst = (char*)uniform_ptr(yout_b + (size_t)z * PV * 32);
-          *(f32x4*)(ydst + (unsigned)srco[k]) = x;
-        }
-        amax = fmaxf(fmaxf(amax, fabsf(x[0])), fabsf(x[1]));
-        amax = fmaxf(fmaxf(amax, fabsf(x[2])), fabsf(x[3]));
-        split2(x, t1, t2);
       }
-      *z3_lds<u32x2>(dsto[k] + sbase) = t1;
-      *z3_lds<u32x2>(dsto[k] + sbase + 32) = t2;
+      amax = fmaxf(fmaxf(amax, fabsf(x[0])), fabsf(x[1]));
+      amax = fmaxf(fmaxf(amax, fabsf(x[2])), fabsf(x[3]));
+      split2(x, t1, t2);
+      int d = dsto[k] + sbase;
+      asm volatile("" : "+v"(d));  // (one address register, the second write through the offset field)
+      *z3_lds<u32x2>(d) = t1;
+      *z3_lds<u32x2>(d + 32) = t2;
     }
     if (amax > 65504.f) *flag_lds = 1;  // (rare; flushed to a.status at the end)
   };
@@ -788,39 +771,18 @@ __device__ __forceinline__ void z3_wave(const ConvZsArgs& a, char* lds) {
   // latency for the lot -- the three or four planes of step 0
   trk_init(0);
   int zpend = trk_next();
-  if (zpend != -2) {
-    if (!CLOSE) {
-      issue(zpend);
-    } else {
-      // (CLOSE: twice the staging registers -- under that pressure the compiler may move the asm-loaded registers before their
-      // data has landed, which it cannot know about; this one plane is loaded with ordinary loads, whose waits it tracks)
-      const int zc = min(max(zpend, 0), a.D - 1);
-      const char* src = (const char*)(src_b + (size_t)zc * PV * a.ldc);
-      const char* rsrc = (const char*)(res_b + (size_t)zc * PV * 32);
-#pragma unroll
-      for (int k = 0; k < ZS_NSL; ++k) {
-        ld[k] = *(const f32x4*)(src + srco[k]);
-        ldr[CLOSE ? k : 0] = *(const f32x4*)(rsrc + srco[k]);
-      }
-    }
-  }
+  if (zpend != -2) issue(zpend);
   {
     f32x4 ldp[4][ZS_NSL];
-    f32x4 ldpr[4][CLOSE ? ZS_NSL : 1];
-    auto fetch = [&](f32x4 (&dst)[ZS_NSL], f32x4 (&dstr)[CLOSE ? ZS_NSL : 1], int z) {
+    auto fetch = [&](f32x4 (&dst)[ZS_NSL], int z) {
       const int zc = min(max(z, 0), a.D - 1);
       const char* src = (const char*)(src_b + (size_t)zc * PV * a.ldc);
 #pragma unroll
       for (int k = 0; k < ZS_NSL; ++k) dst[k] = *(const f32x4*)(src + srco[k]);
-      if (CLOSE) {
-        const char* rsrc = (const char*)(res_b + (size_t)zc * PV * 32);
-#pragma unroll
-        for (int k = 0; k < ZS_NSL; ++k) dstr[CLOSE ? k : 0] = *(const f32x4*)(rsrc + srco[k]);
-      }
     };
 #pragma unroll
-    for (int i = 0; i < 3; ++i) fetch(ldp[i], ldpr[i], zp0 + i);
-    if (zp0 + 3 <= zstaged0) fetch(ldp[3], ldpr[3], zp0 + 3);
+    for (int i = 0; i < 3; ++i) fetch(ldp[i], zp0 + i);
+    if (zp0 + 3 <= zstaged0) fetch(ldp[3], zp0 + 3);
     if (NORMED) {
       if (a.defer.part) {  // table of all defer.C channels built by the whole workgroup in the (still unused) exchange region
         char* scratch = lds + G.ZPART;
@@ -832,8 +794,8 @@ __device__ __forceinline__ void z3_wave(const ConvZsArgs& a, char* lds) {
     }
     __syncthreads();  // the table is complete, the ring zeroed
 #pragma unroll
-    for (int i = 0; i < 3; ++i) convert(ldp[i], ldpr[i], zp0 + i);
-    if (zp0 + 3 <= zstaged0) convert(ldp[3], ldpr[3], zp0 + 3);
+    for (int i = 0; i < 3; ++i) convert(ldp[i], zp0 + i);
+    if (zp0 + 3 <= zstaged0) convert(ldp[3], zp0 + 3);
   }
 
   // ---- matrix role: per-lane position of its row (voxel) in the next tile, advanced tile by tile: phi row gh and r column
@@ -877,7 +839,8 @@ __device__ __forceinline__ void z3_wave(const ConvZsArgs& a, char* lds) {
   auto prepare = [&]() {
     {
       constexpr int t = 0;
-      const bool eL = gw == 0, eR = gw == W1;
+      // edge lanes keep only the low byte of the address (= the zero area at the same offset mod 256): one v_and per base
+      const int mL = gw == 0 ? 255 : -1, mR = gw == W1 ? 255 : -1;
       int ro0, ro2;
       if (HALO) {  // strips carry their phi neighbours as halo rows
         ro0 = -RWB;
@@ -902,9 +865,8 @@ __device__ __forceinline__ void z3_wave(const ConvZsArgs& a, char* lds) {
           if (Z3_PAD) {
             aL[t][kz][kh] = aR[t][kz][kh] = r;
           } else {
-            const int zl = r & 255;
-            aL[t][kz][kh] = eL ? zl : r;
-            aR[t][kz][kh] = eR ? zl : r;
+            aL[t][kz][kh] = r & mL;
+            aR[t][kz][kh] = r & mR;
           }
         }
       advance_step();
@@ -1056,7 +1018,7 @@ __device__ __forceinline__ void z3_wave(const ConvZsArgs& a, char* lds) {
     if (zpend != -2) {
       if (!first) Z3_LANDED(NYOUNG);  // (first: the loads were awaited by the full drain before the loop)
       if (DBG) { t1 = z3_stamp(); st[0] += t1 - t0; t0 = t1; }
-      convert(ld, ldr, zpend);  // read first by step s + 1
+      convert(ld, zpend);  // read first by step s + 1
       if (DBG) { t1 = z3_stamp(); st[1] += t1 - t0; t0 = t1; st[6] += 1; }
     }
     if (s >= 1) reduce_store(s - 1);
@@ -1109,7 +1071,7 @@ __global__ void __launch_bounds__(256, 1) conv_zslide_sw_f16x2_kernel(ConvZsArgs
 
 // launch of one K-block: the specialisation for (continuation, normed input, strips, rescaled input)
 void z3_launch(const ConvZsArgs& a, bool acc, dim3 grid, size_t lds, hipStream_t s) {
-  const int mode = ((a.coef || a.defer.part) ? 1 : 0) | (a.HS < a.H ? 2 : 0) | (a.in_absmax ? 4 : 0) | (a.close_out ? 8 : 0);
+  const int mode = ((a.coef || a.defer.part) ? 1 : 0) | (a.HS < a.H ? 2 : 0) | (a.in_absmax ? 4 : 0);
 #define Z3_CASE(ACCV, M)                                                                                                        \
   if (acc == ACCV && mode == M) {                                                                                               \
     static bool attr = false;                                                                                                   \
@@ -1122,7 +1084,6 @@ void z3_launch(const ConvZsArgs& a, bool acc, dim3 grid, size_t lds, hipStream_t
     return;                                                                                                                     \
   }
   Z3_CASE(false, 0) Z3_CASE(false, 1) Z3_CASE(false, 2) Z3_CASE(false, 3) Z3_CASE(false, 4) Z3_CASE(false, 6)
-  Z3_CASE(false, 9) Z3_CASE(false, 11)
   Z3_CASE(true, 0) Z3_CASE(true, 2) Z3_CASE(true, 4) Z3_CASE(true, 6)
 #undef Z3_CASE
   CD_REQUIRE(false, "z-slide conv: no kernel instance for this combination of continuation / normalised / strip / rescaled input");
@@ -1134,7 +1095,7 @@ void z3_launch(const ConvZsArgs& a, bool acc, dim3 grid, size_t lds, hipStream_t
 // hold 64..160 voxels and fit the LDS ring: Dataset-2's 16x9 planes whole, Dataset-3's 50x18 in 10 strips of 5 rows, HGCal's
 // 12x21 in 3 strips of 4.  Returns false otherwise.
 bool try_launch_conv_zslide(const float* in0, int c0, const float* in1, int c1, const void* wpk_f16x2, const float* bias, float* out,
-                            int batch, int cout, const ConvGeom& g, hipStream_t s, const ConvFusion& fu, bool query_only) {
+                            int batch, int cout, const ConvGeom& g, hipStream_t s, const ConvFusion& fu) {
   // (environment switches of this launcher are read once: it sits on the eager hot path, one call per K-block)
   static const bool no_zslide = getenv("CD_NO_ZSLIDE") != nullptr;
   static const int strip_env = getenv("CD_ZS_STRIP") ? atoi(getenv("CD_ZS_STRIP")) : 0;  // testing: force a strip height
@@ -1149,8 +1110,6 @@ bool try_launch_conv_zslide(const float* in0, int c0, const float* in1, int c1, 
   static const bool v1_env = getenv("CD_ZS_V1") != nullptr;
   const bool normed_in = fu.coef || fu.defer.part;
   const bool v1 = v1_env || (normed_in && !fu.act) || (normed_in && fu.in_absmax) || (normed_in && (c0 + c1) > 32);
-  // the fused block close (ConvFusion::close_out) exists in the one-wave-per-SIMD form only, for one 32-channel K-block
-  if (fu.close_out && (v1 || c0 != 32 || c1 != 0 || !normed_in || !fu.close_res)) return false;
   auto lds_for = [&](int hs) {
     const int rows = hs + (hs < H ? 2 : 0);
     const size_t ring = (size_t)ring_for(hs) * (((size_t)rows * W * ZS_VB + 255) & ~(size_t)255);
@@ -1176,7 +1135,6 @@ bool try_launch_conv_zslide(const float* in0, int c0, const float* in1, int c1, 
   const int64_t svox = (int64_t)g.in.d * SPV;  // voxels per strip
   if (svox < 2 * ZS_STEP) return false;
   const size_t lds = lds_for(HS);
-  if (query_only) return true;
   const int CTtot = cout / 32;
   // chunks per strip: fill the 256 CUs (one workgroup each) with as few rounds and as little halo restaging as possible
   int best = 1;
@@ -1214,7 +1172,6 @@ bool try_launch_conv_zslide(const float* in0, int c0, const float* in1, int c1, 
     a.defer = fu.defer;
     a.choff = ch;
     a.in_absmax = fu.in_absmax;
-    a.close_res = fu.close_res; a.close_out = fu.close_out;
     a.act = fu.act;
     a.wpk = (const u32x4*)wpk_f16x2 + (size_t)(kb * 2) * 27 * CTtot * 128;
     a.CTtot = CTtot;

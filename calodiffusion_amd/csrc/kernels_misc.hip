@@ -433,15 +433,6 @@ void launch_randn_step(float* out, int64_t n, const uint64_t* seed_offset_stride
 // Generic sampler programs (cd_sampler_run): every per-step scalar is a column of row (*counter - 1) of a device table, so a
 // step whose op list does not change is one captured graph replayed for the whole trajectory.
 // ------------------------------------------------------------------------------------------------------------
-// (experiment) one idle wave for ~`us` microseconds: does a pause after a hot kernel speed the following ones up?
-__global__ void delay_kernel(int us) {
-  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
-  while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)us * 100ull) __builtin_amdgcn_s_sleep(32);
-}
-void launch_delay(int us, hipStream_t s) {
-  hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, s, us);
-  CD_HIP(hipGetLastError());
-}
 __global__ void or_word_kernel(int* word, int bits) { atomicOr(word, bits); }
 void launch_or_word(int* word, int bits, hipStream_t s) {
   hipLaunchKernelGGL(or_word_kernel, dim3(1), dim3(1), 0, s, word, bits);

@@ -60,16 +60,10 @@ class Arena {
     base_ = base; cap_ = cap; dry_ = dry; high_ = 0;
     blocks_.clear();
     blocks_.push_back({0, (size_t)1 << 60, true});
-    // (placement experiment: CD_ARENA_SHIFT_MB holds the first N MB of the workspace back, shifting every block)
-    static const size_t shift = getenv("CD_ARENA_SHIFT_MB") ? (size_t)atol(getenv("CD_ARENA_SHIFT_MB")) << 20 : 0;
-    if (shift) alloc(shift);
   }
   void* alloc(size_t bytes) {
     bytes = (bytes + 255) & ~(size_t)255;
     if (bytes == 0) bytes = 256;
-    // (placement experiment: CD_ARENA_PAD_KB adds that much to every block, changing the blocks' relative offsets)
-    static const size_t pad = getenv("CD_ARENA_PAD_KB") ? (size_t)atol(getenv("CD_ARENA_PAD_KB")) << 10 : 0;
-    bytes += pad;
     for (size_t i = 0; i < blocks_.size(); ++i) {
       if (blocks_[i].free && blocks_[i].size >= bytes) {
         const size_t off = blocks_[i].off;
@@ -463,8 +457,7 @@ float* stats_pass(Run& r, const float* x, int C, int64_t vox, int* units) {
 // kernel itself; coef_buf is the [B][Cin][4] table a kernel without that prologue gets materialised.
 float* conv3_with_stats(Run& r, const float* x0, int c0, const float* x1, int c1, const float* wpk, const void* wpk3,
                         const float* bias, float* out, int cout, Dims3 dims, const float* coef_in, int* units,
-                        const GnDefer* defer_in = nullptr, float* coef_buf = nullptr, const ConvFusion::GnOut* gn_out = nullptr,
-                        const float* close_res = nullptr, float* close_out = nullptr) {
+                        const GnDefer* defer_in = nullptr, float* coef_buf = nullptr, const ConvFusion::GnOut* gn_out = nullptr) {
   const int64_t vox = dims.vox();
   const int cap = (int)((vox + 31) / 32);
   float* part = r.ws->get<float>((size_t)r.B * cap * cout * 2);
@@ -475,7 +468,6 @@ float* conv3_with_stats(Run& r, const float* x0, int c0, const float* x1, int c1
     fu.coef = coef_in; fu.act = 1; fu.ch_part = part; fu.units = &u; fu.wpk_bf16x3 = wpk3; fu.status = r.status;
     if (defer_in) { fu.defer = *defer_in; fu.coef_buf = coef_buf; fu.coef = nullptr; }
     if (gn_out) fu.gn_out = *gn_out;
-    fu.close_res = close_res; fu.close_out = close_out;
     launch_conv_mfma(x0, c0, x1, c1, wpk, bias, out, r.B, cout, g, r.s, fu);
     if (gn_out && *gn_out->done) {
       // (the kernel normalised its own output: `out` is the block output, there are no partials of the conv output)
@@ -493,44 +485,18 @@ float* conv3_with_stats(Run& r, const float* x0, int c0, const float* x1, int c1
 //   conv1 (stats epilogue) -> finalize -> conv2 normalises h1 while staging it (stats epilogue) -> finalize ->
 //   one elementwise pass: silu(gn(h2)) + shortcut.  `part_out`/`units_out` (optional): channel partials of the block
 //   output for a following PreNorm.
-// `lazy` (optional): leave the closing GroupNorm + SiLU + shortcut to the consumer -- the head kernel, or the next block's first
-// conv (in_lazy).  If the block qualifies it returns its second conv's raw output, lazy->gn describes the normalisation, lazy->part
-// (to be released by the caller) holds its partials; the shortcut is lazy->shortcut: x0 (identity) or the res conv's output
-// (lazy->shortcut_owned: a workspace block the caller releases once the consumer has run).
-// `in_lazy` (optional): x0 is the previous block's un-closed output (32 channels): this block's first conv closes it while staging
-// it (ConvFusion::close_out) and the closed tensor becomes this block's input and shortcut.
+// `lazy` (optional): leave the closing GroupNorm + SiLU + identity shortcut to the consumer (the head kernel).  If the block
+// qualifies it returns its second conv's raw output, lazy->gn describes the normalisation, lazy->part (to be released by the
+// caller) holds its partials and the shortcut is x0.
 struct LazyClose {
   GnDefer gn;
   float* part = nullptr;
-  const float* shortcut = nullptr;
-  float* shortcut_owned = nullptr;
   bool on = false;
 };
-// would the z-slide conv take `next`'s first conv with a fused close of the previous block on this grid?
-bool zslide_close_ok(Run& r, const ResP& next, Dims3 dims) {
-  // OFF by default (CD_FUSED_CLOSE=1 turns it on; read per call: the parity test switches it in one process).  Measured on MI355X,
-  // Dataset-2 batch 64, same box, alternating runs: the fused form saves the gn_apply launches (-2 x 21 us per step) for +13.5 us
-  // in each fused conv -- and yet the step is 3.7 % SLOWER (76.8 against 79.9 showers/s): under rocprofv3 every kernel of levels 1
-  // and 2 that follows takes 5-25 % longer in the fused variant (the flat convs +12 %, the strided and transposed convs +20 %, the
-  // deep-level launch +5 %, even load_step's 150 KB copy +40 %) at LOWER socket power (1100 W against 1128 W) and a higher
-  // reported clock: those kernels stall on memory more, not less.  Neither a uniform shift of the workspace nor padding every
-  // block changed it; DESIGN.md section 4 lists what was ruled out.  The code stays as the measured alternative.
-  const bool off = getenv("CD_FUSED_CLOSE") == nullptr || getenv("CD_NO_FUSED_CLOSE") != nullptr;
-  if (off || conv_precision() != PREC_F16X2 || next.cin != 32 || !next.c1w3 || dims.vox() <= 128) return false;
-  ConvGeom g{dims, dims, 3, 3, 3, 1, 1, 1};
-  ConvFusion fu;
-  fu.act = 1;
-  fu.defer.part = (const float*)16;  // (markers: a query dereferences nothing)
-  fu.defer.C = 32;
-  fu.close_res = (const float*)16;
-  fu.close_out = (float*)16;
-  return try_launch_conv_zslide(nullptr, 32, nullptr, 0, (const void*)16, nullptr, nullptr, r.B, next.cout, g, r.s, fu, true);
-}
 float* res_block(Run& r, const ResP& w, const float* x0, int c0, const float* x1, int c1, Dims3 dims,
-                 float** part_out = nullptr, int* units_out = nullptr, LazyClose* lazy = nullptr, const LazyClose* in_lazy = nullptr) {
+                 float** part_out = nullptr, int* units_out = nullptr, LazyClose* lazy = nullptr) {
   Arena* ws = r.ws;
   CD_REQUIRE(c0 + c1 == w.cin, "internal: resnet block input width mismatch");
-  CD_REQUIRE(!in_lazy || (c0 == 32 && c1 == 0 && in_lazy->on && in_lazy->shortcut), "internal: fused block close needs one 32-channel input");
   const int64_t vox = dims.vox();
   const int G = r.groups;
   int u1 = 0, u2 = 0;
@@ -539,16 +505,7 @@ float* res_block(Run& r, const ResP& w, const float* x0, int c0, const float* x1
   // a 32-channel block on a grid of <= 128 voxels is ONE launch (kernels_conv_small.hip): decided below, once the shortcut exists
   const bool whole = vox <= 128 && w.cout == 32 && defer_gn && conv_precision() == PREC_F16X2 && w.c1w3 && w.c2w3;
   float* p1 = nullptr;
-  float* closed = nullptr;  // (in_lazy) the previous block's output, written by this block's first conv
-  if (in_lazy) {
-    CD_REQUIRE(!whole, "internal: fused block close on a small grid");
-    closed = ws->get<float>((size_t)r.B * vox * 32);
-    float* cbuf = ws->get<float>((size_t)r.B * 32 * 4);
-    p1 = conv3_with_stats(r, x0, 32, nullptr, 0, w.c1w, w.c1w3, w.c1b, h1, w.cout, dims, nullptr, &u1, &in_lazy->gn, cbuf, nullptr,
-                          in_lazy->shortcut, closed);
-    ws->release(cbuf);
-    x0 = closed;  // the block's input from here on (shortcut, res conv)
-  } else if (!whole) p1 = conv3_with_stats(r, x0, c0, x1, c1, w.c1w, w.c1w3, w.c1b, h1, w.cout, dims, nullptr, &u1);
+  if (!whole) p1 = conv3_with_stats(r, x0, c0, x1, c1, w.c1w, w.c1w3, w.c1b, h1, w.cout, dims, nullptr, &u1);
   else p1 = ws->get<float>((size_t)r.B * ((vox + 31) / 32) * w.cout * 2);  // (same block as conv3_with_stats would take)
   float* coef1 = ws->get<float>((size_t)r.B * w.cout * 4);
   GnDefer d1;
@@ -606,21 +563,13 @@ float* res_block(Run& r, const ResP& w, const float* x0, int c0, const float* x1
   if (!r.dry() && !defer_gn) launch_gn_finalize(p2, u2, w.n2g, w.n2b, nullptr, 0, coef2, r.B, w.cout, G, vox, r.s);
   const GnDefer* dp2 = defer_gn ? &d2 : nullptr;
   if (part_out) *units_out = fused ? 1 : bps;
-  const bool lazy_ok = lazy && !small && defer_gn && w.cout == 32 && !part_out;
   if (w.has_res) {
     if (!res) shortcut_conv();
-    if (lazy_ok) {
-      lazy->gn = d2; lazy->part = p2; lazy->shortcut = res; lazy->shortcut_owned = res; lazy->on = true;
-      ws->release(coef2);
-      if (closed) ws->release(closed);
-      return h2;
-    }
     if (!r.dry() && !fused) launch_gn_apply(h2, h2, coef2, r.B, w.cout, vox, 1, res, nullptr, 0, po, r.s, dp2);
     ws->release(res);
-  } else if (lazy_ok && c1 == 0 && !closed) {
+  } else if (lazy && !small && defer_gn && c1 == 0 && w.cout == 32 && !part_out) {
     lazy->gn = d2;
     lazy->part = p2;
-    lazy->shortcut = x0;
     lazy->on = true;
     ws->release(coef2);
     return h2;
@@ -630,7 +579,6 @@ float* res_block(Run& r, const ResP& w, const float* x0, int c0, const float* x1
   }
   ws->release(p2);
   ws->release(coef2);
-  if (closed) ws->release(closed);
   return h2;
 }
 
@@ -908,21 +856,12 @@ float* unet_body(CdPlan* p, Run& r, const float* emb, float* h, LazyClose* lazy 
       x = y;
       break;
     }
-    // the first block's closing elementwise pass is left to the second block's first conv where the z-slide kernel takes it
-    const ResP dr2 = resolve(p, p->downs[i].r2, emb);
-    LazyClose lz;
-    float* t = res_block(r, resolve(p, p->downs[i].r1, emb), x, cx, nullptr, 0, dims, nullptr, nullptr,
-                         zslide_close_ok(r, dr2, dims) ? &lz : nullptr);
-    float* const xin1 = x;  // (released below: a lazily closed block's shortcut may be its input)
+    float* t = res_block(r, resolve(p, p->downs[i].r1, emb), x, cx, nullptr, 0, dims);
+    r.ws->release(x);
     x = t; cx = p->downs[i].r1.cout;
     float* xp = nullptr;
     int xu = 0;
-    t = res_block(r, dr2, x, cx, nullptr, 0, dims, d.block_attn ? &xp : nullptr, &xu, nullptr, lz.on ? &lz : nullptr);
-    r.ws->release(xin1);
-    if (lz.on) {
-      r.ws->release(lz.part);
-      if (lz.shortcut_owned) r.ws->release(lz.shortcut_owned);
-    }
+    t = res_block(r, resolve(p, p->downs[i].r2, emb), x, cx, nullptr, 0, dims, d.block_attn ? &xp : nullptr, &xu);
     r.ws->release(x);
     x = t;
     if (d.block_attn) {
@@ -972,20 +911,13 @@ float* unet_body(CdPlan* p, Run& r, const float* emb, float* h, LazyClose* lazy 
     const int cs = d.layer_sizes[lv + 1];  // width of the skip (and of x after the previous stage)
     if (!(deep_on && i == 0)) {  // (the deep-level launch already ran ups[0]'s blocks: x is their output, layer_sizes[lv] wide)
       CD_REQUIRE(cx == cs, "internal: up path width mismatch");
-      const ResP ur2 = resolve(p, p->ups[i].r2, emb);
-      LazyClose lz;
-      t = res_block(r, resolve(p, p->ups[i].r1, emb), x, cx, skips[lv], cs, dims, nullptr, nullptr,
-                    zslide_close_ok(r, ur2, dims) ? &lz : nullptr);
+      t = res_block(r, resolve(p, p->ups[i].r1, emb), x, cx, skips[lv], cs, dims);
       r.ws->release(x);
       r.ws->release(skips[lv]);
       x = t; cx = p->ups[i].r1.cout;
       float* up = nullptr;
       int uu = 0;
-      t = res_block(r, ur2, x, cx, nullptr, 0, dims, d.block_attn ? &up : nullptr, &uu, nullptr, lz.on ? &lz : nullptr);
-      if (lz.on) {
-        r.ws->release(lz.part);
-        if (lz.shortcut_owned) r.ws->release(lz.shortcut_owned);
-      }
+      t = res_block(r, resolve(p, p->ups[i].r2, emb), x, cx, nullptr, 0, dims, d.block_attn ? &up : nullptr, &uu);
       r.ws->release(x);
       x = t;
       if (d.block_attn) {
@@ -1097,7 +1029,7 @@ void forward_impl(CdPlan* p, int B, const float* x, const float* cond, const flo
     HeadArgs ha;
     ha.h = hf; ha.w = p->raw(p->head_w); ha.bias = p->raw(p->head_b); ha.out = out; ha.batch = B; ha.vox = dims.vox();
     if (!raw) { ha.x = x; ha.scal = scal; ha.objective = d.objective; }
-    if (lazy.on) { ha.defer = lazy.gn; ha.res = lazy.shortcut; }
+    if (lazy.on) { ha.defer = lazy.gn; ha.res = xin; }
     if (opt && opt->upd) {
       ha.upd_stepvals = opt->upd->upd_stepvals; ha.upd_noise = opt->upd->upd_noise; ha.upd_x_next = opt->upd->upd_x_next;
       ha.upd_xs = opt->upd->upd_xs; ha.upd_x0s = opt->upd->upd_x0s;
@@ -1107,7 +1039,6 @@ void forward_impl(CdPlan* p, int B, const float* x, const float* cond, const flo
   if (lazy.on) {
     r.ws->release(lazy.part);
     r.ws->release(xin);
-    if (lazy.shortcut_owned) r.ws->release(lazy.shortcut_owned);
   }
   r.ws->release(hf);
   if (!pre) {
