@@ -628,19 +628,9 @@ __device__ __forceinline__ void z3_wave(const ConvZsArgs& a, char* lds) {
   int* const flag_lds = (int*)(lds + ZS_ZERO + 640);
 
   // ---- weights of this wave's K-slice: registers for the whole chunk --------------------------------------------
+  // (requested in the prologue AFTER the planes of step 0, which the prologue's converts wait for: the 216 KB of weights per
+  // workgroup then stream in from L2 under those converts instead of in front of the plane loads)
   u32x4 w1[27], w2[27];
-  {
-    const u32x4* wq = a.wpk + ((size_t)(KSTEP * 27) * a.CTtot + ct) * 128 + lane;
-#pragma unroll
-    for (int j = 0; j < 27; ++j) {
-      w1[j] = wq[(size_t)j * a.CTtot * 128];
-      w2[j] = wq[(size_t)j * a.CTtot * 128 + 64];
-    }
-    // in accumulation registers (MFMA reads its A/B operands from either file): the 216 of them leave the vector registers to
-    // the accumulators, whose hand-over then needs no v_accvgpr_read
-#pragma unroll
-    for (int j = 0; j < 27; ++j) asm volatile("" : "+a"(w1[j]), "+a"(w2[j]));
-  }
 
   // ---- staging role (thread = channel quad q = tid & 7 of image voxels p0 + 32k, p0 = tid >> 3, k < 5) -------------
   // Pieces beyond the image (p0 + 32k >= NIMG) repeat its last voxel: the same bytes written twice instead of a branch per piece.
@@ -792,11 +782,23 @@ __device__ __forceinline__ void z3_wave(const ConvZsArgs& a, char* lds) {
         if (tid < 32) *(f32x4*)(coef_lds + tid * 4) = *(const f32x4*)(a.coef + ((size_t)b * a.coef_c + tid) * 4);
       }
     }
+    {
+      const u32x4* wq = a.wpk + ((size_t)(KSTEP * 27) * a.CTtot + ct) * 128 + lane;
+#pragma unroll
+      for (int j = 0; j < 27; ++j) {
+        w1[j] = wq[(size_t)j * a.CTtot * 128];
+        w2[j] = wq[(size_t)j * a.CTtot * 128 + 64];
+      }
+    }
     __syncthreads();  // the table is complete, the ring zeroed
 #pragma unroll
     for (int i = 0; i < 3; ++i) convert(ldp[i], zp0 + i);
     if (zp0 + 3 <= zstaged0) convert(ldp[3], zp0 + 3);
   }
+  // the weights in accumulation registers (MFMA reads its A/B operands from either file): the 216 of them leave the vector
+  // registers to the accumulators, whose hand-over then needs no v_accvgpr_read
+#pragma unroll
+  for (int j = 0; j < 27; ++j) asm volatile("" : "+a"(w1[j]), "+a"(w2[j]));
 
   // ---- matrix role: per-lane position of its row (voxel) in the next tile, advanced tile by tile: phi row gh and r column
   // gw in the strip-plane, po = byte offset of its record in a plane image (+ this wave's constants), sb = byte offset of the ring
