@@ -216,6 +216,11 @@ struct PointwiseArgs {
                                 // A_EXPNORM: [B][Cin][2] {max, 1/sum}: a <- exp(a - max)/sum (the voxel softmax of k)
   int out_ld = 0, out_off = 0;  // output row stride / channel offset (0 = cout, packed)
   float* ch_part = nullptr;     // optional channel partials of the output: [B][ceil(vox/128)][cout][2]
+  // Block close of a ResnetBlock whose shortcut is this 1x1 conv (models.py:200): the epilogue adds  silu(gn(gn_res)) + add  --
+  // gn_res the block's second conv output (B, vox, cout), normalisation folded from gn_defer's channel partials -- so the
+  // shortcut tensor is never written and the block's own elementwise pass (gn_apply) never runs.  `out` may be gn_res itself.
+  const float* gn_res = nullptr;
+  GnDefer gn_defer;
 };
 inline int pointwise_units(int64_t vox) { return (int)((vox + 127) / 128); }
 void launch_pointwise(const PointwiseArgs& a, hipStream_t s);

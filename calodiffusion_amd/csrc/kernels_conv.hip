@@ -2121,6 +2121,24 @@ __global__ void __launch_bounds__(256) pointwise_kernel(PointwiseArgs a, int CTt
   const int64_t n = n0 + col;
   const bool valid = n < a.vox;
 
+  // fused block close (PointwiseArgs::gn_res): the normalisation's coefficients folded here, and this lane's 16 x CT values of the
+  // normalised tensor requested before the matrix loop
+  __shared__ __attribute__((aligned(16))) float sGn[128 * 4];
+  __shared__ __attribute__((aligned(16))) char sGnScratch[128 * 16 + 64 * 8];
+  float hv[CT][16];
+  if (a.gn_res) {
+    gn_defer_to_lds(a.gn_defer, b, sGn, sGnScratch);
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const int co = min((ct0 + ct) * 32 + col, a.cout - 1);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t nr = min(n0 + (r & 3) + 8 * (r >> 2) + 4 * half, a.vox - 1);
+        hv[ct][r] = a.gn_res[((size_t)b * a.vox + nr) * a.cout + co];
+      }
+    }
+  }
+
   f32x16 acc[CT];
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct)
@@ -2189,6 +2207,26 @@ __global__ void __launch_bounds__(256) pointwise_kernel(PointwiseArgs a, int CTt
     }
   }
 
+  // final values in place (bias, residual, fused block close), then the stores and the channel statistics read them
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    const int co = (ct0 + ct) * 32 + col;
+    const bool cok = co < a.cout;
+    const float bv = (a.bias && cok) ? a.bias[co] : 0.f;
+    f32x4 cf = {0.f, 0.f, 0.f, 0.f};
+    if (a.gn_res && cok) cf = *(const f32x4*)(sGn + co * 4);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t nr = n0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      float v = acc[ct][r] + bv;
+      if (a.residual && cok && nr < a.vox) v += a.residual[((size_t)b * a.vox + nr) * a.cout + co];
+      if (a.gn_res) {  // + silu(scale h + shift) + add, SiLU on the transcendental unit as in gn_apply_kernel
+        const float u = cf[0] * hv[ct][r] + cf[1];
+        v += u * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(u * -1.4426950408889634f)) + cf[2];
+      }
+      acc[ct][r] = v;
+    }
+  }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -2197,12 +2235,7 @@ __global__ void __launch_bounds__(256) pointwise_kernel(PointwiseArgs a, int CTt
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
         const int co = (ct0 + ct) * 32 + col;
-        if (co < a.cout) {
-          const size_t o = ((size_t)b * a.vox + nr) * a.cout + co;
-          float v = acc[ct][r] + (a.bias ? a.bias[co] : 0.f);
-          if (a.residual) v += a.residual[o];
-          a.out[((size_t)b * a.vox + nr) * (a.out_ld ? a.out_ld : a.cout) + a.out_off + co] = v;
-        }
+        if (co < a.cout) a.out[((size_t)b * a.vox + nr) * (a.out_ld ? a.out_ld : a.cout) + a.out_off + co] = acc[ct][r];
       }
     }
   }
@@ -2210,15 +2243,12 @@ __global__ void __launch_bounds__(256) pointwise_kernel(PointwiseArgs a, int CTt
     __shared__ float red[4][CT * 32][2];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
-      const int co = (ct0 + ct) * 32 + col;
-      const float bv = (a.bias && co < a.cout) ? a.bias[co] : 0.f;
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
         if (n0 + row < a.vox) {
-          float v = acc[ct][r] + bv;
-          if (a.residual && co < a.cout) v += a.residual[((size_t)b * a.vox + n0 + row) * a.cout + co];
+          const float v = acc[ct][r];
           s1 += v;
           s2 += v * v;
         }
@@ -2244,6 +2274,8 @@ __global__ void __launch_bounds__(256) pointwise_kernel(PointwiseArgs a, int CTt
 void launch_pointwise(const PointwiseArgs& a, hipStream_t s) {
   CD_REQUIRE(a.c0 % 32 == 0 && a.c1 % 32 == 0 && a.c0 > 0, "pointwise conv: channels must be multiples of 32");
   CD_REQUIRE(a.prologue != A_SOFTMAX32 || (a.c0 == 32 && a.c1 == 0), "softmax prologue needs exactly 32 channels");
+  CD_REQUIRE(!a.gn_res || (a.gn_defer.part && a.gn_defer.C == a.cout && a.cout <= 128 && !a.out_ld),
+             "pointwise conv: the fused block close normalises a packed tensor of the output's width (<= 128 channels)");
   const int CTtot = (a.cout + 31) / 32;
   const int CT = CTtot <= 3 ? CTtot : (CTtot % 2 == 0 ? 2 : 1);
   dim3 grid((unsigned)((a.vox + 127) / 128), (unsigned)a.batch, (unsigned)(CTtot / CT));

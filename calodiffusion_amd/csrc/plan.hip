@@ -517,18 +517,24 @@ float* res_block(Run& r, const ResP& w, const float* x0, int c0, const float* x1
   // itself -- GroupNorm, SiLU, shortcut -- so the shortcut has to exist before it runs.
   const bool small = vox <= 128;
   float* po = nullptr;
-  const int bps = gn_apply_blocks_per_sample(r.B, w.cout, vox);  // partials per sample if gn_apply closes the block (else 1)
+  // A block whose shortcut is a 1x1 conv (models.py:200) is closed BY that conv (PointwiseArgs::gn_res): after the second conv it
+  // computes shortcut + silu(gn(h2)) in one pass -- the shortcut tensor and the elementwise pass over the grid never exist.
+  static const bool no_pw_close = getenv("CD_NO_PW_CLOSE") != nullptr;
+  const bool pw_close = w.has_res && !small && defer_gn && !no_pw_close && w.cout <= 128;
+  // partials per sample of the block's output: those of whichever kernel closes it (1 if the second conv does)
+  const int bps = pw_close ? pointwise_units(vox) : gn_apply_blocks_per_sample(r.B, w.cout, vox);
   if (part_out) {
     po = ws->get<float>((size_t)r.B * bps * w.cout * 2);
     *part_out = po;
   }
   float* res = nullptr;
-  auto shortcut_conv = [&]() {
-    res = ws->get<float>((size_t)r.B * vox * w.cout);
+  auto shortcut_conv = [&](const GnDefer* close = nullptr) {
+    if (!close) res = ws->get<float>((size_t)r.B * vox * w.cout);
     if (!r.dry()) {
       PointwiseArgs a;
       a.in0 = x0; a.ld0 = c0; a.off0 = 0; a.c0 = c0; a.in1 = x1; a.ld1 = c1; a.c1 = c1;
-      a.wpk = w.rw; a.bias = w.rb; a.out = res; a.batch = r.B; a.cout = w.cout; a.vox = vox;
+      a.wpk = w.rw; a.bias = w.rb; a.out = close ? h2 : res; a.batch = r.B; a.cout = w.cout; a.vox = vox;
+      if (close) { a.gn_res = h2; a.gn_defer = *close; a.ch_part = po; }
       launch_pointwise(a, r.s);
     }
   };
@@ -563,7 +569,9 @@ float* res_block(Run& r, const ResP& w, const float* x0, int c0, const float* x1
   if (!r.dry() && !defer_gn) launch_gn_finalize(p2, u2, w.n2g, w.n2b, nullptr, 0, coef2, r.B, w.cout, G, vox, r.s);
   const GnDefer* dp2 = defer_gn ? &d2 : nullptr;
   if (part_out) *units_out = fused ? 1 : bps;
-  if (w.has_res) {
+  if (pw_close) {
+    shortcut_conv(&d2);
+  } else if (w.has_res) {
     if (!res) shortcut_conv();
     if (!r.dry() && !fused) launch_gn_apply(h2, h2, coef2, r.B, w.cout, vox, 1, res, nullptr, 0, po, r.s, dp2);
     ws->release(res);
