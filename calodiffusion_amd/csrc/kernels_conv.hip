@@ -2126,15 +2126,28 @@ __global__ void __launch_bounds__(256) pointwise_kernel(PointwiseArgs a, int CTt
   __shared__ __attribute__((aligned(16))) float sGn[128 * 4];
   __shared__ __attribute__((aligned(16))) char sGnScratch[128 * 16 + 64 * 8];
   float hv[CT][16];
+  // `full`: the wave's 32 voxels and the workgroup's channel tiles all exist (every tile but a sample's last): the epilogue then
+  // addresses its 16 rows as 32-bit offsets from one wave-uniform pointer, without a predicate per element (the general form costs
+  // ~25 vector instructions per element in 64-bit index arithmetic and exec masking)
+  const bool full = n0 + 32 <= a.vox && (ct0 + CT) * 32 <= a.cout;
+  const int rl = 4 * half;  // accumulator register r of a tile = row (r & 3) + 8 (r >> 2) + rl, column col
   if (a.gn_res) {
     gn_defer_to_lds(a.gn_defer, b, sGn, sGnScratch);
+    if (full) {
+      const float* hp = a.gn_res + ((size_t)b * a.vox + n0) * a.cout + ct0 * 32 + col;
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-      const int co = min((ct0 + ct) * 32 + col, a.cout - 1);
+      for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t nr = min(n0 + (r & 3) + 8 * (r >> 2) + 4 * half, a.vox - 1);
-        hv[ct][r] = a.gn_res[((size_t)b * a.vox + nr) * a.cout + co];
+        for (int r = 0; r < 16; ++r) hv[ct][r] = hp[((r & 3) + 8 * (r >> 2) + rl) * a.cout + ct * 32];
+    } else {
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        const int co = min((ct0 + ct) * 32 + col, a.cout - 1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t nr = min(n0 + (r & 3) + 8 * (r >> 2) + 4 * half, a.vox - 1);
+          hv[ct][r] = a.gn_res[((size_t)b * a.vox + nr) * a.cout + co];
+        }
       }
     }
   }
@@ -2208,6 +2221,33 @@ __global__ void __launch_bounds__(256) pointwise_kernel(PointwiseArgs a, int CTt
   }
 
   // final values in place (bias, residual, fused block close), then the stores and the channel statistics read them
+  if (full) {
+    const int ld = a.out_ld ? a.out_ld : a.cout;
+    float* op = a.out + ((size_t)b * a.vox + n0) * ld + a.out_off + ct0 * 32 + col;
+    const float* rp = a.residual ? a.residual + ((size_t)b * a.vox + n0) * a.cout + ct0 * 32 + col : nullptr;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const float bv = a.bias ? a.bias[(ct0 + ct) * 32 + col] : 0.f;
+      f32x4 cf = {0.f, 0.f, 0.f, 0.f};
+      if (a.gn_res) cf = *(const f32x4*)(sGn + ((ct0 + ct) * 32 + col) * 4);
+      float rv[16];
+      if (rp) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rv[r] = rp[((r & 3) + 8 * (r >> 2) + rl) * a.cout + ct * 32];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[ct][r] + bv;
+        if (rp) v += rv[r];
+        if (a.gn_res) {
+          const float u = cf[0] * hv[ct][r] + cf[1];
+          v += u * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(u * -1.4426950408889634f)) + cf[2];
+        }
+        acc[ct][r] = v;
+        op[((r & 3) + 8 * (r >> 2) + rl) * ld + ct * 32] = v;
+      }
+    }
+  } else {
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) {
     const int co = (ct0 + ct) * 32 + col;
@@ -2239,6 +2279,7 @@ __global__ void __launch_bounds__(256) pointwise_kernel(PointwiseArgs a, int CTt
       }
     }
   }
+  }
   if (a.ch_part) {  // per-channel {sum, sum of squares} of this workgroup's 128 output voxels
     __shared__ float red[4][CT * 32][2];
 #pragma unroll
@@ -2247,7 +2288,7 @@ __global__ void __launch_bounds__(256) pointwise_kernel(PointwiseArgs a, int CTt
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (n0 + row < a.vox) {
+        if (full || n0 + row < a.vox) {
           const float v = acc[ct][r];
           s1 += v;
           s2 += v * v;
