@@ -519,7 +519,7 @@ float* res_block(Run& r, const ResP& w, const float* x0, int c0, const float* x1
   float* po = nullptr;
   // A block whose shortcut is a 1x1 conv (models.py:200) is closed BY that conv (PointwiseArgs::gn_res): after the second conv it
   // computes shortcut + silu(gn(h2)) in one pass -- the shortcut tensor and the elementwise pass over the grid never exist.
-  static const bool no_pw_close = getenv("CD_NO_PW_CLOSE") != nullptr;
+  const bool no_pw_close = getenv("CD_NO_PW_CLOSE") != nullptr;  // (read per call: the parity test switches it in one process)
   const bool pw_close = w.has_res && !small && defer_gn && !no_pw_close && w.cout <= 128;
   // partials per sample of the block's output: those of whichever kernel closes it (1 if the second conv does)
   const int bps = pw_close ? pointwise_units(vox) : gn_apply_blocks_per_sample(r.B, w.cout, vox);

@@ -11,6 +11,40 @@ from helpers import t
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("name,B", [("dataset2", 3), ("dataset3", 2), ("hgcal", 2)])
+def test_block_close_by_the_shortcut_conv_equals_the_elementwise_pass(name, B, monkeypatch):
+    """A ResnetBlock whose shortcut is a 1x1 conv is closed by that conv (PointwiseArgs::gn_res: shortcut + silu(gn(h2)) in its
+    epilogue, partial last tiles included: 6480 = 50 x 128 + 80 voxels) against the separate shortcut conv + gn_apply launches
+    (CD_NO_PW_CLOSE=1), with fewer launches."""
+    from calodiffusion_amd import engine
+    from test_gpu_parity import _model
+    m = _model(name)
+    cfg = m.config
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn([B] + list(cfg["SHAPE_PAD"][1:]), generator=g).cuda()
+    n_e = 3 if cfg.get("HGCAL", False) else 1
+    E = torch.rand((B, n_e), generator=g).cuda()
+    layers = torch.randn((B, cfg["SHAPE_PAD"][2] + 1), generator=g).cuda() if "layer" in cfg.get("SHOWERMAP", "") else None
+    sig = torch.tensor([3.0, 0.4, 40.0][:B]).cuda()
+
+    def run():
+        out = m.denoise(x, E=E, sigma=sig, layers=layers)
+        engine.profile_begin()
+        m.denoise(x, E=E, sigma=sig, layers=layers)
+        return out, {k: v["launches"] for k, v in engine.profile_end().items()}
+
+    fused, n_fused = run()
+    monkeypatch.setenv("CD_NO_PW_CLOSE", "1")
+    plain, n_plain = run()
+    monkeypatch.delenv("CD_NO_PW_CLOSE")
+    err = float((fused - plain).norm() / plain.norm())
+    gn = lambda d: sum(v for k, v in d.items() if k.startswith("gn_apply"))  # noqa: E731
+    print(f"[{name}] block close by the shortcut conv vs gn_apply: rel L2 {err:.2e}; gn_apply launches {gn(n_fused)} vs {gn(n_plain)}; "
+          f"all launches {sum(n_fused.values())} vs {sum(n_plain.values())}")
+    assert err < 3e-6
+    assert gn(n_fused) < gn(n_plain)
+
+
 def test_ddim_with_chunked_embeddings_matches_the_reference_over_chunk_boundaries():
     """The sampler loop computes its embeddings 16 steps ahead in one launch and updates x inside the head kernel: 50 steps cross
     three chunk boundaries and end on a partial chunk; against the reference's DDIM trajectory (golden) in graph and eager mode,
