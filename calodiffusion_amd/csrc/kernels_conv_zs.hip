@@ -603,7 +603,7 @@ __device__ __forceinline__ Z3Geo z3_geo(const ConvZsArgs& a) {
 // MODE (compile-time specialisation: every run-time switch costs select / branch instructions in all 256 threads):
 //   1 = NORMED (input = GroupNorm + SiLU + embedding of the tensor read), 2 = HALO (phi strips with halo rows instead of whole
 //   planes), 4 = SCALED (input rescaled by a power of two from its max: the training gradients)
-template <int WV, bool ACC, int MODE, int DBG = 0>
+template <int WV, bool ACC, int MODE, int DBG = 0, int NSL = ZS_NSL>
 __device__ __forceinline__ void z3_wave(const ConvZsArgs& a, char* lds) {
   constexpr bool NORMED = (MODE & 1) != 0, HALO = (MODE & 2) != 0, SCALED = (MODE & 4) != 0;
   // matrix role: all 27 taps of row tile TILE of the step, for the 16 input channels of k-step KSTEP.  (The K split used to be
@@ -639,18 +639,18 @@ __device__ __forceinline__ void z3_wave(const ConvZsArgs& a, char* lds) {
   const int src_off = (G.h0 - G.halo) * W;  // image voxel p comes from plane voxel p + src_off (mod PV: phi halo rows wrap)
   float gscale = 1.f, ginv = 1.f;
   if (SCALED) pow2_scale_for(*a.in_absmax, &gscale, &ginv);
-  int srco[ZS_NSL];  // byte offset in a plane of the quad this thread's piece k is filled from
-  int dsto[ZS_NSL];  // byte offset in a plane image of the record quad it fills
+  int srco[NSL];  // byte offset in a plane of the quad this thread's piece k is filled from
+  int dsto[NSL];  // byte offset in a plane image of the record quad it fills
 #pragma unroll
-  for (int k = 0; k < ZS_NSL; ++k) {
+  for (int k = 0; k < NSL; ++k) {
     const int pi = min(p0 + 32 * k, NIMG - 1);
     int v = pi + src_off;
     v = v < 0 ? v + PV : (v >= PV ? v - PV : v);
     srco[k] = (v * a.ldc + q * 4) * 4;
     dsto[k] = (Z3_PAD ? pi + pi / W + 1 : pi) * ZS_VB + (q >> 2) * 64 + (q & 3) * 8 + G.RB;
   }
-  f32x4 ld[ZS_NSL];
-  static_assert(ZS_NSL == 5, "Z3_LANDED names the five staging registers");
+  f32x4 ld[NSL];
+  static_assert(NSL == 5 || NSL == 7, "Z3_LANDED names five or seven staging registers");
   // Plane loads are issued and awaited by hand, but -- unlike zs_helper_wave -- with nothing to count: they are the LAST
   // vector-memory operations of a step (after the reduction's row stores), so the wait one step later is a plain vmcnt(0); the
   // stores it also covers were issued a whole matrix phase before the loads and have long been acknowledged.
@@ -664,18 +664,19 @@ __device__ __forceinline__ void z3_wave(const ConvZsArgs& a, char* lds) {
     const int zc = min(max(z, 0), a.D - 1);
     const float* src = uniform_ptr(src_b + (size_t)zc * PV * a.ldc);
 #pragma unroll
-    for (int k = 0; k < ZS_NSL; ++k)
+    for (int k = 0; k < NSL; ++k)
       asm volatile("global_load_dwordx4 %0, %1, %2 ; zs_plane_load" : "=v"(ld[k]) : "v"(srco[k]), "s"(src) : "memory");
   };
 #define Z3_LANDED(younger)                                                                                   \
   do {                                                                                                       \
-    asm volatile("s_waitcnt vmcnt(%5) ; zs_landed"                                                           \
-                 : "+v"(ld[0]), "+v"(ld[1]), "+v"(ld[2]), "+v"(ld[3]), "+v"(ld[4])                           \
+    asm volatile("s_waitcnt vmcnt(%7) ; zs_landed"                                                           \
+                 : "+v"(ld[0]), "+v"(ld[1]), "+v"(ld[2]), "+v"(ld[3]), "+v"(ld[4]), "+v"(ld[NSL > 5 ? 5 : 0]),  \
+                   "+v"(ld[NSL > 5 ? 6 : 1])                                                                  \
                  : "n"(younger)                                                                              \
                  : "memory");                                                                                \
   } while (0)
   // normalise + split the five pieces in v[] (this thread's quad of image voxels p0 + 32k) into the ring slot of plane z
-  auto convert = [&](f32x4 (&v)[ZS_NSL], int z) {
+  auto convert = [&](f32x4 (&v)[NSL], int z) {
     float amax = 0.f;
     const int zz = z + a.NR;  // ring slot (z + NR) mod NR, z >= -1, NR = 4 or 5, without a division
     const int slot = a.NR == 4 ? (zz & 3) : zz - 5 * ((zz * 205) >> 10);
@@ -692,7 +693,7 @@ __device__ __forceinline__ void z3_wave(const ConvZsArgs& a, char* lds) {
     }
     if (zero) {  // a plane outside the volume (wave-uniform: one branch, not one per piece)
 #pragma unroll
-      for (int k = 0; k < ZS_NSL; ++k) {
+      for (int k = 0; k < NSL; ++k) {
         int d = dsto[k] + sbase;
         asm volatile("" : "+v"(d));  // (one address register, the second write through the offset field)
         *z3_lds<u32x2>(d) = u32x2{0u, 0u};
@@ -701,7 +702,7 @@ __device__ __forceinline__ void z3_wave(const ConvZsArgs& a, char* lds) {
       return;
     }
 #pragma unroll
-    for (int k = 0; k < ZS_NSL; ++k) {
+    for (int k = 0; k < NSL; ++k) {
       u32x2 t1, t2;
       f32x4 x = v[k];
       if (SCALED) x = x * gscale;  // (training: input gradients rescaled by a power of two)
@@ -763,12 +764,12 @@ __device__ __forceinline__ void z3_wave(const ConvZsArgs& a, char* lds) {
   int zpend = trk_next();
   if (zpend != -2) issue(zpend);
   {
-    f32x4 ldp[4][ZS_NSL];
-    auto fetch = [&](f32x4 (&dst)[ZS_NSL], int z) {
+    f32x4 ldp[4][NSL];
+    auto fetch = [&](f32x4 (&dst)[NSL], int z) {
       const int zc = min(max(z, 0), a.D - 1);
       const char* src = (const char*)(src_b + (size_t)zc * PV * a.ldc);
 #pragma unroll
-      for (int k = 0; k < ZS_NSL; ++k) dst[k] = *(const f32x4*)(src + srco[k]);
+      for (int k = 0; k < NSL; ++k) dst[k] = *(const f32x4*)(src + srco[k]);
     };
 #pragma unroll
     for (int i = 0; i < 3; ++i) fetch(ldp[i], zp0 + i);
@@ -1060,33 +1061,40 @@ __device__ __forceinline__ void z3_wave(const ConvZsArgs& a, char* lds) {
   if (a.status && tid == 0 && *flag_lds) atomicOr(a.status, 1);  // (the loop ends with a barrier)
 }
 
-template <bool ACC, int MODE, int DBG = 0>
+// NSL: staging pieces per thread and plane = plane images of up to 32 NSL voxels (5: 160 -- Dataset-2's whole planes; 7: 224 --
+// Dataset-3's strips of 10 phi rows + 2 halo rows of 18 voxels instead of 5 + 2, HGCal's of 6 + 2 rows of 21 instead of 4 + 2:
+// less halo restaged per output row)
+template <bool ACC, int MODE, int DBG = 0, int NSL = ZS_NSL>
 __global__ void __launch_bounds__(256, 1) conv_zslide_sw_f16x2_kernel(ConvZsArgs a) {
   extern __shared__ __attribute__((aligned(16))) char zs_lds[];
   switch (threadIdx.x >> 6) {
-    case 0: z3_wave<0, ACC, MODE, DBG>(a, zs_lds); break;
-    case 1: z3_wave<1, ACC, MODE, DBG>(a, zs_lds); break;
-    case 2: z3_wave<2, ACC, MODE, DBG>(a, zs_lds); break;
-    default: z3_wave<3, ACC, MODE, DBG>(a, zs_lds); break;
+    case 0: z3_wave<0, ACC, MODE, DBG, NSL>(a, zs_lds); break;
+    case 1: z3_wave<1, ACC, MODE, DBG, NSL>(a, zs_lds); break;
+    case 2: z3_wave<2, ACC, MODE, DBG, NSL>(a, zs_lds); break;
+    default: z3_wave<3, ACC, MODE, DBG, NSL>(a, zs_lds); break;
   }
 }
 
 // launch of one K-block: the specialisation for (continuation, normed input, strips, rescaled input)
 void z3_launch(const ConvZsArgs& a, bool acc, dim3 grid, size_t lds, hipStream_t s) {
   const int mode = ((a.coef || a.defer.part) ? 1 : 0) | (a.HS < a.H ? 2 : 0) | (a.in_absmax ? 4 : 0);
-#define Z3_CASE(ACCV, M)                                                                                                        \
-  if (acc == ACCV && mode == M) {                                                                                               \
-    static bool attr = false;                                                                                                   \
-    if (!attr) {                                                                                                                \
-      CD_HIP(hipFuncSetAttribute((const void*)conv_zslide_sw_f16x2_kernel<ACCV, M>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                 160 * 1024));                                                                                  \
-      attr = true;                                                                                                              \
-    }                                                                                                                           \
-    hipLaunchKernelGGL((conv_zslide_sw_f16x2_kernel<ACCV, M>), grid, dim3(256), lds, s, a);                                      \
-    return;                                                                                                                     \
+  const int staged = (a.HS + (a.HS < a.H ? 2 : 0)) * a.W;  // voxels of a plane image
+  const int nsl = staged > ZS_NSL * 32 ? 7 : ZS_NSL;
+#define Z3_CASE(ACCV, M, N)                                                                                                           \
+  if (acc == ACCV && mode == M && nsl == N) {                                                                                         \
+    static bool attr = false;                                                                                                         \
+    if (!attr) {                                                                                                                      \
+      CD_HIP(hipFuncSetAttribute((const void*)conv_zslide_sw_f16x2_kernel<ACCV, M, 0, N>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                 160 * 1024));                                                                                        \
+      attr = true;                                                                                                                    \
+    }                                                                                                                                 \
+    hipLaunchKernelGGL((conv_zslide_sw_f16x2_kernel<ACCV, M, 0, N>), grid, dim3(256), lds, s, a);                                      \
+    return;                                                                                                                           \
   }
-  Z3_CASE(false, 0) Z3_CASE(false, 1) Z3_CASE(false, 2) Z3_CASE(false, 3) Z3_CASE(false, 4) Z3_CASE(false, 6)
-  Z3_CASE(true, 0) Z3_CASE(true, 2) Z3_CASE(true, 4) Z3_CASE(true, 6)
+  Z3_CASE(false, 0, 5) Z3_CASE(false, 1, 5) Z3_CASE(false, 2, 5) Z3_CASE(false, 3, 5) Z3_CASE(false, 4, 5) Z3_CASE(false, 6, 5)
+  Z3_CASE(true, 0, 5) Z3_CASE(true, 2, 5) Z3_CASE(true, 4, 5) Z3_CASE(true, 6, 5)
+  Z3_CASE(false, 0, 7) Z3_CASE(false, 1, 7) Z3_CASE(false, 2, 7) Z3_CASE(false, 3, 7) Z3_CASE(false, 4, 7) Z3_CASE(false, 6, 7)
+  Z3_CASE(true, 0, 7) Z3_CASE(true, 2, 7) Z3_CASE(true, 4, 7) Z3_CASE(true, 6, 7)
 #undef Z3_CASE
   CD_REQUIRE(false, "z-slide conv: no kernel instance for this combination of continuation / normalised / strip / rescaled input");
 }
@@ -1118,11 +1126,15 @@ bool try_launch_conv_zslide(const float* in0, int c0, const float* in1, int c1, 
     const size_t ring3 = Z3_PAD ? (size_t)ring_for(hs) * ((((size_t)rows * (W + 1) + 1) * ZS_VB + 255) & ~(size_t)255) : ring;
     return v1 ? (size_t)ZS_ZERO + ring + ZS_PART : (size_t)ZS_ZERO + Z3_COEF + ring3 + 2 * Z3_XCH;
   };
+  // voxels of a plane image the staging threads cover: 5 pieces of 32; the one-wave-per-SIMD form also has a 7-piece instance for
+  // strips (CD_ZS_NSL5=1: without it, A/B)
+  static const bool nsl5_env = getenv("CD_ZS_NSL5") != nullptr;
+  const int max_staged = (v1 || nsl5_env) ? ZS_NSL * 32 : 7 * 32;
   int HS = 0;
   for (int hs = H; hs >= 1; --hs) {  // the largest strip that fits: least halo restaging
     if (H % hs) continue;
     const int rows = hs + (hs < H ? 2 : 0);
-    if (hs * W < ZS_STEP || rows * W > ZS_NSL * 32 || lds_for(hs) > 160 * 1024) continue;
+    if (hs * W < ZS_STEP || rows * W > max_staged || lds_for(hs) > 160 * 1024) continue;
     HS = hs;
     break;
   }
@@ -1130,7 +1142,7 @@ bool try_launch_conv_zslide(const float* in0, int c0, const float* in1, int c1, 
   if (strip_env) {
     const int hs = strip_env;
     const int rows = hs + (hs < H ? 2 : 0);
-    if (hs >= 1 && H % hs == 0 && hs * W >= ZS_STEP && rows * W <= ZS_NSL * 32 && lds_for(hs) <= 160 * 1024) HS = hs;
+    if (hs >= 1 && H % hs == 0 && hs * W >= ZS_STEP && rows * W <= max_staged && lds_for(hs) <= 160 * 1024) HS = hs;
   }
   const int nstrip = H / HS;
   const int SPV = HS * W;
