@@ -650,7 +650,7 @@ __device__ __forceinline__ void z3_wave(const ConvZsArgs& a, char* lds) {
     dsto[k] = (Z3_PAD ? pi + pi / W + 1 : pi) * ZS_VB + (q >> 2) * 64 + (q & 3) * 8 + G.RB;
   }
   f32x4 ld[NSL];
-  static_assert(NSL == 5 || NSL == 7, "Z3_LANDED names five or seven staging registers");
+  static_assert(NSL == 5 || NSL == 7 || NSL == 8, "Z3_LANDED names five, seven or eight staging registers");
   // Plane loads are issued and awaited by hand, but -- unlike zs_helper_wave -- with nothing to count: they are the LAST
   // vector-memory operations of a step (after the reduction's row stores), so the wait one step later is a plain vmcnt(0); the
   // stores it also covers were issued a whole matrix phase before the loads and have long been acknowledged.
@@ -669,9 +669,9 @@ __device__ __forceinline__ void z3_wave(const ConvZsArgs& a, char* lds) {
   };
 #define Z3_LANDED(younger)                                                                                   \
   do {                                                                                                       \
-    asm volatile("s_waitcnt vmcnt(%7) ; zs_landed"                                                           \
+    asm volatile("s_waitcnt vmcnt(%8) ; zs_landed"                                                           \
                  : "+v"(ld[0]), "+v"(ld[1]), "+v"(ld[2]), "+v"(ld[3]), "+v"(ld[4]), "+v"(ld[NSL > 5 ? 5 : 0]),  \
-                   "+v"(ld[NSL > 5 ? 6 : 1])                                                                  \
+                   "+v"(ld[NSL > 5 ? 6 : 1]), "+v"(ld[NSL > 7 ? 7 : 2])                                       \
                  : "n"(younger)                                                                              \
                  : "memory");                                                                                \
   } while (0)
@@ -1063,7 +1063,7 @@ __device__ __forceinline__ void z3_wave(const ConvZsArgs& a, char* lds) {
 
 // NSL: staging pieces per thread and plane = plane images of up to 32 NSL voxels (5: 160 -- Dataset-2's whole planes; 7: 224 --
 // Dataset-3's strips of 10 phi rows + 2 halo rows of 18 voxels instead of 5 + 2, HGCal's of 6 + 2 rows of 21 instead of 4 + 2:
-// less halo restaged per output row)
+// less halo restaged per output row; 8: 256 -- Dataset-3's level-1 planes of 25 x 9 voxels whole)
 template <bool ACC, int MODE, int DBG = 0, int NSL = ZS_NSL>
 __global__ void __launch_bounds__(256, 1) conv_zslide_sw_f16x2_kernel(ConvZsArgs a) {
   extern __shared__ __attribute__((aligned(16))) char zs_lds[];
@@ -1079,7 +1079,7 @@ __global__ void __launch_bounds__(256, 1) conv_zslide_sw_f16x2_kernel(ConvZsArgs
 void z3_launch(const ConvZsArgs& a, bool acc, dim3 grid, size_t lds, hipStream_t s) {
   const int mode = ((a.coef || a.defer.part) ? 1 : 0) | (a.HS < a.H ? 2 : 0) | (a.in_absmax ? 4 : 0);
   const int staged = (a.HS + (a.HS < a.H ? 2 : 0)) * a.W;  // voxels of a plane image
-  const int nsl = staged > ZS_NSL * 32 ? 7 : ZS_NSL;
+  const int nsl = staged > 7 * 32 ? 8 : (staged > ZS_NSL * 32 ? 7 : ZS_NSL);
 #define Z3_CASE(ACCV, M, N)                                                                                                           \
   if (acc == ACCV && mode == M && nsl == N) {                                                                                         \
     static bool attr = false;                                                                                                         \
@@ -1095,6 +1095,8 @@ void z3_launch(const ConvZsArgs& a, bool acc, dim3 grid, size_t lds, hipStream_t
   Z3_CASE(true, 0, 5) Z3_CASE(true, 2, 5) Z3_CASE(true, 4, 5) Z3_CASE(true, 6, 5)
   Z3_CASE(false, 0, 7) Z3_CASE(false, 1, 7) Z3_CASE(false, 2, 7) Z3_CASE(false, 3, 7) Z3_CASE(false, 4, 7) Z3_CASE(false, 6, 7)
   Z3_CASE(true, 0, 7) Z3_CASE(true, 2, 7) Z3_CASE(true, 4, 7) Z3_CASE(true, 6, 7)
+  Z3_CASE(false, 0, 8) Z3_CASE(false, 1, 8) Z3_CASE(false, 2, 8) Z3_CASE(false, 3, 8) Z3_CASE(false, 4, 8) Z3_CASE(false, 6, 8)
+  Z3_CASE(true, 0, 8) Z3_CASE(true, 2, 8) Z3_CASE(true, 4, 8) Z3_CASE(true, 6, 8)
 #undef Z3_CASE
   CD_REQUIRE(false, "z-slide conv: no kernel instance for this combination of continuation / normalised / strip / rescaled input");
 }
@@ -1129,7 +1131,8 @@ bool try_launch_conv_zslide(const float* in0, int c0, const float* in1, int c1, 
   // voxels of a plane image the staging threads cover: 5 pieces of 32; the one-wave-per-SIMD form also has a 7-piece instance for
   // strips (CD_ZS_NSL5=1: without it, A/B)
   static const bool nsl5_env = getenv("CD_ZS_NSL5") != nullptr;
-  const int max_staged = (v1 || nsl5_env) ? ZS_NSL * 32 : 7 * 32;
+  static const int nsl_env = getenv("CD_ZS_NSL") ? atoi(getenv("CD_ZS_NSL")) : 8;  // (A/B: cap the pieces at 5, 7 or 8)
+  const int max_staged = (v1 || nsl5_env) ? ZS_NSL * 32 : std::min(8, std::max(5, nsl_env)) * 32;
   int HS = 0;
   for (int hs = H; hs >= 1; --hs) {  // the largest strip that fits: least halo restaging
     if (H % hs) continue;
