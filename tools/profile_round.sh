@@ -2,6 +2,7 @@
 # One GPU-box call that collects what profiles/ holds for a round:  bash tools/profile_round.sh <tag>
 #   * HBM traffic (PMC) of the z-slide conv at the level-0 grid of every sampling configuration of BASELINE.json,
 #   * its instruction / busy counters,
+#   * HBM traffic (PMC) of the level-0 HBM passes (gn_apply, attention, shortcut conv, head, init conv) against their algorithmic bytes,
 #   * rocprofv3 kernel stats of the headline bench command WITHOUT the side legs (--no-extra: the percentages are those of the
 #     timed region), and of the Dataset-3, HGCal (the config's own 200-step DDPM) and training (batch 32) configurations,
 #   * the bench lines of the same commands outside the profiler (with the clock / power sampled during the timed region).
@@ -12,6 +13,7 @@ for cfg in dataset2 dataset3 hgcal; do
   timeout -k 10 400 python3 tools/zs_traffic.py --config $cfg > $out/traffic_$cfg.log 2>&1; echo "traffic $cfg rc=$?"; tail -1 $out/traffic_$cfg.log
   rm -rf gpurun_out/pmc_traffic
 done
+timeout -k 10 400 python3 tools/l0_traffic.py > $out/l0_traffic.log 2>&1; echo "l0 traffic rc=$?"; cp gpurun_out/l0_traffic_dataset2.json $out/ 2>/dev/null; rm -rf gpurun_out/pmc_l0
 timeout -k 10 500 bash tools/zs_pmc.sh $(basename $out)_pmc > $out/pmc.log 2>&1; echo "pmc rc=$?"
 cp gpurun_out/$(basename $out)_pmc/summary.txt $out/zslide_pmc_summary.txt; rm -rf gpurun_out/$(basename $out)_pmc; cat $out/zslide_pmc_summary.txt
 stats() {  # stats <name> <bench args...>
