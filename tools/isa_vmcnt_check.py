@@ -110,15 +110,19 @@ def check_kernel(sym: str, body: List[str], verbose=True) -> Tuple[int, List[str
     blocks = build_cfg(body)
     errors: List[str] = []
     checked = 0
-    # plane loads come in whole groups: consecutive marked loads, uninterrupted by other vector-memory instructions
+    # plane loads come in whole groups: consecutive marked loads, uninterrupted by other vector-memory instructions.  A group has
+    # one load per staging piece: 5 (ZS_NSL), or the last template argument of the one-wave-per-SIMD kernel's instances
+    # (conv_zslide_sw_f16x2_kernel<ACC, MODE, DBG, NSL>: ...ELi<DBG>ELi<NSL>EEEv...)
+    m = re.search(r"conv_zslide_sw_f16x2_kernelILb[01]ELi\d+ELi\d+ELi(\d+)EEE", sym)
+    group = int(m.group(1)) if m else 5
     for b in blocks.values():
         run = 0
         for t in b.ins + ["<end>"]:
             if "zs_plane_load" in t:
                 run += 1
             elif VMEM.match(t) or t == "<end>":
-                if run and run % 5:
-                    errors.append(f"{sym}: plane-load group of {run} in block {b.label} (expected multiples of 5)")
+                if run and run % group:
+                    errors.append(f"{sym}: plane-load group of {run} in block {b.label} (expected multiples of {group})")
                 run = 0
     for b in blocks.values():
         for pos, t in enumerate(b.ins):
