@@ -2413,6 +2413,7 @@ __global__ void __launch_bounds__(256) init_conv_kernel(InitConvArgs a) {
 // grid, phi rows wrapped) sits in LDS as fp32, so every tap of every voxel is "base + constant".
 __global__ void __launch_bounds__(256) init_conv_f16x2_kernel(InitConvArgs a, const float* __restrict__ table, int TZ) {
   extern __shared__ __attribute__((aligned(16))) float img[];
+  __shared__ __attribute__((aligned(16))) float trn[4 * 32 * 36];  // per-wave output tile on its way to row-major quads
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
   const int b = blockIdx.y;
   const int D = a.dims.d, H = a.dims.h, W = a.dims.w, PV = H * W;
@@ -2472,13 +2473,14 @@ __global__ void __launch_bounds__(256) init_conv_f16x2_kernel(InitConvArgs a, co
       const int v = min(tile * 32 + col, nvox - 1);
       const int lz = v / PV, p = v - lz * PV, h = p / W, w = p - h * W;
       const float* base = img + (lz * HP + h) * WP + w;
-      // the table rows of this tile are requested first, unconditionally (clamped), so that all 16 loads are in flight
-      // under the gather and the MFMAs instead of one load-store round trip per row
-      float tb[16];
+      // the table rows of this tile are requested first, unconditionally (clamped), so that all loads are in flight under the
+      // gather and the MFMAs: as whole 16-byte quads, row 8 k + (lane >> 3), channels 4 (lane & 7) .. + 3 -- the layout the tile is
+      // stored in after a transpose through LDS (16 scalar row stores per lane in accumulator layout ran at a third of the HBM rate)
+      f32x4 tb[4];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int vr = min(tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, nvox - 1);
-        tb[r] = table[((size_t)z0 * PV + vr) * a.cout + ct * 32 + col];
+      for (int k = 0; k < 4; ++k) {
+        const int vr = min(tile * 32 + 8 * k + (lane >> 3), nvox - 1);
+        tb[k] = *(const f32x4*)(table + ((size_t)z0 * PV + vr) * a.cout + ct * 32 + (lane & 7) * 4);
       }
       f32x16 accA, accB;
 #pragma unroll
@@ -2496,13 +2498,16 @@ __global__ void __launch_bounds__(256) init_conv_f16x2_kernel(InitConvArgs a, co
         accB = MFMA_F16(x1, w2[ks], accB);
         accB = MFMA_F16(x2, w1[ks], accB);
       }
+      float* tr = trn + wave * (32 * 36);  // this wave's 32 x 32 tile, rows padded to 36 floats
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int vr = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (vr < nvox) {
-          const size_t g = (size_t)z0 * PV + vr;
-          a.out[((size_t)b * vox + g) * a.cout + ct * 32 + col] = accA[r] + accB[r] * (1.f / 2048.f) + tb[r];
-        }
+      for (int r = 0; r < 16; ++r) tr[((r & 3) + 8 * (r >> 2) + 4 * half) * 36 + col] = accA[r] + accB[r] * (1.f / 2048.f);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (one wave: its own LDS writes are visible to its reads in order)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int row = 8 * k + (lane >> 3);
+        const int vr = tile * 32 + row;
+        const f32x4 o = *(const f32x4*)(tr + row * 36 + (lane & 7) * 4) + tb[k];
+        if (vr < nvox) *(f32x4*)(a.out + ((size_t)b * vox + (size_t)z0 * PV + vr) * a.cout + ct * 32 + (lane & 7) * 4) = o;
       }
     }
   }
