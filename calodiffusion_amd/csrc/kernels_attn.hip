@@ -342,7 +342,7 @@ __device__ __forceinline__ void attn_fold_weights(const AttnArgs& a, int b, floa
 // pass 2 of sample b over tiles [t0, t1): y and, as unit `unit` of `nunits`, its channel partials
 template <int NCH>
 __device__ __forceinline__ void attn_pass2(const AttnArgs& a, int b, int unit, int nunits, int64_t t0, int64_t t1,
-                                           const f32x4 (&cf)[NCH][8]) {
+                                           const f32x4 (&cf)[NCH][8], float* trbuf = nullptr) {
   __shared__ float sRed[8][NCH * 32][2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, col = lane & 31;
@@ -454,6 +454,26 @@ __device__ __forceinline__ void attn_pass2(const AttnArgs& a, int b, int unit, i
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[r] += ob[r] * (1.f / 2048.f);
+      if (trbuf && t * 32 + 32 <= a.vox) {
+        // whole tile: out as 16-byte quads (row 8 k + (lane >> 3), channels 4 (lane & 7) .. + 3) after a transpose through the wave's
+        // LDS tile -- 16 scalar row stores per lane in accumulator layout ran at a fraction of the HBM rate
+        float* tr = trbuf + wave * (32 * 36);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = o[r] + bv[ct];
+          tr[((r & 3) + 8 * (r >> 2) + 4 * half) * 36 + col] = v;
+          s1[ct] += v;
+          s2[ct] += v * v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (one wave: its own LDS writes are visible to its reads in order)
+        float* yt = yb + (size_t)t * 32 * a.C + ct * 32 + (lane & 7) * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int row = 8 * k + (lane >> 3);
+          *(f32x4*)(yt + (size_t)row * a.C) = *(const f32x4*)(tr + row * 36 + (lane & 7) * 4);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the tile buffer is reused)
+      } else {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t n = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -463,6 +483,7 @@ __device__ __forceinline__ void attn_pass2(const AttnArgs& a, int b, int unit, i
           s1[ct] += v;
           s2[ct] += v * v;
         }
+      }
       }
     }
   }
@@ -501,7 +522,8 @@ __global__ void __launch_bounds__(512) attn_out_kernel(AttnArgs a) {
   const int64_t t1 = (t0 + a.tiles_per_wg < T) ? t0 + a.tiles_per_wg : T;
   f32x4 cf[NCH][8];
   load_coef<NCH>(a, b, half, cf);
-  attn_pass2<NCH>(a, b, unit, (int)gridDim.x, t0, t1, cf);
+  __shared__ __attribute__((aligned(16))) float sTr[8 * 32 * 36];  // per-wave output tile on its way to row-major quads
+  attn_pass2<NCH>(a, b, unit, (int)gridDim.x, t0, t1, cf, sTr);
 }
 
 // The whole Residual(PreNorm(LinearAttention)) of one sample in ONE workgroup, for grids of a few hundred voxels (Dataset-2 below

@@ -2223,7 +2223,11 @@ __global__ void __launch_bounds__(256) pointwise_kernel(PointwiseArgs a, int CTt
   // final values in place (bias, residual, fused block close), then the stores and the channel statistics read them
   if (full) {
     const int ld = a.out_ld ? a.out_ld : a.cout;
-    float* op = a.out + ((size_t)b * a.vox + n0) * ld + a.out_off + ct0 * 32 + col;
+    // the output tile leaves as 16-byte quads (row 8 k + (lane >> 3), channels 4 (lane & 7) .. + 3) after a transpose through LDS:
+    // 16 scalar row stores per lane in accumulator layout ran at a fraction of the HBM rate (see init_conv_f16x2_kernel)
+    __shared__ __attribute__((aligned(16))) float sTr[4][32 * 36];
+    float* tr = sTr[wave];
+    float* op = a.out + ((size_t)b * a.vox + n0) * ld + a.out_off + ct0 * 32 + (lane & 7) * 4;
     const float* rp = a.residual ? a.residual + ((size_t)b * a.vox + n0) * a.cout + ct0 * 32 + col : nullptr;
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
@@ -2244,8 +2248,15 @@ __global__ void __launch_bounds__(256) pointwise_kernel(PointwiseArgs a, int CTt
           v += u * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(u * -1.4426950408889634f)) + cf[2];
         }
         acc[ct][r] = v;
-        op[((r & 3) + 8 * (r >> 2) + rl) * ld + ct * 32] = v;
+        tr[((r & 3) + 8 * (r >> 2) + rl) * 36 + col] = v;
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (one wave: its own LDS writes are visible to its reads in order)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int row = 8 * k + (lane >> 3);
+        *(f32x4*)(op + (size_t)row * ld + ct * 32) = *(const f32x4*)(tr + row * 36 + (lane & 7) * 4);
+      }
+      if (ct + 1 < CT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the tile buffer is reused by the next channel tile)
     }
   } else {
 #pragma unroll
@@ -2317,6 +2328,7 @@ void launch_pointwise(const PointwiseArgs& a, hipStream_t s) {
   CD_REQUIRE(a.prologue != A_SOFTMAX32 || (a.c0 == 32 && a.c1 == 0), "softmax prologue needs exactly 32 channels");
   CD_REQUIRE(!a.gn_res || (a.gn_defer.part && a.gn_defer.C == a.cout && a.cout <= 128 && !a.out_ld),
              "pointwise conv: the fused block close normalises a packed tensor of the output's width (<= 128 channels)");
+  CD_REQUIRE(a.out_off % 4 == 0 && a.out_ld % 4 == 0 && (a.cout % 4 == 0 || a.out_ld), "pointwise conv: output rows must be 16-byte aligned");
   const int CTtot = (a.cout + 31) / 32;
   const int CT = CTtot <= 3 ? CTtot : (CTtot % 2 == 0 ? 2 : 1);
   dim3 grid((unsigned)((a.vox + 127) / 128), (unsigned)a.batch, (unsigned)(CTtot / CT));
