@@ -1946,17 +1946,14 @@ __global__ void __launch_bounds__(256) conv_transpose_f16x2_kernel(ConvTArgs a) 
   if (a.in_absmax) pow2_scale_for(*a.in_absmax, &gscale, &ginv);
   {  // stage + split all input channels of the haloed tile
     const int c4 = a.cin >> 2;
-    const int items = tileVox * c4;
     const float* src = a.in + (size_t)b * a.Din * a.Hin * a.Win * a.cin;
     float amax = 0.f;
-    for (int idx = tid; idx < items; idx += blockDim.x) {
-      const int q = idx % c4, vox = idx / c4;
-      const int iw = vox % a.Win;
-      const int r = vox / a.Win;
-      const int lh = r % PH, lz = r / PH;
+    auto stage = [&](int vox, int q, int iw, int lh, int lz) {
       const int gz = a0 - 1 + lz;
-      int gh = (b0 - 1 + lh) % a.Hin;
-      if (gh < 0) gh += a.Hin;
+      int gh = b0 - 1 + lh;  // (circular halo: -1 .. b0 + TH < 2 Hin)
+      gh = gh < 0 ? gh + a.Hin : gh;
+      gh = gh >= a.Hin ? gh - a.Hin : gh;
+      gh = gh >= a.Hin ? gh - a.Hin : gh;  // (a tile of a ring shorter than its halo: TH + 2 <= 3 Hin always)
       f32x4 val = {0.f, 0.f, 0.f, 0.f};
       if (gz >= 0 && gz < a.Din) val = *(const f32x4*)(src + ((size_t)(gz * a.Hin + gh) * a.Win + iw) * a.cin + q * 4);
       val *= gscale;
@@ -1966,6 +1963,30 @@ __global__ void __launch_bounds__(256) conv_transpose_f16x2_kernel(ConvTArgs a) 
       char* dst = (char*)(lds + vox * a.CS) + (q >> 2) * 64 + (q & 3) * 8;
       *(u32x2*)dst = t1;
       *(u32x2*)(dst + 32) = t2;
+    };
+    const int nthr = blockDim.x;
+    if (nthr % c4 == 0) {
+      // a thread keeps its channel quad and walks the tile's voxels in steps of nthr / c4, its (iw, lh, lz) advanced with carries:
+      // six integer divisions by run-time values per item (~40 instructions each) were most of this loop
+      const int q = tid % c4, vstep = nthr / c4;
+      int vox = tid / c4;
+      int iw = vox % a.Win, r = vox / a.Win;
+      int lh = r % PH, lz = r / PH;
+      const int dw = vstep % a.Win, dr = vstep / a.Win, dh = dr % PH, dz = dr / PH;
+      for (; vox < tileVox; vox += vstep) {
+        stage(vox, q, iw, lh, lz);
+        iw += dw; lh += dh; lz += dz;
+        if (iw >= a.Win) { iw -= a.Win; lh += 1; }
+        if (lh >= PH) { lh -= PH; lz += 1; }
+      }
+    } else {
+      const int items = tileVox * c4;
+      for (int idx = tid; idx < items; idx += nthr) {
+        const int q = idx % c4, vox = idx / c4;
+        const int iw = vox % a.Win;
+        const int r = vox / a.Win;
+        stage(vox, q, iw, r % PH, r / PH);
+      }
     }
     if (a.status && amax > 65504.f) atomicOr(a.status, 1);
   }
@@ -1995,29 +2016,58 @@ __global__ void __launch_bounds__(256) conv_transpose_f16x2_kernel(ConvTArgs a) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) { accA[ct][r] = 0.f; accB[ct][r] = 0.f; }
 
-    for (int kz = (pz + 1) % a.SZ; kz < a.KZ; kz += a.SZ) {
+    // The class's taps -- kz in {kz0, kz0 + SZ, ..}, two kh, two kw -- times the k-steps as ONE flat sequence of stages, software-
+    // pipelined two deep: the fragment (LDS) and weight (L2) loads of stage j + 1 are requested before the MFMAs of stage j.  (As
+    // nested loops every k-step waited for its own weight loads: an L2 round trip per 3 MFMAs.)  The last request repeats the last
+    // stage instead of being conditional: a conditional load in a pipelined loop costs a full vmcnt(0) per trip.
+    const int kz0 = (pz + 1) % a.SZ, kh0 = (ph + 3) & 1, kw0 = (pw + 1) & 1;
+    const int nkz = (a.KZ - kz0 + a.SZ - 1) / a.SZ;
+    const int nstage = nkz * 4 * nks;
+    struct Stage {
+      u32x4 x1, x2, w[CT][2];
+    };
+    int ti_n = 0, ks_n = 0, tap_n = 0;  // the next stage to request: tap number (kz-major), k-step; its weight tap index
+    const char* rec_n = nullptr;        // ... and this lane's record of that tap
+    auto setup = [&](int ti) {
+      const int kz = kz0 + (ti >> 2) * a.SZ, kh = kh0 + ((ti >> 1) & 1) * 2, kw = kw0 + (ti & 1) * 2;
       const int lz = aa + (pz + 1 - kz) / a.SZ + 1;
-      for (int kh = (ph + 3) & 1; kh < 4; kh += 2) {
-        const int lh = bb + (ph + 3 - kh) / 2;  // (.. )/2 - 1 (circular halo) + 1 (tile halo)
-        for (int kw = (pw + 1) & 1; kw < 4; kw += 2) {
-          const int iw = c + (pw + 1 - kw) / 2;
-          const bool ok = valid && iw >= 0 && iw < a.Win;
-          const char* rec = (const char*)(lds + (ok ? ((lz * PH + lh) * a.Win + iw) * a.CS : ZERO)) + half * 16;
-          const int tap = (kz * 4 + kh) * 4 + kw;
-          for (int ks = 0; ks < nks; ++ks) {
-            const u32x4 x1 = *(const u32x4*)(rec + ks * 64);
-            const u32x4 x2 = *(const u32x4*)(rec + ks * 64 + 32);
-            const u32x4* wq = a.wpk16 + ((size_t)(ks * T + tap) * a.CTtot) * 128 + lane;
+      const int lh = bb + (ph + 3 - kh) / 2;  // (.. )/2 - 1 (circular halo) + 1 (tile halo)
+      const int iw = c + (pw + 1 - kw) / 2;
+      const bool ok = valid && iw >= 0 && iw < a.Win;
+      rec_n = (const char*)(lds + (ok ? ((lz * PH + lh) * a.Win + iw) * a.CS : ZERO)) + half * 16;
+      tap_n = (kz * 4 + kh) * 4 + kw;
+    };
+    setup(0);
+    auto fetch = [&](Stage& st) {
+      st.x1 = *(const u32x4*)(rec_n + ks_n * 64);
+      st.x2 = *(const u32x4*)(rec_n + ks_n * 64 + 32);
+      const u32x4* wq = a.wpk16 + ((size_t)(ks_n * T + tap_n) * a.CTtot) * 128 + lane;
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-              const u32x4 w1 = wq[ct * 128], w2 = wq[ct * 128 + 64];
-              accA[ct] = MFMA_F16(x1, w1, accA[ct]);
-              accB[ct] = MFMA_F16(x1, w2, accB[ct]);
-              accB[ct] = MFMA_F16(x2, w1, accB[ct]);
-            }
-          }
-        }
+      for (int ct = 0; ct < CT; ++ct) {
+        st.w[ct][0] = wq[ct * 128];
+        st.w[ct][1] = wq[ct * 128 + 64];
       }
+      if (ks_n + 1 < nks) ++ks_n;
+      else if (ti_n + 1 < nkz * 4) { ks_n = 0; setup(++ti_n); }
+    };
+    auto mfmas = [&](const Stage& st) {
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        accA[ct] = MFMA_F16(st.x1, st.w[ct][0], accA[ct]);
+        accB[ct] = MFMA_F16(st.x1, st.w[ct][1], accB[ct]);
+        accB[ct] = MFMA_F16(st.x2, st.w[ct][0], accB[ct]);
+      }
+    };
+    Stage s0, s1;
+    fetch(s0);
+    for (int j = 0; j < nstage; j += 2) {
+      fetch(s1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(s0);
+      __builtin_amdgcn_sched_barrier(0);
+      fetch(s0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (j + 1 < nstage) mfmas(s1);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
