@@ -1633,7 +1633,11 @@ static bool try_launch_conv3_flat(const float* in0, int c0, const float* in1, in
       const int NT = c[0], VT = c[1];
       if (VT * CT > 8 || (CT == 3 && VT > 2)) continue;
       if (prec == 2 && VT * CT > 4) continue;
-      if ((int64_t)32 * (NT - 1) >= g.out.vox()) continue;
+      // (more row tiles than the sample has: skipped -- except one tile per wave on grids of <= 128 output voxels, where the
+      // surplus waves have no rows but share the staging, whose few threads are the latency of such launches)
+      static const bool no_extra_waves = getenv("CD_FLAT_NO_EXTRA_WAVES") != nullptr;
+      const bool extra_ok = !no_extra_waves && g.out.vox() <= 128 && VT == 1 && NT <= 8;
+      if ((int64_t)32 * (NT - 1) >= g.out.vox() && !extra_ok) continue;
       if (((size_t)planes(NT) * HW + 1) * vox_bytes > 150 * 1024) continue;
       if (pass == 1 && NT > 4) continue;
       cand.push_back({NT, VT, CT});
