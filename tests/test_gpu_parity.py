@@ -143,6 +143,18 @@ def test_full_resolution_conv_kernel(ops):
         assert err < 2e-6, (B, c0, c1, cout, shape, err)
 
 
+def test_wide_plane_images_of_the_full_resolution_conv(ops):
+    """Round 3: plane images of up to 224 and 256 voxels (7 / 8 staging pieces per thread).  Dataset-3's level 1 (25x9 = 225-voxel
+    planes, whole), whole planes of 161..224 voxels, HGCal's strips of 6 + 2 rows of 21, a strip grid of 10 + 2 rows with a
+    concatenated input and a 64-channel output, ragged depths; every sample compared."""
+    gen = torch.Generator().manual_seed(13)
+    for B, c0, c1, cout, shape in ((3, 32, 0, 32, (23, 25, 9)), (2, 32, 32, 32, (7, 25, 9)), (2, 32, 0, 64, (5, 14, 13)),
+                                   (2, 32, 0, 32, (11, 12, 17)), (3, 32, 0, 32, (28, 12, 21)), (2, 32, 32, 64, (6, 20, 18)),
+                                   (2, 64, 0, 32, (4, 16, 16)), (1, 32, 0, 32, (3, 8, 32))):
+        err = _conv_case(ops, gen, B, c0, c1, cout, shape, nb=None)
+        assert err < 2e-6, (B, c0, c1, cout, shape, err)
+
+
 def test_strip_conv_many_samples_every_sample_checked(ops):
     """Regression: with many workgroups in flight a staged plane was once converted before its loads had landed (the count
     of vector-memory operations the kernel's `s_waitcnt vmcnt(n)` relies on had been changed by the compiler): wrong rows in
