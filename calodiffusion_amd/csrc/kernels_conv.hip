@@ -2002,13 +2002,20 @@ __global__ void __launch_bounds__(256) conv_transpose_f16x2_kernel(ConvTArgs a) 
   const int T = a.KZ * 16;
   float* outb = a.out + (size_t)b * a.Do * a.Ho * a.Wo * a.cout;
 
-  for (int job = wave; job < ncls * njt; job += nw) {
-    const int cls = job / njt, jt = job % njt;
-    const int pz = cls >> 2, ph = (cls >> 1) & 1, pw = cls & 1;
+  // Work = (row tile jt, parity class cls).  With at least one tile per wave a wave takes tiles jt = wave, wave + nw, .. and runs all
+  // SZ x 4 classes on each: the tile's 32 class-space positions are decomposed once (four integer divisions by run-time values per
+  // lane) instead of once per class.  Tiles of fewer row tiles than waves (the deepest levels) spread (class, tile) pairs over the
+  // waves instead.
+  const bool tile_major = njt >= nw;
+  for (int item = wave; item < (tile_major ? njt : ncls * njt); item += nw) {
+    const int jt = tile_major ? item : item % njt;
     const int v = jt * 32 + col;
     const int c = v % a.Cw;
     const int t = v / a.Cw;
     const int bb = t % a.TH, aa = t / a.TH;
+  for (int ci = 0; ci < (tile_major ? ncls : 1); ++ci) {
+    const int cls = tile_major ? ci : item / njt;
+    const int pz = cls >> 2, ph = (cls >> 1) & 1, pw = cls & 1;
     const int oz = a.SZ * (a0 + aa) + pz, oh = 2 * (b0 + bb) + ph, ow = 2 * c + pw;
     const bool valid = (aa < a.TZ) && (oz < a.Do) && (oh < a.Ho) && (ow < a.Wo);
     if (!__any(valid)) continue;
@@ -2021,9 +2028,10 @@ __global__ void __launch_bounds__(256) conv_transpose_f16x2_kernel(ConvTArgs a) 
       for (int r = 0; r < 16; ++r) { accA[ct][r] = 0.f; accB[ct][r] = 0.f; }
 
     // The class's taps -- kz in {kz0, kz0 + SZ, ..}, two kh, two kw -- times the k-steps as ONE flat sequence of stages, software-
-    // pipelined two deep: the fragment (LDS) and weight (L2) loads of stage j + 1 are requested before the MFMAs of stage j.  (As
-    // nested loops every k-step waited for its own weight loads: an L2 round trip per 3 MFMAs.)  The last request repeats the last
-    // stage instead of being conditional: a conditional load in a pipelined loop costs a full vmcnt(0) per trip.
+    // pipelined over a ring of four: the fragment (LDS) and weight (L2) loads of stage j + 3 are requested before the MFMAs of
+    // stage j -- three stages = 9 MFMAs = ~300 cycles of cover for an L2 round trip.  (As nested loops every k-step waited for its
+    // own weight loads: a round trip per 3 MFMAs.)  Requests past the end repeat the last stage instead of being conditional: a
+    // conditional load in a pipelined loop costs a full vmcnt(0) per trip.
     const int kz0 = (pz + 1) % a.SZ, kh0 = (ph + 3) & 1, kw0 = (pw + 1) & 1;
     const int nkz = (a.KZ - kz0 + a.SZ - 1) / a.SZ;
     const int nstage = nkz * 4 * nks;
@@ -2062,16 +2070,26 @@ __global__ void __launch_bounds__(256) conv_transpose_f16x2_kernel(ConvTArgs a) 
         accB[ct] = MFMA_F16(st.x2, st.w[ct][0], accB[ct]);
       }
     };
-    Stage s0, s1;
+    Stage s0, s1, s2, s3;
     fetch(s0);
-    for (int j = 0; j < nstage; j += 2) {
-      fetch(s1);
+    fetch(s1);
+    fetch(s2);
+    for (int j = 0; j < nstage; j += 4) {
+      fetch(s3);
       __builtin_amdgcn_sched_barrier(0);
       mfmas(s0);
       __builtin_amdgcn_sched_barrier(0);
       fetch(s0);
       __builtin_amdgcn_sched_barrier(0);
       if (j + 1 < nstage) mfmas(s1);
+      __builtin_amdgcn_sched_barrier(0);
+      fetch(s1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (j + 2 < nstage) mfmas(s2);
+      __builtin_amdgcn_sched_barrier(0);
+      fetch(s2);
+      __builtin_amdgcn_sched_barrier(0);
+      if (j + 3 < nstage) mfmas(s3);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -2085,6 +2103,7 @@ __global__ void __launch_bounds__(256) conv_transpose_f16x2_kernel(ConvTArgs a) 
         }
       }
     }
+  }
   }
 }
 
