@@ -1821,6 +1821,7 @@ struct ConvTArgs {
   const u32x4* wpk16;    // f16x2 image [k-step][tap][ct][term][lane] (conv_transpose_f16x2_kernel)
   int* status;           // bit 0: a staged value exceeded the fp16 range
   const unsigned* in_absmax;  // power-of-two input rescaling (gradients: ConvFusion::in_absmax) or null
+  int tr_off = 0;             // (f16x2 kernel) float offset of the per-wave output transpose tiles behind the input tile
 };
 
 template <int CT>
@@ -2091,17 +2092,24 @@ __global__ void __launch_bounds__(256) conv_transpose_f16x2_kernel(ConvTArgs a) 
       __builtin_amdgcn_sched_barrier(0);
       if (j + 3 < nstage) mfmas(s3);
     }
+    // the tile's rows (output voxels of one parity class: 128 contiguous bytes each per channel tile) leave as 16-byte quads after
+    // a transpose through the wave's LDS tile (behind the input tile): row 8 k + (lane >> 3), channels 4 (lane & 7) .. + 3
+    float* tr = lds + a.tr_off + wave * (32 * 36);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-      const int off = __shfl(ooff, row, 64);
-      if (off >= 0) {
+    for (int ct = 0; ct < CT; ++ct) {
+      const float bv = a.bias ? a.bias[ct * 32 + col] : 0.f;
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-          const int co = ct * 32 + col;
-          outb[off + co] = (accA[ct][r] + accB[ct][r] * (1.f / 2048.f)) * ginv + (a.bias ? a.bias[co] : 0.f);
-        }
+      for (int r = 0; r < 16; ++r)
+        tr[((r & 3) + 8 * (r >> 2) + 4 * half) * 36 + col] = (accA[ct][r] + accB[ct][r] * (1.f / 2048.f)) * ginv + bv;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (one wave: its own LDS writes are visible to its reads in order)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int row = 8 * k + (lane >> 3);
+        const int off = __shfl(ooff, row, 64);
+        const f32x4 q = *(const f32x4*)(tr + row * 36 + (lane & 7) * 4);
+        if (off >= 0) *(f32x4*)(outb + off + ct * 32 + (lane & 7) * 4) = q;
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the tile buffer is reused)
     }
   }
   }
@@ -2142,7 +2150,7 @@ void launch_conv_transpose_mfma(const float* in, int cin, const float* wpk, cons
   for (int TZ = 1; TZ <= Az; ++TZ)
     for (int TH = 1; TH <= Bh; ++TH) {
       const size_t lds = ((size_t)(TZ + 2) * (TH + 2) * din.w + 1) * a.CS * 4;
-      if (lds > 150 * 1024) break;
+      if (lds > 140 * 1024) break;  // (+ 18 KB of output transpose tiles in the f16x2 kernel)
       if (TH != Bh && (Bh + TH - 1) / TH == (Bh + TH) / (TH + 1)) continue;  // a larger TH gives the same tile count
       if (TZ != Az && (Az + TZ - 1) / TZ == (Az + TZ) / (TZ + 1)) continue;
       const long nblocks = (long)batch * ((Az + TZ - 1) / TZ) * ((Bh + TH - 1) / TH);
@@ -2163,7 +2171,12 @@ void launch_conv_transpose_mfma(const float* in, int cin, const float* wpk, cons
     ConvTArgs b = a;
     b.TZ = t.tz; b.TH = t.th;
     b.nTZ = (Az + b.TZ - 1) / b.TZ; b.nTH = (Bh + b.TH - 1) / b.TH;
-    const size_t lds = ((size_t)(b.TZ + 2) * (b.TH + 2) * din.w + 1) * b.CS * 4;
+    size_t lds = ((size_t)(b.TZ + 2) * (b.TH + 2) * din.w + 1) * b.CS * 4;
+    if (b.wpk16) {  // four per-wave 32 x 36 float tiles behind the input tile (16-byte aligned)
+      lds = (lds + 15) & ~(size_t)15;
+      b.tr_off = (int)(lds / 4);
+      lds += 4 * 32 * 36 * 4;
+    }
     dim3 grid((unsigned)(batch * b.nTZ * b.nTH));
     switch (b.CTtot) {
       case 1: launch_convT_inst<1>(b, grid, lds, s); break;
