@@ -413,6 +413,7 @@ __global__ void __launch_bounds__(256) randn_kernel(float* __restrict__ out, int
 }
 void launch_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, hipStream_t s) {
   if (n <= 0) return;
+  prof::Scope scope("randn", s, 0, 4.0 * n);  // (a one-workgroup draw doubles as the profiler's own per-launch overhead: bench.py)
   int64_t blocks = (n / 4 + 256) / 256;
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(randn_kernel, dim3((unsigned)blocks), dim3(256), 0, s, out, n, seed, offset, (const uint64_t*)nullptr,
