@@ -221,6 +221,11 @@ struct PointwiseArgs {
   // shortcut tensor is never written and the block's own elementwise pass (gn_apply) never runs.  `out` may be gn_res itself.
   const float* gn_res = nullptr;
   GnDefer gn_defer;
+  // f16x2 image of the weights ([k-step][cout tile][w1 | w2'] as the conv kernels hold them; shared weights only): with prologue
+  // A_NONE the products run on the fp16 pipe -- two-term splits, 3 x 32-cycle MFMAs per 16 channels instead of 8 x 64-cycle fp32
+  // ones -- in fp16 RANGE: an input beyond it sets bit 0 of *status (the caller's range fallback re-runs at full range, wpk16 = null)
+  const void* wpk16 = nullptr;
+  int* status = nullptr;
 };
 inline int pointwise_units(int64_t vox) { return (int)((vox + 127) / 128); }
 void launch_pointwise(const PointwiseArgs& a, hipStream_t s);

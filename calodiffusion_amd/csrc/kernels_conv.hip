@@ -2246,6 +2246,50 @@ __global__ void __launch_bounds__(256) pointwise_kernel(PointwiseArgs a, int CTt
 
   const int nchunk = (a.c0 + a.c1) >> 5;
   const float* wb = a.wpk + (size_t)b * a.w_batch_stride;
+  if (PRO == A_NONE && a.wpk16) {
+    // fp16 pipe.  The lane keeps the f32 path's loads -- its voxel's channels 16 half .. 16 half + 15 of the chunk, 64 contiguous
+    // bytes -- and runs them as two k-steps of 8: k-slot (half, j) of k-step s' is channel 16 half + 8 s' + j, which in the packed
+    // image (k-step s: slot (h, j) = channel 16 s + 8 h + j) is what lane (h = s', col) of k-step s = half holds -- the same image,
+    // another lane's entry.
+    f32x16 accB[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accB[ct][r] = 0.f;
+    float amax = 0.f;
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+      const float* src;
+      if (chunk * 32 < a.c0) src = a.in0 + ((size_t)b * a.vox + (valid ? n : 0)) * a.ld0 + a.off0 + chunk * 32 + half * 16;
+      else src = a.in1 + ((size_t)b * a.vox + (valid ? n : 0)) * a.ld1 + (chunk * 32 - a.c0) + half * 16;
+      f32x4 av[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        av[q] = *(const f32x4*)(src + q * 4);
+        if (!valid) av[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        amax = fmaxf(fmaxf(fmaxf(amax, fabsf(av[q][0])), fabsf(av[q][1])), fmaxf(fabsf(av[q][2]), fabsf(av[q][3])));
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        u32x2 h0, l0, h1, l1;
+        split2(av[2 * ks], h0, l0);
+        split2(av[2 * ks + 1], h1, l1);
+        const u32x4 a1 = {h0[0], h0[1], h1[0], h1[1]}, a2 = {l0[0], l0[1], l1[0], l1[1]};
+        const u32x4* wp = (const u32x4*)a.wpk16 + ((size_t)(chunk * 2 + half) * CTtot + ct0) * 128 + ks * 32 + col;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          const u32x4 w1 = wp[ct * 128], w2 = wp[ct * 128 + 64];
+          acc[ct] = MFMA_F16(a1, w1, acc[ct]);
+          accB[ct] = MFMA_F16(a1, w2, accB[ct]);
+          accB[ct] = MFMA_F16(a2, w1, accB[ct]);
+        }
+      }
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ct][r] += accB[ct][r] * (1.f / 2048.f);
+    if (a.status && amax > 65504.f) atomicOr(a.status, 1);
+  } else
   for (int chunk = 0; chunk < nchunk; ++chunk) {
     const float* src;
     if (chunk * 32 < a.c0) src = a.in0 + ((size_t)b * a.vox + (valid ? n : 0)) * a.ld0 + a.off0 + chunk * 32 + half * 16;
@@ -2415,6 +2459,8 @@ void launch_pointwise(const PointwiseArgs& a, hipStream_t s) {
   CD_REQUIRE(!a.gn_res || (a.gn_defer.part && a.gn_defer.C == a.cout && a.cout <= 128 && !a.out_ld),
              "pointwise conv: the fused block close normalises a packed tensor of the output's width (<= 128 channels)");
   CD_REQUIRE(a.out_off % 4 == 0 && a.out_ld % 4 == 0 && (a.cout % 4 == 0 || a.out_ld), "pointwise conv: output rows must be 16-byte aligned");
+  CD_REQUIRE(!a.wpk16 || (a.prologue == A_NONE && !a.w_batch_stride && a.cout % 32 == 0),
+             "pointwise conv: the fp16-pipe form takes shared weights, whole 32-channel tiles and no input prologue");
   const int CTtot = (a.cout + 31) / 32;
   const int CT = CTtot <= 3 ? CTtot : (CTtot % 2 == 0 ? 2 : 1);
   dim3 grid((unsigned)((a.vox + 127) / 128), (unsigned)a.batch, (unsigned)(CTtot / CT));

@@ -414,6 +414,7 @@ struct ResP {
   const void *c1w3 = nullptr, *c2w3 = nullptr;  // split-bf16 images of the two 3x3x3 convs
   const float *c2w = nullptr, *c2b = nullptr, *n2g = nullptr, *n2b = nullptr;
   const float *rw = nullptr, *rb = nullptr;
+  const void* rw16 = nullptr;  // f16x2 image of the 1x1 shortcut conv
   const float* emb = nullptr;  // (B, emb_ld) slice for this block, or null
   int emb_ld = 0;
 };
@@ -429,7 +430,10 @@ ResP resolve(const CdPlan* p, const ResW& w, const float* emb) {
   r.c1w3 = p->packed3(w.c1w); r.c2w3 = p->packed3(w.c2w);
   r.c1w = p->packed(w.c1w); r.c1b = p->raw(w.c1b); r.n1g = p->raw(w.n1g); r.n1b = p->raw(w.n1b);
   r.c2w = p->packed(w.c2w); r.c2b = p->raw(w.c2b); r.n2g = p->raw(w.n2g); r.n2b = p->raw(w.n2b);
-  if (w.has_res) { r.rw = p->packed(w.rw); r.rb = p->raw(w.rb); }
+  if (w.has_res) {
+    r.rw = p->packed(w.rw); r.rb = p->raw(w.rb);
+    if (p->packed3(w.rw)) r.rw16 = (const char*)p->packed3(w.rw) + packed_bf16x3_bytes(w.cin, w.cout, 1);
+  }
   if (w.has_mlp && emb) { r.emb = emb + w.emb_off; r.emb_ld = p->emb_ld; }
   return r;
 }
@@ -534,6 +538,7 @@ float* res_block(Run& r, const ResP& w, const float* x0, int c0, const float* x1
       PointwiseArgs a;
       a.in0 = x0; a.ld0 = c0; a.off0 = 0; a.c0 = c0; a.in1 = x1; a.ld1 = c1; a.c1 = c1;
       a.wpk = w.rw; a.bias = w.rb; a.out = close ? h2 : res; a.batch = r.B; a.cout = w.cout; a.vox = vox;
+      if (conv_precision() == PREC_F16X2 && !getenv("CD_PW_F32")) { a.wpk16 = w.rw16; a.status = r.status; }  // (fp16 pipe, under the range fallback)
       if (close) { a.gn_res = h2; a.gn_defer = *close; a.ch_part = po; }
       launch_pointwise(a, r.s);
     }
