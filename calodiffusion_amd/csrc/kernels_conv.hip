@@ -873,7 +873,16 @@ __global__ void __launch_bounds__(512, (VT * CT * (NTERM == 2 ? 2 : 1) <= 2 ? 3 
 
     const u32x4* wq = (const u32x4*)a.wpk + ((size_t)sc * T * a.CTtot + ct0) * WS + lane;
     // Register rings: weight fragments (L1/L2) are requested WD taps ahead, LDS fragments AD taps ahead.
-    constexpr int WD = 1, AD = 1;  // deeper rings were measured: they cost occupancy (VGPRs) and gain nothing
+#ifndef CD_FLAT_WD
+#define CD_FLAT_WD 3
+#endif
+#ifndef CD_FLAT_AD
+#define CD_FLAT_AD 2
+#endif
+    // Measured again in round 3 (same box, alternating runs): WD 1 / AD 1 -> 3 / 2 takes the strided 32->32 conv from 48.8 to 41.8 us
+    // and the 128->32 conv at 23x8x4 from 46.9 to 41.3 us (one tap of cover = 3 VT CT MFMAs is less than an L2 round trip for the
+    // narrow tilings), -2 % on the Dataset-2 step, -4 % on HGCal; 4 / 2 the same, 5 / 3 slower (registers).
+    constexpr int WD = CD_FLAT_WD, AD = CD_FLAT_AD;
     u32x4 bw[WD + 1][CT][NTERM], av[AD + 1][VT][NTERM];
     auto load_w = [&](int tap) {
 #pragma unroll
