@@ -35,8 +35,8 @@ namespace {
 constexpr int DC_THREADS = 256;
 constexpr int DC_NW = 4;    // one wave per SIMD
 template <int NT>
-struct DcRing {  // weight fragments requested this many pairs ahead (4 row tiles leave fewer registers)
-  static constexpr int PD = NT >= 4 ? 4 : 6;
+struct DcRing {  // weight fragments requested this many pairs ahead (even).  Measured at 12x4x2 (three row tiles): 2 / 4 / 6 / 8 / 10
+  static constexpr int PD = 4;  // pairs = 208.8 / 201.7 / 208.2 / 209 / 216 us per launch -- deeper rings only cost registers
 };
 constexpr int DC_VB = 272;  // bytes per image record: 64 channels x (2 + 2) B + 16 B pad (conflict-free ds_read_b128)
 
