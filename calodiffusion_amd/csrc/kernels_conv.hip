@@ -882,7 +882,10 @@ __global__ void __launch_bounds__(512, (VT * CT * (NTERM == 2 ? 2 : 1) <= 2 ? 3 
     // Measured again in round 3 (same box, alternating runs): WD 1 / AD 1 -> 3 / 2 takes the strided 32->32 conv from 48.8 to 41.8 us
     // and the 128->32 conv at 23x8x4 from 46.9 to 41.3 us (one tap of cover = 3 VT CT MFMAs is less than an L2 round trip for the
     // narrow tilings), -2 % on the Dataset-2 step, -4 % on HGCal; 4 / 2 the same, 5 / 3 slower (registers).
-    constexpr int WD = CD_FLAT_WD, AD = CD_FLAT_AD;
+    // (the f16x2 arm only: the three-term bf16 arm spills hundreds of registers with the deeper rings and keeps one tap of cover;
+    // restricting them to the narrow f16x2 tilings as well was measured 0.8 % slower on the Dataset-2 step)
+    constexpr bool DEEP = NTERM == 2;
+    constexpr int WD = DEEP ? CD_FLAT_WD : 1, AD = DEEP ? CD_FLAT_AD : 1;
     u32x4 bw[WD + 1][CT][NTERM], av[AD + 1][VT][NTERM];
     auto load_w = [&](int tap) {
 #pragma unroll
