@@ -1385,51 +1385,68 @@ __global__ void __launch_bounds__(512, (VT * CT * (NTERM == 2 ? 2 : 1) <= 2 ? 3 
       for (int e = 0; e < 4; ++e) cf[e] = *(const f32x4*)(a.coef + ((size_t)b * (a.c0 + a.c1) + sc * 16 + pq * 4 + e) * 4);
     }
     __syncthreads();
-    for (int i0 = tid; i0 < items; i0 += 4 * nthreads) {
-      f32x4 val[4];
+    // a thread keeps its channel quad (pq) and walks the tile's voxels in steps of nthreads / 4, four voxels per trip with their loads
+    // in flight together; each voxel's (iw, ih, iz) advances by one trip's stride with carries -- five integer divisions by
+    // run-time values per item (~40 instructions each) were most of this loop
+    {
+      const int vq = nthreads >> 2;          // voxels between a thread's slots
+      int viw[4], vih[4], viz[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const int idx = i0 + k * nthreads;
-        val[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (idx < items) {
-          const int vox = idx >> 2;
-          const int iw = vox % a.Win;
-          const int r = vox / a.Win;
-          const int ih = r % a.IH, iz = r / a.IH;
-          const int gz = gz0 + iz;
-          int gh = (gh0 + ih) % a.Hin;
-          if (gh < 0) gh += a.Hin;
-          if (gz >= 0 && gz < a.Din) {
-            val[k] = *(const f32x4*)(src + ((size_t)(gz * a.Hin + gh) * a.Win + iw) * ldc);
-            if (a.coef) {
+        const int vox = (tid >> 2) + k * vq;
+        viw[k] = vox % a.Win;
+        const int r = vox / a.Win;
+        vih[k] = r % a.IH;
+        viz[k] = r / a.IH;
+      }
+      const int DW = nthreads % a.Win, dr = nthreads / a.Win, DH = dr % a.IH, DZ = dr / a.IH;  // one trip = nthreads voxels on
+      for (int i0 = tid; i0 < items; i0 += 4 * nthreads) {
+        f32x4 val[4];
 #pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                float t = cf[e][0] * val[k][e] + cf[e][1];
-                if (a.act) t = cd_fast_silu(t);
-                val[k][e] = t + cf[e][2];
+        for (int k = 0; k < 4; ++k) {
+          const int idx = i0 + k * nthreads;
+          val[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (idx < items) {
+            const int gz = gz0 + viz[k];
+            int gh = gh0 + vih[k];  // (circular in phi: gh0 >= -1, the tile's rows reach at most Hin - 1 + its halo)
+            gh = gh < 0 ? gh + a.Hin : gh;
+            gh = gh >= a.Hin ? gh - a.Hin : gh;
+            gh = gh >= a.Hin ? gh - a.Hin : gh;
+            if (gz >= 0 && gz < a.Din) {
+              val[k] = *(const f32x4*)(src + ((size_t)(gz * a.Hin + gh) * a.Win + viw[k]) * ldc);
+              if (a.coef) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  float t = cf[e][0] * val[k][e] + cf[e][1];
+                  if (a.act) t = cd_fast_silu(t);
+                  val[k][e] = t + cf[e][2];
+                }
               }
             }
           }
         }
-      }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int idx = i0 + k * nthreads;
-        if (idx < items) {
-          char* d = ldsb + (size_t)(idx >> 2) * VB + pq * 8;
-          if (NTERM == 3) {
-            u32x2 t1, t2, t3;
-            split3(val[k], t1, t2, t3);
-            *(u32x2*)d = t1;
-            *(u32x2*)(d + 32) = t2;
-            *(u32x2*)(d + 64) = t3;
-          } else {
-            amax = fmaxf(amax, fmaxf(fmaxf(fabsf(val[k][0]), fabsf(val[k][1])), fmaxf(fabsf(val[k][2]), fabsf(val[k][3]))));
-            u32x2 t1, t2;
-            split2(val[k], t1, t2);
-            *(u32x2*)d = t1;
-            *(u32x2*)(d + 32) = t2;
+        for (int k = 0; k < 4; ++k) {
+          const int idx = i0 + k * nthreads;
+          if (idx < items) {
+            char* d = ldsb + (size_t)(idx >> 2) * VB + pq * 8;
+            if (NTERM == 3) {
+              u32x2 t1, t2, t3;
+              split3(val[k], t1, t2, t3);
+              *(u32x2*)d = t1;
+              *(u32x2*)(d + 32) = t2;
+              *(u32x2*)(d + 64) = t3;
+            } else {
+              amax = fmaxf(amax, fmaxf(fmaxf(fabsf(val[k][0]), fabsf(val[k][1])), fmaxf(fabsf(val[k][2]), fabsf(val[k][3]))));
+              u32x2 t1, t2;
+              split2(val[k], t1, t2);
+              *(u32x2*)d = t1;
+              *(u32x2*)(d + 32) = t2;
+            }
           }
+          viw[k] += DW; vih[k] += DH; viz[k] += DZ;
+          if (viw[k] >= a.Win) { viw[k] -= a.Win; vih[k] += 1; }
+          if (vih[k] >= a.IH) { vih[k] -= a.IH; viz[k] += 1; }
         }
       }
     }
@@ -1437,42 +1454,60 @@ __global__ void __launch_bounds__(512, (VT * CT * (NTERM == 2 ? 2 : 1) <= 2 ? 3 
     if (!wave_active) continue;
 
     const u32x4* wq = (const u32x4*)a.wpk + ((size_t)sc * T * a.CTtot + ct0) * WS + lane;
-    for (int kd = 0; kd < a.KD; ++kd) {
-      for (int kh = 0; kh < a.KH; ++kh) {
-        const int rowoff = (kd * a.IH + kh) * a.Win * VB;
-        for (int kw = 0; kw < a.KW; ++kw) {
-          const int tap = (kd * a.KH + kh) * a.KW + kw;
-          u32x4 bw[CT][NTERM];
+    // The taps as one flat sequence, software-pipelined over a ring of three weight sets: the (L2) weight loads of tap t + 2 are
+    // requested before the MFMAs of tap t.  (Loaded inside the tap they were an L2 round trip per VT x CT MFMA blocks.)  Requests
+    // past the end repeat the last tap instead of being conditional.
+    u32x4 bw0[CT][NTERM], bw1[CT][NTERM], bw2[CT][NTERM];
+    auto loadw = [&](u32x4 (&bw)[CT][NTERM], int tap) {
+      const int tc = min(tap, T - 1);
 #pragma unroll
-          for (int ct = 0; ct < CT; ++ct)
+      for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-            for (int t = 0; t < NTERM; ++t) bw[ct][t] = wq[((size_t)tap * a.CTtot + ct) * WS + t * 64];
+        for (int t = 0; t < NTERM; ++t) bw[ct][t] = wq[((size_t)tc * a.CTtot + ct) * WS + t * 64];
+    };
+    int kd = 0, kh = 0, kw = 0;  // of the tap whose MFMAs run next
+    auto run_tap = [&](const u32x4 (&bw)[CT][NTERM]) {
+      const int rowoff = (kd * a.IH + kh) * a.Win * VB;
 #pragma unroll
-          for (int vt = 0; vt < VT; ++vt) {
-            const int off = ((wmask[vt] >> kw) & 1u) ? abase[vt] + rowoff + kw * VB : ZERO + half * 16;
-            u32x4 av[NTERM];
+      for (int vt = 0; vt < VT; ++vt) {
+        const int off = ((wmask[vt] >> kw) & 1u) ? abase[vt] + rowoff + kw * VB : ZERO + half * 16;
+        u32x4 av[NTERM];
 #pragma unroll
-            for (int t = 0; t < NTERM; ++t) av[t] = *(const u32x4*)(ldsb + off + t * 32);
+        for (int t = 0; t < NTERM; ++t) av[t] = *(const u32x4*)(ldsb + off + t * 32);
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-              if (NTERM == 3) {
-                f32x16 c = acc[vt][ct];
-                c = MFMA_BF16(av[2], bw[ct][0], c);
-                c = MFMA_BF16(av[NTERM - 2], bw[ct][NTERM - 2], c);
-                c = MFMA_BF16(av[0], bw[ct][NTERM - 1], c);
-                c = MFMA_BF16(av[NTERM - 2], bw[ct][0], c);
-                c = MFMA_BF16(av[0], bw[ct][NTERM - 2], c);
-                c = MFMA_BF16(av[0], bw[ct][0], c);
-                acc[vt][ct] = c;
-              } else {
-                acc[vt][ct] = MFMA_F16(av[0], bw[ct][0], acc[vt][ct]);
-                accB[vt][ct] = MFMA_F16(av[0], bw[ct][NTERM - 1], accB[vt][ct]);
-                accB[vt][ct] = MFMA_F16(av[NTERM - 1], bw[ct][0], accB[vt][ct]);
-              }
-            }
+        for (int ct = 0; ct < CT; ++ct) {
+          if (NTERM == 3) {
+            f32x16 c = acc[vt][ct];
+            c = MFMA_BF16(av[2], bw[ct][0], c);
+            c = MFMA_BF16(av[NTERM - 2], bw[ct][NTERM - 2], c);
+            c = MFMA_BF16(av[0], bw[ct][NTERM - 1], c);
+            c = MFMA_BF16(av[NTERM - 2], bw[ct][0], c);
+            c = MFMA_BF16(av[0], bw[ct][NTERM - 2], c);
+            c = MFMA_BF16(av[0], bw[ct][0], c);
+            acc[vt][ct] = c;
+          } else {
+            acc[vt][ct] = MFMA_F16(av[0], bw[ct][0], acc[vt][ct]);
+            accB[vt][ct] = MFMA_F16(av[0], bw[ct][NTERM - 1], accB[vt][ct]);
+            accB[vt][ct] = MFMA_F16(av[NTERM - 1], bw[ct][0], accB[vt][ct]);
           }
         }
       }
+      if (++kw == a.KW) { kw = 0; if (++kh == a.KH) { kh = 0; ++kd; } }
+    };
+    loadw(bw0, 0);
+    loadw(bw1, 1);
+    for (int tap = 0; tap < T; tap += 3) {
+      loadw(bw2, tap + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      run_tap(bw0);
+      __builtin_amdgcn_sched_barrier(0);
+      loadw(bw0, tap + 3);
+      __builtin_amdgcn_sched_barrier(0);
+      if (tap + 1 < T) run_tap(bw1);
+      __builtin_amdgcn_sched_barrier(0);
+      loadw(bw1, tap + 4);
+      __builtin_amdgcn_sched_barrier(0);
+      if (tap + 2 < T) run_tap(bw2);
     }
   }
 
