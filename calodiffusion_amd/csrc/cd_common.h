@@ -283,8 +283,10 @@ void launch_ksoftmax_bwd(const float* qkv, const float* dks, const float* kstat,
 void launch_pack_sample32(const float* m, float* wpk, int batch, bool transpose, float scale, hipStream_t s);
 int head_bwd_blocks(int batch, int64_t vox);
 // loss_type (here and below): CD_LOSS_* of calodiff.h -- 0 l2 (hybrid weight), 1 l1, 2 mse, 3 huber (models/loss.py:97-116)
-void launch_head_loss_bwd(const float* x0, const float* data, const float* scal, const float* h, const float* wh, float* dh,
-                          float* part, float* dwh, float* dbh, int batch, int64_t vox, hipStream_t s, int loss_type = 0);
+// objective: CD_OBJ_* (objective_residual / objective_weight below); noise is only read for noise_pred
+void launch_head_loss_bwd(const float* x0, const float* data, const float* noise, const float* scal, const float* h, const float* wh,
+                          float* dh, float* part, float* dwh, float* dbh, int batch, int64_t vox, hipStream_t s, int loss_type = 0,
+                          int objective = 0);
 struct LinearWgradJob {
   const float* delta;  // (B, delta_ld) rows, nout used
   const float* in;     // (B, in_ld) rows, nin used
@@ -450,14 +452,38 @@ void launch_fill_from_table(float* dst, int count, const float* table, int ncol,
 // out[i] = sum_k table[row][col + k] * src[k][i]   (nsrc <= 6; out may alias a source)
 void launch_lincomb(float* out, const float* const* src, int nsrc, const float* table, int ncol, int col, const int* step_counter,
                     int64_t n, hipStream_t s);
+void launch_lincomb_div(float* out, const float* const* src, int nsrc, const float* table, int ncol, int col, const int* step_counter,
+                    int64_t n, hipStream_t s);
 // traj[(*step_counter - 1) * n + i] = src[i]
 void launch_record_step(float* traj, const float* src, const int* step_counter, int64_t n, hipStream_t s);
 void launch_axpy_sigma(const float* data, const float* noise, const float* sigma_b, float* out, int batch, int64_t per,
                        hipStream_t s);
-void launch_loss_partial(const float* x0, const float* data, const float* sigma_b, double* partial, int batch,
-                         int64_t per, hipStream_t s, int loss_type = 0);
+// The training objectives of models/loss.py on top of the denoiser's output `out` (calodiffusion.py:161-169), objective =
+// CD_OBJ_*:  what the loss compares, its per-sample weight (used by 'l2' only) and d pred / d F for the backward pass
+//   0 hybrid_weight (:163-179)  pred = out = c_skip x + c_out F        target = data    w = 1 + sigma^-2   dpred/dF = c_out
+//   1 noise_pred    (:181-196)  pred = (data - (data - sigma out)) / sigma, out = x - sigma F   target = noise   w = 1   dpred/dF = -sigma
+//   2 mean_pred     (:198-210)  pred = out = F                         target = data    w = sigma^-2       dpred/dF = 1
+// (noise_pred's round trip through x0_pred is evaluated as written, product / difference / quotient each rounded on its own)
+__device__ __forceinline__ float objective_residual(int objective, float out, float data, float noise, float sigma) {
+#pragma clang fp contract(off)
+  if (objective == 1) {
+    const float so = sigma * out;
+    const float x0p = data - so;
+    const float num = data - x0p;
+    const float pred = num / sigma;
+    return pred - noise;
+  }
+  return out - data;
+}
+__device__ __forceinline__ float objective_weight(int objective, int loss_type, float sg) {
+  if (loss_type != 0 || objective == 1) return 1.0f;
+  return objective == 0 ? 1.0f + 1.0f / (sg * sg) : 1.0f / (sg * sg);
+}
+
+void launch_loss_partial(const float* x0, const float* data, const float* noise, const float* sigma_b, double* partial, int batch,
+                         int64_t per, hipStream_t s, int loss_type = 0, int objective = 0);
 void launch_loss_final(const double* partial, const float* sigma_b, double* loss, int batch, int64_t per, hipStream_t s,
-                       int loss_type = 0);
+                       int loss_type = 0, int objective = 0);
 void launch_transpose_to_cl(const float* ncdhw, float* ndhwc, int batch, int channels, int64_t vox, hipStream_t s);
 void launch_transpose_to_planar(const float* ndhwc, float* ncdhw, int batch, int channels, int64_t vox, hipStream_t s);
 

@@ -856,9 +856,11 @@ void launch_pack_sample32(const float* m, float* wpk, int batch, bool transpose,
 // part: [blocks][33] partial sums (32 weights + bias)
 // ------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) head_loss_bwd_kernel(const float* __restrict__ x0, const float* __restrict__ data,
+                                                            const float* __restrict__ noise,
                                                             const float* __restrict__ scal, const float* __restrict__ h,
                                                             const float* __restrict__ wh, float* __restrict__ dh,
-                                                            float* __restrict__ part, int batch, int64_t vox, int loss_type) {
+                                                            float* __restrict__ part, int batch, int64_t vox, int loss_type,
+                                                            int objective) {
   __shared__ float sW[32];
   __shared__ float sAcc[8][33];
   __shared__ float sNorm;
@@ -867,8 +869,7 @@ __global__ void __launch_bounds__(256) head_loss_bwd_kernel(const float* __restr
   if (tid == 0) {
     double wsum = 0.0;
     for (int b = 0; b < batch; ++b) {
-      const float sg = scal[b * 4 + 3];
-      wsum += (double)(1.0f + 1.0f / (sg * sg));
+      wsum += (double)objective_weight(objective, 0, scal[b * 4 + 3]);
     }
     // d loss / d x0 = sNorm * w_b * f'(d):  l2: 2 w d / (mean(w) N);  mse: 2 d / N;  l1: sign(d) / N;  huber: clamp(d, -1, 1) / N
     sNorm = loss_type == 0 ? (float)(2.0 / ((wsum / batch) * (double)batch * (double)vox))
@@ -881,10 +882,12 @@ __global__ void __launch_bounds__(256) head_loss_bwd_kernel(const float* __restr
   for (int64_t i = (int64_t)blockIdx.x * 32 + grp; i < total; i += (int64_t)gridDim.x * 32) {
     const int b = (int)(i / vox);
     const float sg = scal[b * 4 + 3];
-    const float dd = x0[i] - data[i];
+    const float dd = objective_residual(objective, x0[i], data[i], objective == 1 ? noise[i] : 0.f, sg);
     const float fp = loss_type == 1 ? (dd > 0.f ? 1.f : (dd < 0.f ? -1.f : 0.f))
                                     : (loss_type == 3 ? fminf(fmaxf(dd, -1.f), 1.f) : dd);
-    const float dF = sNorm * (loss_type == 0 ? 1.0f + 1.0f / (sg * sg) : 1.0f) * fp * scal[b * 4 + 2];
+    // d pred / d F: c_out (hybrid), -sigma (noise_pred: out = x - sigma F and pred ~ out), 1 (mean_pred)
+    const float chain = objective == 0 ? scal[b * 4 + 2] : (objective == 1 ? -sg : 1.0f);
+    const float dF = sNorm * objective_weight(objective, loss_type, sg) * fp * chain;
     const f32x4 hv = *(const f32x4*)(h + (size_t)i * 32 + sub * 4);
     f32x4 o;
 #pragma unroll
@@ -942,10 +945,12 @@ int head_bwd_blocks(int batch, int64_t vox) {
   int64_t n = ((int64_t)batch * vox + 255) / 256;
   return (int)(n > 1024 ? 1024 : (n < 1 ? 1 : n));
 }
-void launch_head_loss_bwd(const float* x0, const float* data, const float* scal, const float* h, const float* wh, float* dh,
-                          float* part, float* dwh, float* dbh, int batch, int64_t vox, hipStream_t s, int loss_type) {
+void launch_head_loss_bwd(const float* x0, const float* data, const float* noise, const float* scal, const float* h, const float* wh,
+                          float* dh, float* part, float* dwh, float* dbh, int batch, int64_t vox, hipStream_t s, int loss_type,
+                          int objective) {
   const int nb = head_bwd_blocks(batch, vox);
-  hipLaunchKernelGGL(head_loss_bwd_kernel, dim3(nb), dim3(256), 0, s, x0, data, scal, h, wh, dh, part, batch, vox, loss_type);
+  hipLaunchKernelGGL(head_loss_bwd_kernel, dim3(nb), dim3(256), 0, s, x0, data, noise, scal, h, wh, dh, part, batch, vox, loss_type,
+                     objective);
   hipLaunchKernelGGL(head_grad_reduce_kernel, dim3(1), dim3(256), 0, s, part, nb, dwh, dbh);
   CD_HIP(hipGetLastError());
 }

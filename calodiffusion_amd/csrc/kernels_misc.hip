@@ -478,6 +478,42 @@ void launch_lincomb(float* out, const float* const* src, int nsrc, const float* 
   hipLaunchKernelGGL(lincomb_kernel, dim3((unsigned)blocks), dim3(256), 0, s, out, ls, nsrc, table, ncol, col, step_counter, n);
   CD_HIP(hipGetLastError());
 }
+// The same in the operation order of a chain of torch elementwise kernels (CD_SOP_LINDIV): every product and every sum is
+// rounded to fp32 on its own (no contraction into fused multiply-adds), the terms are added left to right and the result is
+// divided (IEEE, correctly rounded) by the coefficient that follows the terms.  DPM-Solver's second- and third-order steps
+// amplify the rounding of their intermediate states by sigma_max / sigma_mid (utils/sampling.py:419-456), so matching the
+// reference there means rounding where it rounds.
+__global__ void __launch_bounds__(256) lincomb_div_kernel(float* out, LincombSrc src, int nsrc, const float* __restrict__ table,
+                                                          int ncol, int col, const int* __restrict__ counter, int64_t n) {
+#pragma clang fp contract(off)
+  float c[6];
+  const float* row = table + (size_t)(*counter - 1) * ncol + col;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) c[k] = k < nsrc ? row[k] : 0.f;
+  const float div = row[nsrc];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    // (plain operators: the pragma above governs them, while the __f*_rn helpers of the HIP headers carry the contraction
+    // flags of the translation unit and come out as v_fmac)
+    float acc = c[0] * src.p[0][i];
+#pragma unroll
+    for (int k = 1; k < 6; ++k)
+      if (k < nsrc) {
+        const float prod = c[k] * src.p[k][i];
+        acc = acc + prod;
+      }
+    out[i] = acc / div;
+  }
+}
+void launch_lincomb_div(float* out, const float* const* src, int nsrc, const float* table, int ncol, int col,
+                        const int* step_counter, int64_t n, hipStream_t s) {
+  CD_REQUIRE(nsrc >= 1 && nsrc <= 6, "lincomb: 1..6 terms");
+  LincombSrc ls{};
+  for (int k = 0; k < 6; ++k) ls.p[k] = src[k < nsrc ? k : 0];
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(lincomb_div_kernel, dim3((unsigned)blocks), dim3(256), 0, s, out, ls, nsrc, table, ncol, col, step_counter, n);
+  CD_HIP(hipGetLastError());
+}
 __global__ void __launch_bounds__(256) record_step_kernel(float* __restrict__ traj, const float* __restrict__ src,
                                                           const int* __restrict__ counter, int64_t n) {
   float* dst = traj + (size_t)(*counter - 1) * n;
@@ -509,17 +545,18 @@ void launch_axpy_sigma(const float* data, const float* noise, const float* sigma
   CD_HIP(hipGetLastError());
 }
 
-// partial[b] = sum_i (x0 - data)^2 over sample b (fp64), one block per sample
-// per-sample sum of the element loss of Loss._loss (models/loss.py:97-116): 0 'l2' and 2 'mse': d^2; 1 'l1': |d|;
-// 3 'huber' = torch smooth_l1_loss, beta 1: d^2 / 2 below |d| = 1, |d| - 1/2 above
+// per-sample sum of the element loss of Loss._loss (models/loss.py:97-116) in fp64, one block per sample: 0 'l2' and 2 'mse':
+// d^2; 1 'l1': |d|; 3 'huber' = torch smooth_l1_loss, beta 1: d^2 / 2 below |d| = 1, |d| - 1/2 above
 __global__ void __launch_bounds__(256) loss_partial_kernel(const float* __restrict__ x0, const float* __restrict__ data,
-                                                           double* __restrict__ partial, int64_t per, int loss_type) {
+                                                           const float* __restrict__ noise, const float* __restrict__ sigma_b,
+                                                           double* __restrict__ partial, int64_t per, int loss_type, int objective) {
   __shared__ double sh[256];
   const int b = blockIdx.x, tid = threadIdx.x;
   const size_t base = (size_t)b * per;
+  const float sg = sigma_b[b];
   double acc = 0.0;
   for (int64_t i = tid; i < per; i += 256) {
-    const float d = x0[base + i] - data[base + i];
+    const float d = objective_residual(objective, x0[base + i], data[base + i], objective == 1 ? noise[base + i] : 0.f, sg);
     const float ad = fabsf(d);
     const float e = loss_type == 1 ? ad : (loss_type == 3 ? (ad < 1.f ? 0.5f * d * d : ad - 0.5f) : d * d);
     acc += (double)e;
@@ -532,21 +569,19 @@ __global__ void __launch_bounds__(256) loss_partial_kernel(const float* __restri
   }
   if (tid == 0) partial[b] = sh[0];
 }
-void launch_loss_partial(const float* x0, const float* data, const float* sigma_b, double* partial, int batch, int64_t per,
-                         hipStream_t s, int loss_type) {
-  (void)sigma_b;
-  hipLaunchKernelGGL(loss_partial_kernel, dim3(batch), dim3(256), 0, s, x0, data, partial, per, loss_type);
+void launch_loss_partial(const float* x0, const float* data, const float* noise, const float* sigma_b, double* partial, int batch,
+                         int64_t per, hipStream_t s, int loss_type, int objective) {
+  hipLaunchKernelGGL(loss_partial_kernel, dim3(batch), dim3(256), 0, s, x0, data, noise, sigma_b, partial, per, loss_type, objective);
   CD_HIP(hipGetLastError());
 }
-// loss = sum_b w_b * partial[b] / (mean_b(w_b) * B * per),  w_b = 1 + 1/sigma_b^2
-// (only 'l2' carries the hybrid weight; the torch.nn.functional losses of the other types are plain means, loss.py:106-111)
+// loss = sum_b w_b * partial[b] / (mean_b(w_b) * B * per)
+// (only 'l2' carries the weight; the torch.nn.functional losses of the other types are plain means, loss.py:106-111)
 __global__ void loss_final_kernel(const double* __restrict__ partial, const float* __restrict__ sigma_b, double* loss,
-                                  int batch, int64_t per, int loss_type) {
+                                  int batch, int64_t per, int loss_type, int objective) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     double num = 0.0, wsum = 0.0;
     for (int b = 0; b < batch; ++b) {
-      const float sg = sigma_b[b];
-      const float w = loss_type == 0 ? 1.0f + 1.0f / (sg * sg) : 1.0f;
+      const float w = objective_weight(objective, loss_type, sigma_b[b]);
       num += (double)w * partial[b];
       wsum += (double)w;
     }
@@ -554,8 +589,8 @@ __global__ void loss_final_kernel(const double* __restrict__ partial, const floa
   }
 }
 void launch_loss_final(const double* partial, const float* sigma_b, double* loss, int batch, int64_t per, hipStream_t s,
-                       int loss_type) {
-  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, s, partial, sigma_b, loss, batch, per, loss_type);
+                       int loss_type, int objective) {
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, s, partial, sigma_b, loss, batch, per, loss_type, objective);
   CD_HIP(hipGetLastError());
 }
 
@@ -639,7 +674,7 @@ void launch_adam(const AdamChunk& c, int ntensors, int64_t max_numel, double lr,
 // negatives and rescale every calorimeter layer to the layer energy given by the conditioning vector, scale to the incident
 // energy, apply the read-out threshold.  One workgroup per (sample, layer z): the layer sum is a workgroup reduction.
 // ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float rev_logit(float x, float alpha = 1e-6f) {  // utils.py:233-237 (HGCal_utils.py:13-17: alpha 1e-8)
+__device__ __forceinline__ float rev_logit(float x, float alpha) {  // utils.py:233-237 (alpha 1e-6); HGCal_utils.py:13-17 (alpha 1e-8): always the caller's
   const float ex = expf(x);
   const float o = ex / (1.f + ex);
   return (o - alpha) / (1.f - 2.f * alpha);
@@ -655,7 +690,7 @@ __global__ void __launch_bounds__(256) reverse_norm_kernel(ReverseNormArgs a) {
     // this sample's layer energies: reverse transform, normalise to the total deposited energy (utils.py:519-528)
     const float* le = a.layerE + (size_t)b * (a.D + 1);
     float part = 0.f;
-    for (int i = tid; i < a.D; i += 256) part += rev_logit(le[1 + i] * a.layers_std + a.layers_mean);
+    for (int i = tid; i < a.D; i += 256) part += rev_logit(le[1 + i] * a.layers_std + a.layers_mean, a.alpha);
     red[tid] = part;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
@@ -664,7 +699,7 @@ __global__ void __launch_bounds__(256) reverse_norm_kernel(ReverseNormArgs a) {
     }
     if (tid == 0) {
       const float total = le[0] * a.totalE_std + a.totalE_mean;
-      s_layer = rev_logit(le[1 + z] * a.layers_std + a.layers_mean) / red[0] * total;
+      s_layer = rev_logit(le[1 + z] * a.layers_std + a.layers_mean, a.alpha) / red[0] * total;
     }
     __syncthreads();
     layer_e = s_layer;

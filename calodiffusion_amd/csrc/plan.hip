@@ -1062,15 +1062,23 @@ void forward_impl(CdPlan* p, int B, const float* x, const float* cond, const flo
 
 #include "train.inc"
 
+// Every C-ABI entry point runs inside guarded().  The launchers check `hipGetLastError()` after each launch, and that call
+// reports the thread's LAST error whoever set it -- a HIP call that failed earlier in the process (another library's, the
+// caller's own, or a previous entry point of this one) would otherwise fail the first unrelated launch here (round 3:
+// a refused hipEventElapsedTime surfaced as "cd_randn: invalid resource handle").  So the error state is cleared on the way
+// in, and again on the way out of a failed call.
 template <typename F>
 int guarded(F&& f) {
+  (void)hipGetLastError();
   try {
     f();
     return CD_OK;
   } catch (const Fail& e) {
+    (void)hipGetLastError();
     set_error(e.msg);
     return e.code;
   } catch (const std::exception& e) {
+    (void)hipGetLastError();
     set_error(std::string("internal error: ") + e.what());
     return CD_EINVAL;
   }
@@ -1671,13 +1679,14 @@ int cd_sampler_run(CdPlan* plan, int batch, const float* start, float start_scal
     int randn_per_step = 0;
     for (int k = 0; k < n_ops; ++k) {
       const CdSamplerOp& o = ops[k];
-      CD_REQUIRE(o.kind >= CD_SOP_LINCOMB && o.kind <= CD_SOP_RECORD, "sampler op: unknown kind");
-      const int ns = o.kind == CD_SOP_LINCOMB ? o.nsrc : (o.kind == CD_SOP_RANDN ? 0 : 1);
-      CD_REQUIRE(ns >= 0 && ns <= 6 && (o.kind != CD_SOP_LINCOMB || ns >= 1), "sampler op: 1..6 sources");
+      CD_REQUIRE(o.kind >= CD_SOP_LINCOMB && o.kind <= CD_SOP_LINDIV, "sampler op: unknown kind");
+      const bool lin = o.kind == CD_SOP_LINCOMB || o.kind == CD_SOP_LINDIV;
+      const int ns = lin ? o.nsrc : (o.kind == CD_SOP_RANDN ? 0 : 1);
+      CD_REQUIRE(ns >= 0 && ns <= 6 && (!lin || ns >= 1), "sampler op: 1..6 sources");
       for (int j = 0; j < ns; ++j) CD_REQUIRE(o.src[j] >= 0 && o.src[j] < n_bufs, "sampler op: source buffer out of range");
       if (o.kind == CD_SOP_RECORD) CD_REQUIRE(o.dst == 0 || o.dst == 1, "record op: dst is 0 (xs) or 1 (x0s)");
       else CD_REQUIRE(o.dst >= 0 && o.dst < n_bufs, "sampler op: destination buffer out of range");
-      if (o.kind == CD_SOP_LINCOMB) CD_REQUIRE(o.col >= 0 && o.col + ns <= n_coef, "lincomb op: coefficient columns out of range");
+      if (lin) CD_REQUIRE(o.col >= 0 && o.col + ns + (o.kind == CD_SOP_LINDIV ? 1 : 0) <= n_coef, "lincomb op: coefficient columns out of range");
       if (o.kind == CD_SOP_DENOISE) {
         CD_REQUIRE(o.col >= 0 && o.col < n_coef, "denoise op: sigma column out of range");
         CD_REQUIRE(o.dst != o.src[0], "denoise op: output must not alias its input");
@@ -1711,6 +1720,12 @@ int cd_sampler_run(CdPlan* plan, int batch, const float* start, float start_scal
           const float* src[6];
           for (int j = 0; j < o.nsrc; ++j) src[j] = bufs[o.src[j]];
           launch_lincomb(bufs[o.dst], src, o.nsrc, table, n_coef, o.col, counter, n, st);
+          break;
+        }
+        case CD_SOP_LINDIV: {
+          const float* src[6];
+          for (int j = 0; j < o.nsrc; ++j) src[j] = bufs[o.src[j]];
+          launch_lincomb_div(bufs[o.dst], src, o.nsrc, table, n_coef, o.col, counter, n, st);
           break;
         }
         case CD_SOP_DENOISE:
@@ -1831,7 +1846,6 @@ int cd_train_step(CdPlan* plan, int batch, const float* data, const float* noise
                   int loss_type, double* loss_out, float* grads, void* workspace, size_t workspace_bytes, void* stream) {
   return guarded([&] {
     CD_REQUIRE(plan && data && noise && sigma && cond && loss_out && grads && workspace && batch > 0, "bad argument");
-    CD_REQUIRE(plan->desc.objective == CD_OBJ_HYBRID, "cd_train_step implements the hybrid_weight objective");
     CD_REQUIRE(loss_type >= CD_LOSS_L2 && loss_type <= CD_LOSS_HUBER, "loss_type must be one of CD_LOSS_L2 / L1 / MSE / HUBER");
     check_ready(plan, true);
     plan->ws.reset((char*)workspace, workspace_bytes, false);
@@ -1848,7 +1862,6 @@ int cd_loss_hybrid(CdPlan* plan, int batch, const float* data, const float* nois
                    int loss_type, double* loss_out, void* workspace, size_t workspace_bytes, void* stream) {
   return guarded([&] {
     CD_REQUIRE(plan && data && noise && sigma && cond && loss_out && workspace && batch > 0, "bad argument");
-    CD_REQUIRE(plan->desc.objective == CD_OBJ_HYBRID, "cd_loss_hybrid needs a hybrid_weight plan");
     CD_REQUIRE(loss_type >= CD_LOSS_L2 && loss_type <= CD_LOSS_HUBER, "loss_type must be one of CD_LOSS_L2 / L1 / MSE / HUBER");
     check_ready(plan, true);
     hipStream_t s = (hipStream_t)stream;
@@ -1862,8 +1875,8 @@ int cd_loss_hybrid(CdPlan* plan, int batch, const float* data, const float* nois
     launch_axpy_sigma(data, noise, sigma, xn, batch, per, s);
     plan->ws.reset((char*)workspace + used, workspace_bytes > used ? workspace_bytes - used : 0, false);
     forward_impl(plan, batch, xn, cond, sigma, x0, false, s);
-    launch_loss_partial(x0, data, sigma, part, batch, per, s, loss_type);
-    launch_loss_final(part, sigma, loss_out, batch, per, s, loss_type);
+    launch_loss_partial(x0, data, noise, sigma, part, batch, per, s, loss_type, plan->desc.objective);
+    launch_loss_final(part, sigma, loss_out, batch, per, s, loss_type, plan->desc.objective);
   });
 }
 

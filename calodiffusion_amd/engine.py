@@ -45,7 +45,7 @@ class CdUnetDesc(C.Structure):
     ]
 
 
-SOP_LINCOMB, SOP_DENOISE, SOP_RANDN, SOP_RECORD = 0, 1, 2, 3
+SOP_LINCOMB, SOP_DENOISE, SOP_RANDN, SOP_RECORD, SOP_LINDIV = 0, 1, 2, 3, 4
 
 
 class CdSamplerOp(C.Structure):

@@ -19,7 +19,13 @@ class Loss:
         if "log" in config.get("NOISE_SCHED", "linear"):
             self.discrete_time = False
             self.P_mean, self.P_std, self.sigma_data = -1.2, 1.2, 1.0
+        # Loss._loss (models/loss.py:97-116) raises at construction for an unknown LOSS_TYPE; the reductions themselves run on
+        # the device (cd_train_step / cd_loss_hybrid)
+        if loss_type not in self.LOSS_TYPES:
+            raise NotImplementedError("Loss type %s not implemented, pick from (%s)" % (loss_type, self.LOSS_TYPES))
         self.loss_type = loss_type
+
+    LOSS_TYPES = ("l1", "l2", "mse", "huber")
 
     def get_scaling(self, sigma):
         s2 = sigma ** 2 + self.sigma_data ** 2
@@ -54,6 +60,17 @@ class Loss:
     def loss_function(self, model, data, E, sigma=None, noise=None, layers=None):
         raise NotImplementedError
 
+    def _device_loss(self, model, data, E, sigma, noise, layers):
+        """What the three objective classes share: the engine's plan carries the objective (CdUnetDesc.objective, set from the class
+        name in CaloDiffusion.init_model as the reference's denoise branches on it, calodiffusion.py:156-169), so one call
+        evaluates pred / target / weight of that class and, in training, every parameter gradient."""
+        cond = model.cond_tensor(E, layers)
+        params = list(model.model.parameters())
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            # training: TrainDiffusion.training_loop calls loss.backward(); optimizer.step() on the result
+            return _TrainStep.apply(model.engine(), self.loss_type, data, noise, sigma, cond, *params)
+        return model.engine().loss_hybrid(data, noise, sigma, cond, self.loss_type)
+
 
 class _TrainStep(torch.autograd.Function):
     """Loss value and parameter gradients from ONE call into the HIP library (cd_train_step); autograd only sees a
@@ -80,14 +97,38 @@ class hybrid_weight(Loss):
     def __init__(self, config, n_steps, loss_type="l1") -> None:
         super().__init__(config, n_steps, loss_type)
 
-    LOSS_TYPES = ("l2", "l1", "mse", "huber")  # Loss._loss (models/loss.py:97-116)
+    def loss_function(self, model, data, E, sigma=None, noise=None, layers=None):
+        return self._device_loss(model, data, E, sigma, noise, layers)
+
+
+class noise_pred(Loss):
+    """models/loss.py:181-196: the network predicts the noise; denoise returns x - sigma F (calodiffusion.py:161-162), the loss
+    compares (data - (data - sigma denoise(x_noisy))) / sigma with the noise, unweighted."""
+
+    def __init__(self, config, n_steps, loss_type="l1") -> None:
+        super().__init__(config, n_steps, loss_type)
 
     def loss_function(self, model, data, E, sigma=None, noise=None, layers=None):
-        if self.loss_type not in self.LOSS_TYPES:  # (the reference raises the same from Loss._loss at construction)
-            raise NotImplementedError("Loss type %s not implemented, pick from (%s)" % (self.loss_type, self.LOSS_TYPES))
-        cond = model.cond_tensor(E, layers)
-        params = list(model.model.parameters())
-        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
-            # training: TrainDiffusion.training_loop calls loss.backward(); optimizer.step() on the result
-            return _TrainStep.apply(model.engine(), self.loss_type, data, noise, sigma, cond, *params)
-        return model.engine().loss_hybrid(data, noise, sigma, cond, self.loss_type)
+        return self._device_loss(model, data, E, sigma, noise, layers)
+
+
+class mean_pred(Loss):
+    """models/loss.py:198-210: the network output itself is the shower estimate (calodiffusion.py:164-165), weight sigma^-2."""
+
+    def __init__(self, config, n_steps, loss_type="l1") -> None:
+        super().__init__(config, n_steps, loss_type)
+
+    def loss_function(self, model, data, E, sigma=None, noise=None, layers=None):
+        return self._device_loss(model, data, E, sigma, noise, layers)
+
+
+class minsnr(Loss):
+    """models/loss.py:144-161, kept with the reference's signature: its __init__ takes no loss_type, so Diffusion.__init__
+    (models/diffusion.py:30, which passes one) cannot construct it there either -- `TRAINING_OBJ: minsnr` raises the same
+    TypeError in both -- and CaloDiffusion.denoise has no branch for it (`('hybrid' or 'minsnr') in name` tests 'hybrid' only)."""
+
+    def __init__(self, config, n_steps) -> None:
+        super().__init__(config, n_steps)
+
+    def loss_function(self, model, data, E, sigma=None, noise=None, layers=None):
+        raise ValueError("??? Training obj %s" % type(self).__name__)  # what model.denoise raises there (calodiffusion.py:169)

@@ -25,7 +25,7 @@ import numpy as np
 import torch
 
 from . import schedule
-from .engine import SOP_DENOISE, SOP_LINCOMB, SOP_RANDN, SOP_RECORD
+from .engine import SOP_DENOISE, SOP_LINCOMB, SOP_LINDIV, SOP_RANDN, SOP_RECORD
 
 
 class Sample:
@@ -95,6 +95,13 @@ class _Step:
         assert 1 <= len(terms) <= 6
         self.ops.append((SOP_LINCOMB, dst, tuple(b for b, _ in terms), len(self.coefs)))
         self.coefs += [float(c) for _, c in terms]
+
+    def lin_div(self, dst: int, terms: Sequence[Tuple[int, float]], div: float = 1.0):
+        """buf[dst] = ((c0 * buf[s0] + c1 * buf[s1]) + ...) / div in the operation order of a chain of torch elementwise ops: every
+        product, every sum (left to right) and the division rounded to fp32 on its own, nothing fused."""
+        assert 1 <= len(terms) <= 6
+        self.ops.append((SOP_LINDIV, dst, tuple(b for b, _ in terms), len(self.coefs)))
+        self.coefs += [float(c) for _, c in terms] + [float(div)]
 
     def denoise(self, dst: int, src: int, sigma: float):
         self.ops.append((SOP_DENOISE, dst, (src,), len(self.coefs)))
@@ -439,37 +446,44 @@ class DPM(_ProgramSampler):
         ts = torch.linspace(t_start, t_end, m + 1)
         orders = [3] * (m - 2) + [2, 1] if nfe % 3 == 0 else [3] * (m - 1) + [nfe % 3]
         prog = Program(10, _f(sig[0]))
-        EPS, U1, EPS1, U2, EPS2 = H0, X2, H1, H2, H3
-        s = lambda tt: _f(self.sigma_fn(tt))  # noqa: E731
+        EPS, U1, EPS1, U2, EPS2, DIF = H0, X2, H1, H2, H3, XH
+        sg = self.sigma_fn
 
-        def eps_of(st, dst, src, tt):  # eps = (x - D(x, sigma(t))) / sigma(t)
-            st.denoise(DN, src, s(tt))
-            st.lin(dst, [(src, 1.0 / s(tt)), (DN, -1.0 / s(tt))])
+        # Every update below is emitted in the reference's own operation order (DPMSolver.eps / dpm_solver_{1,2,3}_step,
+        # utils/sampling.py:402-456) as LINDIV ops -- products, sums and the division each rounded to fp32, scalars combined in
+        # fp32 torch arithmetic exactly as the reference's 0-dim tensors are: the higher-order steps subtract terms of order
+        # sigma_max from each other and amplify the rounding of u1 / u2 by sigma(t) / sigma(s1), so a re-associated update
+        # (x / sigma - D / sigma, folded coefficients) that is just as accurate still ends 1.5e-4 away from the reference.
+        def eps_of(st, dst, src, tt):  # eps = (x - model(x, sigma(t))) / sigma(t)                                  :402-411
+            st.denoise(DN, src, _f(sg(tt)))
+            st.lin_div(dst, [(src, 1.0), (DN, -1.0)], _f(sg(tt)))
 
         for i, order in enumerate(orders):
             t, t_next = ts[i], ts[i + 1]
             h = t_next - t
             st = prog.step()
             eps_of(st, EPS, X, t)
-            a = -s(t_next) * _f(h.expm1())  # coefficient of eps in every final update
-            if order == 1:
-                st.lin(X, [(X, 1.0), (EPS, a)])
+            a = sg(t_next) * h.expm1()  # x - sigma(t_next) * h.expm1() * eps: the scalar product first, as python evaluates it
+            if order == 1:                                                                                        # :413-418
+                st.lin_div(X, [(X, 1.0), (EPS, -_f(a))])
                 continue
             r1 = 1 / 2 if order == 2 else 1 / 3
             s1 = t + r1 * h
-            st.lin(U1, [(X, 1.0), (EPS, -s(s1) * _f((r1 * h).expm1()))])
+            st.lin_div(U1, [(X, 1.0), (EPS, -_f(sg(s1) * (r1 * h).expm1()))])
             eps_of(st, EPS1, U1, s1)
-            if order == 2:
-                b = -s(t_next) / (2 * r1) * _f(h.expm1())
-                st.lin(X, [(X, 1.0), (EPS, a - b), (EPS1, b)])
+            st.lin_div(DIF, [(EPS1, 1.0), (EPS, -1.0)])  # (eps_r1 - eps)
+            if order == 2:                                                                                        # :420-432
+                b = sg(t_next) / (2 * r1) * h.expm1()
+                st.lin_div(X, [(X, 1.0), (EPS, -_f(a)), (DIF, -_f(b))])
                 continue
-            r2 = 2 / 3
+            r2 = 2 / 3                                                                                            # :434-456
             s2 = t + r2 * h
-            c = -s(s2) * (r2 / r1) * (_f((r2 * h).expm1()) / _f(r2 * h) - 1)
-            st.lin(U2, [(X, 1.0), (EPS, -s(s2) * _f((r2 * h).expm1()) - c), (EPS1, c)])
+            c = sg(s2) * (r2 / r1) * ((r2 * h).expm1() / (r2 * h) - 1)
+            st.lin_div(U2, [(X, 1.0), (EPS, -_f(sg(s2) * (r2 * h).expm1())), (DIF, -_f(c))])
             eps_of(st, EPS2, U2, s2)
-            b = -s(t_next) / r2 * (_f(h.expm1()) / _f(h) - 1)
-            st.lin(X, [(X, 1.0), (EPS, a - b), (EPS2, b)])
+            st.lin_div(DIF, [(EPS2, 1.0), (EPS, -1.0)])  # (eps_r2 - eps)
+            b = sg(t_next) / r2 * (h.expm1() / h - 1)
+            st.lin_div(X, [(X, 1.0), (EPS, -_f(a)), (DIF, -_f(b))])
         return prog
 
     def finish(self, x, xs, x0s, debug):

@@ -162,6 +162,10 @@ int cd_ddim_sample(CdPlan* plan, int batch, const float* start, const float* con
 #define CD_SOP_DENOISE 1 /* buf[dst] = denoise(buf[src[0]], sigma = coef[col])  (CaloDiffusion.denoise, as cd_denoise) */
 #define CD_SOP_RANDN 2   /* buf[dst] = unit normals: the next tensor of step_noise, or of the Philox stream */
 #define CD_SOP_RECORD 3  /* trajectory slot of this step <- buf[src[0]]; dst: 0 = xs, 1 = x0s (skipped if that pointer is NULL) */
+#define CD_SOP_LINDIV 4  /* buf[dst] = (((coef[col] * buf[src[0]]) + coef[col+1] * buf[src[1]]) + ...) / coef[col + nsrc]: like \
+                            LINCOMB, but in the operation order of a chain of torch elementwise ops -- every product, sum and the \
+                            final division rounded to fp32 on its own, no fused multiply-add (DPM-Solver's eps = (x - D) / sigma \
+                            and its cancelling updates, utils/sampling.py:402-456) */
 typedef struct CdSamplerOp {
   int32_t kind, dst, nsrc;
   int32_t src[6];
@@ -194,12 +198,19 @@ int cd_loss_hybrid_l2(CdPlan* plan, int batch, const float* data, const float* n
 #define CD_LOSS_L1 1
 #define CD_LOSS_MSE 2
 #define CD_LOSS_HUBER 3
+/* The plan's objective (CdUnetDesc.objective) selects which loss class of models/loss.py this is -- the entry point keeps its
+ * name from the shipped configs' hybrid_weight:
+ *   CD_OBJ_HYBRID     hybrid_weight (:163-179)  pred = denoise(x_noisy), target = data, weight 1 + sigma^-2
+ *   CD_OBJ_NOISE_PRED noise_pred    (:181-196)  pred = (data - (data - sigma denoise(x_noisy))) / sigma, target = noise, weight 1
+ *   CD_OBJ_MEAN_PRED  mean_pred     (:198-210)  pred = denoise(x_noisy) = F, target = data, weight sigma^-2
+ * (the weight enters CD_LOSS_L2 only).  minsnr (:144-161) cannot be constructed in the reference (its __init__ takes no
+ * loss_type, models/diffusion.py:30 passes one) and has no counterpart here. */
 int cd_loss_hybrid(CdPlan* plan, int batch, const float* data, const float* noise, const float* sigma, const float* cond,
                    int loss_type, double* loss_out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- training step ----------------------------------------------------------------------------------------------- */
-/* Body of TrainDiffusion.training_loop (train/train_diffusion.py:52-63) up to loss.backward(): the hybrid_weight/l2 loss
- * (as cd_loss_hybrid, any CD_LOSS_* type) AND the gradient of that loss with respect to every parameter, written to `grads`, a flat fp32
+/* Body of TrainDiffusion.training_loop (train/train_diffusion.py:52-63) up to loss.backward(): the loss of the plan's objective
+ * (as cd_loss_hybrid: hybrid_weight / noise_pred / mean_pred, any CD_LOSS_* type) AND the gradient of that loss with respect to every parameter, written to `grads`, a flat fp32
  * buffer laid out as cd_plan_grad_layout reports (tensor idx of cd_plan_weight_name starts at *offset, torch layout;
  * *total_floats = size of the buffer).  Workspace: cd_plan_train_workspace_bytes (the forward's activations are kept
  * until the backward has consumed them). */

@@ -370,6 +370,11 @@ def gold_reverse_norm_hgcal():
     data, gen = ref_hg.ReverseNormHGCal(vox.copy(), e.copy(), emax=1000., emin=1., max_deposit=2, logE=True, layerE=None,
                                         showerMap="logit-norm", dataset_num=120, embed=True, NN_embed=_ReshapeDecoder())
     out["plain.data"], out["plain.gen"] = np.asarray(data, dtype=np.float32), np.asarray(gen, dtype=np.float32)
+    # dataset 121 in layer mode: layers_mean -11.6 / layers_std 7.3 put many layer energies near reverse_logit's alpha (1e-8
+    # here, 1e-6 in utils.py), so this case separates the two
+    data, gen = ref_hg.ReverseNormHGCal(vox.copy(), e.copy(), emax=1000., emin=1., max_deposit=2, logE=True, layerE=layerE.copy(),
+                                        showerMap="layer-logit-norm", dataset_num=121, embed=True, NN_embed=_ReshapeDecoder())
+    out["layer121.data"], out["layer121.gen"] = np.asarray(data, dtype=np.float32), np.asarray(gen, dtype=np.float32)
     print("reverse_norm hgcal", out["layer.data"].shape, float(np.abs(out["layer.data"]).mean()), out["plain.data"].shape)
     save("reverse_norm_hgcal", **out)
 
@@ -655,6 +660,55 @@ def gold_grads_round3():
     save("losstypes_tiny", **out)
 
 
+def gold_objectives():
+    """Round 4: TRAINING_OBJ 'noise_pred' and 'mean_pred' on the tiny config, from the reference's own classes: denoise at three
+    noise levels (the branches of CaloDiffusion.denoise, models/calodiffusion.py:161-165), the loss value and .grad of
+    compute_loss(...).backward() (models/loss.py:181-210) for LOSS_TYPE l2 and huber, and a 6-step DDIM end point (the sampler
+    runs on whatever denoise returns).  'minsnr' cannot be constructed by the reference (TypeError, recorded)."""
+    base = my_configs.load_config("tiny")
+    data, E, layers = synth_inputs(base, 4, SEED + 95)
+    g = torch.Generator().manual_seed(SEED + 96)
+    noise = torch.randn(data.shape, generator=g)
+    rnd = torch.randn((4,), generator=g)
+    out = {"data": npf(data), "E": npf(E), "layers": npf(layers), "noise": npf(noise), "rnd_normal": npf(rnd),
+           "sigmas": np.array([40.0, 1.02, 0.05], dtype=np.float32)}
+    for obj in ("noise_pred", "mean_pred"):
+        for lt in ("l2", "huber"):
+            c = copy.deepcopy(base)
+            c["TRAINING_OBJ"], c["LOSS_TYPE"] = obj, lt
+            m = build_ref(c)
+            assert type(m.loss_function).__name__ == obj
+            if lt == "l2":
+                with torch.no_grad():
+                    for i, sg in enumerate(out["sigmas"]):
+                        sig = torch.full((4, 1, 1, 1, 1), float(sg))
+                        xin = data * float(np.sqrt(1.0 + float(sg) ** 2))
+                        out[f"{obj}.denoise_{i}"] = npf(m.denoise(xin, E=E, sigma=sig, layers=layers))
+                    xf, _, _ = ref_sample.DDim(c)(m, data, E, layers, 6, 0, False)
+                    out[f"{obj}.ddim_6"] = npf(xf)
+            m.train()
+            m.zero_grad()
+            loss = m.compute_loss(data, E, noise=noise, layers=layers, rnd_normal=rnd)
+            loss.backward()
+            grads = {k: p.grad for k, p in m.model.named_parameters()}
+            keys, cks = checksums(grads)
+            out[f"{obj}.{lt}.ck_keys"], out[f"{obj}.{lt}.ck_vals"] = keys, cks
+            out[f"{obj}.{lt}.loss"] = np.array(float(loss), dtype=np.float64)
+            for k in ("init_conv.conv.weight", "mid_block1.block1.proj.conv.weight", "final_conv.1.conv.weight", "time_mlp.1.weight",
+                      "downs_attn.0.fn.fn.to_qkv.conv.weight"):
+                out[f"{obj}.{lt}.grad.{k}"] = npf(grads[k])
+            print("objective", obj, lt, float(loss), float(sum(float((v.double() ** 2).sum()) for v in grads.values()) ** 0.5))
+    c = copy.deepcopy(base)
+    c["TRAINING_OBJ"] = "minsnr"
+    try:
+        build_ref(c)
+        out["minsnr.constructs"] = np.array(1)
+    except TypeError as e:
+        out["minsnr.constructs"] = np.array(0)
+        print("minsnr:", e)
+    save("objectives_tiny", **out)
+
+
 def gold_trajectories():
     """Dataset-3 DDIM (10 and 50 steps, batch 1) and HGCal DDPM (200 steps, batch 2, seeded noise stream) end points."""
     cfg3 = my_configs.load_config("dataset3")
@@ -706,6 +760,8 @@ if __name__ == "__main__":
         gold_sinusoidal()
     if "grads" in which:
         gold_grads()
+    if "objectives" in which:
+        gold_objectives()
     if "traj" in which:
         gold_trajectories()
     if "grads3" in which:

@@ -435,8 +435,8 @@ class OracleModel:
     def hybrid_l2_loss(self, data: Tensor, E: Tensor, noise: Tensor, layers: Optional[Tensor],
                        rnd_normal: Optional[Tensor] = None, time: Optional[Tensor] = None,
                        n_steps: int = 400, loss_type: str = "l2") -> Tensor:
-        """Loss.__call__ + hybrid_weight + the reduction of Loss._loss (models/loss.py:97-116, 118-142, 163-179): 'l2' (weighted),
-        'l1', 'mse', 'huber' (= smooth_l1_loss, beta 1)."""
+        """Loss.__call__ + the objective class named by TRAINING_OBJ (hybrid_weight / noise_pred / mean_pred) + the reduction of
+        Loss._loss (models/loss.py:97-116, 118-142, 163-210): 'l2' (weighted), 'l1', 'mse', 'huber' (= smooth_l1_loss, beta 1)."""
         shp = (data.shape[0], 1, 1, 1, 1)
         if "log" in self.cfg.get("NOISE_SCHED", "linear"):
             sigma = (rnd_normal * 1.2 + (-1.2)).exp().reshape(shp)
@@ -444,14 +444,21 @@ class OracleModel:
             tb = ddim_tables(n_steps)
             sigma = (tb.sqrt_one_minus_alphas_cumprod[time] / tb.sqrt_alphas_cumprod[time]).reshape(shp)
         x0 = self.denoise(data + sigma * noise, E, sigma, layers)
+        # the three objective classes (self.objective = the loss class name, as the reference's denoise branches on it)
+        if "noise_pred" in self.objective:      # models/loss.py:181-196
+            x0_pred = data - sigma * x0
+            pred, target, w = (data - x0_pred) / sigma, noise, torch.ones_like(x0)
+        elif "mean_pred" in self.objective:     # models/loss.py:198-210
+            pred, target, w = x0, data, 1.0 / (sigma ** 2)
+        else:                                   # hybrid_weight, models/loss.py:163-179
+            pred, target, w = x0, data, (1.0 + 1.0 / sigma ** 2).reshape(shp)
         if loss_type == "l1":
-            return F.l1_loss(x0, data)
+            return F.l1_loss(pred, target)
         if loss_type == "mse":
-            return F.mse_loss(x0, data)
+            return F.mse_loss(pred, target)
         if loss_type == "huber":
-            return F.smooth_l1_loss(x0, data)
-        w = (1.0 + 1.0 / sigma ** 2).reshape(shp)
-        return (w * (x0 - data) ** 2).sum() / (torch.mean(w) * float(np.prod(data.shape)))
+            return F.smooth_l1_loss(pred, target)
+        return (w * (pred - target) ** 2).sum() / (torch.mean(w) * float(np.prod(data.shape)))
 
 
 # --------------------------------------------------------------------------

@@ -55,28 +55,13 @@ def test_sampler_programs_match_reference_trajectories(tag):
     to_np = lambda seq: None if seq is None or isinstance(seq, list) and not seq else [v.cpu().numpy() for v in seq]  # noqa: E731
     if name == "Consistency":
         x0s = None  # (the reference returns the last denoised tensor there, not a list)
+    # every case holds north_star's 1e-4, dpm_2 included: DPM-Solver-fast runs as LINDIV ops in the reference's operation order
+    # (round 3 had re-associated its updates, which one second-order step from sigma = 142 to 1 amplified to 1.5e-4; the
+    # CPU-interpreted program now equals the reference bit for bit, tests/test_host.py), so what is left on the device is the
+    # case's 9.8x amplification (tests/test_oracle_golden.py) of the denoise kernels' own ~1e-6
     tol = TOL_TRAJ
     if tag == "dpm_2":
-        # dpm_2 is ONE second-order step from sigma = 142 down to sigma = 1: x_next = x - 141 eps_r1 cancels terms of order
-        # sigma_max against each other (|x| ~ 142 -> |result| ~ 2).  Two measured numbers bound what a correct device run can
-        # show here (both printed): the SAME step program interpreted on the CPU with the exact oracle denoiser already differs
-        # from the reference by `reassoc` (fp32 re-association of the update alone: 4.0e-5), and a denoiser error comes out
-        # `amp` times larger (9.8x for white noise, tests/test_oracle_golden.py).  The device is held to
-        # reassoc + amp x (its denoise bound 1e-5), doubled for the fused-multiply-add order of the device's linear
-        # combinations: ~2.8e-4 (observed on MI355X: 1.4e-4); every other case keeps north_star's 1e-4.
-        from oracle import torch_oracle as O
-        from test_host import _interpret_program
-        from test_oracle_golden import denoise_error_amplification
-        om = O.OracleModel(m.config, {k: v.cpu() for k, v in m.state_dict().items()})
-        den = lambda xx, ss: om.denoise(xx, E.cpu(), ss.float().expand(rows), layers.cpu())  # noqa: E731
-        with torch.no_grad():
-            xc = _interpret_program(prog, den, start.cpu(), [])[0]
-        reassoc = rel_l2(np.asarray(xc), g[f"{tag}.x"])
-        amp = denoise_error_amplification("dpm_2")
-        tol = 2 * (reassoc + amp * TOL_OP)
-        print(f"dpm_2: device {rel_l2(np.asarray(x), g[f'{tag}.x']):.2e}; CPU-interpreted program {reassoc:.2e}, "
-              f"denoise-error amplification {amp:.1f}x -> bound {tol:.2e}")
-        assert tol < 5e-4
+        print(f"dpm_2: device {rel_l2(np.asarray(x), g[f'{tag}.x']):.2e}")
     check_sampler_case(tag, g, x, to_np(xs), to_np(x0s), tol)
 
 

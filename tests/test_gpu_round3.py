@@ -126,11 +126,20 @@ def test_reverse_norm_hgcal_on_device():
     data, gen = postprocess.ReverseNorm(g["vox"], g["e"], hgcal=True, emax=1000., emin=1., max_deposit=2, logE=True, layerE=g["layerE"],
                                         showerMap="layer-logit-norm", dataset_num=111, embed=True, NN_embed=Decoder())
     assert data.shape == g["layer.data"].shape and np.allclose(gen, g["layer.gen"], rtol=1e-6)
-    # (HGCal's logit_mean is -17.3: sigmoid values of ~3e-8 minus alpha = 1e-8 in fp32, here with the device's expf -- the
-    # cancellation leaves ~1e-5 of relative difference to numpy's fp32 result; the CaloChallenge maps hold 1e-5)
-    assert rel_l2(data, g["layer.data"]) < 3e-5
+    # 1e-5 like the CaloChallenge maps, over the whole array AND per (shower, layer) row -- round 3 had widened this to 3e-5:
+    # the layer energies were transformed with utils.py's alpha (1e-6) instead of HGCal_utils.py's (1e-8), which the
+    # energy-weighted norm only just showed
+    from test_oracle_golden import per_layer_worst
+    e_all, e_row = rel_l2(data, g["layer.data"]), per_layer_worst(data, g["layer.data"])
+    print(f"ReverseNormHGCal 111 layer mode: rel L2 {e_all:.2e}, worst (shower, layer) row {e_row:.2e}")
+    assert e_all < 1e-5 and e_row < 3e-5
+    data, gen = postprocess.ReverseNorm(g["vox"], g["e"], hgcal=True, emax=1000., emin=1., max_deposit=2, logE=True, layerE=g["layerE"],
+                                        showerMap="layer-logit-norm", dataset_num=121, embed=True, NN_embed=Decoder())
+    e_all, e_row = rel_l2(data, g["layer121.data"]), per_layer_worst(data, g["layer121.data"])
+    print(f"ReverseNormHGCal 121 layer mode: rel L2 {e_all:.2e}, worst (shower, layer) row {e_row:.2e}")
+    assert e_all < 1e-5 and e_row < 3e-5
     data, gen = postprocess.ReverseNormHGCal(g["vox"], g["e"], emax=1000., emin=1., max_deposit=2, layerE=None, showerMap="logit-norm",
                                              dataset_num=120, embed=True, NN_embed=Decoder())
-    assert data.shape == g["plain.data"].shape and rel_l2(data, g["plain.data"]) < 3e-5
+    assert data.shape == g["plain.data"].shape and rel_l2(data, g["plain.data"]) < 1e-5
     with pytest.raises(NotImplementedError, match="geometry"):
         postprocess.ReverseNormHGCal(g["vox"], g["e"], layerE=g["layerE"], showerMap="layer-logit-norm", dataset_num=111, embed=True)

@@ -1,0 +1,78 @@
+"""GPU (MI355X): round-4 additions -- the noise_pred / mean_pred objectives behind cd_denoise / cd_loss_hybrid / cd_train_step
+against the reference's own outputs, and the C ABI's independence of HIP errors left behind by earlier calls."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import gold, rel_l2
+from helpers import t
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("obj", ["noise_pred", "mean_pred"])
+def test_objectives_match_the_reference(obj):
+    """TRAINING_OBJ noise_pred / mean_pred: cd_denoise objectives 1 / 2 (calodiffusion.py:161-165) at three noise levels, a 6-step
+    DDIM trajectory on that denoiser, and the loss classes of models/loss.py:181-210 -- value (cd_loss_hybrid) and every
+    gradient (cd_train_step) for LOSS_TYPE l2 and huber -- against the reference (tests/golden/objectives_tiny.npz)."""
+    from test_gpu_round2 import _model
+    g = gold("objectives_tiny")
+    data, E, noise, layers = (t(g[k]).cuda() for k in ("data", "E", "noise", "layers"))
+    rnd = t(g["rnd_normal"]).cuda()
+    m = _model("tiny", {"TRAINING_OBJ": obj, "LOSS_TYPE": "l2"})
+    assert type(m.loss_function).__name__ == obj
+    with torch.no_grad():
+        for i, sg in enumerate(g["sigmas"]):
+            xin = data * float(np.sqrt(1.0 + float(sg) ** 2))
+            got = m.denoise(xin, E=E, sigma=torch.full((4,), float(sg)).cuda(), layers=layers)
+            err = rel_l2(got.cpu().numpy(), g[f"{obj}.denoise_{i}"])
+            assert err < 1e-5, (obj, i, err)
+        x = m.sample(E, layers, num_steps=6, start=data)
+        assert rel_l2(x, g[f"{obj}.ddim_6"]) < 1e-4
+    for lt in ("l2", "huber"):
+        m = _model("tiny", {"TRAINING_OBJ": obj, "LOSS_TYPE": lt})
+        m.zero_grad()
+        loss = m.compute_loss(data, E, noise=noise, layers=layers, rnd_normal=rnd)
+        loss.backward()
+        want = float(g[f"{obj}.{lt}.loss"])
+        assert abs(float(loss) - want) <= 1e-5 * abs(want), (obj, lt, float(loss), want)
+        with torch.no_grad():
+            assert abs(float(m.compute_loss(data, E, noise=noise, layers=layers, rnd_normal=rnd)) - want) <= 1e-5 * abs(want)
+        grads = dict(m.model.named_parameters())
+        pre, worst = f"{obj}.{lt}.grad.", 0.0
+        for k in g.files:
+            if k.startswith(pre):
+                err = rel_l2(grads[k[len(pre):]].grad.cpu().numpy(), g[k])
+                worst = max(worst, err)
+                assert err < 1e-4, (k, err)
+        for k, (s1, s2) in zip(g[f"{obj}.{lt}.ck_keys"], g[f"{obj}.{lt}.ck_vals"]):
+            gr = grads[str(k)].grad.double()
+            assert abs(float((gr * gr).sum()) - s2) <= 2e-4 * max(s2, 1e-30), (obj, lt, k)
+        print(f"[{obj}/{lt}] loss {float(loss):.6f} (reference {want:.6f}); worst whole-tensor gradient error {worst:.2e}")
+
+
+def test_a_stale_hip_error_does_not_fail_the_next_entry_point():
+    """The launchers check hipGetLastError() after every launch, which reports the thread's last error whoever caused it (round 3:
+    a refused hipEventElapsedTime made the next cd_randn fail with 'invalid resource handle').  Every C-ABI entry point now
+    clears the error state on the way in: provoke a HIP error outside the library, then call into it."""
+    from calodiffusion_amd import engine
+    lib = engine.load_library()
+    torch.cuda.init()
+    # the HIP runtime this process already runs on (torch ships its own copy: a second one would keep its own error state)
+    path = next(ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64" in ln)
+    hip = ctypes.CDLL(path)
+    hip.hipFree.argtypes, hip.hipFree.restype = [ctypes.c_void_p], ctypes.c_int
+    hip.hipPeekAtLastError.restype = ctypes.c_int
+    torch.cuda.synchronize()
+    assert hip.hipFree(ctypes.c_void_p(0x1234)) != 0      # not an allocation: fails and leaves the error behind
+    assert hip.hipPeekAtLastError() != 0
+    out = torch.empty(4096, dtype=torch.float32, device="cuda")
+    rc = lib.cd_randn(out.data_ptr(), out.numel(), 7, 0, engine._stream())
+    assert rc == 0, lib.cd_last_error().decode(errors="replace")
+    torch.cuda.synchronize()
+    assert abs(float(out.mean())) < 0.1 and 0.9 < float(out.std()) < 1.1
+    # ... and a failing entry point leaves nothing behind for the next one either
+    assert lib.cd_randn(None, 16, 7, 0, engine._stream()) != 0
+    assert lib.cd_randn(out.data_ptr(), out.numel(), 7, 0, engine._stream()) == 0

@@ -48,3 +48,23 @@ def test_checker_catches_a_merged_store(zs_asm, tmp_path):
     bad.write_text(s[:line_start] + "\tglobal_load_dword v0, v[2:3], off\n" + s[line_start:])
     with pytest.raises(SystemExit, match="unmarked vector-memory"):
         chk.check_file(str(bad), "conv_zslide", verbose=False)
+
+
+def test_lindiv_op_is_not_contracted(tmp_path):
+    """CD_SOP_LINDIV promises the rounding of a chain of torch elementwise ops: in the compiled gfx950 code every term of
+    lincomb_div_kernel is a v_mul_f32 followed by a v_add_f32 -- the only fused instructions are those of the IEEE division
+    sequence (v_div_scale ... v_div_fixup)."""
+    if not (os.path.exists(HIPCC) or shutil.which(HIPCC)):
+        pytest.skip("hipcc not available")
+    from calodiffusion_amd.build import FLAGS
+    out = tmp_path / "misc.s"
+    src = os.path.join(ROOT, "calodiffusion_amd", "csrc", "kernels_misc.hip")
+    subprocess.run([HIPCC, *[f for f in FLAGS if f != "-fPIC"], "-S", "--cuda-device-only", "-o", str(out), src], check=True,
+                   capture_output=True)
+    s = open(out).read()
+    m = re.search(r"^(_ZN2cd18lincomb_div_kernel\w+):[^\n]*\n(.*?)s_endpgm", s, re.S | re.M)
+    assert m, "lincomb_div_kernel not found in the assembly"
+    ops = re.findall(r"^\s+(v_\w+)", m.group(2), re.M)
+    assert ops.count("v_mul_f32_e32") >= 6 and ops.count("v_add_f32_e32") == 5, ops
+    fused = [o for o in ops if o.startswith(("v_fma", "v_fmac", "v_mac", "v_pk_fma"))]
+    assert len(fused) <= 5 and "v_div_fixup_f32" in ops, fused  # the division's Newton steps only
