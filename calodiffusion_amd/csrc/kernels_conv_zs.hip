@@ -1152,6 +1152,14 @@ bool try_launch_conv_zslide(const float* in0, int c0, const float* in1, int c1, 
   const int64_t svox = (int64_t)g.in.d * SPV;  // voxels per strip
   if (svox < 2 * ZS_STEP) return false;
   const size_t lds = lds_for(HS);
+  // what the kernels assume about this launch, checked where it is cheap: the GroupNorm fold of the prologue builds its table of
+  // all defer.C channels plus its scratch (gn_defer_scratch_bytes) inside the exchange region, before the first exchange
+  if (fu.defer.part) {
+    CD_REQUIRE(fu.defer.C >= c0 + c1 && fu.defer.C % 4 == 0, "z-slide conv: the deferred GroupNorm must cover the input channels");
+    CD_REQUIRE((size_t)fu.defer.C * 16 + (size_t)gn_defer_scratch_bytes(fu.defer.C) <= (size_t)(v1 ? ZS_PART : 2 * Z3_XCH),
+               "z-slide conv: the GroupNorm fold's scratch does not fit the exchange region");
+  }
+  CD_REQUIRE(lds <= 160 * 1024 && (int64_t)batch * (H / HS) <= 65535 * 64, "z-slide conv: launch geometry out of range");
   const int CTtot = cout / 32;
   // chunks per strip: fill the 256 CUs (one workgroup each) with as few rounds and as little halo restaging as possible
   int best = 1;

@@ -709,6 +709,28 @@ def gold_objectives():
     save("objectives_tiny", **out)
 
 
+def gold_dpm_tables():
+    """The DPM-Solver-fast step tables (calodiffusion_amd.sample.DPM.build) of the three `dpm_*` sampler cases AS COMPUTED ON THIS
+    HOST, where tests/test_host.py shows the programs reproduce the reference's trajectories bit for bit.  torch's vectorised
+    cos / exp / log / expm1 differ in the last bit between CPUs (measured: this container's Xeon against the GPU box's EPYC 9575F:
+    the 2-step table's entries differ by 1-5 ulp), and `dpm_2` amplifies a 4e-7 change of its coefficients to 1.5e-4 of its end
+    point -- the reference itself, run on that other host, lands 1.5e-4 from its own result here.  With these tables the
+    device test can hold the reference's trajectory from THIS host on any host."""
+    from sampler_cases import CASES
+    from calodiffusion_amd.calodiffusion import CaloDiffusion as MyCaloDiffusion
+    g = np.load(os.path.join(GOLD, "samplers_tiny.npz"))
+    out = {}
+    for tag in ("dpm_7", "dpm_6", "dpm_2"):
+        name, over, _, off, rows = CASES[tag]
+        cfg = copy.deepcopy(my_configs.load_config("tiny"))
+        cfg.update(over)
+        cfg["SAMPLER"] = name
+        m = MyCaloDiffusion(cfg, n_steps=cfg["NSTEPS"], loss_type=cfg["LOSS_TYPE"])
+        prog = m.sampler_algorithm.build(m, int(g[f"{tag}.n"]), off).finalize()
+        out[f"{tag}.coefs"], out[f"{tag}.start_scale"] = prog.coefs, np.array(prog.start_scale, dtype=np.float64)
+    save("dpm_tables", **out)
+
+
 def gold_trajectories():
     """Dataset-3 DDIM (10 and 50 steps, batch 1) and HGCal DDPM (200 steps, batch 2, seeded noise stream) end points."""
     cfg3 = my_configs.load_config("dataset3")
@@ -760,6 +782,9 @@ if __name__ == "__main__":
         gold_sinusoidal()
     if "grads" in which:
         gold_grads()
+    if "dpm_tables" in which:
+        sys.path.insert(0, os.path.join(REPO, "tests"))
+        gold_dpm_tables()
     if "objectives" in which:
         gold_objectives()
     if "traj" in which:

