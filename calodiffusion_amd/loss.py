@@ -80,14 +80,25 @@ class _TrainStep(torch.autograd.Function):
     def forward(ctx, engine, loss_type, data, noise, sigma, cond, *params):
         loss, flat = engine.train_step(data, noise, sigma, cond, loss_type)
         allreduce_mean_(flat)  # data parallel: identical replicas, one flat-buffer all-reduce per step
-        ctx.engine, ctx.flat = engine, flat
+        ctx.engine, ctx.flat, ctx.params = engine, flat, params
         return loss.to(torch.float32)
 
     @staticmethod
     def backward(ctx, grad_out):
-        # one scaling of the flat buffer, then per-parameter views (no per-tensor kernels)
-        grads = ctx.engine.param_grads(ctx.flat * grad_out.to(ctx.flat.dtype))
-        return (None, None, None, None, None, None) + tuple(grads)
+        # ONE scaling of the flat buffer (this call's own: train_step allocates it), then every parameter's .grad is a VIEW of it.
+        # Handing the views back to autograd instead made AccumulateGrad clone each of the ~230 of them into a fresh .grad tensor --
+        # one elementwise launch and one allocation per parameter and step (rocprofv3, round 3: 233 launches) -- so the hand-over
+        # is done here, with torch's accumulation semantics: a parameter without a gradient takes the view, one that already
+        # has a gradient (no zero_grad between two backward passes) gets the view added.
+        flat = ctx.flat.mul_(grad_out.to(ctx.flat.dtype))
+        for p, g in zip(ctx.params, ctx.engine.param_grads(flat)):
+            if not p.requires_grad:
+                continue
+            if p.grad is None:
+                p.grad = g
+            else:
+                p.grad = p.grad + g if p.grad.requires_grad else p.grad.add_(g)
+        return (None,) * (6 + len(ctx.params))
 
 
 class hybrid_weight(Loss):
