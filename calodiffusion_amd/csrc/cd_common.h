@@ -303,7 +303,10 @@ size_t gn_backward_scratch_floats(int batch, int channels, int64_t vox);
 // backward of y = act(scale*h + shift) + add: dh, dgamma, dbeta (accumulated if asked), dadd[b][c] (optional)
 void launch_gn_backward(const float* dy, const float* h, const float* coef, const float* stat, const float* gamma, float* dh,
                         float* dgamma, float* dbeta, float* dadd, int dadd_ld, int batch, int channels, int64_t vox, int groups,
-                        int silu, float* scratch, bool accumulate_params, hipStream_t s);
+                        int silu, float* scratch, bool accumulate_params, hipStream_t s,
+                        // (optional, round 4) the bias gradient of the conv that produced h, and sum_{b,v} dy per channel (the bias
+                        // gradient of a conv that adds into y): both fall out of the statistics pass, see kernels_bwd.hip
+                        float* dbias = nullptr, float* dsumdy = nullptr);
 int gn_apply_blocks_per_sample(int batch, int channels, int64_t vox);
 // y = act(scale*x + shift) + add (+ residual; residual1/res_c0: shortcut read from a two-source channel concat);
 // part_out (optional): channel partials of y, [B][gn_apply_blocks_per_sample][C][2]

@@ -490,8 +490,13 @@ void launch_bias_grad(const float* part, int units, int batch, int channels, flo
 // y = act(z) + add [+ residual].  Given dy:
 //   dz = dy * act'(z);  dgamma[c] = sum dz*hhat;  dbeta[c] = sum dz;  dadd[b][c] = sum_v dy
 //   dh = rstd * (dhhat - mean_g(dhhat) - hhat * mean_g(dhhat*hhat)),  dhhat = dz*gamma,  hhat = (h - mean)*rstd
-// Pass 1 (gn_bwd_stats_kernel): per (b, split, c): {sum dz, sum dz*hhat, sum dy}.  Pass 2 (gn_bwd_apply_kernel).
+// Pass 1 (gn_bwd_stats_kernel): per (b, split, c): {sum dz, sum dz*hhat, sum dy, sum (h - mean)}.  Pass 2 (gn_bwd_apply_kernel).
 // `stat` = saved {mean, rstd} per (b, g).
+// Two more parameter gradients fall out of those sums without another pass over a tensor (round 4: ch_stats + bias_grad were two
+// launches and a re-read of dh / dy per convolution bias):
+//   the bias of the convolution that PRODUCED h:  sum_v dh = A sum_v dz - rstd (vox m1 + rstd m2 sum_v (h - mean))
+//       (dh = A dz + Bh h + C0 with A = rstd gamma, Bh = -rstd^2 m2, C0 = rstd (-m1 + mean rstd m2): gn_bwd_finalize_kernel)
+//   the bias of a convolution that adds into y (a ResnetBlock's 1x1 shortcut):  sum_v dy.
 // ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float silu_grad(float z) {
   const float sg = 1.f / (1.f + expf(-z));
@@ -502,7 +507,7 @@ __global__ void __launch_bounds__(256) gn_bwd_stats_kernel(const float* __restri
                                                            const float* __restrict__ coef, const float* __restrict__ stat,
                                                            float* __restrict__ part, int channels, int64_t vox, int groups,
                                                            int silu, int nsplit) {
-  __shared__ double sP[256][3];
+  __shared__ double sP[256][4];
   const int tid = threadIdx.x;
   const int split = blockIdx.x, b = blockIdx.y;
   const int cols = channels >> 2, rows = 256 / cols;
@@ -510,7 +515,7 @@ __global__ void __launch_bounds__(256) gn_bwd_stats_kernel(const float* __restri
   const int64_t v0 = split * per, v1 = (v0 + per < vox) ? v0 + per : vox;
   const int colid = tid % cols, row = tid / cols;
   const int c = colid * 4, cpg = channels / groups;
-  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
   if (row < rows) {
     f32x4 cf[4];
 #pragma unroll
@@ -527,17 +532,20 @@ __global__ void __launch_bounds__(256) gn_bwd_stats_kernel(const float* __restri
         s0[e] += dz;
         s1[e] += dz * (hv[e] - mean) * rstd;
         s2[e] += g[e];
+        s3[e] += hv[e] - mean;
       }
     }
   }
-  float* dst = part + (((size_t)b * nsplit + split) * channels) * 3;
+  float* dst = part + (((size_t)b * nsplit + split) * channels) * 4;
   for (int e = 0; e < 4; ++e) {
-    sP[tid][0] = (double)s0[e]; sP[tid][1] = (double)s1[e]; sP[tid][2] = (double)s2[e];
+    sP[tid][0] = (double)s0[e]; sP[tid][1] = (double)s1[e]; sP[tid][2] = (double)s2[e]; sP[tid][3] = (double)s3[e];
     __syncthreads();
     if (tid < cols) {
-      double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-      for (int r = 0; r < rows; ++r) { a0 += sP[r * cols + tid][0]; a1 += sP[r * cols + tid][1]; a2 += sP[r * cols + tid][2]; }
-      dst[(tid * 4 + e) * 3] = (float)a0; dst[(tid * 4 + e) * 3 + 1] = (float)a1; dst[(tid * 4 + e) * 3 + 2] = (float)a2;
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      for (int r = 0; r < rows; ++r) {
+        a0 += sP[r * cols + tid][0]; a1 += sP[r * cols + tid][1]; a2 += sP[r * cols + tid][2]; a3 += sP[r * cols + tid][3];
+      }
+      *(f32x4*)(dst + (tid * 4 + e) * 4) = f32x4{(float)a0, (float)a1, (float)a2, (float)a3};
     }
     __syncthreads();
   }
@@ -553,14 +561,18 @@ __global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(const float* __res
   __shared__ float m1[64], m2[64];
   const int b = blockIdx.x, c = threadIdx.x;
   const int cpg = channels / groups;
-  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
   if (c < channels) {
-    const float* p = part + ((size_t)b * nsplit * channels + c) * 3;
-    for (int u = 0; u < nsplit; ++u) { a0 += (double)p[(size_t)u * channels * 3]; a1 += (double)p[(size_t)u * channels * 3 + 1]; a2 += (double)p[(size_t)u * channels * 3 + 2]; }
+    const float* p = part + ((size_t)b * nsplit * channels + c) * 4;
+    for (int u = 0; u < nsplit; ++u) {
+      const f32x4 v = *(const f32x4*)(p + (size_t)u * channels * 4);
+      a0 += (double)v[0]; a1 += (double)v[1]; a2 += (double)v[2]; a3 += (double)v[3];
+    }
     s0[c] = a0 * (double)gamma[c];   // sum dhhat
     s1[c] = a1 * (double)gamma[c];   // sum dhhat*hhat
-    sums_bc[((size_t)b * channels + c) * 2] = (float)a0;      // dbeta contribution of this sample
-    sums_bc[((size_t)b * channels + c) * 2 + 1] = (float)a1;  // dgamma contribution
+    sums_bc[((size_t)b * channels + c) * 4] = (float)a0;      // dbeta contribution of this sample
+    sums_bc[((size_t)b * channels + c) * 4 + 1] = (float)a1;  // dgamma contribution
+    sums_bc[((size_t)b * channels + c) * 4 + 3] = (float)a2;  // sum_v dy: bias of a conv that adds into y (the shortcut)
     if (dadd) dadd[(size_t)b * dadd_ld + c] = (float)a2;
   }
   __syncthreads();
@@ -582,25 +594,34 @@ __global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(const float* __res
     o[2] = rstd * (-m1[g] + mean * rstd * m2[g]);
     o[3] = 0.f;
     *(f32x4*)(gcoef + ((size_t)b * channels + c) * 4) = o;
+    // sum_v dh of this sample and channel (the bias gradient of the conv that produced h), from the sums in hand
+    sums_bc[((size_t)b * channels + c) * 4 + 2] =
+        (float)((double)o[0] * a0 - (double)rstd * ((double)m1[g] * (double)vox + (double)rstd * (double)m2[g] * a3));
   }
 }
 
 __global__ void param_grad_from_samples_kernel(const float* __restrict__ sums_bc, int batch, int channels, float* __restrict__ dgamma,
-                                               float* __restrict__ dbeta, int accumulate) {
+                                               float* __restrict__ dbeta, int accumulate, float* __restrict__ dbias,
+                                               float* __restrict__ dsumdy) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= channels) return;
-  double g = 0.0, bt = 0.0;
+  double g = 0.0, bt = 0.0, bs = 0.0, sy = 0.0;
   int n = 0;
-  for (; n + 8 <= batch; n += 8) {  // eight samples' pairs in flight (fixed summation order)
-    float2 v[8];
+  for (; n + 8 <= batch; n += 8) {  // eight samples' rows in flight (fixed summation order)
+    f32x4 v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = *(const float2*)(sums_bc + ((size_t)(n + u) * channels + c) * 2);
+    for (int u = 0; u < 8; ++u) v[u] = *(const f32x4*)(sums_bc + ((size_t)(n + u) * channels + c) * 4);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) { bt += (double)v[u].x; g += (double)v[u].y; }
+    for (int u = 0; u < 8; ++u) { bt += (double)v[u][0]; g += (double)v[u][1]; bs += (double)v[u][2]; sy += (double)v[u][3]; }
   }
-  for (; n < batch; ++n) { bt += (double)sums_bc[((size_t)n * channels + c) * 2]; g += (double)sums_bc[((size_t)n * channels + c) * 2 + 1]; }
+  for (; n < batch; ++n) {
+    const f32x4 v = *(const f32x4*)(sums_bc + ((size_t)n * channels + c) * 4);
+    bt += (double)v[0]; g += (double)v[1]; bs += (double)v[2]; sy += (double)v[3];
+  }
   dgamma[c] = accumulate ? dgamma[c] + (float)g : (float)g;
   dbeta[c] = accumulate ? dbeta[c] + (float)bt : (float)bt;
+  if (dbias) dbias[c] = (float)bs;
+  if (dsumdy) dsumdy[c] = (float)sy;
 }
 
 // dh = gc0*dz + gc1*h + gc2 (+ dh_accum), dz = dy*act'(scale*h+shift)
@@ -650,18 +671,18 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const float* __restri
 
 void launch_gn_backward(const float* dy, const float* h, const float* coef, const float* stat, const float* gamma, float* dh,
                         float* dgamma, float* dbeta, float* dadd, int dadd_ld, int batch, int channels, int64_t vox, int groups,
-                        int silu, float* scratch, bool accumulate_params, hipStream_t s) {
+                        int silu, float* scratch, bool accumulate_params, hipStream_t s, float* dbias, float* dsumdy) {
   CD_REQUIRE(channels % 4 == 0 && channels <= 256 && groups <= 64, "group norm backward: <= 256 channels, <= 64 groups");
   const int ns = gn_nsplit_for(vox, batch);
-  float* part = scratch;                                         // [B][ns][C][3]
-  float* gcoef = part + (size_t)batch * ns * channels * 3;        // [B][C][4]
-  float* sums_bc = gcoef + (size_t)batch * channels * 4;          // [B][C][2]
+  float* part = scratch;                                         // [B][ns][C][4]
+  float* gcoef = part + (size_t)batch * ns * channels * 4;        // [B][C][4]
+  float* sums_bc = gcoef + (size_t)batch * channels * 4;          // [B][C][4]
   prof::Scope scope("gn_backward", s, 0, 4.0 * batch * (double)vox * channels * 5);
   hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(ns, batch), dim3(256), 0, s, dy, h, coef, stat, part, channels, vox, groups, silu, ns);
   hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(batch), dim3(256), 0, s, part, ns, gamma, stat, gcoef, sums_bc, dadd, dadd_ld,
                      channels, groups, vox);
   hipLaunchKernelGGL(param_grad_from_samples_kernel, dim3((channels + 63) / 64), dim3(64), 0, s, sums_bc, batch, channels, dgamma,
-                     dbeta, accumulate_params ? 1 : 0);
+                     dbeta, accumulate_params ? 1 : 0, dbias, dsumdy);
   const int bps = gn_apply_blocks_per_sample(batch, channels, vox);
   unsigned* amax_word = absmax_word_fresh(dh, s);  // zeroed; the consumer's launch_absmax_bits(dh) finds it instead of re-reading dh
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)(batch * bps)), dim3(256), 0, s, dy, h, coef, gcoef, dh, channels, vox, silu, bps,
@@ -1271,7 +1292,7 @@ void launch_fold_phi(const float* src, float* dst, int batch, Dims3 d, int C, hi
 
 size_t gn_backward_scratch_floats(int batch, int channels, int64_t vox) {
   const int ns = gn_nsplit_for(vox, batch);
-  return (size_t)batch * ns * channels * 3 + (size_t)batch * channels * 6 + 64;
+  return (size_t)batch * ns * channels * 4 + (size_t)batch * channels * 8 + 64;
 }
 
 }  // namespace cd

@@ -24,19 +24,19 @@ namespace cd {
 typedef __fp16 fh4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 typedef __fp16 fh8 __attribute__((__vector_size__(8 * sizeof(__fp16))));
 
-// max |x| as a bit pattern (non-negative floats order like their bit patterns).  Four loads in flight per thread and ONE
+// max |x| as a bit pattern (non-negative floats order like their bit patterns).  Eight loads in flight per thread and ONE
 // atomic per workgroup (one load per trip and one atomic per wave made this HBM-sized pass 50 us: 4096 same-address atomics).
 __global__ void __launch_bounds__(256) absmax_bits_kernel(const float* __restrict__ x, size_t n4, unsigned* __restrict__ out) {
   __shared__ float sm[4];
   float m = 0.f;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  for (; i + 3 * stride < n4; i += 4 * stride) {
-    f32x4 v[4];
+  for (; i + 7 * stride < n4; i += 8 * stride) {
+    f32x4 v[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) v[u] = ((const f32x4*)x)[i + u * stride];
+    for (int u = 0; u < 8; ++u) v[u] = ((const f32x4*)x)[i + u * stride];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < 8; ++u)
       m = fmaxf(m, fmaxf(fmaxf(fabsf(v[u][0]), fabsf(v[u][1])), fmaxf(fabsf(v[u][2]), fabsf(v[u][3]))));
   }
   for (; i < n4; i += stride) {
@@ -281,9 +281,28 @@ bool g_absmax_fresh = false;  // the word was filled by the producer of g_absmax
 // A producer that can track max |x| while it writes x (gn_bwd_apply_kernel) takes the zeroed word here; the next
 // launch_absmax_bits call claims it if (and only if) it asks for the same tensor -- a later tensor at a recycled workspace
 // address can never match a stale note.
+// The words come from a ring that is zeroed as a whole when it wraps (a hipMemsetAsync per request was ~80 four-byte fills per
+// training step, 4 us each): a request takes the next word, still zero -- every launch that used the ring's previous round was
+// enqueued on the stream before the wrap's memset.
+namespace {
+constexpr int ABSMAX_RING = 4096;
+unsigned* g_absmax_ring = nullptr;
+int g_absmax_next = 0;
+unsigned* absmax_next_word(hipStream_t s) {
+  if (!g_absmax_ring) {
+    CD_HIP(hipMalloc((void**)&g_absmax_ring, sizeof(unsigned) * ABSMAX_RING));
+    CD_HIP(hipMemsetAsync(g_absmax_ring, 0, sizeof(unsigned) * ABSMAX_RING, s));
+    g_absmax_next = 0;
+  }
+  if (g_absmax_next == ABSMAX_RING) {
+    CD_HIP(hipMemsetAsync(g_absmax_ring, 0, sizeof(unsigned) * ABSMAX_RING, s));
+    g_absmax_next = 0;
+  }
+  return g_absmax_ring + g_absmax_next++;
+}
+}  // namespace
 unsigned* absmax_word_fresh(const float* x, hipStream_t s) {
-  if (!g_absmax_word) CD_HIP(hipMalloc((void**)&g_absmax_word, 64));
-  CD_HIP(hipMemsetAsync(g_absmax_word, 0, sizeof(unsigned), s));
+  g_absmax_word = absmax_next_word(s);
   g_absmax_of = x;
   g_absmax_n = 0;
   g_absmax_fresh = true;
@@ -302,10 +321,15 @@ const unsigned* launch_absmax_bits(const float* x, size_t n, hipStream_t s) {
     return g_absmax_word;
   }
   g_absmax_fresh = false;
-  if (!g_absmax_word) CD_HIP(hipMalloc((void**)&g_absmax_word, 64));
   CD_REQUIRE(n % 4 == 0, "absmax: element count must be a multiple of 4");
-  CD_HIP(hipMemsetAsync(g_absmax_word, 0, sizeof(unsigned), s));
-  hipLaunchKernelGGL(absmax_bits_kernel, dim3(2048), dim3(256), 0, s, x, n / 4, g_absmax_word);
+  g_absmax_word = absmax_next_word(s);
+  // one atomic per workgroup on ONE word: same-address atomics retire at ~12 ns each, so the 2048 workgroups this pass used to
+  // launch spent 25 us in them whatever the tensor's size (rocprofv3, round 4: 35 calls x 25 us per training step).  256-512
+  // workgroups with eight 16-byte loads in flight per thread stream a level-0 gradient (26 MB) in ~7 us.
+  size_t blocks = (n / 4 + 256 * 8 - 1) / (256 * 8);
+  if (blocks < 1) blocks = 1;
+  if (blocks > 512) blocks = 512;
+  hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, n / 4, g_absmax_word);
   CD_HIP(hipGetLastError());
   g_absmax_of = x;
   g_absmax_n = n;
