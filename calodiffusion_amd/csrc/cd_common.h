@@ -181,6 +181,8 @@ struct PackJob {
   void* f16;         // f16x2 image or null
   int cout, cin, taps;
   int kind;          // 0 = raw only, 1 = conv, 2 = transposed conv (images in transposed channel order), 3 = init conv
+  int tr, flip;      // (the input-gradient images of the training step: plan.hip dgrad_images) stored [ci][co][tap] / taps reversed;
+                     // raw may then be null (numel 0) and src is the plan's own copy of the tensor
   unsigned long long numel, n_pk, n_bf3, n_f16;  // work items of the four phases
 };
 void launch_pack_jobs(const PackJob* d_jobs, int njobs, hipStream_t s);        // raw copy, f32 / init and bf16x3 images (kernels_conv.hip)

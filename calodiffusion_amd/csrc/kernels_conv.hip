@@ -695,11 +695,12 @@ __global__ void __launch_bounds__(256) pack_jobs_kernel(const PackJob* __restric
     if (j.kind == 3) {
       for (size_t i = t0; i < j.n_pk; i += stride) pack_init_weights_elem((int)i, j.src, j.pk, j.cout, j.cin);
     } else {
-      for (size_t i = t0; i < j.n_pk; i += stride) pack_weights_elem(i, j.src, j.pk, j.cout, j.cin, j.taps, j.kind == 2, 0);
+      for (size_t i = t0; i < j.n_pk; i += stride) pack_weights_elem(i, j.src, j.pk, j.cout, j.cin, j.taps, j.kind == 2 || j.tr, j.flip);
     }
   }
   if (j.bf3)
-    for (size_t i = t0; i < j.n_bf3; i += stride) pack_weights_bf16x3_elem(i, j.src, (u32x4*)j.bf3, j.cout, j.cin, j.taps, j.kind == 2, 0);
+    for (size_t i = t0; i < j.n_bf3; i += stride)
+      pack_weights_bf16x3_elem(i, j.src, (u32x4*)j.bf3, j.cout, j.cin, j.taps, j.kind == 2 || j.tr, j.flip);
 }
 void launch_pack_jobs(const PackJob* d_jobs, int njobs, hipStream_t s) {
   if (njobs <= 0) return;

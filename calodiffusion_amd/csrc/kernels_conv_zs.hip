@@ -67,7 +67,8 @@ __global__ void __launch_bounds__(256) pack_jobs_f16x2_kernel(const PackJob* __r
   const PackJob j = jobs[blockIdx.y];
   if (!j.f16) return;
   const size_t t0 = blockIdx.x * (size_t)256 + threadIdx.x, stride = gridDim.x * (size_t)256;
-  for (size_t i = t0; i < j.n_f16; i += stride) pack_weights_f16x2_elem(i, j.src, (u32x4*)j.f16, j.cout, j.cin, j.taps, j.kind == 2, 0);
+  for (size_t i = t0; i < j.n_f16; i += stride)
+    pack_weights_f16x2_elem(i, j.src, (u32x4*)j.f16, j.cout, j.cin, j.taps, j.kind == 2 || j.tr, j.flip);
 }
 void launch_pack_jobs_f16x2(const PackJob* d_jobs, int njobs, hipStream_t s) {
   if (njobs <= 0) return;

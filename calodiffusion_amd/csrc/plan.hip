@@ -32,6 +32,14 @@ struct WeightEntry {
   size_t pk3_off = 0;  // split-bf16 image of 3x3x3 convs (floats into the arena; 0 = none)
   size_t grad_off = 0; // floats into the flat gradient buffer of cd_train_step
   bool set = false;
+  // input-gradient images of the training step (dgrad_images below), floats into CdPlan::dg_arena; dg_mode 0 = none
+  int dg_mode = 0;
+  size_t dg_pk_off = 0, dg_pk3_off = 0;
+};
+// packed images a convolution's input gradient reads (conv_backward / conv_transpose_backward); null members: pack on the fly
+struct DgImg {
+  const float* pk = nullptr;
+  const void* pk3 = nullptr;
 };
 
 struct ResW {
@@ -156,6 +164,20 @@ struct CdPlan {
   // job list of cd_plan_set_weights: host copy (with the callers' pointers of the last call) and device copy
   std::vector<PackJob> pack_jobs;
   PackJob* d_pack_jobs = nullptr;
+  // training: the re-packed (channel-transposed, tap-flipped) weight images of every convolution's input gradient, made by ONE
+  // job list per step (two launches) instead of two or three pack launches inside each conv_backward (118 launches per step)
+  float* dg_arena = nullptr;
+  PackJob* d_dg_jobs = nullptr;
+  int n_dg_jobs = 0;
+  DgImg dg(int i) const {
+    DgImg g;
+    const WeightEntry& w = weights[i];
+    if (dg_arena && w.dg_mode) {
+      g.pk = dg_arena + w.dg_pk_off;
+      if (w.dg_mode != 1) g.pk3 = dg_arena + w.dg_pk3_off;
+    }
+    return g;
+  }
   hipGraphExec_t graph_exec = nullptr;
   struct GraphKey {
     int batch = 0; const void* ws = nullptr; const void* cond = nullptr; const void* x = nullptr; int noisy = 0; uint64_t seed = 0, offset = 0;
@@ -706,51 +728,58 @@ void bias_grad(Run& r, const float* dy, int C, int64_t vox, float* db) {
 // Backward of a phi-periodic Conv3d y = conv(cat(x0, x1), w) + b  (3x3x3 stride 1, 1x1x1, or the (3,4,4) strided conv).
 //   dx (optional): (B, vox_in, c0+c1) gradient of the concatenated input
 //   dw: torch layout (cout, c0+c1, taps);  db: (cout) or null.   w_raw: torch-layout weights (device).
+// img (optional): the input gradient's weight images already packed for this step (CdPlan::dg); without them they are packed here.
 void conv_backward(Run& r, const float* x0, int c0, const float* x1, int c1, const float* w_raw, const float* dy, float* dx,
-                   float* dw, float* db, int cout, const ConvGeom& g) {
+                   float* dw, float* db, int cout, const ConvGeom& g, const DgImg* img = nullptr) {
   Arena* ws = r.ws;
   const int cin = c0 + c1, T = g.kd * g.kh * g.kw;
+  const bool pre = img && img->pk;
   if (dx) {
     if (T == 1) {
-      float* wp = ws->get<float>(packed_weight_floats(cout, cin, 1));
+      float* wp = pre ? nullptr : ws->get<float>(packed_weight_floats(cout, cin, 1));
       if (!r.dry()) {
-        launch_pack_weights(w_raw, wp, cin, cout, 1, true, r.s);
+        if (!pre) launch_pack_weights(w_raw, wp, cin, cout, 1, true, r.s);
         PointwiseArgs a;
-        a.in0 = dy; a.ld0 = cout; a.c0 = cout; a.wpk = wp; a.out = dx; a.batch = r.B; a.cout = cin; a.vox = g.in.vox();
+        a.in0 = dy; a.ld0 = cout; a.c0 = cout; a.wpk = pre ? img->pk : wp; a.out = dx; a.batch = r.B; a.cout = cin; a.vox = g.in.vox();
         launch_pointwise(a, r.s);
       }
-      ws->release(wp);
+      if (wp) ws->release(wp);
     } else if (g.sz == 1 && g.sh == 1 && g.sw == 1) {
       // dx = conv(dy, W^T flipped): the forward kernels with re-packed weights
-      float* wp = ws->get<float>(packed_weight_floats(cout, cin, T));
-      float* wp3 = ws->get<float>(packed_split16_bytes(cout, cin, T) / 4);
+      float* wp = pre ? nullptr : ws->get<float>(packed_weight_floats(cout, cin, T));
+      float* wp3 = pre ? nullptr : ws->get<float>(packed_split16_bytes(cout, cin, T) / 4);
       if (!r.dry()) {
-        launch_pack_weights(w_raw, wp, cin, cout, T, true, r.s, true);
-        launch_pack_weights_split16(w_raw, wp3, cin, cout, T, r.s, true, true);
+        if (!pre) {
+          launch_pack_weights(w_raw, wp, cin, cout, T, true, r.s, true);
+          launch_pack_weights_split16(w_raw, wp3, cin, cout, T, r.s, true, true);
+        }
         ConvGeom gd{g.out, g.in, g.kd, g.kh, g.kw, 1, 1, 1};
         ConvFusion fu;
-        fu.wpk_bf16x3 = wp3;
+        fu.wpk_bf16x3 = pre ? img->pk3 : wp3;
         fu.in_absmax = launch_absmax_bits(dy, (size_t)r.B * g.out.vox() * cout, r.s);  // also serves the weight gradient below
-        launch_conv_mfma(dy, cout, nullptr, 0, wp, nullptr, dx, r.B, cin, gd, r.s, fu);
+        launch_conv_mfma(dy, cout, nullptr, 0, pre ? img->pk : wp, nullptr, dx, r.B, cin, gd, r.s, fu);
       }
-      ws->release(wp3);
-      ws->release(wp);
+      if (wp3) ws->release(wp3);
+      if (wp) ws->release(wp);
     } else if (g.in.h & 1) {
       // odd phi ring: the circular halo breaks the parity classes of the gather kernel (see kernels_bwd.hip)
       if (!r.dry()) launch_strided_dgrad_naive(dy, w_raw, dx, r.B, cin, cout, g.in, g.out, g.kd, g.sz, r.s);
     } else {
       // strided conv: its adjoint is the transposed-conv gather kernel
       // (on the fp16 pipe like the forward up-conv, the tiny gradients rescaled by a power of two from their max)
-      float* wp = ws->get<float>(packed_weight_floats(cout, cin, T));
-      float* wp16 = ws->get<float>(packed_f16x2_bytes(cout, cin, T) / 4 + 64);
+      float* wp = pre ? nullptr : ws->get<float>(packed_weight_floats(cout, cin, T));
+      float* wp16 = pre ? nullptr : ws->get<float>(packed_f16x2_bytes(cout, cin, T) / 4 + 64);
       if (!r.dry()) {
-        launch_pack_weights(w_raw, wp, cin, cout, T, true, r.s);
-        launch_pack_weights_f16x2(w_raw, wp16, cin, cout, T, r.s, true, false);
+        if (!pre) {
+          launch_pack_weights(w_raw, wp, cin, cout, T, true, r.s);
+          launch_pack_weights_f16x2(w_raw, wp16, cin, cout, T, r.s, true, false);
+        }
         const unsigned* amax = launch_absmax_bits(dy, (size_t)r.B * g.out.vox() * cout, r.s);
-        launch_conv_transpose_mfma(dy, cout, wp, nullptr, dx, r.B, cin, g.out, g.in, g.kd, g.sz, r.s, wp16, r.status, amax);
+        launch_conv_transpose_mfma(dy, cout, pre ? img->pk : wp, nullptr, dx, r.B, cin, g.out, g.in, g.kd, g.sz, r.s,
+                                   pre ? img->pk3 : wp16, r.status, amax);
       }
-      ws->release(wp16);
-      ws->release(wp);
+      if (wp16) ws->release(wp16);
+      if (wp) ws->release(wp);
     }
   }
   float* part = ws->get<float>(wgrad_partial_floats(g.out.vox(), r.B, false, cout, c0 > c1 ? c0 : c1, T));
@@ -765,9 +794,10 @@ void conv_backward(Run& r, const float* x0, int c0, const float* x1, int c1, con
 
 // Backward of the phi-periodic ConvTranspose3d (Upsample): y = convT(x, w) + b, w stored (cin, cout, kz, 4, 4)
 void conv_transpose_backward(Run& r, const float* x, const float* w_raw, const float* dy, float* dx, float* dw, float* db, int c,
-                             Dims3 din, Dims3 dout, int kz, int sz) {
+                             Dims3 din, Dims3 dout, int kz, int sz, const DgImg* img = nullptr) {
   Arena* ws = r.ws;
   const int T = kz * 16;
+  const bool pre = img && img->pk;
   // Odd output phi extent (output_padding 1 along phi: Dataset-3 level 1, Dataset-1 grid): the forward's last phi row
   // duplicates row 0, so fold its gradient into row 0 and continue on the even ring (kernels_bwd.hip: fold_phi_kernel).
   float* folded = nullptr;
@@ -781,19 +811,21 @@ void conv_transpose_backward(Run& r, const float* x, const float* w_raw, const f
   }
   if (dx) {
     // dx[i][ci] = sum_k dy[s*i + k - 1][co] w[ci][co][k]: a strided conv of dy with w viewed as (co' = ci, ci' = co)
-    float* wp = ws->get<float>(packed_weight_floats(c, c, T));
-    float* wp3 = ws->get<float>(packed_split16_bytes(c, c, T) / 4);
+    float* wp = pre ? nullptr : ws->get<float>(packed_weight_floats(c, c, T));
+    float* wp3 = pre ? nullptr : ws->get<float>(packed_split16_bytes(c, c, T) / 4);
     if (!r.dry()) {
-      launch_pack_weights(w_raw, wp, c, c, T, false, r.s);
-      launch_pack_weights_split16(w_raw, wp3, c, c, T, r.s, false, false);
+      if (!pre) {
+        launch_pack_weights(w_raw, wp, c, c, T, false, r.s);
+        launch_pack_weights_split16(w_raw, wp3, c, c, T, r.s, false, false);
+      }
       ConvGeom gd{dout, din, kz, 4, 4, sz, 2, 2};
       ConvFusion fu;
-      fu.wpk_bf16x3 = wp3;
+      fu.wpk_bf16x3 = pre ? img->pk3 : wp3;
       fu.in_absmax = launch_absmax_bits(dy, (size_t)r.B * dout.vox() * c, r.s);
-      launch_conv_mfma(dy, c, nullptr, 0, wp, nullptr, dx, r.B, c, gd, r.s, fu);
+      launch_conv_mfma(dy, c, nullptr, 0, pre ? img->pk : wp, nullptr, dx, r.B, c, gd, r.s, fu);
     }
-    ws->release(wp3);
-    ws->release(wp);
+    if (wp3) ws->release(wp3);
+    if (wp) ws->release(wp);
   }
   // dw[ci][co][k] = sum_i x[i][ci] * dy[s*i + k - 1][co]: the strided-conv weight gradient with the two tensors' roles swapped
   float* part = ws->get<float>(wgrad_partial_floats(din.vox(), r.B, false, c, c, T));
@@ -1192,6 +1224,8 @@ int cd_plan_destroy(CdPlan* plan) {
     destroy_prog_graph(plan);
     if (plan->cap_stream) hipStreamDestroy(plan->cap_stream);
     if (plan->d_pack_jobs) hipFree(plan->d_pack_jobs);
+    if (plan->d_dg_jobs) hipFree(plan->d_dg_jobs);
+    if (plan->dg_arena) hipFree(plan->dg_arena);
     if (plan->arena) hipFree(plan->arena);
     if (plan->d_embed_layers) hipFree(plan->d_embed_layers);
     if (plan->d_coords) hipFree(plan->d_coords);
@@ -1832,10 +1866,69 @@ int cd_plan_grad_layout(const CdPlan* plan, int idx, int64_t* offset, int64_t* t
   });
 }
 
+// The weight images every convolution's INPUT gradient reads (the forward kernels run on channel-transposed, tap-flipped weights:
+// conv_backward / conv_transpose_backward), laid out once in a plan-owned arena and described by one job list whose sources are
+// the plan's own raw copies of the tensors -- stable pointers, so the list never changes; train_step_impl launches it once per
+// step.  dg_mode: 1 = 1x1 conv (f32 image, transposed), 2 = 3x3x3 stride 1 (f32 + split16 images, transposed + flipped),
+// 3 = strided down conv (f32 + f16x2 images, transposed: its adjoint is the up-conv gather kernel), 4 = up conv (f32 + split16
+// images of the tensor read as a plain conv: its adjoint is the strided conv).
+static void dgrad_images(CdPlan* p) {
+  if (p->dg_arena) return;
+  size_t off = 0;
+  auto bump = [&](size_t n) { size_t o = off; off += (n + 63) & ~(size_t)63; return o; };
+  std::vector<PackJob> jobs;
+  for (auto& w : p->weights) {
+    if (w.pack != PK_CONV && w.pack != PK_CONVT) continue;
+    PackJob j{};
+    j.kind = 1;
+    j.taps = w.taps;
+    if (w.pack == PK_CONVT) {
+      w.dg_mode = 4;
+      j.cout = w.cout; j.cin = w.cin;
+    } else {
+      w.dg_mode = w.taps == 1 ? 1 : (w.taps == 27 ? 2 : 3);
+      j.cout = w.cin; j.cin = w.cout;  // the gradient's convolution maps the conv's output channels back to its input channels
+      j.tr = 1;
+      j.flip = w.dg_mode == 2 ? 1 : 0;
+    }
+    if (j.cin % 32 || j.cout % 32) {  // (the init conv's 3 / 4 input channels never need an input gradient)
+      w.dg_mode = 0;
+      continue;
+    }
+    w.dg_pk_off = bump(packed_weight_floats(j.cin, j.cout, w.taps));
+    const unsigned long long n16 = (unsigned long long)(j.cin / 16) * w.taps * ((j.cout + 31) / 32) * 64;
+    if (w.dg_mode == 2 || w.dg_mode == 4) w.dg_pk3_off = bump(packed_split16_bytes(j.cin, j.cout, w.taps) / 4);
+    else if (w.dg_mode == 3) w.dg_pk3_off = bump(packed_f16x2_bytes(j.cin, j.cout, w.taps) / 4 + 64);
+    j.n_pk = packed_weight_floats(j.cin, j.cout, w.taps);
+    if (w.dg_mode == 2 || w.dg_mode == 4) j.n_bf3 = j.n_f16 = n16;
+    else if (w.dg_mode == 3) j.n_f16 = n16;
+    jobs.push_back(j);
+  }
+  CD_HIP(hipMalloc((void**)&p->dg_arena, (off + 64) * sizeof(float)));
+  CD_HIP(hipMemset(p->dg_arena, 0, (off + 64) * sizeof(float)));
+  size_t k = 0;
+  for (auto& w : p->weights) {
+    if (!w.dg_mode) continue;
+    PackJob& j = jobs[k++];
+    j.src = p->arena + w.raw_off;
+    j.pk = p->dg_arena + w.dg_pk_off;
+    if (w.dg_mode == 2 || w.dg_mode == 4) {
+      j.bf3 = p->dg_arena + w.dg_pk3_off;
+      j.f16 = (char*)(p->dg_arena + w.dg_pk3_off) + packed_bf16x3_bytes(j.cin, j.cout, w.taps);
+    } else if (w.dg_mode == 3) {
+      j.f16 = p->dg_arena + w.dg_pk3_off;
+    }
+  }
+  p->n_dg_jobs = (int)jobs.size();
+  CD_HIP(hipMalloc((void**)&p->d_dg_jobs, sizeof(PackJob) * (jobs.size() + 1)));
+  CD_HIP(hipMemcpy(p->d_dg_jobs, jobs.data(), sizeof(PackJob) * jobs.size(), hipMemcpyHostToDevice));
+}
+
 int cd_plan_train_workspace_bytes(CdPlan* plan, int batch, size_t* bytes) {
   return guarded([&] {
     CD_REQUIRE(plan && bytes && batch > 0, "bad argument");
     CD_REQUIRE(!plan->desc.time_sin && !plan->desc.cond_sin, "the training step needs the Linear time/cond embeddings");
+    dgrad_images(plan);
     plan->ws.reset(nullptr, 0, true);
     train_step_impl(plan, batch, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     *bytes = plan->ws.high() + 4096;
@@ -1848,6 +1941,7 @@ int cd_train_step(CdPlan* plan, int batch, const float* data, const float* noise
     CD_REQUIRE(plan && data && noise && sigma && cond && loss_out && grads && workspace && batch > 0, "bad argument");
     CD_REQUIRE(loss_type >= CD_LOSS_L2 && loss_type <= CD_LOSS_HUBER, "loss_type must be one of CD_LOSS_L2 / L1 / MSE / HUBER");
     check_ready(plan, true);
+    dgrad_images(plan);
     plan->ws.reset((char*)workspace, workspace_bytes, false);
     train_step_impl(plan, batch, data, noise, sigma, cond, loss_out, grads, (hipStream_t)stream, loss_type);
   });
