@@ -232,6 +232,43 @@ def roofline_leg(model, cfg, batch, E, layers):
     return roof, breakdown
 
 
+def train_roofline_leg(model, step, data, E, layers, B, step_ms):
+    """Roofline entry of the training step (outside the timed region).  Algorithmic work = 3 x the forward's FLOPs (forward, input
+    gradients, weight gradients: every convolution / linear map runs three times), the forward's FLOPs being what the launchers of
+    one eager denoise call at this batch declare (the SURVEY 8d accounting: 5.44 GFLOP per Dataset-2 shower); achieved =
+    that / the measured step time, against the roof of the pipe the convolutions run on (fp16 MFMA / 3 MFMAs per MAC block).  Next
+    to it the step's HBM-bound part: the GroupNorm backward passes (statistics + apply: dy and h read twice, dh written) with
+    HIP events around their launches, as GB/s against the HBM roof."""
+    from calodiffusion_amd import engine
+    sig = torch.full((B,), 1.0, device="cuda")
+    with torch.no_grad():
+        model.denoise(data, E=E, sigma=sig, layers=layers)
+        torch.cuda.synchronize()
+        engine.profile_begin()
+        model.denoise(data, E=E, sigma=sig, layers=layers)
+        fwd = engine.profile_end()
+    fwd_flops = sum(v["flops_total"] for v in fwd.values())
+    engine.profile_begin()
+    step()
+    prof = engine.profile_end()
+    gn = prof.get("gn_backward")
+    mode = engine.get_conv_precision()
+    peak = {"f32": PEAK_FP32_MFMA_TFLOPS, "bf16x3": PEAK_BF16_MFMA_TFLOPS / BF16X3_TERMS}.get(mode, PEAK_BF16_MFMA_TFLOPS / 3)
+    achieved = 3.0 * fwd_flops / (step_ms * 1e-3) / 1e12
+    out = {"bound": "mfma", "kernel": "whole training step (forward + input gradients + weight gradients)",
+           "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+           "traffic": None, "alg_flops_per_step": 3.0 * fwd_flops, "forward_gflop_per_sample": round(fwd_flops / B / 1e9, 3),
+           "frac_of_fp32_mfma_peak": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+           "eager_step_ms_sum_of_profiled_launches": round(sum(v["ms"] for v in prof.values()), 3)}
+    if gn and gn["launches"]:
+        gbs = gn["bytes_total"] / (gn["ms"] * 1e-3) / 1e9
+        out["groupnorm_backward"] = {"bound": "hbm", "launch_groups_per_step": gn["launches"], "ms_per_step": round(gn["ms"], 3),
+                                     "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)}
+    top = sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:8]
+    out["top_categories_ms"] = {k: round(v["ms"], 3) for k, v in top}
+    return out
+
+
 def train_bench(args, model, cfg, E, layers, rank, world):
     """Training throughput (BASELINE configs[2]): zero_grad -> compute_loss -> backward -> Adam.step per iteration, as
     TrainDiffusion.training_loop does; data-parallel replicas with one flat gradient all-reduce per step."""
@@ -266,6 +303,10 @@ def train_bench(args, model, cfg, E, layers, rank, world):
     events, cd_utils.ALLREDUCE_EVENTS = cd_utils.ALLREDUCE_EVENTS, None
     ar_ms = max_over_ranks(sum(a.elapsed_time(b) for a, b in events) / max(1, args.steps))
     nbytes = model.engine().grad_layout()[1] * 4
+    step_ms = 1e3 * dt / args.steps
+    roof = None
+    if rank == 0 and world == 1 and not args.no_extra:
+        roof = train_roofline_leg(model, step, data, E, layers, B, step_ms)
     result = {"metric": f"training samples/sec ({args.config}, hybrid_weight l2, Adam)", "value": world * args.steps * B / dt,
               "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -274,6 +315,8 @@ def train_bench(args, model, cfg, E, layers, rank, world):
                          "final_loss": float(loss)},
               "collective": dict(collective_info(), allreduce_bytes=nbytes, allreduces_per_step=len(events) / max(1, args.steps),
                                  allreduce_ms=ar_ms, allreduce_share_of_step=ar_ms / (1e3 * dt / args.steps))}
+    if roof:
+        result["roofline"] = roof
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

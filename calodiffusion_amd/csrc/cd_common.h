@@ -303,12 +303,30 @@ void launch_add_slices(const float* a, int lda, int aoff, const float* b, int ld
 void launch_bias_grad(const float* part, int units, int batch, int channels, float* db, bool accumulate, hipStream_t s);
 size_t gn_backward_scratch_floats(int batch, int channels, int64_t vox);
 // backward of y = act(scale*h + shift) + add: dh, dgamma, dbeta (accumulated if asked), dadd[b][c] (optional)
+// Deferred batch reduction of the GroupNorm parameter gradients: one job per layer, passed to the kernel by value
+struct GnParamJob {
+  const float* sums_bc;  // [batch][channels][4] = {dbeta, dgamma, conv-bias, sum dy} contributions per sample
+  float *dgamma, *dbeta, *dbias, *dsumdy;
+  int batch, channels;
+};
+struct GnParamJobs {
+  static constexpr int kMax = 64;
+  GnParamJob job[kMax];
+  int n = 0;
+};
+struct GnParamQueue {
+  GnParamJobs jobs;
+  float* next_sums = nullptr;  // bump pointer into a region of gn_param_queue_floats(...) the caller keeps until the flush
+};
+void launch_gn_param_jobs(const GnParamJobs& jobs, hipStream_t s);
 void launch_gn_backward(const float* dy, const float* h, const float* coef, const float* stat, const float* gamma, float* dh,
                         float* dgamma, float* dbeta, float* dadd, int dadd_ld, int batch, int channels, int64_t vox, int groups,
                         int silu, float* scratch, bool accumulate_params, hipStream_t s,
                         // (optional, round 4) the bias gradient of the conv that produced h, and sum_{b,v} dy per channel (the bias
                         // gradient of a conv that adds into y): both fall out of the statistics pass, see kernels_bwd.hip
-                        float* dbias = nullptr, float* dsumdy = nullptr);
+                        float* dbias = nullptr, float* dsumdy = nullptr,
+                        // (optional) queue the batch reduction of the parameter gradients instead of launching it (training step)
+                        GnParamQueue* queue = nullptr);
 int gn_apply_blocks_per_sample(int batch, int channels, int64_t vox);
 // y = act(scale*x + shift) + add (+ residual; residual1/res_c0: shortcut read from a two-source channel concat);
 // part_out (optional): channel partials of y, [B][gn_apply_blocks_per_sample][C][2]

@@ -669,20 +669,218 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const float* __restri
   }
 }
 
+// The whole GroupNorm backward of ONE sample in one workgroup, for the grids where the three launches above are three prologues
+// around microseconds of streaming (the deepest levels of the U-Net: <= 100 KB per sample and tensor; 24 of the 44 GroupNorm layers
+// of a Dataset-2 training step): statistics -> the finalize arithmetic in LDS -> apply, the second pass over dy / h served by L2.
+// Same summation structure as the split form with nsplit = 1 (per-thread float partials, fp64 column sums, fp64 group means).
+__global__ void __launch_bounds__(512) gn_bwd_small_kernel(const float* __restrict__ dy, const float* __restrict__ h,
+                                                           const float* __restrict__ coef, const float* __restrict__ stat,
+                                                           const float* __restrict__ gamma, float* __restrict__ dh,
+                                                           float* __restrict__ sums_bc, float* __restrict__ dadd, int dadd_ld,
+                                                           int channels, int64_t vox, int groups, int silu,
+                                                           unsigned* __restrict__ amax_out) {
+  __shared__ double sP[512][4];
+  __shared__ double sCol[256][4];
+  __shared__ float m1[64], m2[64];
+  __shared__ __attribute__((aligned(16))) float sG[256][4];
+  __shared__ float sAmax[8];
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int cols = channels >> 2, rows = 512 / cols;
+  const int colid = tid % cols, row = tid / cols;
+  const int c = colid * 4, cpg = channels / groups;
+  const size_t sb = (size_t)b * vox * channels + c;
+  f32x4 cf[4];
+  float mean = 0.f, rstd = 0.f;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+  if (row < rows) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) cf[e] = *(const f32x4*)(coef + ((size_t)b * channels + c + e) * 4);
+    mean = stat[((size_t)b * groups + c / cpg) * 2];
+    rstd = stat[((size_t)b * groups + c / cpg) * 2 + 1];
+    // four voxel rows per trip: eight 16-byte loads in flight per thread (one workgroup streams the whole sample: a load per
+    // trip left it waiting on a memory latency per 32 bytes)
+    int64_t v = row;
+    for (; v + 3 * rows < vox; v += 4 * rows) {
+      f32x4 g[4], hv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        g[u] = *(const f32x4*)(dy + sb + (size_t)(v + u * rows) * channels);
+        hv[u] = *(const f32x4*)(h + sb + (size_t)(v + u * rows) * channels);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float z = cf[e][0] * hv[u][e] + cf[e][1];
+          const float dz = silu ? g[u][e] * silu_grad(z) : g[u][e];
+          s0[e] += dz;
+          s1[e] += dz * (hv[u][e] - mean) * rstd;
+          s2[e] += g[u][e];
+          s3[e] += hv[u][e] - mean;
+        }
+    }
+    for (; v < vox; v += rows) {
+      const f32x4 g = *(const f32x4*)(dy + sb + (size_t)v * channels);
+      const f32x4 hv = *(const f32x4*)(h + sb + (size_t)v * channels);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float z = cf[e][0] * hv[e] + cf[e][1];
+        const float dz = silu ? g[e] * silu_grad(z) : g[e];
+        s0[e] += dz;
+        s1[e] += dz * (hv[e] - mean) * rstd;
+        s2[e] += g[e];
+        s3[e] += hv[e] - mean;
+      }
+    }
+  }
+  for (int e = 0; e < 4; ++e) {
+    sP[tid][0] = (double)s0[e]; sP[tid][1] = (double)s1[e]; sP[tid][2] = (double)s2[e]; sP[tid][3] = (double)s3[e];
+    __syncthreads();
+    if (tid < cols) {
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      for (int r = 0; r < rows; ++r) {
+        a0 += sP[r * cols + tid][0]; a1 += sP[r * cols + tid][1]; a2 += sP[r * cols + tid][2]; a3 += sP[r * cols + tid][3];
+      }
+      // (rounded to float like the split form's partials, so that both forms give the same coefficients)
+      sCol[tid * 4 + e][0] = (double)(float)a0; sCol[tid * 4 + e][1] = (double)(float)a1;
+      sCol[tid * 4 + e][2] = (double)(float)a2; sCol[tid * 4 + e][3] = (double)(float)a3;
+    }
+    __syncthreads();
+  }
+  if (tid < groups) {
+    double t0 = 0.0, t1 = 0.0;
+    for (int k = 0; k < cpg; ++k) {
+      t0 += sCol[tid * cpg + k][0] * (double)gamma[tid * cpg + k];
+      t1 += sCol[tid * cpg + k][1] * (double)gamma[tid * cpg + k];
+    }
+    const double cnt = (double)vox * cpg;
+    m1[tid] = (float)(t0 / cnt);
+    m2[tid] = (float)(t1 / cnt);
+  }
+  __syncthreads();
+  if (tid < channels) {
+    const int cc = tid, g = cc / cpg;
+    const float mn = stat[((size_t)b * groups + g) * 2], rs = stat[((size_t)b * groups + g) * 2 + 1];
+    const float A = rs * gamma[cc];
+    sG[cc][0] = A;
+    sG[cc][1] = -rs * rs * m2[g];
+    sG[cc][2] = rs * (-m1[g] + mn * rs * m2[g]);
+    sG[cc][3] = 0.f;
+    float* o = sums_bc + ((size_t)b * channels + cc) * 4;
+    o[0] = (float)sCol[cc][0];
+    o[1] = (float)sCol[cc][1];
+    o[2] = (float)((double)A * sCol[cc][0] - (double)rs * ((double)m1[g] * (double)vox + (double)rs * (double)m2[g] * sCol[cc][3]));
+    o[3] = (float)sCol[cc][2];
+    if (dadd) dadd[(size_t)b * dadd_ld + cc] = (float)sCol[cc][2];
+  }
+  __syncthreads();
+  float am = 0.f;
+  if (row < rows) {
+    f32x4 gc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) gc[e] = *(const f32x4*)sG[c + e];
+    auto one = [&](const f32x4 g, const f32x4 hv, int64_t v) {
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float z = cf[e][0] * hv[e] + cf[e][1];
+        const float dz = silu ? g[e] * silu_grad(z) : g[e];
+        o[e] = gc[e][0] * dz + gc[e][1] * hv[e] + gc[e][2];
+      }
+      *(f32x4*)(dh + sb + (size_t)v * channels) = o;
+      am = fmaxf(am, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
+    };
+    int64_t v = row;
+    for (; v + 3 * rows < vox; v += 4 * rows) {
+      f32x4 g[4], hv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        g[u] = *(const f32x4*)(dy + sb + (size_t)(v + u * rows) * channels);
+        hv[u] = *(const f32x4*)(h + sb + (size_t)(v + u * rows) * channels);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) one(g[u], hv[u], v + u * rows);
+    }
+    for (; v < vox; v += rows) one(*(const f32x4*)(dy + sb + (size_t)v * channels), *(const f32x4*)(h + sb + (size_t)v * channels), v);
+  }
+  if (amax_out) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) am = fmaxf(am, __shfl_xor(am, o, 64));
+    if ((tid & 63) == 0) sAmax[tid >> 6] = am;
+    __syncthreads();
+    if (tid == 0) {
+      float m = sAmax[0];
+      for (int w = 1; w < 8; ++w) m = fmaxf(m, sAmax[w]);
+      atomicMax(amax_out, __float_as_uint(m));
+    }
+  }
+}
+
+// dgamma / dbeta (/ the conv-bias gradients that fall out of the same sums) of MANY GroupNorm layers in one launch: the training
+// step queues one job per layer while it walks the network backwards and flushes the queue at the end (44 launches -> 1).
+__global__ void __launch_bounds__(64) param_grad_multi_kernel(GnParamJobs jobs) {
+  const GnParamJob j = jobs.job[blockIdx.y];
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= j.channels) return;
+  double g = 0.0, bt = 0.0, bs = 0.0, sy = 0.0;
+  for (int n = 0; n < j.batch; ++n) {
+    const f32x4 v = *(const f32x4*)(j.sums_bc + ((size_t)n * j.channels + c) * 4);
+    bt += (double)v[0]; g += (double)v[1]; bs += (double)v[2]; sy += (double)v[3];
+  }
+  j.dgamma[c] = (float)g;
+  j.dbeta[c] = (float)bt;
+  if (j.dbias) j.dbias[c] = (float)bs;
+  if (j.dsumdy) j.dsumdy[c] = (float)sy;
+}
+void launch_gn_param_jobs(const GnParamJobs& jobs, hipStream_t s) {
+  if (jobs.n <= 0) return;
+  int cmax = 0;
+  for (int i = 0; i < jobs.n; ++i) cmax = jobs.job[i].channels > cmax ? jobs.job[i].channels : cmax;
+  hipLaunchKernelGGL(param_grad_multi_kernel, dim3((unsigned)((cmax + 63) / 64), (unsigned)jobs.n), dim3(64), 0, s, jobs);
+  CD_HIP(hipGetLastError());
+}
+
 void launch_gn_backward(const float* dy, const float* h, const float* coef, const float* stat, const float* gamma, float* dh,
                         float* dgamma, float* dbeta, float* dadd, int dadd_ld, int batch, int channels, int64_t vox, int groups,
-                        int silu, float* scratch, bool accumulate_params, hipStream_t s, float* dbias, float* dsumdy) {
+                        int silu, float* scratch, bool accumulate_params, hipStream_t s, float* dbias, float* dsumdy,
+                        GnParamQueue* queue) {
   CD_REQUIRE(channels % 4 == 0 && channels <= 256 && groups <= 64, "group norm backward: <= 256 channels, <= 64 groups");
   const int ns = gn_nsplit_for(vox, batch);
   float* part = scratch;                                         // [B][ns][C][4]
   float* gcoef = part + (size_t)batch * ns * channels * 4;        // [B][C][4]
   float* sums_bc = gcoef + (size_t)batch * channels * 4;          // [B][C][4]
+  if (queue) {  // the per-sample sums go to the caller's persistent slot and the batch reduction joins the queue
+    CD_REQUIRE(!accumulate_params, "gn backward: queued parameter gradients do not accumulate");
+    if (queue->jobs.n == GnParamJobs::kMax) {  // (deeper networks than the shipped ones: flush and go on)
+      launch_gn_param_jobs(queue->jobs, s);
+      queue->jobs.n = 0;
+    }
+    sums_bc = queue->next_sums;
+    queue->next_sums += (size_t)batch * channels * 4;
+    GnParamJob& j = queue->jobs.job[queue->jobs.n++];
+    j.sums_bc = sums_bc; j.batch = batch; j.channels = channels; j.dgamma = dgamma; j.dbeta = dbeta; j.dbias = dbias; j.dsumdy = dsumdy;
+  }
   prof::Scope scope("gn_backward", s, 0, 4.0 * batch * (double)vox * channels * 5);
+  static const bool no_small = getenv("CD_NO_GN_BWD_SMALL") != nullptr;
+  // (one workgroup streams its sample twice: 24 KB at the deepest level in ~6 us against four launches' ~20; at 188 KB -- level 1
+  // with 64 channels -- it took 35 us against the split form's 27, so the bound sits between the two)
+  static const size_t small_max = getenv("CD_GN_BWD_SMALL_KB") ? (size_t)atoi(getenv("CD_GN_BWD_SMALL_KB")) * 1024 : 100 * 1024;
+  if (!no_small && (size_t)vox * channels * 4 <= small_max && channels <= 256 && 512 % (channels >> 2) == 0) {
+    unsigned* amax_word = absmax_word_fresh(dh, s);
+    hipLaunchKernelGGL(gn_bwd_small_kernel, dim3((unsigned)batch), dim3(512), 0, s, dy, h, coef, stat, gamma, dh, sums_bc, dadd, dadd_ld,
+                       channels, vox, groups, silu, amax_word);
+    if (!queue)
+      hipLaunchKernelGGL(param_grad_from_samples_kernel, dim3((channels + 63) / 64), dim3(64), 0, s, sums_bc, batch, channels, dgamma,
+                         dbeta, accumulate_params ? 1 : 0, dbias, dsumdy);
+    CD_HIP(hipGetLastError());
+    return;
+  }
   hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(ns, batch), dim3(256), 0, s, dy, h, coef, stat, part, channels, vox, groups, silu, ns);
   hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(batch), dim3(256), 0, s, part, ns, gamma, stat, gcoef, sums_bc, dadd, dadd_ld,
                      channels, groups, vox);
-  hipLaunchKernelGGL(param_grad_from_samples_kernel, dim3((channels + 63) / 64), dim3(64), 0, s, sums_bc, batch, channels, dgamma,
-                     dbeta, accumulate_params ? 1 : 0, dbias, dsumdy);
+  if (!queue)
+    hipLaunchKernelGGL(param_grad_from_samples_kernel, dim3((channels + 63) / 64), dim3(64), 0, s, sums_bc, batch, channels, dgamma,
+                       dbeta, accumulate_params ? 1 : 0, dbias, dsumdy);
   const int bps = gn_apply_blocks_per_sample(batch, channels, vox);
   unsigned* amax_word = absmax_word_fresh(dh, s);  // zeroed; the consumer's launch_absmax_bits(dh) finds it instead of re-reading dh
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)(batch * bps)), dim3(256), 0, s, dy, h, coef, gcoef, dh, channels, vox, silu, bps,

@@ -425,6 +425,7 @@ struct Run {
   int B;
   int groups;
   int* status = nullptr;  // device word for sticky range flags (cd_plan_status), or null
+  GnParamQueue* gq = nullptr;  // training step: the GroupNorm layers' parameter-gradient reductions, flushed once at the end
   bool dry() const { return ws->dry(); }
 };
 

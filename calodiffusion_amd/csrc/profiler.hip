@@ -49,13 +49,14 @@ Scope::~Scope() {
 int end(char* buf, int cap) {
   g_enabled = false;
   hipDeviceSynchronize();
-  struct Agg { long n = 0; double ms = 0, flops = 0, bytes = 0; };
+  struct Agg { long n = 0; double ms = 0, flops = 0, bytes = 0, flops_total = 0, bytes_total = 0; };
   std::map<std::string, Agg> agg;
   for (auto& r : g_records) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
       Agg& a = agg[r.cat];
       a.n += 1; a.ms += ms; a.flops = r.flops; a.bytes = r.bytes;
+      a.flops_total += r.flops; a.bytes_total += r.bytes;  // (a category may mix shapes: the GroupNorm backward of every level)
     }
     hipEventDestroy(r.a);
     hipEventDestroy(r.b);
@@ -65,8 +66,10 @@ int end(char* buf, int cap) {
   bool first = true;
   for (auto& kv : agg) {
     char line[512];
-    std::snprintf(line, sizeof line, "%s\"%s\": {\"launches\": %ld, \"ms\": %.6f, \"flops\": %.0f, \"bytes\": %.0f}",
-                  first ? "" : ", ", kv.first.c_str(), kv.second.n, kv.second.ms, kv.second.flops, kv.second.bytes);
+    std::snprintf(line, sizeof line,
+                  "%s\"%s\": {\"launches\": %ld, \"ms\": %.6f, \"flops\": %.0f, \"bytes\": %.0f, \"flops_total\": %.0f, \"bytes_total\": %.0f}",
+                  first ? "" : ", ", kv.first.c_str(), kv.second.n, kv.second.ms, kv.second.flops, kv.second.bytes, kv.second.flops_total,
+                  kv.second.bytes_total);
     out += line;
     first = false;
   }

@@ -641,8 +641,8 @@ def profile_begin():
 
 def profile_end() -> dict:
     import json
-    buf = C.create_string_buffer(1 << 16)
-    _check(load_library().cd_profile_end(buf, 1 << 16))
+    buf = C.create_string_buffer(1 << 18)
+    _check(load_library().cd_profile_end(buf, 1 << 18))
     return json.loads(buf.value.decode())
 
 

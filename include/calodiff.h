@@ -307,7 +307,9 @@ const char* cd_get_conv_precision(void);
 /* ---- measurement ---------------------------------------------------------------------------------------------- */
 /* Per-launch timing with HIP events on the launch stream (eager mode; graphs are bypassed while active).
  * cd_profile_end synchronises the device and writes a JSON object
- *   {"<kernel category>": {"launches": n, "ms": total_ms, "flops": algorithmic_per_launch, "bytes": algorithmic_per_launch}} */
+ *   {"<kernel category>": {"launches": n, "ms": total_ms, "flops": algorithmic_per_launch, "bytes": algorithmic_per_launch,
+ *                          "flops_total": sum over the launches, "bytes_total": sum over the launches}}
+ * (per-launch figures are those of the category's last launch; the totals serve categories that mix shapes). */
 int cd_profile_begin(void);
 int cd_profile_end(char* json, int cap);
 
