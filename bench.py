@@ -143,8 +143,11 @@ def cpu_baseline(cfg, sample_steps, batch, timed=3):
     {8, 16, 32} probe (one denoise step each).  More is pointless and expensive to find out: the box's CPU share is 16 for one
     GPU, PyTorch's CPU convolutions stop scaling long before, and at all 256 visible cores one step took 64 s (r2b)."""
     from oracle import torch_oracle as O
-    from tests.helpers import seeded_unet  # same seeded weights as the GPU model
-    net = seeded_unet(cfg["_name"])
+    from calodiffusion_amd.unet import CondUnet, unet_kwargs_from_config
+    state = torch.random.get_rng_state()
+    torch.manual_seed(1234)  # the same seeded weights as the GPU model (torch default init under this seed)
+    net = CondUnet(**unet_kwargs_from_config(cfg))
+    torch.random.set_rng_state(state)
     model = O.OracleModel(cfg, net.state_dict())
     g = torch.Generator().manual_seed(7)
     x = torch.randn([batch] + list(cfg["SHAPE_PAD"][1:]), generator=g)

@@ -551,6 +551,7 @@ LayerTapeLayout layer_tape_layout(int dim, int hidden, int cond_emb, int cond_si
 struct LayerMlpTrainArgs {
   const float* w[64];
   int dim_in, hidden, cond_emb, cond_size, n_res, time_kind, batch;
+  int loss_type = 0;  // CD_LOSS_* (Loss._loss, models/loss.py:97-116): 0 l2 (weighted), 1 l1, 2 mse, 3 huber
   float sigma_data;
   const float *data, *noise, *sigma, *cond;  // (B, dim), (B, dim), (B), (B, cond_size)
   LayerTapeLayout layout;

@@ -162,13 +162,19 @@ __global__ void __launch_bounds__(512) layer_mlp_train_kernel(LayerMlpTrainArgs 
   tm_dense(W[14 + 6 * R], W[15 + 6 * R], h, x0s, Hd, dim);  // pred (out_lay)
 
   // ---- loss and d pred ----------------------------------------------------------------------------------------------------
-  const float gscale = 2.f * wb / (wmean * (float)a.batch * (float)dim);
+  // the element losses of Loss._loss (models/loss.py:97-116) as in head_loss_bwd_kernel: only 'l2' carries the hybrid weight; the
+  // torch.nn.functional losses are plain means -- d loss / d x0 = gscale f'(d): l2 2 w d / (mean(w) N), mse 2 d / N,
+  // l1 sign(d) / N, huber (smooth_l1, beta 1) clamp(d, -1, 1) / N
+  const int lt = a.loss_type;
+  const float gscale = lt == 0 ? 2.f * wb / (wmean * (float)a.batch * (float)dim) : (lt == 2 ? 2.f : 1.f) / ((float)a.batch * (float)dim);
   double lacc = 0.0;
   for (int i = tid; i < dim; i += nt) {
     const float x0 = c_skip * xs_[i] + c_out * x0s[i];
     const float d = x0 - a.data[(size_t)b * dim + i];
-    lacc += (double)(d * d);
-    dvec[i] = gscale * d * c_out;
+    const float ad = fabsf(d);
+    lacc += (double)(lt == 1 ? ad : (lt == 3 ? (ad < 1.f ? 0.5f * d * d : ad - 0.5f) : d * d));
+    const float fp = lt == 1 ? (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) : (lt == 3 ? fminf(fmaxf(d, -1.f), 1.f) : d);
+    dvec[i] = gscale * fp * c_out;
     T[L.dpred + i] = dvec[i];
   }
   for (int o = 32; o > 0; o >>= 1) lacc += __shfl_xor(lacc, o, 64);
@@ -177,7 +183,7 @@ __global__ void __launch_bounds__(512) layer_mlp_train_kernel(LayerMlpTrainArgs 
   if (tid == 0) {
     double s = 0.0;
     for (int i = 0; i < (nt >> 6); ++i) s += sred[i];
-    a.loss_part[b] = s * (double)wb;
+    a.loss_part[b] = lt == 0 ? s * (double)wb : s;
   }
 
   // ---- backward -----------------------------------------------------------------------------------------------------------
@@ -220,7 +226,7 @@ __global__ void __launch_bounds__(512) layer_mlp_train_kernel(LayerMlpTrainArgs 
 }
 
 __global__ void layer_loss_final_kernel(const double* __restrict__ part, const float* __restrict__ sigma, int batch, int dim,
-                                        double* __restrict__ loss) {
+                                        double* __restrict__ loss, int loss_type) {
   if (threadIdx.x || blockIdx.x) return;
   double s = 0.0, w = 0.0;
   for (int n = 0; n < batch; ++n) {
@@ -228,7 +234,7 @@ __global__ void layer_loss_final_kernel(const double* __restrict__ part, const f
     const float sg = sigma[n];
     w += (double)(1.0f + 1.0f / (sg * sg));
   }
-  const float wmean = (float)(w / batch);
+  const float wmean = loss_type == 0 ? (float)(w / batch) : 1.0f;
   *loss = s / ((double)wmean * (double)batch * (double)dim);
 }
 
@@ -251,7 +257,7 @@ void launch_layer_mlp_train(LayerMlpTrainArgs a, float* grads, double* loss_out,
   LinearWgradJob* jobs_dev = (LinearWgradJob*)ws;
   hipLaunchKernelGGL(layer_mlp_train_kernel, dim3(a.batch), dim3(512), 0, s, a);
   CD_HIP(hipGetLastError());
-  hipLaunchKernelGGL(layer_loss_final_kernel, dim3(1), dim3(64), 0, s, a.loss_part, a.sigma, a.batch, a.dim_in, loss_out);
+  hipLaunchKernelGGL(layer_loss_final_kernel, dim3(1), dim3(64), 0, s, a.loss_part, a.sigma, a.batch, a.dim_in, loss_out, a.loss_type);
   CD_HIP(hipGetLastError());
   // weight / bias gradients of the 20 Linear layers: one launch over a job table
   const int half = a.cond_emb / 2, q = half / 2, Hd = a.hidden, D = a.dim_in;

@@ -1139,7 +1139,9 @@ size_t dry_forward_bytes(CdPlan* plan, int batch, F&& front) {
     ~Restore() { set_conv_precision_override(-1); }
   } restore;
   size_t need = 0;
-  for (int mode : {-1, (int)PREC_BF16X3}) {
+  // (all three arithmetic modes, not only the one in force and the fallback's: cd_set_conv_precision may switch after the caller
+  // sized -- and cached -- its workspace)
+  for (int mode : {(int)PREC_F16X2, (int)PREC_BF16X3, (int)PREC_F32}) {
     set_conv_precision_override(mode);
     plan->ws.reset(nullptr, 0, true);
     front();
@@ -1503,9 +1505,18 @@ int cd_layer_train_workspace_bytes(const CdLayerMlpDesc* desc, int batch, size_t
 int cd_layer_train_step(const CdLayerMlpDesc* desc, const float* const* weights, int n_weights, int batch, const float* data,
                         const float* noise, const float* sigma, const float* cond, double* loss_out, float* grads,
                         void* workspace, size_t workspace_bytes, void* stream) {
+  return cd_layer_train_step_loss(desc, weights, n_weights, batch, data, noise, sigma, cond, CD_LOSS_L2, loss_out, grads, workspace,
+                                  workspace_bytes, stream);
+}
+
+int cd_layer_train_step_loss(const CdLayerMlpDesc* desc, const float* const* weights, int n_weights, int batch, const float* data,
+                             const float* noise, const float* sigma, const float* cond, int loss_type, double* loss_out,
+                             float* grads, void* workspace, size_t workspace_bytes, void* stream) {
   return guarded([&] {
     CD_REQUIRE(weights && data && noise && sigma && cond && loss_out && grads && workspace, "bad argument");
+    CD_REQUIRE(loss_type >= CD_LOSS_L2 && loss_type <= CD_LOSS_HUBER, "loss_type must be one of CD_LOSS_L2 / L1 / MSE / HUBER");
     LayerMlpTrainArgs a = layer_train_args(desc, batch);
+    a.loss_type = loss_type;
     CD_REQUIRE(desc->objective == CD_OBJ_HYBRID, "cd_layer_train_step implements the hybrid_weight objective");
     CD_REQUIRE(n_weights == 2 * (8 + 3 * desc->n_res), "layer MLP: n_weights must be 2*(8 + 3*n_res)");
     CD_REQUIRE(workspace_bytes >= layer_train_workspace_bytes(a), "workspace too small: call cd_layer_train_workspace_bytes");

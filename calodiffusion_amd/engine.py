@@ -93,6 +93,8 @@ _SIGNATURES = {
     "cd_layer_sample": (C.c_int, [_P, C.POINTER(C.c_void_p), C.c_int, C.c_int, _P, _P, _P, C.c_int, _P, _P, _P, _P, _P]),
     "cd_layer_train_workspace_bytes": (C.c_int, [_P, C.c_int, C.POINTER(C.c_size_t)]),
     "cd_layer_train_step": (C.c_int, [_P, C.POINTER(C.c_void_p), C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "cd_layer_train_step_loss": (C.c_int, [_P, C.POINTER(C.c_void_p), C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, _P, _P, _P, C.c_size_t,
+                                           _P]),
     "cd_reverse_norm": (C.c_int, [_P, _P, _P, _P, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.c_float, C.c_float, _P]),
     "cd_reverse_norm_staged": (C.c_int, [_P, _P, _P, _P, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.c_float, C.c_float,
                                          C.c_float, C.c_float, C.c_int, _P]),
@@ -237,7 +239,7 @@ class UnetEngine:
         self._weight_order = None  # [(state_dict name, tensor)] in the plan's order
         self._weight_ids = None
         self._held_weights = []
-        self._ws: Dict[int, torch.Tensor] = {}
+        self._ws: Dict[tuple, torch.Tensor] = {}
         self.device = next(unet.parameters()).device
         if self.device.type != "cuda":
             raise RuntimeError("move the model to the GPU first (model.to('cuda')): calodiffusion_amd has no CPU path")
@@ -298,16 +300,25 @@ class UnetEngine:
         self._held_weights = tensors  # (conversions made by _dev32 must outlive the launches)
         self._weights_version = ver
 
+    # launch-sequence switches the library reads per call (tests and A/B runs flip them inside one process): a workspace sized
+    # under one setting is not valid under another, so they are part of the cache key.  (The arithmetic mode is not: the
+    # library sizes for the largest of its three modes.)
+    _WS_SWITCHES = ("CD_NO_DEEP_LEVEL", "CD_NO_PW_CLOSE", "CD_NO_FUSED_ATTN", "CD_NO_GNDEFER", "CD_ATTN_COMBINE_LAUNCH", "CD_PW_F32")
+
+    def _ws_key(self, batch: int):
+        return (int(batch),) + tuple(os.environ.get(k) for k in self._WS_SWITCHES)
+
     def workspace(self, batch: int) -> torch.Tensor:
-        ws = self._ws.get(batch)
+        key = ("net",) + self._ws_key(batch)
+        ws = self._ws.get(key)
         if ws is None:
             nbytes = C.c_size_t()
             _check(self.lib.cd_plan_workspace_bytes(self.plan, batch, C.byref(nbytes)))
+            # keep ONE network workspace and ONE sampler-program workspace (each ~1 GB at the headline batch: alternating
+            # denoise / sampler calls would otherwise reallocate every time, a ragged last batch would double the footprint)
+            self._ws = {k: v for k, v in self._ws.items() if k[0] != "net"}
             ws = torch.empty(nbytes.value, dtype=torch.uint8, device=self.device)
-            # keep ONE network workspace (they are large) -- and the sampler-program workspaces cached by sampler_run under
-            # ("sampler", B), which alternating denoise / sampler calls would otherwise reallocate (~1 GB) every time
-            self._ws = {k: v for k, v in self._ws.items() if isinstance(k, tuple)}
-            self._ws[batch] = ws
+            self._ws[key] = ws
         return ws
 
     # ------------------------------------------------------------------ compute
@@ -403,9 +414,10 @@ class UnetEngine:
         self.sync_weights()
         nbytes = C.c_size_t()
         _check(self.lib.cd_plan_sampler_workspace_bytes(self.plan, B, program.n_bufs, n_steps, n_coef, C.byref(nbytes)))
-        key = ("sampler", B)
+        key = ("sampler",) + self._ws_key(B)
         ws = self._ws.get(key)
         if ws is None or ws.numel() < nbytes.value:
+            self._ws = {k: v for k, v in self._ws.items() if k[0] != "sampler"}  # (other batch sizes / switch settings: evicted)
             ws = torch.empty(nbytes.value, dtype=torch.uint8, device=self.device)
             self._ws[key] = ws
         x_out = torch.empty_like(start)
@@ -569,9 +581,8 @@ class LayerMlpEngine:
         return lay, off
 
     def train_step(self, data, noise, sigma, cond, loss_type="l2"):
-        """hybrid_weight / l2 loss and the gradient of every parameter of the layer model (cd_layer_train_step)."""
-        if loss_type != "l2":
-            raise NotImplementedError("the layer model's training step implements LOSS_TYPE 'l2' (cd_layer_train_step)")
+        """hybrid_weight loss (LOSS_TYPE l2 / l1 / mse / huber) and the gradient of every parameter of the layer model
+        (cd_layer_train_step_loss)."""
         data, cond, B = self._io(data, cond)
         noise = _dev32(noise, "noise")
         sigma = _dev32(sigma, "sigma").reshape(-1)
@@ -584,9 +595,9 @@ class LayerMlpEngine:
         _, total = self.grad_layout()
         flat = torch.empty(total, dtype=torch.float32, device=data.device)
         loss = torch.empty((), dtype=torch.float64, device=data.device)
-        _check(self.lib.cd_layer_train_step(C.byref(self.desc), w, n, B, data.data_ptr(), noise.data_ptr(), sigma.data_ptr(),
-                                            cond.data_ptr(), loss.data_ptr(), flat.data_ptr(), ws.data_ptr(), ws.numel(),
-                                            _stream()))
+        _check(self.lib.cd_layer_train_step_loss(C.byref(self.desc), w, n, B, data.data_ptr(), noise.data_ptr(), sigma.data_ptr(),
+                                                 cond.data_ptr(), LOSS_TYPES[loss_type], loss.data_ptr(), flat.data_ptr(),
+                                                 ws.data_ptr(), ws.numel(), _stream()))
         return loss, flat
 
     def param_grads(self, flat):

@@ -295,6 +295,11 @@ int cd_layer_train_workspace_bytes(const CdLayerMlpDesc* desc, int batch, size_t
 int cd_layer_train_step(const CdLayerMlpDesc* desc, const float* const* weights, int n_weights, int batch, const float* data,
                         const float* noise, const float* sigma, const float* cond, double* loss_out, float* grads,
                         void* workspace, size_t workspace_bytes, void* stream);
+/* The same for every LOSS_TYPE of Loss._loss (models/loss.py:97-116; cd_layer_train_step is loss_type CD_LOSS_L2): the reference's
+ * CI fixture trains the layer model with 'huber' (tests/test_execution.py:94). */
+int cd_layer_train_step_loss(const CdLayerMlpDesc* desc, const float* const* weights, int n_weights, int batch, const float* data,
+                             const float* noise, const float* sigma, const float* cond, int loss_type /* CD_LOSS_* */,
+                             double* loss_out, float* grads, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Arithmetic of the matrix-core kernels, process-wide: "f16x2" (default; fp32 operands as two-term fp16 splits, 3 MFMAs per
  * block, fp16 RANGE -- the 3x3x3 / strided / transposed convolutions and the fused attention's projections and products),

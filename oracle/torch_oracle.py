@@ -507,9 +507,10 @@ class OracleLayerModel(OracleModel):
         return c_skip * x + c_out * pred
 
     def hybrid_l2_loss(self, data: Tensor, E: Tensor, noise: Tensor, layers: Optional[Tensor] = None,
-                       rnd_normal: Optional[Tensor] = None, time: Optional[Tensor] = None, n_steps: int = 400) -> Tensor:
-        """Loss.__call__ + hybrid_weight + l2 on (B, D+1) layer vectors (models/loss.py:103-104,118-142,163-179), as
-        LayerDiffusion.compute_loss applies it in the layer state (layerdiffusion.py:52-57)."""
+                       rnd_normal: Optional[Tensor] = None, time: Optional[Tensor] = None, n_steps: int = 400,
+                       loss_type: str = "l2") -> Tensor:
+        """Loss.__call__ + hybrid_weight + the reduction of Loss._loss on (B, D+1) layer vectors (models/loss.py:97-116,118-142,
+        163-179), as LayerDiffusion.compute_loss applies it in the layer state (layerdiffusion.py:52-57)."""
         B = data.shape[0]
         if "log" in self.cfg.get("NOISE_SCHED", "linear"):
             sigma = (rnd_normal * 1.2 + (-1.2)).exp().reshape(B, 1)
@@ -517,6 +518,12 @@ class OracleLayerModel(OracleModel):
             tb = ddim_tables(n_steps)
             sigma = (tb.sqrt_one_minus_alphas_cumprod[time] / tb.sqrt_alphas_cumprod[time]).reshape(B, 1)
         x0 = self.denoise(data + sigma * noise, E, sigma)
+        if loss_type == "l1":
+            return F.l1_loss(x0, data)
+        if loss_type == "mse":
+            return F.mse_loss(x0, data)
+        if loss_type == "huber":
+            return F.smooth_l1_loss(x0, data)
         w = 1.0 + 1.0 / sigma ** 2
         return (w * (x0 - data) ** 2).sum() / (torch.mean(w) * float(np.prod(data.shape)))
 

@@ -139,11 +139,14 @@ def test_layer_model_other_widths_against_oracle():
         assert rel_l2(got.cpu().numpy(), want.numpy()) < TOL_TRAJ, (dim, "ddim")
 
 
-def test_layer_model_training_step_against_autograd():
+@pytest.mark.parametrize("lt", ["l2", "huber", "l1", "mse"])
+def test_layer_model_training_step_against_autograd(lt):
     """LayerDiffusion.compute_loss in the layer state (layerdiffusion.py:52-57): loss and every parameter gradient of the layer
-    model from one cd_layer_train_step call against torch autograd through the oracle; FusedAdam then steps the layer model."""
+    model from one cd_layer_train_step_loss call against torch autograd through the oracle, for every LOSS_TYPE of Loss._loss
+    (the reference's CI fixture trains with 'huber'); FusedAdam then steps the layer model."""
     from calodiffusion_amd.optim import FusedAdam
-    m = _model()
+    m = _model(LOSS_TYPE=lt)
+    assert m.loss_function.loss_type == lt
     gen = torch.Generator().manual_seed(21)
     B = 9
     layers = torch.randn((B, 46), generator=gen)
@@ -152,7 +155,7 @@ def test_layer_model_training_step_against_autograd():
     rnd = torch.randn((B,), generator=gen)
     sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.layer_model.state_dict().items()}
     om = O.OracleLayerModel(m.config, sd)
-    want = om.hybrid_l2_loss(layers, E, noise, rnd_normal=rnd)
+    want = om.hybrid_l2_loss(layers, E, noise, rnd_normal=rnd, loss_type=lt)
     want.backward()
     m.set_layer_state(True)
     m.noise_generation = lambda shape: noise.cuda()
@@ -168,7 +171,8 @@ def test_layer_model_training_step_against_autograd():
         g, w = p.grad.cpu().double(), sd[k].grad.double()
         num += float(((g - w) ** 2).sum()); den += float((w ** 2).sum())
         worst = max(worst, float(((g - w) ** 2).sum().sqrt() / (w ** 2).sum().sqrt().clamp_min(1e-30)))
-    assert (num / den) ** 0.5 < 5e-6 and worst < 1e-4, ((num / den) ** 0.5, worst)
+    # (l1: the gradient is sign(d) / N -- an x0 within rounding of its target may flip one of the 414 signs)
+    assert (num / den) ** 0.5 < (2e-3 if lt == "l1" else 5e-6) and worst < (2e-2 if lt == "l1" else 1e-4), (lt, (num / den) ** 0.5, worst)
     with torch.no_grad():
         assert abs(float(m.compute_loss(None, E.cuda(), None, layers.cuda(), rnd_normal=rnd.cuda())) - float(want.detach())) < 2e-6 * abs(float(want.detach()))
     before = m.layer_model.out_lay.weight.detach().clone()

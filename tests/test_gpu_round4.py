@@ -107,3 +107,34 @@ def test_full_resolution_conv_writes_nothing_outside_its_output():
         assert bool(torch.isfinite(y).all()) and not bool((y == 7.25).any()), (B, cin, cout, shape)  # every element written
         ref = ops.cyl_conv(x, w, bias)
         assert torch.equal(ref, y)  # (deterministic: the same launch into an ordinary tensor)
+
+
+def test_workspace_cache_follows_precision_and_switches(monkeypatch):
+    """A cached workspace stays valid when the arithmetic mode changes after the first call (the library sizes for the largest of
+    its modes), a launch-sequence switch gets its own workspace, and at most one network / one sampler workspace is kept (ADVICE
+    r03: a ragged last batch doubled the footprint, a precision switch after the first call failed with CD_EWORKSPACE)."""
+    from calodiffusion_amd import engine
+    from test_gpu_round2 import _model
+    m = _model("dataset2", {"SAMPLER": "Heun"})
+    eng = m.engine()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn((2, 1, 45, 16, 9), generator=g).cuda()
+    E, layers = torch.rand((2, 1), generator=g).cuda(), torch.randn((2, 46), generator=g).cuda()
+    sig = torch.tensor([2.0, 0.3]).cuda()
+    ref = m.denoise(x, E=E, sigma=sig, layers=layers)
+    try:
+        for mode in ("f32", "bf16x3"):
+            engine.set_conv_precision(mode)
+            y = m.denoise(x, E=E, sigma=sig, layers=layers)
+            assert rel_l2(y.cpu().numpy(), ref.cpu().numpy()) < 1e-5, mode
+    finally:
+        engine.set_conv_precision("f16x2")
+    monkeypatch.setenv("CD_NO_DEEP_LEVEL", "1")
+    y = m.denoise(x, E=E, sigma=sig, layers=layers)
+    assert rel_l2(y.cpu().numpy(), ref.cpu().numpy()) < 3e-6
+    monkeypatch.delenv("CD_NO_DEEP_LEVEL")
+    m.denoise(x[:1], E=E[:1], sigma=sig[:1], layers=layers[:1])  # another batch size: the previous workspace is evicted
+    m.sample(E, layers, num_steps=3, start=x)
+    m.sample(E[:1], layers[:1], num_steps=3, start=x[:1])
+    kinds = [k[0] for k in eng._ws]
+    assert kinds.count("net") == 1 and kinds.count("sampler") == 1, list(eng._ws)
