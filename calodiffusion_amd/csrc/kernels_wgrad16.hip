@@ -318,6 +318,8 @@ void absmax_note_drop() {
 const unsigned* launch_absmax_bits(const float* x, size_t n, hipStream_t s) {
   if (g_absmax_fresh && g_absmax_of == x && g_absmax_word) {
     g_absmax_fresh = false;
+    g_absmax_n = n;  // the note now has the consumer's size: the weight gradient of the same conv_backward re-uses it too
+                     // (it was left at 0, so every weight gradient behind a producer-tracked dy ran its own pass: 28 per step)
     return g_absmax_word;
   }
   g_absmax_fresh = false;
