@@ -20,11 +20,12 @@ stats() {  # stats <name> <bench args...>
   name=$1; shift
   timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$name -o bench -- python3 bench.py --steps 1 --warmup 1 --no-extra --no-clocks "$@" > $out/${name}_bench_under_rocprof.json 2> $out/stats_$name.err; echo "stats $name rc=$?"
   cp $(find $out/stats_$name -name "*kernel_stats.csv" | head -1) $out/${name}_kernel_stats.csv; rm -rf $out/stats_$name
-  timeout -k 10 400 python bench.py --no-cpu "$@" > $out/${name}_bench.json 2> $out/${name}_bench.err; echo "bench $name rc=$?"; cut -c1-160 $out/${name}_bench.json
+  timeout -k 10 400 python bench.py "$@" > $out/${name}_bench.json 2> $out/${name}_bench.err; echo "bench $name rc=$?"; cut -c1-160 $out/${name}_bench.json
 }
 stats dataset2
 stats dataset3 --config dataset3
 stats hgcal --config hgcal
-stats train --mode train
+bash tools/train_prof.sh $(basename $out)_train > $out/train_prof.log 2>&1; echo "train prof rc=$?"  # (timed steps only: trace_stats.py)
+for f in train_bench.json train_bench_under_rocprof.json train_kernel_stats.csv; do cp gpurun_out/$(basename $out)_train/$f $out/ 2>/dev/null; done; head -8 $out/train_prof.log | cut -c1-200
 timeout -k 10 120 python tools/clock_trace.py --out $out/clock_trace.json > $out/clock_trace.log 2>&1; echo "clock trace rc=$?"
 du -sh gpurun_out; ls -la $out

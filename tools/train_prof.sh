@@ -1,16 +1,9 @@
 #!/bin/bash
-# bash tools/train_prof.sh <tag>: training bench line (batch 32) + rocprofv3 kernel stats of the same command with the autotune
-# probes and first-call work outside the trace window as far as --warmup allows (3 warm-up steps, 3 timed).
+# bash tools/train_prof.sh <tag>: the training bench line (batch 32, with its roofline leg) + per-kernel totals of the TIMED steps only
+# (rocprofv3 kernel trace cut at the first timed step: tools/trace_stats.py), so that autotune probes and warm-up steps are outside.
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 out=gpurun_out/${1:-trainprof}; mkdir -p $out
-bash tools/logrun.sh $out/train_bench.log python bench.py --mode train --steps 10 --warmup 3; tail -3 $out/train_bench.log | cut -c1-400
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o bench -- python3 bench.py --mode train --steps 3 --warmup 3 > $out/train_bench_under_rocprof.json 2> $out/stats.err; echo "stats rc=$?"
-cp $(find $out/stats -name "*kernel_stats.csv" | head -1) $out/train_kernel_stats.csv; rm -rf $out/stats
-python3 - <<PY
-import csv
-rows=list(csv.DictReader(open("$out/train_kernel_stats.csv")))
-tot=sum(float(r['TotalDurationNs']) for r in rows)
-print("total ms over 6 steps", tot/1e6)
-for r in rows[:40]:
-    print(f"{r['Name'][:90]:90s} calls {r['Calls']:>5s} avg {float(r['AverageNs'])/1000:8.1f}us {float(r['TotalDurationNs'])/tot*100:5.1f}%")
-PY
+bash tools/logrun.sh $out/train_bench.log python bench.py --mode train --steps 10 --warmup 3; tail -2 $out/train_bench.log | head -1 > $out/train_bench.json; cut -c1-300 $out/train_bench.json
+timeout -k 10 600 rocprofv3 --kernel-trace --output-format csv -d $out/tr -o bench -- python3 bench.py --mode train --steps 3 --warmup 3 --no-extra > $out/train_bench_under_rocprof.json 2> $out/tr.err; echo "trace rc=$?"
+python3 tools/trace_stats.py $(find $out/tr -name "*kernel_trace.csv" | head -1) --marker pack_jobs_kernel --last 12 --steps 3 --out $out/train_kernel_stats.csv
+rm -rf $out/tr
