@@ -379,7 +379,10 @@ void launch_deep_level(const DeepLevelDesc& d, const float* x_in, float* x_out, 
 bool attn_small_eligible(int64_t vox);
 void launch_attn_small(const float* x, int C, const float* coef, const void* wqkv_f16x2, float* partials, const float* w_out,
                        float scale, const float* bias, const float* out_gamma, const float* out_beta, float* y, float* ch_part,
-                       int batch, int64_t vox, hipStream_t s, const GnDefer* defer, int* status = nullptr);
+                       int batch, int64_t vox, hipStream_t s, const GnDefer* defer, int* status = nullptr,
+                       // capacity of partials ([B][max_parts][1088]) and ch_part ([B][max_parts][C][2]) in parts per sample: with
+                       // CD_ATTN_COOP the sample's voxels are dealt to up to that many co-operating workgroups
+                       int max_parts = 1);
 void launch_attn_kv_context(const float* x, int C, const float* coef, const void* wqkv_f16x2, float* partials, int batch,
                             int64_t vox, int nsplit, hipStream_t s, const GnDefer* defer = nullptr, int* status = nullptr);
 void launch_attn_out(const float* x, int C, const float* coef, const void* wqkv_f16x2, const float* wT_b, const float* bias,

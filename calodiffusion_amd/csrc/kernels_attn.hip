@@ -48,7 +48,15 @@ struct AttnArgs {
   GnDefer defer;      // PreNorm coefficients folded in the prologue instead of read from `coef`
   const float *out_gamma, *out_beta;  // attn_small_kernel: affine parameters of the closing GroupNorm(1, C)
   int* status;        // bit 0: an operand of the fp16-pipe products (normalised x, v, the folded output weights) left the fp16 range
+  // attn_coop_kernel: the nsplit workgroups of a sample meet at two barriers inside the launch
+  unsigned* sync;     // [B][2] = {arrivals, generation}: zero once, self-resetting
+  int coop;           // the partials / channel sums read below were written by OTHER workgroups of this launch
 };
+// value written by another workgroup of the SAME launch (same XCD, see attn_coop_kernel): an agent-scope load, which does not
+// linger in this CU's vector cache
+__device__ __forceinline__ float attn_peer_load(const float* p, int coop) {
+  return coop ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
 
 // A fragments of one 32-voxel tile for v_mfma_f32_32x32x16_f16: lane (voxel n0 + col, half) holds, per 16-channel k-step ks,
 // channels ks*16 + half*8 + 0..7 of the normalised input as two fp16 terms (f16x2).  NKS = C / 16 k-steps.
@@ -311,10 +319,11 @@ __device__ __forceinline__ void attn_fold_weights(const AttnArgs& a, int b, floa
   if (tid < 32) {
     float M = -3.0e38f;
 #pragma unroll 4
-    for (int i = 0; i < a.nsplit; ++i) M = fmaxf(M, p[(size_t)i * 1088 + tid]);
+    for (int i = 0; i < a.nsplit; ++i) M = fmaxf(M, attn_peer_load(p + (size_t)i * 1088 + tid, a.coop));
     float S = 0.f;
 #pragma unroll 4
-    for (int i = 0; i < a.nsplit; ++i) S += p[(size_t)i * 1088 + 32 + tid] * expf(p[(size_t)i * 1088 + tid] - M);
+    for (int i = 0; i < a.nsplit; ++i)
+      S += attn_peer_load(p + (size_t)i * 1088 + 32 + tid, a.coop) * expf(attn_peer_load(p + (size_t)i * 1088 + tid, a.coop) - M);
     sM[tid] = M;
     sInv[tid] = a.fold_scale / S;
   }
@@ -323,7 +332,8 @@ __device__ __forceinline__ void attn_fold_weights(const AttnArgs& a, int b, floa
     const int d = i >> 5;
     float c = 0.f;
 #pragma unroll 4
-    for (int k = 0; k < a.nsplit; ++k) c += p[(size_t)k * 1088 + 64 + i] * expf(p[(size_t)k * 1088 + d] - sM[d]);
+    for (int k = 0; k < a.nsplit; ++k)
+      c += attn_peer_load(p + (size_t)k * 1088 + 64 + i, a.coop) * expf(attn_peer_load(p + (size_t)k * 1088 + d, a.coop) - sM[d]);
     sCtx[i] = c * sInv[d];
   }
   __syncthreads();
@@ -581,6 +591,98 @@ __global__ void __launch_bounds__(512) attn_small_kernel(AttnArgs a) {
   }
 }
 
+// Barrier among the P workgroups of one sample inside a launch (sense-reversing: the last arriver resets the count and bumps the
+// generation the others poll).  Measured on MI355X (tools/micro/group_barrier.hip, profiles/r04_group_barrier.txt): 3.3 us per
+// barrier when the P workgroups sit on ONE XCD -- their L2 is the point of coherence, agent-scope relaxed atomics and s_waitcnt
+// suffice, no cache write-back -- 11 us with release / acquire fences, and it never completes across XCDs with relaxed polls (each
+// XCD's L2 keeps its own copy of the polled line): hence attn_coop_kernel's blockIdx -> (sample, part) mapping.  The spin is
+// BOUNDED: a barrier that does not complete raises the range flag, which makes the caller re-run the call on the full-range
+// (single-workgroup, unfused) path, and falls through -- the grid always drains.
+__device__ __forceinline__ void attn_group_barrier(unsigned* sync, int P, int* status) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have reached L2
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned g = __hip_atomic_load(sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned arrived = __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (arrived == (unsigned)P - 1) {
+      __hip_atomic_store(sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_fetch_add(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      int spins = 0;
+      while (__hip_atomic_load(sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1 << 21)) {  // ~0.1 s: the peers are not coming (not co-resident, another launch on the same words)
+          if (status) atomicOr(status, 1);
+          break;
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// attn_small_kernel with the voxels of a sample dealt to P co-operating workgroups: pass 1 over the part's
+// tiles -> {max, sum, context} partial -> barrier -> pass 2 over the part's tiles (its fold merges the P partials exactly as the
+// two-launch form merges its splits) -> barrier -> closing GroupNorm(1, C) from all parts' channel sums and  out = gn(y) + x
+// over the part's voxels.  Same arithmetic as the level-0 three-launch path with nsplit = P (bit-identical to it, not to the
+// single-workgroup form, whose partial is one piece).  blockIdx -> (sample, part): workgroups are dealt round-robin over the 8
+// XCDs, so the parts of sample b = 8 j + x are blockIdx = 8 (P j + part) + x: one XCD, consecutive in its dispatch order.
+template <int NCH>
+__global__ void __launch_bounds__(512) attn_coop_kernel(AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) float sOut[NCH * 32][2];
+  __shared__ double sTot[2];
+  const int tid = threadIdx.x, half = (tid & 63) >> 5;
+  const int P = a.nsplit;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int b = (slot / P) * 8 + xcd, part = slot % P;
+  const int64_t T = (a.vox + 31) / 32;
+  const int64_t t0 = (int64_t)part * a.tiles_per_wg;
+  const int64_t t1 = (t0 + a.tiles_per_wg < T) ? t0 + a.tiles_per_wg : T;
+  unsigned* const sync = a.sync + (size_t)b * 2;
+  f32x4 cf[NCH][8];
+  load_coef<NCH>(a, b, half, cf);
+  attn_pass1<NCH>(a, b, part, t0, t1, cf);
+  attn_group_barrier(sync, P, a.status);
+  attn_pass2<NCH>(a, b, part, P, t0, t1, cf);
+  attn_group_barrier(sync, P, a.status);
+  const int C = NCH * 32;
+  if (tid == 0) {
+    double a1 = 0.0, a2 = 0.0;
+    for (int u = 0; u < P; ++u) {
+      const float* cp = a.ch_part + ((size_t)b * P + u) * C * 2;
+      for (int c = 0; c < C; ++c) {
+        a1 += (double)attn_peer_load(cp + c * 2, 1);
+        a2 += (double)attn_peer_load(cp + c * 2 + 1, 1);
+      }
+    }
+    const double cnt = (double)a.vox * C;
+    const double mu = a1 / cnt;
+    double var = a2 / cnt - mu * mu;
+    var = var < 0.0 ? 0.0 : var;
+    sTot[0] = mu;
+    sTot[1] = 1.0 / sqrt(var + 1e-5);
+  }
+  __syncthreads();
+  if (tid < C) {
+    const float sc = (float)sTot[1] * a.out_gamma[tid];
+    sOut[tid][0] = sc;
+    sOut[tid][1] = a.out_beta[tid] - (float)sTot[0] * sc;
+  }
+  __syncthreads();
+  float* const yb = a.y + (size_t)b * a.vox * C;
+  const float* const xb = a.x + (size_t)b * a.vox * C;
+  const int64_t v0 = t0 * 32, v1 = t1 * 32 < a.vox ? t1 * 32 : a.vox;
+  for (int64_t i = v0 * C / 4 + tid; i < v1 * C / 4; i += 512) {
+    const int c = (int)((i * 4) % C);
+    const f32x4 y = ((const f32x4*)yb)[i], x = ((const f32x4*)xb)[i];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = sOut[c + e][0] * y[e] + sOut[c + e][1] + x[e];
+    ((f32x4*)yb)[i] = o;
+  }
+}
+
 int tiles_per_wg_for(int64_t vox, int nsplit) {
   const int64_t T = (vox + 31) / 32;
   int64_t per = (T + nsplit - 1) / nsplit;
@@ -660,7 +762,7 @@ bool attn_small_eligible(int64_t vox) {
 }
 void launch_attn_small(const float* x, int C, const float* coef, const void* wqkv_f16x2, float* partials, const float* w_out,
                        float scale, const float* bias, const float* out_gamma, const float* out_beta, float* y, float* ch_part,
-                       int batch, int64_t vox, hipStream_t s, const GnDefer* defer, int* status) {
+                       int batch, int64_t vox, hipStream_t s, const GnDefer* defer, int* status, int max_parts) {
   CD_REQUIRE(C == 32 || C == 64 || C == 96 || C == 128, "fused attention: 32..128 channels");
   CD_REQUIRE((vox * C) % 4 == 0, "fused attention: whole float4 rows");
   AttnArgs a{};
@@ -672,6 +774,36 @@ void launch_attn_small(const float* x, int C, const float* coef, const void* wqk
   char cat[64];
   std::snprintf(cat, sizeof cat, "attn_small C%d n%ld", C, (long)vox);
   prof::Scope scope(cat, s, 2.0 * (4.0 * C + 32) * 32 * (double)vox * batch, 4.0 * batch * (double)vox * C * 3);
+  // several co-operating workgroups per sample (attn_coop_kernel): opt-in through CD_ATTN_COOP=<parts> (2 .. max_parts) while it
+  // is being measured.  Needs whole XCD groups (batch a multiple of 8), every part at least one tile per wave-pair, and all
+  // batch x parts workgroups co-resident (one 512-thread workgroup per CU).
+  static const int coop_env = getenv("CD_ATTN_COOP") ? atoi(getenv("CD_ATTN_COOP")) : 0;
+  const int64_t T = (vox + 31) / 32;
+  int P = coop_env < max_parts ? coop_env : max_parts;
+  while (P > 1 && ((int64_t)batch * P > 256 || T < 4 * P)) --P;
+  if (P > 1 && batch % 8 == 0 && status) {
+    int per = (int)((T + P - 1) / P);
+    while (P > 1 && (int64_t)(P - 1) * per >= T) { --P; per = (int)((T + P - 1) / P); }  // (every part has a tile)
+    if (P > 1) {
+      static unsigned* sync = nullptr;
+      static const int kSyncSamples = 8192;
+      if (!sync) {
+        CD_HIP(hipMalloc((void**)&sync, sizeof(unsigned) * 2 * kSyncSamples));
+        CD_HIP(hipMemset(sync, 0, sizeof(unsigned) * 2 * kSyncSamples));
+      }
+      CD_REQUIRE(batch <= kSyncSamples, "attention: batch too large for the co-operative form");
+      a.sync = sync; a.coop = 1; a.nsplit = P; a.tiles_per_wg = per;
+      const dim3 cgrid((unsigned)(batch * P));
+      switch (C / 32) {
+        case 1: hipLaunchKernelGGL(attn_coop_kernel<1>, cgrid, dim3(512), 0, s, a); break;
+        case 2: hipLaunchKernelGGL(attn_coop_kernel<2>, cgrid, dim3(512), 0, s, a); break;
+        case 3: hipLaunchKernelGGL(attn_coop_kernel<3>, cgrid, dim3(512), 0, s, a); break;
+        default: hipLaunchKernelGGL(attn_coop_kernel<4>, cgrid, dim3(512), 0, s, a); break;
+      }
+      CD_HIP(hipGetLastError());
+      return;
+    }
+  }
   const dim3 grid((unsigned)batch);
   switch (C / 32) {
     case 1: hipLaunchKernelGGL(attn_small_kernel<1>, grid, dim3(512), 0, s, a); break;

@@ -649,14 +649,15 @@ float* attn_block(Run& r, const AttnP& w, const float* x, Dims3 dims, float* xpa
   if (!no_fused) {
     // fused path (kernels_attn.hip): x -> {max, sum, context} partials -> per-sample folded W_out -> y; qkv never exists
     const int nsp = attn_fused_nsplit_for(vox, r.B);
-    float* part = ws->get<float>(attn_partial_floats(r.B, nsp));
+    const int cap = single && nsp < 4 ? 4 : nsp;  // (the single-launch form may deal a sample to up to 4 co-operating workgroups)
+    float* part = ws->get<float>(attn_partial_floats(r.B, cap));
     float* wpb = ws->get<float>((size_t)r.B * CT * 1024);
     y = ws->get<float>((size_t)r.B * vox * C);
     yu = nsp;
-    ypart = ws->get<float>((size_t)r.B * yu * C * 2);
+    ypart = ws->get<float>((size_t)r.B * cap * C * 2);
     if (!r.dry() && single) {
       launch_attn_small(x, C, coefn, w.qkv16, part, w.ow, 0.17677669529663689f /* 32^-1/2 */, w.ob, w.gg, w.gb, y, ypart, r.B, vox,
-                        r.s, dnp, r.status);
+                        r.s, dnp, r.status, cap);
     } else if (!r.dry()) {
       launch_attn_kv_context(x, C, coefn, w.qkv16, part, r.B, vox, nsp, r.s, dnp, r.status);
       static const bool sep_combine = getenv("CD_ATTN_COMBINE_LAUNCH") != nullptr;  // A/B: the separate combine launch

@@ -138,3 +138,42 @@ def test_workspace_cache_follows_precision_and_switches(monkeypatch):
     m.sample(E[:1], layers[:1], num_steps=3, start=x[:1])
     kinds = [k[0] for k in eng._ws]
     assert kinds.count("net") == 1 and kinds.count("sampler") == 1, list(eng._ws)
+
+
+@pytest.mark.parametrize("parts", [2, 4])
+def test_cooperating_workgroups_attention_equals_the_single_workgroup_form(parts):
+    """attn_coop_kernel (CD_ATTN_COOP: a sample's voxels dealt to several co-operating workgroups with two in-launch barriers)
+    against the one-workgroup-per-sample attn_small_kernel at Dataset-2's level-1 grids (736 voxels, 32 and 64 channels, batch a
+    multiple of 8 so that a sample's workgroups share an XCD) -- run in a child process, CD_ATTN_COOP is read once.  The two forms
+    merge their {max, sum, context} partials differently, so they agree to rounding, not bit for bit; the range flag must stay
+    clear (a barrier that times out raises it)."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from test_gpu_round2 import _model
+m = _model("dataset2")
+g = torch.Generator().manual_seed(5)
+B = 16
+x = torch.randn((B, 1, 45, 16, 9), generator=g).cuda()
+E, layers = torch.rand((B, 1), generator=g).cuda(), torch.randn((B, 46), generator=g).cuda()
+sig = torch.linspace(0.05, 30.0, B).cuda()
+eng = m.engine()
+eng.safe_denoise = False
+y = m.denoise(x, E=E, sigma=sig, layers=layers)
+torch.cuda.synchronize()
+eng.check_status()
+np.save(sys.argv[1], y.cpu().numpy())
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for tag, env in (("single", {}), ("coop", {"CD_ATTN_COOP": str(parts)})):
+        path = f"/tmp/coop_{parts}_{tag}.npy"
+        e = dict(os.environ, **env)
+        subprocess.run([sys.executable, "-c", code % (root, os.path.join(root, "tests")), path], check=True, env=e, timeout=600)
+        outs[tag] = np.load(path)
+    err = rel_l2(outs["coop"], outs["single"])
+    print(f"co-operative attention ({parts} workgroups per sample) vs single workgroup: rel L2 {err:.2e}")
+    assert err < 3e-6

@@ -2,8 +2,8 @@
 """Per-kernel totals of the TIMED region of a bench run from a rocprofv3 kernel trace (`--kernel-trace --output-format csv`), in the
 column layout of rocprofv3's own `--stats` file.  `--stats` covers the whole process: kernel autotuning probes, first-call packs and
 the warm-up steps sit in its totals (the training profile mixed them in).  Here the region is cut at a marker kernel:
-rows from the N-th last launch of `--marker` on (training: every step begins with two `pack_jobs_kernel` launches of the weight
-re-pack and two of the input-gradient images, so `--marker pack_jobs_kernel --last 4*steps`).
+rows from the N-th last launch of `--marker` on (training: every step launches `pack_jobs_kernel` twice -- the weight re-pack and
+the input-gradient images -- so `--marker pack_jobs_kernel --last 2*steps`).
 
     python3 tools/trace_stats.py <kernel_trace.csv> --marker pack_jobs_kernel --last 12 --out train_kernel_stats.csv
 """
