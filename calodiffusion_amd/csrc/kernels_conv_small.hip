@@ -57,13 +57,13 @@ struct ConvSmallArgs {
 };
 
 constexpr int CS_PD = 6;  // weight fragments requested this many pairs ahead
-#ifndef CS_NW
-#define CS_NW 4           // waves per workgroup (8 was measured: same step time, twice the partial exchange): the (tap, k-step) pairs of a conv are dealt round-robin to them (K split)
-#endif
-constexpr int CS_THREADS = CS_NW * 64;
-
-template <int NT>  // row tiles (32 voxels each) of the sample: ceil(vox / 32) <= 4
-__global__ void __launch_bounds__(CS_THREADS, 1) conv_small_f16x2_kernel(ConvSmallArgs a) {
+// waves per workgroup: the (tap, k-step) pairs of a conv are dealt round-robin to them (K split).  4 where the step is power-bound
+// (Dataset-2's deepest level: 8 waves measured the same step time for twice the partial exchange); 8 on four-tile samples (HGCal's 7 x 3 x 5
+// grid at batch 16 lights 48 CUs, nothing is power-bound there: 1.466 -> 1.442 ms per denoise step, same-box A/B, round 4).  The choice
+// depends on the geometry only, never on the batch: a shower's result must not change with the batch it is sampled in.
+template <int NT, int CS_NW>  // NT: row tiles (32 voxels each) of the sample: ceil(vox / 32) <= 4
+__global__ void __launch_bounds__(CS_NW * 64, 1) conv_small_f16x2_kernel(ConvSmallArgs a) {
+  constexpr int CS_THREADS = CS_NW * 64;
   extern __shared__ __attribute__((aligned(16))) char cs_lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
   const int b = blockIdx.x, ct = blockIdx.y;
@@ -392,14 +392,16 @@ __global__ void __launch_bounds__(CS_THREADS, 1) conv_small_f16x2_kernel(ConvSma
   }
 }
 
+constexpr int cs_waves_for(int NT) { return NT >= 4 ? 8 : 4; }
 template <int NT>
 void launch_small_inst(const ConvSmallArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+  constexpr int NW = cs_waves_for(NT);
   static bool attr_set = false;
   if (!attr_set) {
-    CD_HIP(hipFuncSetAttribute((const void*)conv_small_f16x2_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CD_HIP(hipFuncSetAttribute((const void*)conv_small_f16x2_kernel<NT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL(conv_small_f16x2_kernel<NT>, grid, dim3(CS_THREADS), lds, s, a);
+  hipLaunchKernelGGL((conv_small_f16x2_kernel<NT, NW>), grid, dim3(NW * 64), lds, s, a);
   CD_HIP(hipGetLastError());
 }
 
@@ -419,7 +421,7 @@ bool try_launch_conv_small(const float* in0, int c0, const float* in1, int c1, c
   const int VB = (cin < 64 ? cin : 64) * 4 + 16;
   const int NT = (int)((vox + 31) / 32);
   const size_t image = (size_t)(g.in.d + 2) * (g.in.h + 2) * (g.in.w + 1) * VB;
-  const size_t partial = (size_t)NT * CS_NW * 4096;
+  const size_t partial = (size_t)NT * cs_waves_for(NT) * 4096;
   size_t lds = image > partial ? image : partial;
   lds = (lds + 255) & ~(size_t)255;
   const size_t coef_off = lds;
@@ -466,7 +468,7 @@ bool try_launch_res_block_small(const float* x0, int c0, const float* x1, int c1
   const int VB = (cin < 64 ? cin : 64) * 4 + 16;  // (conv2's 32 input channels need no more)
   const int NT = (int)((vox + 31) / 32);
   const size_t image = (size_t)(dims.d + 2) * (dims.h + 2) * (dims.w + 1) * VB;
-  const size_t partial = (size_t)NT * CS_NW * 4096;
+  const size_t partial = (size_t)NT * cs_waves_for(NT) * 4096;
   size_t lds = image > partial ? image : partial;
   lds = (lds + 255) & ~(size_t)255;
   const size_t coef_off = lds;
