@@ -97,6 +97,9 @@ def launch_ranks(argv, gpus: int) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+FORCE_COLLECTIVE = False  # --force-collective: a one-rank run still goes through RCCL (what a single-GPU box can show of that branch)
+
+
 def collective_info():
     """What the timing barrier / max-over-ranks (and, in --mode train, the gradient all-reduce) actually ran on."""
     import torch.distributed as dist
@@ -108,7 +111,7 @@ def collective_info():
 def max_over_ranks(value: float) -> float:
     """Slowest rank's time (MAX all-reduce); identity in a single-process run."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not FORCE_COLLECTIVE):
         return float(value)
     dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
     t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
@@ -322,7 +325,7 @@ def train_bench(args, model, cfg, E, layers, rank, world):
         result["roofline"] = roof
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if world > 1 or FORCE_COLLECTIVE:
         import torch.distributed as dist
         dist.destroy_process_group()
 
@@ -341,6 +344,8 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the roofline and cpu_baseline legs")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel breakdown to stderr")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg only")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="under a launcher with ONE rank: initialise RCCL anyway and run the barrier / MAX / gradient all-reduce through it")
     ap.add_argument("--no-clocks", action="store_true", help="do not sample the GPU's clocks / power during the timed region")
     ap.add_argument("--mode", default="sample", choices=["sample", "train"],
                     help="train: BASELINE configs[2], a step = one training iteration (fwd + bwd + grad all-reduce + Adam)")
@@ -360,9 +365,16 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or args.force_collective:
         import torch.distributed as dist
+        if args.force_collective and "RANK" not in os.environ:
+            raise SystemExit("--force-collective needs a launcher (python -m torch.distributed.run --nproc-per-node 1 ... bench.py --gpus 1 ...)")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.force_collective:
+            global FORCE_COLLECTIVE
+            FORCE_COLLECTIVE = True
+            from calodiffusion_amd import utils as _u
+            _u.FORCE_SINGLE_RANK_COLLECTIVE = True
 
     from calodiffusion_amd import engine as engine_mod
     from calodiffusion_amd.calodiffusion import CaloDiffusion
@@ -463,7 +475,7 @@ def main():
             result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if world > 1 or FORCE_COLLECTIVE:
         import torch.distributed as dist
         dist.destroy_process_group()
 

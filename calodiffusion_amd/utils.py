@@ -86,6 +86,8 @@ def shard_batch(n: int, world_size: int, rank: int) -> slice:
 
 # measurement hook (bench.py --mode train): a list to which every device-side all-reduce appends its (start, end) events
 ALLREDUCE_EVENTS = None
+# bench.py --force-collective: run the all-reduce on a one-rank group too (a single-GPU box exercising the RCCL branch)
+FORCE_SINGLE_RANK_COLLECTIVE = False
 
 
 def allreduce_mean_(flat: torch.Tensor) -> torch.Tensor:
@@ -93,7 +95,7 @@ def allreduce_mean_(flat: torch.Tensor) -> torch.Tensor:
     the default process group (RCCL over xGMI on GPUs, gloo in the CPU tests), then the mean.  No-op outside a
     multi-process job.  This is the only collective of the training path."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_SINGLE_RANK_COLLECTIVE):
         if flat.is_cuda and dist.get_backend() == "gloo":
             # gloo moves host memory: bounce the buffer (tests with several ranks on one GPU; RCCL reduces in place on the device)
             host = flat.detach().cpu()

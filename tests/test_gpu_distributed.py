@@ -107,3 +107,30 @@ def test_two_ranks_train_step_and_sharded_sampling(tmp_path):
     err = np.linalg.norm(parts - full) / np.linalg.norm(full)
     assert err < 2e-6, err  # same noise bits; kernel tilings (hence fp32 summation order of the statistics) depend on the batch
     assert not np.allclose(full[0], full[1])
+
+
+def test_bench_goes_through_rccl_with_one_rank():
+    """The RCCL branch of bench.py (init_process_group("nccl"), barrier, MAX all-reduce, and in train mode the flat-gradient SUM
+    all-reduce of utils.allreduce_mean_) on the ONE GPU a test box has: one rank under torch.distributed.run with
+    --force-collective.  The multi-GPU run is the driver's; this shows the calls are accepted by RCCL on this image and the line
+    says which backend carried them."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--mode", "train", "--steps", "2", "--warmup", "1",
+           "--no-extra", "--force-collective"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    c = line["collective"]
+    print("one-rank RCCL:", c)
+    assert c["backend"] == "nccl" and c["ranks"] == 1 and c["allreduces_per_step"] == 1.0 and c["allreduce_ms"] > 0
