@@ -276,6 +276,9 @@ void launch_wgrad(const float* g, int A, Dims3 dg, const float* x, int Bc, int x
 bool wgrad_f16x2_eligible(Dims3 d);
 bool try_launch_wgrad_f16x2(const float* g, int A, const float* x, int Bc, int xld, int xoff, Dims3 d, int batch, float* partial,
                             unsigned* gmax_word, int* nblk_out, hipStream_t s);
+// the strided (KD, 4, 4) convs between the levels (and the transposed conv with the tensors' roles swapped): kernels_wgrad16.hip
+bool try_launch_wgrad_strided_f16x2(const float* g, int A, Dims3 dg, const float* x, int Bc, int xld, int xoff, Dims3 dx, int kd, int sz,
+                                    int batch, float* partial, int max_slots, int* nblk_out, hipStream_t s);
 void launch_strided_dgrad_naive(const float* dy, const float* w, float* dx, int batch, int cin, int cout, Dims3 din, Dims3 dout,
                                 int kd, int sz, hipStream_t s);
 void launch_softmax32(const float* qkv, float* qs, int64_t rows, hipStream_t s);

@@ -434,6 +434,22 @@ void launch_wgrad(const float* g, int A, Dims3 dg, const float* x, int Bc, int x
       return;
     }
   }
+  if (kh == 4 && kw == 4 && sxy == 2 && !per_sample) {
+    // the strided convs between the levels: fp16 matrix pipe (round 4; kernels_wgrad16.hip)
+    const int Ts = kd * 16;
+    const int max_slots = wgrad_chunks(dg.vox(), batch, false, A, Bc, Ts) * batch;
+    int nblk = 0;
+    char cats[96];
+    std::snprintf(cats, sizeof cats, "wgrad T%d C%dx%d n%ld", Ts, A, Bc, (long)dg.vox());
+    prof::Scope scope_s(cats, s, 2.0 * Ts * A * Bc * (double)dg.vox() * batch, 4.0 * batch * ((double)dg.vox() * A + (double)dx.vox() * Bc));
+    if (try_launch_wgrad_strided_f16x2(g, A, dg, x, Bc, xld, xoff, dx, kd, sz, batch, partial, max_slots, &nblk, s)) {
+      const size_t total = (size_t)A * Bc * Ts;
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256), 1), dim3(256), 0, s, partial, dw, A, Bc, Ts, nblk,
+                         accumulate ? 1 : 0, transposed_out ? 1 : 0, (size_t)nblk * total, total, b_total, b_off);
+      CD_HIP(hipGetLastError());
+      return;
+    }
+  }
   a.nchunks = wgrad_chunks(dg.vox(), batch, per_sample, A, Bc, kd * kh * kw);
   int cv = (int)((dg.vox() + a.nchunks - 1) / a.nchunks);
   a.chunk_vox = (cv + 1) & ~1;

@@ -801,6 +801,9 @@ __global__ void __launch_bounds__(512, (VT * CT * (NTERM == 2 ? 2 : 1) <= 2 ? 3 
   const int nslots = nstage * 4;  // one slot = 4 channels of one voxel
 
   auto tap_voxel = [&](int vt, int tap) -> int {
+#ifdef CD_FLAT_ABL_TAPS  // ablation (experiment builds only): what the per-tap address arithmetic costs -- WRONG results
+    return nb[vt] + tap;
+#endif
     const int kz = tap / (KH * KW), kh = (tap / KW) % KH, kw = tap % KW;
     const int n = nb[vt] + kz * HW + rowoff[vt][kh] + kw - 1;
     return ((wmask[vt] >> kw) & 1u) ? n : NZ;

@@ -266,6 +266,179 @@ __global__ void __launch_bounds__(512, 1) wgrad_f16x2_kernel(Wgrad16Args a) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// The same contraction for the STRIDED (KD, 4, 4) convs between the U-Net's levels (Downsample, models.py:360-365; and, with the two
+// tensors' roles swapped, the transposed Upsample conv): dw[tap][a][b] = sum over coarse voxels o of g[o][a] * x[in(o, tap)][b],
+// in(o, tap) = (oz SZ + kz - 1, 2 oh + kh - 1 (phi-periodic), 2 ow + kw - 1).  Round 4: these four weight gradients ran on the
+// f32-input MFMA (wgrad_kernel<4>, K = 2 voxels per instruction, 85 us each = 4 % of the training step).  Here a unit is NZ coarse
+// z-planes: their g rows and the fine planes they touch are staged as f16x2 record images -- the fine one with its phi halo rows
+// (one above, two below) and two zero records closing every r row, so that every tap of every coarse voxel is "record + constant"
+// -- and a K step of 16 coarse voxels takes its operands through the transposing LDS load exactly as wgrad_f16x2_kernel does,
+// each lane addressing the fine record of ITS coarse voxel.  The KD x 16 taps are dealt to the 8 waves of TWO workgroups
+// (blockIdx.z: 3 or 4 taps per wave, the accumulators of more would not fit a wave's registers).  Both operands are rescaled by a
+// power of two from their maxima: whichever of them is the gradient (g for the down conv, x for the up conv) is far below the fp16
+// normal range.
+struct WgradS16Args {
+  const float* g;   // coarse tensor (B, voxo, A), channel tile ta
+  const float* x;   // fine tensor (B, voxi, xld) read at channel offset xoff, channel tile tb
+  int A, xld, xoff;
+  int Do, Ho, Wo, Di, Hi, Wi, KD, SZ, NZ;
+  int units_per_sample, total_units;
+  float* partial;   // [gridDim.x][tilesA][tilesB][KD * 16][32][32]
+  int tilesB;
+  const unsigned *gmax_bits, *xmax_bits;
+};
+
+template <int NTAP>
+__global__ void __launch_bounds__(512, 1) wgrad_strided_f16x2_kernel(WgradS16Args a) {
+  extern __shared__ __attribute__((aligned(16))) char wl[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, col = lane & 31;
+  const int ta = blockIdx.y / a.tilesB, tb = blockIdx.y % a.tilesB;
+  const int T = a.KD * 16;
+  const int Wo = a.Wo, PVo = a.Ho * a.Wo, voxo = a.Do * PVo;
+  const int Hi = a.Hi, Wi = a.Wi, PVi = Hi * Wi, voxi = a.Di * PVi;
+  const int pitch = Wi + 2, prow = (Hi + 3) * pitch;   // fine image: rows -1 .. Hi+1, two zero records after every row
+  const int NZI = (a.NZ - 1) * a.SZ + a.KD;           // fine planes a unit touches
+  const int R = a.NZ * PVo, RP = (R + 15) & ~15;
+  char* const gL = wl;                                  // coarse image [RP][WG_VB]
+  char* const xL = wl + (size_t)(RP + 1) * WG_VB;       // one zero lead record, then [NZI][Hi + 3][Wi + 2] records
+  const int nxrec = NZI * prow;
+  float gscale, ginv, xscale, xinv;
+  pow2_scale_for(*a.gmax_bits, &gscale, &ginv);
+  pow2_scale_for(*a.xmax_bits, &xscale, &xinv);
+  for (int i = tid; i < ((RP + 1) * WG_VB + nxrec * WG_VB) / 16; i += 512) ((u32x4*)wl)[i] = u32x4{0u, 0u, 0u, 0u};
+
+  // this wave's taps: tap = blockIdx.z * (T / 2) + wave + 8 t, t < NTAP
+  int toff[NTAP];
+#pragma unroll
+  for (int t = 0; t < NTAP; ++t) {
+    const int tap = blockIdx.z * (T / 2) + wave + 8 * t;
+    const int kz = tap >> 4, kh = (tap >> 2) & 3, kw = tap & 3;
+    toff[t] = (kz * prow + kh * pitch + kw) * WG_VB;
+  }
+  f32x16 accA[NTAP], accB[NTAP];
+#pragma unroll
+  for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accA[t][r] = accB[t][r] = 0.f;
+  const int g4 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+  const int chan_off = (g4 & 1) * 64 + p4 * 8;
+  const int vrow0 = 8 * (g4 >> 1) + q4;
+  const int adv_h = 16 / Wo, adv_w = 16 - adv_h * Wo;
+
+  for (int u = blockIdx.x; u < a.total_units; u += gridDim.x) {
+    const int n = u / a.units_per_sample, uz = u - n * a.units_per_sample;
+    const int oz0 = uz * a.NZ;
+    const int zin0 = oz0 * a.SZ - 1;  // first fine plane of the image
+    __syncthreads();
+    {  // ---- coarse rows (rescaled) ----
+      const float* gs = a.g + ((size_t)n * voxo + (size_t)oz0 * PVo) * a.A + ta * 32;
+      const int nvalid = min(R, voxo - oz0 * PVo);
+      for (int i = tid; i < RP * 8; i += 512) {
+        const int v = i >> 3, qd = i & 7;
+        f32x4 val = {0.f, 0.f, 0.f, 0.f};
+        if (v < nvalid) val = *(const f32x4*)(gs + (size_t)v * a.A + qd * 4);
+        u32x2 t1, t2;
+        split2(val * gscale, t1, t2);
+        char* d = gL + v * WG_VB + (qd >> 2) * 64 + (qd & 3) * 8;
+        *(u32x2*)d = t1;
+        *(u32x2*)(d + 32) = t2;
+      }
+      // ---- fine planes zin0 .. zin0 + NZI - 1 (zero outside the sample): interior rows + the phi halo copies ----
+      const float* xs = a.x + (size_t)n * voxi * a.xld + a.xoff + tb * 32;
+      const int nst = NZI * PVi * 8;
+      for (int i = tid; i < nst; i += 512) {
+        const int v = i >> 3, qd = i & 7;
+        const int zl = v / PVi, p = v - zl * PVi, h = p / Wi, w = p - h * Wi;
+        const int z = zin0 + zl;
+        f32x4 val = {0.f, 0.f, 0.f, 0.f};
+        if (z >= 0 && z < a.Di) val = *(const f32x4*)(xs + ((size_t)z * PVi + p) * a.xld + qd * 4);
+        u32x2 t1, t2;
+        split2(val * xscale, t1, t2);
+        char* d = xL + (1 + zl * prow + (h + 1) * pitch + w) * WG_VB + (qd >> 2) * 64 + (qd & 3) * 8;
+        *(u32x2*)d = t1;
+        *(u32x2*)(d + 32) = t2;
+        if (h <= 1) {  // rows 0 and 1 again below the last row (kh - 1 reaches 2)
+          char* d2 = d + Hi * pitch * WG_VB;
+          *(u32x2*)d2 = t1;
+          *(u32x2*)(d2 + 32) = t2;
+        }
+        if (h == Hi - 1) {  // the last row again above the first
+          char* d2 = d - Hi * pitch * WG_VB;
+          *(u32x2*)d2 = t1;
+          *(u32x2*)(d2 + 32) = t2;
+        }
+      }
+    }
+    __syncthreads();
+    int vloc[2], vz[2], vh[2], vw[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int v = vrow0 + 4 * j;
+      vloc[j] = v;
+      const int vv = min(v, R - 1);
+      vz[j] = vv / PVo;
+      const int p = vv - vz[j] * PVo;
+      vh[j] = p / Wo;
+      vw[j] = p - vh[j] * Wo;
+    }
+    for (int c = 0; c < RP / 16; ++c) {
+      int xr[2];  // record of fine voxel (vz SZ + 0, 2 vh - 1, 2 vw - 1) = the (kz, kh, kw) = (0, 0, 0) tap; past the unit: any record
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const bool in = vloc[j] < R;
+        xr[j] = in ? (vz[j] * a.SZ * prow + 2 * vh[j] * pitch + 2 * vw[j]) * WG_VB : 0;
+      }
+      fh4 g0[2], g1[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const char* gp = gL + (size_t)min(vloc[j], RP - 1) * WG_VB + chan_off;
+        g0[j] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fh4*)(gp));
+        g1[j] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fh4*)(gp + 32));
+      }
+      const fh8 G0 = cat8(g0[0], g0[1]), G1 = cat8(g1[0], g1[1]);
+      fh8 X0[NTAP], X1[NTAP];
+#pragma unroll
+      for (int t = 0; t < NTAP; ++t) {
+        fh4 x0[2], x1[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const char* xp = xL + xr[j] + toff[t] + chan_off;
+          x0[j] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fh4*)(xp));
+          x1[j] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fh4*)(xp + 32));
+        }
+        X0[t] = cat8(x0[0], x0[1]);
+        X1[t] = cat8(x1[0], x1[1]);
+      }
+#pragma unroll
+      for (int t = 0; t < NTAP; ++t) {
+        accA[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(G0, X0[t], accA[t], 0, 0, 0);
+        accB[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(G0, X1[t], accB[t], 0, 0, 0);
+        accB[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(G1, X0[t], accB[t], 0, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        vloc[j] += 16;
+        vw[j] += adv_w;
+        vh[j] += adv_h;
+        if (vw[j] >= Wo) { vw[j] -= Wo; vh[j] += 1; }
+        while (vh[j] >= a.Ho) { vh[j] -= a.Ho; vz[j] += 1; }
+      }
+    }
+  }
+  float* pbase = a.partial + (((size_t)blockIdx.x * (a.A / 32) + ta) * a.tilesB + tb) * (size_t)T * 1024;
+  const float inv = ginv * xinv;
+#pragma unroll
+  for (int t = 0; t < NTAP; ++t) {
+    const int tap = blockIdx.z * (T / 2) + wave + 8 * t;
+    float* pp = pbase + (size_t)tap * 1024;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pp[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + col] = (accA[t][r] + accB[t][r] * (1.f / 2048.f)) * inv;
+  }
+}
+
 }  // namespace
 
 // returns false when the geometry does not fit (caller falls back to the fp32 kernels).  gmax_word: a device word the
@@ -374,6 +547,60 @@ bool try_launch_wgrad_f16x2(const float* g, int A, const float* x, int Bc, int x
     attr_set = true;
   }
   hipLaunchKernelGGL(wgrad_f16x2_kernel, dim3(nblk, tiles), dim3(512), lds, s, f);
+  CD_HIP(hipGetLastError());
+  *nblk_out = nblk;
+  return true;
+}
+
+// Strided (KD, 4, 4) / stride (SZ, 2, 2) weight gradient on the fp16 pipe (wgrad_strided_f16x2_kernel).  dg = the coarse grid (g), dx
+// the fine grid (x).  max_slots: capacity of `partial` in [A x Bc x T]-float slots.  Returns false when it does not apply (the
+// caller runs the f32-MFMA kernel).
+bool try_launch_wgrad_strided_f16x2(const float* g, int A, Dims3 dg, const float* x, int Bc, int xld, int xoff, Dims3 dx, int kd, int sz,
+                                    int batch, float* partial, int max_slots, int* nblk_out, hipStream_t s) {
+  static const bool off = getenv("CD_NO_WGRAD16") != nullptr || getenv("CD_NO_WGRAD16_STRIDED") != nullptr;
+  if (off || (kd != 3 && kd != 4) || dx.h < 2 || A % 32 || Bc % 32 || xld % 4 || xoff % 4) return false;
+  // the coarse grid must be the strided conv's output of the fine one (padding 1 everywhere, circular in phi)
+  if (dg.d != (dx.d + 2 - kd) / sz + 1 || dg.h != (dx.h - 2) / 2 + 1 || dg.w != (dx.w - 2) / 2 + 1) return false;
+  const int PVo = dg.h * dg.w;
+  const int pitch = dx.w + 2, prow = (dx.h + 3) * pitch;
+  auto lds_for = [&](int nz) {
+    const int RP = (nz * PVo + 15) & ~15;
+    return (size_t)(RP + 1) * WG_VB + (size_t)((nz - 1) * sz + kd) * prow * WG_VB;
+  };
+  int NZ = 0;
+  for (int nz : {4, 2, 1})
+    if (nz <= dg.d && lds_for(nz) <= 160 * 1024) { NZ = nz; break; }
+  if (!NZ) return false;
+  WgradS16Args f;
+  f.g = g; f.x = x; f.A = A; f.xld = xld; f.xoff = xoff;
+  f.Do = dg.d; f.Ho = dg.h; f.Wo = dg.w; f.Di = dx.d; f.Hi = dx.h; f.Wi = dx.w; f.KD = kd; f.SZ = sz; f.NZ = NZ;
+  f.units_per_sample = (dg.d + NZ - 1) / NZ;
+  f.total_units = f.units_per_sample * batch;
+  f.partial = partial; f.tilesB = Bc / 32;
+  // both operands are rescaled from their maxima; the one the caller's input-gradient conv already measured is re-used (it must
+  // be looked up BEFORE the other one's pass replaces the note)
+  const size_t gn = (size_t)batch * dg.vox() * A, xn = (size_t)batch * dx.vox() * xld;
+  auto noted = [&](const float* p, size_t n) { return (g_absmax_of == p && g_absmax_n == n && g_absmax_word) ? g_absmax_word : nullptr; };
+  const unsigned* wg = noted(g, gn);
+  const unsigned* wx = noted(x, xn);
+  if (!wg) wg = launch_absmax_bits(g, gn, s);
+  if (!wx) wx = launch_absmax_bits(x, xn, s);
+  f.gmax_bits = wg; f.xmax_bits = wx;
+  const int tiles = (A / 32) * (Bc / 32);
+  int nblk = 128 / tiles;  // x two tap groups = one round of the 256 CUs
+  if (nblk < 16) nblk = 16;
+  if (nblk > f.total_units) nblk = f.total_units;
+  if (nblk > max_slots) nblk = max_slots;
+  if (nblk < 1) return false;
+  const size_t lds = lds_for(NZ);
+  static bool attr_set = false;
+  if (!attr_set) {
+    CD_HIP(hipFuncSetAttribute((const void*)wgrad_strided_f16x2_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CD_HIP(hipFuncSetAttribute((const void*)wgrad_strided_f16x2_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  if (kd == 3) hipLaunchKernelGGL(wgrad_strided_f16x2_kernel<3>, dim3(nblk, tiles, 2), dim3(512), lds, s, f);
+  else hipLaunchKernelGGL(wgrad_strided_f16x2_kernel<4>, dim3(nblk, tiles, 2), dim3(512), lds, s, f);
   CD_HIP(hipGetLastError());
   *nblk_out = nblk;
   return true;
