@@ -2048,6 +2048,9 @@ __global__ void __launch_bounds__(256) conv_transpose_f16x2_kernel(ConvTArgs a) 
   }
   __syncthreads();
 
+  // (the z stride is 1 or 2 -- the launcher checks it: shifts and masks below where run-time integer divisions by a.SZ cost ~30 vector
+  // instructions each, per tap and parity class, in a kernel that PMC shows bound by vector issue: 21 VALU instructions per MFMA)
+  const int szs = a.SZ - 1;  // log2(SZ)
   const int ncls = a.SZ * 4;
   const int njt = (a.TZ * a.TH * a.Cw + 31) / 32;
   const int nks = a.cin >> 4;
@@ -2068,7 +2071,7 @@ __global__ void __launch_bounds__(256) conv_transpose_f16x2_kernel(ConvTArgs a) 
   for (int ci = 0; ci < (tile_major ? ncls : 1); ++ci) {
     const int cls = tile_major ? ci : item / njt;
     const int pz = cls >> 2, ph = (cls >> 1) & 1, pw = cls & 1;
-    const int oz = a.SZ * (a0 + aa) + pz, oh = 2 * (b0 + bb) + ph, ow = 2 * c + pw;
+    const int oz = ((a0 + aa) << szs) + pz, oh = 2 * (b0 + bb) + ph, ow = 2 * c + pw;
     const bool valid = (aa < a.TZ) && (oz < a.Do) && (oh < a.Ho) && (ow < a.Wo);
     if (!__any(valid)) continue;
     const int ooff = valid ? ((oz * a.Ho + oh) * a.Wo + ow) * a.cout : -1;
@@ -2084,8 +2087,8 @@ __global__ void __launch_bounds__(256) conv_transpose_f16x2_kernel(ConvTArgs a) 
     // stage j -- three stages = 9 MFMAs = ~300 cycles of cover for an L2 round trip.  (As nested loops every k-step waited for its
     // own weight loads: a round trip per 3 MFMAs.)  Requests past the end repeat the last stage instead of being conditional: a
     // conditional load in a pipelined loop costs a full vmcnt(0) per trip.
-    const int kz0 = (pz + 1) % a.SZ, kh0 = (ph + 3) & 1, kw0 = (pw + 1) & 1;
-    const int nkz = (a.KZ - kz0 + a.SZ - 1) / a.SZ;
+    const int kz0 = (pz + 1) & szs, kh0 = (ph + 3) & 1, kw0 = (pw + 1) & 1;
+    const int nkz = (a.KZ - kz0 + a.SZ - 1) >> szs;
     const int nstage = nkz * 4 * nks;
     struct Stage {
       u32x4 x1, x2, w[CT][2];
@@ -2093,10 +2096,10 @@ __global__ void __launch_bounds__(256) conv_transpose_f16x2_kernel(ConvTArgs a) 
     int ti_n = 0, ks_n = 0, tap_n = 0;  // the next stage to request: tap number (kz-major), k-step; its weight tap index
     const char* rec_n = nullptr;        // ... and this lane's record of that tap
     auto setup = [&](int ti) {
-      const int kz = kz0 + (ti >> 2) * a.SZ, kh = kh0 + ((ti >> 1) & 1) * 2, kw = kw0 + (ti & 1) * 2;
-      const int lz = aa + (pz + 1 - kz) / a.SZ + 1;
-      const int lh = bb + (ph + 3 - kh) / 2;  // (.. )/2 - 1 (circular halo) + 1 (tile halo)
-      const int iw = c + (pw + 1 - kw) / 2;
+      const int kz = kz0 + ((ti >> 2) << szs), kh = kh0 + ((ti >> 1) & 1) * 2, kw = kw0 + (ti & 1) * 2;
+      const int lz = aa + ((pz + 1 - kz) >> szs) + 1;  // (pz + 1 - kz is a multiple of SZ, possibly negative: the arithmetic shift is exact)
+      const int lh = bb + ((ph + 3 - kh) >> 1);  // (.. )/2 - 1 (circular halo) + 1 (tile halo); even by the choice of kh0
+      const int iw = c + ((pw + 1 - kw) >> 1);   // even by the choice of kw0
       const bool ok = valid && iw >= 0 && iw < a.Win;
       rec_n = (const char*)(lds + (ok ? ((lz * PH + lh) * a.Win + iw) * a.CS : ZERO)) + half * 16;
       tap_n = (kz * 4 + kh) * 4 + kw;
