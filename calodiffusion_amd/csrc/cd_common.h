@@ -386,13 +386,20 @@ void launch_attn_small(const float* x, int C, const float* coef, const void* wqk
                        // capacity of partials ([B][max_parts][1088]) and ch_part ([B][max_parts][C][2]) in parts per sample: with
                        // CD_ATTN_COOP the sample's voxels are dealt to up to that many co-operating workgroups
                        int max_parts = 1);
+// moments ([B][nsplit][1056], attn_moment_floats): pass 1 also accumulates the first and second moments of softmax(q), from which
+// pass 2 (given the same buffer and the closing GroupNorm's parameters) writes the BLOCK's output gn(y) + x directly -- no y
+// tensor, no channel sums, no gn_apply pass
+bool attn_moments_eligible(int C);
+size_t attn_moment_floats(int batch, int nsplit);
 void launch_attn_kv_context(const float* x, int C, const float* coef, const void* wqkv_f16x2, float* partials, int batch,
-                            int64_t vox, int nsplit, hipStream_t s, const GnDefer* defer = nullptr, int* status = nullptr);
+                            int64_t vox, int nsplit, hipStream_t s, const GnDefer* defer = nullptr, int* status = nullptr,
+                            float* moments = nullptr);
 void launch_attn_out(const float* x, int C, const float* coef, const void* wqkv_f16x2, const float* wT_b, const float* bias,
                      float* y, float* ch_part /* [B][nsplit][C][2] */, int batch, int64_t vox, int nsplit, hipStream_t s,
                      const GnDefer* defer = nullptr,
                      // wT_b == null: every workgroup merges the pass-1 partials and folds W_out itself (no combine launch)
-                     const float* partials = nullptr, const float* w_out = nullptr, float scale = 0.f, int* status = nullptr);
+                     const float* partials = nullptr, const float* w_out = nullptr, float scale = 0.f, int* status = nullptr,
+                     const float* moments = nullptr, const float* out_gamma = nullptr, const float* out_beta = nullptr);
 
 struct EmbedLayer {
   const float* w;  // (cout, 128) torch layout

@@ -51,7 +51,12 @@ struct AttnArgs {
   // attn_coop_kernel: the nsplit workgroups of a sample meet at two barriers inside the launch
   unsigned* sync;     // [B][2] = {arrivals, generation}: zero once, self-resetting
   int coop;           // the partials / channel sums read below were written by OTHER workgroups of this launch
+  // moment form (MOM instances): pass 1 also emits, per partial, s'[d] = sum_n (softmax(q)[n][d] - 1/32) and the 32 x 32 matrix
+  // S'[d][d'] = sum_n (softmax(q)[n][d] - 1/32)(softmax(q)[n][d'] - 1/32), from which pass 2 knows the statistics of its own
+  // output before it computes it
+  float* mom;         // [B][nsplit][32 + 1024]
 };
+constexpr int ATTN_MOM = 32 + 1024;
 // value written by another workgroup of the SAME launch (same XCD, see attn_coop_kernel): an agent-scope load, which does not
 // linger in this CU's vector cache
 __device__ __forceinline__ float attn_peer_load(const float* p, int coop) {
@@ -76,9 +81,11 @@ __device__ __forceinline__ void load_raw(const AttnArgs& a, int b, int64_t t, in
 #pragma unroll
     for (int j = 0; j < 2; ++j) raw.v[ks][j] = *(const f32x4*)(src + ks * 16 + j * 4);
 }
-template <int NCH>
+// cf_lds: the coefficients are re-read per tile from an LDS copy ([ch][8] quads of this half-wave) instead of living in 32 NCH
+// registers (the moment form of pass 1 has none to spare)
+template <int NCH, bool CFL = false>
 __device__ __forceinline__ void norm_split(const AttnArgs& a, int64_t n0, int col, const f32x4 (&cf)[NCH][8], const RawTile<NCH>& raw,
-                                           u32x4 (&x1)[NCH * 2], u32x4 (&x2)[NCH * 2], float& amax) {
+                                           u32x4 (&x1)[NCH * 2], u32x4 (&x2)[NCH * 2], float& amax, const f32x4* cf_lds = nullptr) {
   const bool valid = n0 + col < a.vox;
 #pragma unroll
   for (int ks = 0; ks < NCH * 2; ++ks) {
@@ -89,7 +96,7 @@ __device__ __forceinline__ void norm_split(const AttnArgs& a, int64_t n0, int co
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         // cf[ks >> 1][(ks & 1) * 4 + j * 2 + (e >> 1)] = {scale, shift} pairs of channels ks*16 + half*8 + j*4 + (e & ~1), +1
-        const f32x4 c2 = cf[ks >> 1][(ks & 1) * 4 + j * 2 + (e >> 1)];
+        const f32x4 c2 = CFL ? cf_lds[(ks >> 1) * 8 + (ks & 1) * 4 + j * 2 + (e >> 1)] : cf[ks >> 1][(ks & 1) * 4 + j * 2 + (e >> 1)];
         v[e] = valid ? c2[(e & 1) * 2] * v[e] + c2[(e & 1) * 2 + 1] : 0.f;
       }
       amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
@@ -140,7 +147,7 @@ __device__ __forceinline__ void load_coef(const AttnArgs& a, int b, int half, f3
 }
 
 // pass 1 of sample b over tiles [t0, t1): partial `split` of the sample
-template <int NCH>
+template <int NCH, bool MOM = false>
 __device__ __forceinline__ void attn_pass1(const AttnArgs& a, int b, int split, int64_t t0, int64_t t1, const f32x4 (&cf)[NCH][8]) {
   __shared__ float sMax[8][32];
   __shared__ float sSum[16][32];
@@ -155,6 +162,31 @@ __device__ __forceinline__ void attn_pass1(const AttnArgs& a, int b, int split, 
     wk2[ks] = a.wqkv[(size_t)(ks * 3 + 1) * 128 + 64 + lane];
     wv1[ks] = a.wqkv[(size_t)(ks * 3 + 2) * 128 + lane];
     wv2[ks] = a.wqkv[(size_t)(ks * 3 + 2) * 128 + 64 + lane];
+  }
+  // moment form: the q projection weights, the per-wave tile on its way from the lane-per-voxel layout of the softmax to the
+  // lane-per-channel layout of an MFMA operand, and the accumulators of s' and S'
+  u32x4 wq1[MOM ? NKS : 1], wq2[MOM ? NKS : 1];
+  __shared__ __attribute__((aligned(16))) float sQt[MOM ? 8 * 32 * 36 : 4];
+  f32x16 mS, mSB;
+  float msum = 0.f;
+  __shared__ __attribute__((aligned(16))) f32x4 sCf[MOM ? 2 * NCH * 8 : 1];
+  const f32x4* cf_lds = nullptr;
+  if constexpr (MOM) {
+    if (wave == 0 && col == 0) {
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sCf[(half * NCH + ch) * 8 + i] = cf[ch][i];
+    }
+    __syncthreads();
+    cf_lds = sCf + half * NCH * 8;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      wq1[ks] = a.wqkv[(size_t)(ks * 3 + 0) * 128 + lane];
+      wq2[ks] = a.wqkv[(size_t)(ks * 3 + 0) * 128 + 64 + lane];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mS[r] = mSB[r] = 0.f;
   }
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   // y = x W^T on the fp16 pipe: A += x1 w1, B += x1 w2' + x2' w1, y = A + B / 2048
@@ -214,7 +246,7 @@ __device__ __forceinline__ void attn_pass1(const AttnArgs& a, int b, int split, 
   for (int64_t tt = t0 + wave; tt < t1; tt += 8) {
     u32x4 x1[NKS], x2[NKS];
     load_raw<NCH>(a, b, tt, tlast, col, half, raw);
-    norm_split<NCH>(a, tt * 32, col, cf, raw, x1, x2, amax);
+    norm_split<NCH, MOM>(a, tt * 32, col, cf, raw, x1, x2, amax, cf_lds);
     const f32x16 k = project(x1, x2, wk1, wk2);
     const f32x16 v = project(x1, x2, wv1, wv2);
     const bool full = tt * 32 + 32 <= a.vox;  // (only a sample's last tile can be partial)
@@ -253,6 +285,55 @@ __device__ __forceinline__ void attn_pass1(const AttnArgs& a, int b, int split, 
       ctxB = MFMA_F16(e1, v2, ctxB);
       ctxB = MFMA_F16(e2, v1, ctxB);
     }
+    if constexpr (MOM) {
+      // softmax(q) of the tile as pass 2 computes it (q^T: a lane holds 16 of its voxel's 32 channels, the other half-wave the
+      // rest), centred on 1/32 -- with near-uniform softmaxes S would be a large constant plus a small signal and the quadratic
+      // form W' S W'^T of the fold a difference of large numbers; rows past the end of the sample contribute nothing
+      f32x16 q = zero16, qb = zero16;
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        q = MFMA_F16(wq1[ks], x1[ks], q);
+        qb = MFMA_F16(wq2[ks], x1[ks], qb);
+        qb = MFMA_F16(wq1[ks], x2[ks], qb);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) q[r] += qb[r] * (1.f / 2048.f);
+      float mx = q[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, q[r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      // (the bare 2^(x log2 e): ~|x| 6e-8 relative, ample for statistics -- pass 2's own softmax keeps attn_exp)
+      float ss = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        q[r] = __builtin_amdgcn_exp2f((q[r] - mx) * 1.4426950408889634f);
+        ss += q[r];
+      }
+      ss += __shfl_xor(ss, 32, 64);
+      const bool valid = tt * 32 + col < a.vox;
+      const float inv = valid ? 1.f / ss : 0.f, cen = valid ? (1.f / 32.f) : 0.f;
+      // [voxel][channel] through the wave's LDS tile: written as quads (d = 8 g + 4 half + 0..3), read back with a lane per channel
+      float* tq = sQt + wave * (32 * 36);
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *(f32x4*)(tq + col * 36 + 8 * g + 4 * half) = f32x4{q[4 * g] * inv - cen, q[4 * g + 1] * inv - cen, q[4 * g + 2] * inv - cen,
+                                                            q[4 * g + 3] * inv - cen};
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (one wave: its own LDS writes are visible to its reads in order)
+      float dq[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        dq[r] = tq[((r & 3) + 8 * (r >> 2) + 4 * half) * 36 + col];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) msum += dq[r];
+#pragma unroll
+      for (int s8 = 0; s8 < 2; ++s8) {
+        u32x4 d1, d2;
+        split8(dq, s8, d1, d2);
+        mS = MFMA_F16(d1, d1, mS);
+        mSB = MFMA_F16(d1, d2, mSB);  // P = h^T l; the other cross term is its transpose, added in the merge below
+      }
+    }
   }
   if (a.status && !(amax <= 65504.f)) atomicOr(a.status, 1);  // (also catches NaN)
   // merge the waves: common maximum, every wave's sums and context rescaled to it
@@ -288,9 +369,37 @@ __device__ __forceinline__ void attn_pass1(const AttnArgs& a, int b, int split, 
     for (int w = 0; w < 8; ++w) t += sCtx[w][i];
     out[64 + i] = t;
   }
+  if constexpr (MOM) {
+    __syncthreads();  // the context slices have been read
+    sSum[wave * 2 + half][col] = msum;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int d = (r & 3) + 8 * (r >> 2) + 4 * half;
+      sCtx[wave][d * 32 + col] = mS[r];
+      sQt[wave * 1024 + d * 32 + col] = mSB[r];  // (the transposition tiles are done with: 8 x 1152 floats)
+    }
+    __syncthreads();
+    float* mo = a.mom + ((size_t)b * a.nsplit + split) * ATTN_MOM;
+    if (tid < 32) {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) t += sSum[i][tid];
+      mo[tid] = t;
+    }
+    for (int i = tid; i < 1024; i += 512) {
+      const int it = (i & 31) * 32 + (i >> 5);
+      float t = 0.f, p = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) {
+        t += sCtx[w][i];
+        p += sQt[w * 1024 + i] + sQt[w * 1024 + it];
+      }
+      mo[32 + i] = t + p * (1.f / 2048.f);
+    }
+  }
 }
 
-template <int NCH>
+template <int NCH, bool MOM>
 __global__ void __launch_bounds__(512) attn_kv_context_kernel(AttnArgs a) {
   const int half = (threadIdx.x & 63) >> 5;
   const int split = blockIdx.x, b = blockIdx.y;
@@ -299,15 +408,19 @@ __global__ void __launch_bounds__(512) attn_kv_context_kernel(AttnArgs a) {
   const int64_t t1 = (t0 + a.tiles_per_wg < T) ? t0 + a.tiles_per_wg : T;
   f32x4 cf[NCH][8];
   load_coef<NCH>(a, b, half, cf);
-  attn_pass1<NCH>(a, b, split, t0, t1, cf);
+  attn_pass1<NCH, MOM>(a, b, split, t0, t1, cf);
 }
 
 // Merge of the pass-1 partials and fold of the context into the output projection, by every workgroup of pass 2 for its own
 // sample (same arithmetic, in the same order, as attn_combine_kernel, kernels_norm_attn.hip: the separate launch was 11 us of
 // pure latency per attention block):  W'[c][d] = scale * sum_e W_out[c][e] ctx[d][e] / sum[d]  in the k-slot order of an
 // accumulator-register A operand, into sW[NCH][4][64][4].
-template <int NCH>
-__device__ __forceinline__ void attn_fold_weights(const AttnArgs& a, int b, float* sW) {
+// MOM: also the closing GroupNorm(1, C) of the block, whose statistics follow from the fold and the pass-1 moments without y ever
+// existing: with u = 1/32, m_c = b_c + u sum_d W'[c][d] and delta_n = softmax(q_n) - u,
+//   y[n][c] = m_c + W'_c . delta_n,   sum_n y = N m_c + W'_c . s',   sum_n y^2 = N m_c^2 + 2 m_c W'_c . s' + W'_c S' W'_c^T
+// (fixed-order fp64).  sOut[c] = {scale, shift} with  out = scale * (y - b_c) + shift + x.
+template <int NCH, bool MOM = false>
+__device__ __forceinline__ void attn_fold_weights(const AttnArgs& a, int b, float* sW, float (*sOut)[2] = nullptr) {
   __shared__ float sM[32], sInv[32];
   __shared__ float sCtx[1024];
   __shared__ float sWout[NCH * 32 * 33];  // W_out rows padded to 33 floats: the 32 lanes of a half-wave read 32 different rows
@@ -316,6 +429,16 @@ __device__ __forceinline__ void attn_fold_weights(const AttnArgs& a, int b, floa
   // (this prologue is pure latency for every workgroup of pass 2: independent loads are issued together, W_out is staged while
   // the maxima are merged)
   for (int i = tid; i < NCH * 1024; i += 512) sWout[(i >> 5) * 33 + (i & 31)] = a.fold_wout[i];
+  float mreg[3] = {0.f, 0.f, 0.f};  // moment form: entries tid, tid + 512, tid + 1024 of the merged {s', S'}
+  if constexpr (MOM) {
+    const float* mo = a.mom + (size_t)b * a.nsplit * ATTN_MOM;
+#pragma unroll 4
+    for (int k = 0; k < a.nsplit; ++k) {
+      mreg[0] += attn_peer_load(mo + (size_t)k * ATTN_MOM + tid, a.coop);
+      mreg[1] += attn_peer_load(mo + (size_t)k * ATTN_MOM + 512 + tid, a.coop);
+      if (tid < 32) mreg[2] += attn_peer_load(mo + (size_t)k * ATTN_MOM + 1024 + tid, a.coop);
+    }
+  }
   if (tid < 32) {
     float M = -3.0e38f;
 #pragma unroll 4
@@ -347,13 +470,70 @@ __device__ __forceinline__ void attn_fold_weights(const AttnArgs& a, int b, floa
     sW[i] = acc;
   }
   __syncthreads();
+  if constexpr (MOM) {
+    static_assert(!MOM || NCH == 1, "moment form: 32 channels");
+    __shared__ float sS[1024 + 32];
+    __shared__ double sAB[32][2];
+    // the merged moments (their loads were requested at the top of the function)
+    // (entry i of a partial: i < 32 is s'[i], kept behind the matrix at sS[1024 + i]; the rest is S' flat at sS[i - 32])
+    sS[tid < 32 ? 1024 + tid : tid - 32] = mreg[0];
+    sS[480 + tid] = mreg[1];
+    if (tid < 32) sS[992 + tid] = mreg[2];
+    __syncthreads();
+    // W'[c][d] out of the operand-order image
+    auto wp = [&](int c, int d) { return sW[(((d >> 3) * 64) + c + 32 * ((d >> 2) & 1)) * 4 + (d & 3)]; };
+    // thread (c, d), two channels per thread: W'[c][d] * sum_e S'[e][d] W'[c][e]  (S' is symmetric: row e, column d), W'[c][d],
+    // W'[c][d] s'[d]; then the sums over d inside the half-wave (fixed xor tree)
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+      const int c = (tid >> 5) + 16 * rep, d = tid & 31;
+      double t = 0.0;
+#pragma unroll 8
+      for (int e = 0; e < 32; ++e) t += (double)sS[e * 32 + d] * (double)wp(c, e);
+      const double w = (double)wp(c, d);
+      double quad = t * w, rows = w, lin = w * (double)sS[1024 + d];
+#pragma unroll
+      for (int m = 16; m >= 1; m >>= 1) {
+        quad += __shfl_xor(quad, m, 64);
+        rows += __shfl_xor(rows, m, 64);
+        lin += __shfl_xor(lin, m, 64);
+      }
+      if (d == 0) {
+        const double N = (double)a.vox;
+        const double mc = (a.bias ? (double)a.bias[c] : 0.0) + rows * (1.0 / 32.0);
+        sAB[c][0] = N * mc + lin;
+        sAB[c][1] = N * mc * mc + 2.0 * mc * lin + quad;
+      }
+    }
+    __syncthreads();
+    if (tid < 32) {
+      double a1 = sAB[tid][0], a2 = sAB[tid][1];
+#pragma unroll
+      for (int m = 16; m >= 1; m >>= 1) {
+        a1 += __shfl_xor(a1, m, 64);
+        a2 += __shfl_xor(a2, m, 64);
+      }
+      const double cnt = (double)a.vox * 32.0;
+      const double mu = a1 / cnt;
+      double var = a2 / cnt - mu * mu;
+      var = var < 0.0 ? 0.0 : var;
+      const double rstd = 1.0 / sqrt(var + 1e-5);
+      const float sc = (float)rstd * a.out_gamma[tid];
+      const float bc = a.bias ? a.bias[tid] : 0.f;
+      sOut[tid][0] = sc;
+      sOut[tid][1] = a.out_beta[tid] + (float)((double)bc - mu) * sc;
+    }
+    __syncthreads();
+  }
 }
 
 // pass 2 of sample b over tiles [t0, t1): y and, as unit `unit` of `nunits`, its channel partials
-template <int NCH>
+// MOM: the output is the block's (closing GroupNorm from the fold's closed form, residual added), no channel sums
+template <int NCH, bool MOM = false>
 __device__ __forceinline__ void attn_pass2(const AttnArgs& a, int b, int unit, int nunits, int64_t t0, int64_t t1,
                                            const f32x4 (&cf)[NCH][8], float* trbuf = nullptr) {
-  __shared__ float sRed[8][NCH * 32][2];
+  __shared__ float sRed[MOM ? 1 : 8][NCH * 32][2];
+  __shared__ float sOut[MOM ? NCH * 32 : 1][2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, col = lane & 31;
   constexpr int NKS = NCH * 2;
@@ -371,7 +551,7 @@ __device__ __forceinline__ void attn_pass2(const AttnArgs& a, int b, int unit, i
       for (int q = 0; q < 4; ++q) wt[ch][q] = ((const f32x4*)a.wT)[(((size_t)b * NCH + ch) * 4 + q) * 64 + lane];  // output channel tile ch
   } else {
     __shared__ __attribute__((aligned(16))) float sW[NCH * 1024];
-    attn_fold_weights<NCH>(a, b, sW);
+    attn_fold_weights<NCH, MOM>(a, b, sW, sOut);
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
@@ -397,13 +577,19 @@ __device__ __forceinline__ void attn_pass2(const AttnArgs& a, int b, int unit, i
       wb2[ch][s8] = u32x4{l0[0], l0[1], l1[0], l1[1]};
     }
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  float bv[NCH], s1[NCH], s2[NCH];
+  float bv[NCH], s1[NCH], s2[NCH], osc[NCH];
 #pragma unroll
   for (int ct = 0; ct < NCH; ++ct) {
     bv[ct] = a.bias ? a.bias[ct * 32 + col] : 0.f;
     s1[ct] = s2[ct] = 0.f;
+    osc[ct] = 1.f;
+    if constexpr (MOM) {  // out = osc * o + bv + x  (the bias is inside the shift)
+      osc[ct] = sOut[ct * 32 + col][0];
+      bv[ct] = sOut[ct * 32 + col][1];
+    }
   }
   float* const yb = a.y + (size_t)b * a.vox * a.C;
+  const float* const xb = a.x + (size_t)b * a.vox * a.C;
 
   constexpr int PRE = AttnDepthOut<NCH>::value, DEPTH = PRE ? PRE : 1;
   RawTile<NCH> raw[DEPTH];
@@ -468,19 +654,29 @@ __device__ __forceinline__ void attn_pass2(const AttnArgs& a, int b, int unit, i
         // whole tile: out as 16-byte quads (row 8 k + (lane >> 3), channels 4 (lane & 7) .. + 3) after a transpose through the wave's
         // LDS tile -- 16 scalar row stores per lane in accumulator layout ran at a fraction of the HBM rate
         float* tr = trbuf + wave * (32 * 36);
+        const size_t qoff = (size_t)t * 32 * a.C + ct * 32 + (lane & 7) * 4;
+        f32x4 xres[4];
+        if constexpr (MOM) {  // the residual rows, in the layout of the stores (this wave read the tile a moment ago: cache hits)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) xres[k] = *(const f32x4*)(xb + qoff + (size_t)(8 * k + (lane >> 3)) * a.C);
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float v = o[r] + bv[ct];
+          const float v = MOM ? __builtin_fmaf(o[r], osc[ct], bv[ct]) : o[r] + bv[ct];
           tr[((r & 3) + 8 * (r >> 2) + 4 * half) * 36 + col] = v;
-          s1[ct] += v;
-          s2[ct] += v * v;
+          if (!MOM) {
+            s1[ct] += v;
+            s2[ct] += v * v;
+          }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (one wave: its own LDS writes are visible to its reads in order)
-        float* yt = yb + (size_t)t * 32 * a.C + ct * 32 + (lane & 7) * 4;
+        float* yt = yb + qoff;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int row = 8 * k + (lane >> 3);
-          *(f32x4*)(yt + (size_t)row * a.C) = *(const f32x4*)(tr + row * 36 + (lane & 7) * 4);
+          f32x4 v4 = *(const f32x4*)(tr + row * 36 + (lane & 7) * 4);
+          if constexpr (MOM) v4 += xres[k];
+          *(f32x4*)(yt + (size_t)row * a.C) = v4;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the tile buffer is reused)
       } else {
@@ -488,8 +684,9 @@ __device__ __forceinline__ void attn_pass2(const AttnArgs& a, int b, int unit, i
       for (int r = 0; r < 16; ++r) {
         const int64_t n = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (n < a.vox) {
-          const float v = o[r] + bv[ct];
-          yb[(size_t)n * a.C + ct * 32 + col] = v;
+          const size_t at = (size_t)n * a.C + ct * 32 + col;
+          const float v = MOM ? __builtin_fmaf(o[r], osc[ct], bv[ct]) + xb[at] : o[r] + bv[ct];
+          yb[at] = v;
           s1[ct] += v;
           s2[ct] += v * v;
         }
@@ -499,7 +696,7 @@ __device__ __forceinline__ void attn_pass2(const AttnArgs& a, int b, int unit, i
   }
   }
   if (a.status && !(amax <= 65504.f)) atomicOr(a.status, 1);
-  if (a.ch_part) {
+  if constexpr (!MOM) if (a.ch_part) {
 #pragma unroll
     for (int ct = 0; ct < NCH; ++ct) {
       const float t1s = s1[ct] + __shfl_xor(s1[ct], 32, 64), t2s = s2[ct] + __shfl_xor(s2[ct], 32, 64);
@@ -523,7 +720,7 @@ __device__ __forceinline__ void attn_pass2(const AttnArgs& a, int b, int unit, i
   }
 }
 
-template <int NCH>
+template <int NCH, bool MOM>
 __global__ void __launch_bounds__(512) attn_out_kernel(AttnArgs a) {
   const int half = (threadIdx.x & 63) >> 5;
   const int unit = blockIdx.x, b = blockIdx.y;
@@ -533,7 +730,7 @@ __global__ void __launch_bounds__(512) attn_out_kernel(AttnArgs a) {
   f32x4 cf[NCH][8];
   load_coef<NCH>(a, b, half, cf);
   __shared__ __attribute__((aligned(16))) float sTr[8 * 32 * 36];  // per-wave output tile on its way to row-major quads
-  attn_pass2<NCH>(a, b, unit, (int)gridDim.x, t0, t1, cf, sTr);
+  attn_pass2<NCH, MOM>(a, b, unit, (int)gridDim.x, t0, t1, cf, sTr);
 }
 
 // The whole Residual(PreNorm(LinearAttention)) of one sample in ONE workgroup, for grids of a few hundred voxels (Dataset-2 below
@@ -709,32 +906,47 @@ int attn_fused_nsplit_for(int64_t vox, int batch) {
   return (int)n;
 }
 
+bool attn_moments_eligible(int C) { return C == 32; }  // (64 channels: pass 1 would spill ~130 registers)
+size_t attn_moment_floats(int batch, int nsplit) { return (size_t)batch * nsplit * ATTN_MOM; }
+
 void launch_attn_kv_context(const float* x, int C, const float* coef, const void* wqkv_f16x2, float* partials, int batch,
-                            int64_t vox, int nsplit, hipStream_t s, const GnDefer* defer, int* status) {
+                            int64_t vox, int nsplit, hipStream_t s, const GnDefer* defer, int* status, float* moments) {
   CD_REQUIRE(C == 32 || C == 64 || C == 96 || C == 128, "fused attention: 32..128 input channels");
+  CD_REQUIRE(!moments || attn_moments_eligible(C), "fused attention: the moment form takes 32 channels");
   AttnArgs a{};
+  a.mom = moments;
   a.status = status;
   a.x = x; a.coef = coef; a.wqkv = (const u32x4*)wqkv_f16x2; a.C = C; a.vox = vox; a.tiles_per_wg = tiles_per_wg_for(vox, nsplit);
   a.partials = partials; a.nsplit = nsplit;
   if (defer) a.defer = *defer;
   char cat[64];
   std::snprintf(cat, sizeof cat, "attn_kv_context C%d n%ld", C, (long)vox);
-  prof::Scope scope(cat, s, 2.0 * (2.0 * C + 32) * 32 * (double)vox * batch, 4.0 * batch * (double)vox * C);
+  prof::Scope scope(cat, s, 2.0 * ((moments ? 3.0 : 2.0) * C + (moments ? 64 : 32)) * 32 * (double)vox * batch,
+                    4.0 * batch * (double)vox * C);
   const dim3 grid((unsigned)nsplit, (unsigned)batch);
+  if (moments) {
+    hipLaunchKernelGGL((attn_kv_context_kernel<1, true>), grid, dim3(512), 0, s, a);
+    CD_HIP(hipGetLastError());
+    return;
+  }
   switch (C / 32) {
-    case 1: hipLaunchKernelGGL(attn_kv_context_kernel<1>, grid, dim3(512), 0, s, a); break;
-    case 2: hipLaunchKernelGGL(attn_kv_context_kernel<2>, grid, dim3(512), 0, s, a); break;
-    case 3: hipLaunchKernelGGL(attn_kv_context_kernel<3>, grid, dim3(512), 0, s, a); break;
-    default: hipLaunchKernelGGL(attn_kv_context_kernel<4>, grid, dim3(512), 0, s, a); break;
+    case 1: hipLaunchKernelGGL((attn_kv_context_kernel<1, false>), grid, dim3(512), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((attn_kv_context_kernel<2, false>), grid, dim3(512), 0, s, a); break;
+    case 3: hipLaunchKernelGGL((attn_kv_context_kernel<3, false>), grid, dim3(512), 0, s, a); break;
+    default: hipLaunchKernelGGL((attn_kv_context_kernel<4, false>), grid, dim3(512), 0, s, a); break;
   }
   CD_HIP(hipGetLastError());
 }
 
 void launch_attn_out(const float* x, int C, const float* coef, const void* wqkv_f16x2, const float* wT_b, const float* bias,
                      float* y, float* ch_part, int batch, int64_t vox, int nsplit, hipStream_t s, const GnDefer* defer,
-                     const float* partials, const float* w_out, float scale, int* status) {
+                     const float* partials, const float* w_out, float scale, int* status, const float* moments,
+                     const float* out_gamma, const float* out_beta) {
   CD_REQUIRE(C == 32 || C == 64 || C == 96 || C == 128, "fused attention: 32..128 channels");
+  CD_REQUIRE(!moments || (attn_moments_eligible(C) && !wT_b && out_gamma && out_beta && (vox * C) % 4 == 0),
+             "fused attention: the moment form folds the weights itself and needs the closing GroupNorm's parameters");
   AttnArgs a{};
+  a.mom = const_cast<float*>(moments); a.out_gamma = out_gamma; a.out_beta = out_beta;
   a.status = status;
   a.x = x; a.coef = coef; a.wqkv = (const u32x4*)wqkv_f16x2; a.C = C; a.vox = vox; a.tiles_per_wg = tiles_per_wg_for(vox, nsplit);
   a.wT = wT_b; a.bias = bias; a.y = y; a.ch_part = ch_part;
@@ -745,11 +957,16 @@ void launch_attn_out(const float* x, int C, const float* coef, const void* wqkv_
   std::snprintf(cat, sizeof cat, "attn_out C%d n%ld", C, (long)vox);
   prof::Scope scope(cat, s, 2.0 * (2.0 * C) * 32 * (double)vox * batch, 4.0 * batch * (double)vox * C * 2);
   const dim3 grid((unsigned)nsplit, (unsigned)batch);
+  if (moments) {
+    hipLaunchKernelGGL((attn_out_kernel<1, true>), grid, dim3(512), 0, s, a);
+    CD_HIP(hipGetLastError());
+    return;
+  }
   switch (C / 32) {
-    case 1: hipLaunchKernelGGL(attn_out_kernel<1>, grid, dim3(512), 0, s, a); break;
-    case 2: hipLaunchKernelGGL(attn_out_kernel<2>, grid, dim3(512), 0, s, a); break;
-    case 3: hipLaunchKernelGGL(attn_out_kernel<3>, grid, dim3(512), 0, s, a); break;
-    default: hipLaunchKernelGGL(attn_out_kernel<4>, grid, dim3(512), 0, s, a); break;
+    case 1: hipLaunchKernelGGL((attn_out_kernel<1, false>), grid, dim3(512), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((attn_out_kernel<2, false>), grid, dim3(512), 0, s, a); break;
+    case 3: hipLaunchKernelGGL((attn_out_kernel<3, false>), grid, dim3(512), 0, s, a); break;
+    default: hipLaunchKernelGGL((attn_out_kernel<4, false>), grid, dim3(512), 0, s, a); break;
   }
   CD_HIP(hipGetLastError());
 }

@@ -646,11 +646,24 @@ float* attn_block(Run& r, const AttnP& w, const float* x, Dims3 dims, float* xpa
   int yu = 0;
   // grids of a few hundred voxels: the whole block -- both passes, the closing GroupNorm and the residual -- in one launch
   const bool single = !no_fused && defer_gn && attn_small_eligible(vox);
+  bool moments = false;
   if (!no_fused) {
     // fused path (kernels_attn.hip): x -> {max, sum, context} partials -> per-sample folded W_out -> y; qkv never exists
     const int nsp = attn_fused_nsplit_for(vox, r.B);
     const int cap = single && nsp < 4 ? 4 : nsp;  // (the single-launch form may deal a sample to up to 4 co-operating workgroups)
     float* part = ws->get<float>(attn_partial_floats(r.B, cap));
+    // Moment form (kernels_attn.hip): pass 1 also accumulates the moments of softmax(q), pass 2 then knows the closing GroupNorm's
+    // statistics in closed form and writes gn(y) + x itself -- y is never written and the gn_apply pass below does not run
+    // (read per call: the parity test switches it in one process)
+    static const bool sep_combine = getenv("CD_ATTN_COMBINE_LAUNCH") != nullptr;  // A/B: the separate combine launch
+    // It costs pass 1 ~40 % more per tile and both passes a few microseconds of prologue / epilogue, and saves a pass that moves
+    // 3 B vox C floats: it pays from ~4 M elements per tensor (same-box A/B: Dataset-2 level 0, 13 M, +1.4 %; Dataset-3, 41 M,
+    // +1.8 %; HGCal at batch 16, 3.6 M, -0.3 %)
+    const char* mom_env = getenv("CD_ATTN_MOM_MIN");  // (read per call, like the switch: the parity test sets it)
+    const int64_t mom_min = mom_env ? atoll(mom_env) : (4ll << 20);
+    moments = !single && !sep_combine && defer_gn && attn_moments_eligible(C) && (vox * C) % 4 == 0 && (int64_t)r.B * vox * C >= mom_min &&
+              getenv("CD_NO_ATTN_MOMENTS") == nullptr;
+    float* momb = moments ? ws->get<float>(attn_moment_floats(r.B, nsp)) : nullptr;
     float* wpb = ws->get<float>((size_t)r.B * CT * 1024);
     y = ws->get<float>((size_t)r.B * vox * C);
     yu = nsp;
@@ -659,16 +672,16 @@ float* attn_block(Run& r, const AttnP& w, const float* x, Dims3 dims, float* xpa
       launch_attn_small(x, C, coefn, w.qkv16, part, w.ow, 0.17677669529663689f /* 32^-1/2 */, w.ob, w.gg, w.gb, y, ypart, r.B, vox,
                         r.s, dnp, r.status, cap);
     } else if (!r.dry()) {
-      launch_attn_kv_context(x, C, coefn, w.qkv16, part, r.B, vox, nsp, r.s, dnp, r.status);
-      static const bool sep_combine = getenv("CD_ATTN_COMBINE_LAUNCH") != nullptr;  // A/B: the separate combine launch
+      launch_attn_kv_context(x, C, coefn, w.qkv16, part, r.B, vox, nsp, r.s, dnp, r.status, momb);
       if (sep_combine) {
         launch_attn_combine(part, nsp, w.ow, C, wpb, r.B, 0.17677669529663689f /* 32^-1/2 */, r.s, nullptr, nullptr, true);
         launch_attn_out(x, C, coefn, w.qkv16, wpb, w.ob, y, ypart, r.B, vox, nsp, r.s, dnp, nullptr, nullptr, 0.f, r.status);
       } else {
-        launch_attn_out(x, C, coefn, w.qkv16, nullptr, w.ob, y, ypart, r.B, vox, nsp, r.s, dnp, part, w.ow, 0.17677669529663689f,
-                        r.status);
+        launch_attn_out(x, C, coefn, w.qkv16, nullptr, w.ob, y, moments ? nullptr : ypart, r.B, vox, nsp, r.s, dnp, part, w.ow,
+                        0.17677669529663689f, r.status, momb, w.gg, w.gb);
       }
     }
+    if (momb) ws->release(momb);
     if (own) ws->release(own);
     own = nullptr;
     ws->release(coefn);
@@ -705,7 +718,7 @@ float* attn_block(Run& r, const AttnP& w, const float* x, Dims3 dims, float* xpa
 }
   if (own) ws->release(own);
   float* coefg = ws->get<float>((size_t)r.B * C * 4);
-  if (!r.dry() && !single) {
+  if (!r.dry() && !single && !moments) {
     GnDefer dg;
     dg.part = ypart; dg.units = yu; dg.gamma = w.gg; dg.beta = w.gb; dg.C = C; dg.groups = 1; dg.vox = vox;
     if (!defer_gn) launch_gn_finalize(ypart, yu, w.gg, w.gb, nullptr, 0, coefg, r.B, C, 1, vox, r.s);

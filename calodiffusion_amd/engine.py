@@ -303,7 +303,8 @@ class UnetEngine:
     # launch-sequence switches the library reads per call (tests and A/B runs flip them inside one process): a workspace sized
     # under one setting is not valid under another, so they are part of the cache key.  (The arithmetic mode is not: the
     # library sizes for the largest of its three modes.)
-    _WS_SWITCHES = ("CD_NO_DEEP_LEVEL", "CD_NO_PW_CLOSE", "CD_NO_FUSED_ATTN", "CD_NO_GNDEFER", "CD_ATTN_COMBINE_LAUNCH", "CD_PW_F32")
+    _WS_SWITCHES = ("CD_NO_DEEP_LEVEL", "CD_NO_PW_CLOSE", "CD_NO_FUSED_ATTN", "CD_NO_GNDEFER", "CD_ATTN_COMBINE_LAUNCH", "CD_PW_F32",
+                    "CD_NO_ATTN_MOMENTS", "CD_ATTN_MOM_MIN")
 
     def _ws_key(self, batch: int):
         return (int(batch),) + tuple(os.environ.get(k) for k in self._WS_SWITCHES)

@@ -177,3 +177,43 @@ np.save(sys.argv[1], y.cpu().numpy())
     err = rel_l2(outs["coop"], outs["single"])
     print(f"co-operative attention ({parts} workgroups per sample) vs single workgroup: rel L2 {err:.2e}")
     assert err < 3e-6
+
+
+@pytest.mark.parametrize("shape,batch", [((45, 16, 9), 4), ((28, 12, 21), 3), ((45, 50, 18), 2)])
+def test_attention_moment_form_equals_the_separate_closing_pass(shape, batch, monkeypatch):
+    """Level-0 attention (32 channels, > 1024 voxels): the moment form -- pass 1 also accumulates sum(softmax(q) - 1/32) and its
+    32 x 32 second moment, pass 2 derives the closing GroupNorm(1)'s mean / variance from them and the folded weights and writes
+    gn(y) + x directly -- beside the three-launch form (y written, channel sums, gn_apply), both against the oracle in float64, on grids with a ragged last tile,
+    for near-uniform softmaxes (default-init scale), peaked ones (q weights x 12) and an output projection with a large bias
+    (mean^2 >> variance: the cancellation case of E[y^2] - mean^2)."""
+    from calodiffusion_amd import engine
+    monkeypatch.setenv("CD_ATTN_MOM_MIN", "0")  # (the plan takes this form from 4 M elements per tensor)
+    ops = engine.Ops()
+    gen = torch.Generator().manual_seed(23)
+    D, H, W = shape
+    C = 32
+    x = (torch.randn((batch, D, H, W, C), generator=gen) * 1.5 + 0.3).cuda()
+    for qscale, bias in ((1.0, 0.0), (12.0, 0.0), (1.0, 3.0)):
+        wqkv = torch.randn((96, C, 1, 1, 1), generator=gen) / C ** 0.5
+        wqkv[:32] *= qscale
+        sd = {"fn.norm.weight": 1 + 0.1 * torch.randn(C, generator=gen), "fn.norm.bias": 0.1 * torch.randn(C, generator=gen),
+              "fn.fn.to_qkv.conv.weight": wqkv, "fn.fn.to_out.0.conv.weight": torch.randn((C, 32, 1, 1, 1), generator=gen) / 32 ** 0.5,
+              "fn.fn.to_out.0.conv.bias": 0.1 * torch.randn(C, generator=gen) + bias,
+              "fn.fn.to_out.1.weight": 1 + 0.1 * torch.randn(C, generator=gen), "fn.fn.to_out.1.bias": 0.1 * torch.randn(C, generator=gen)}
+        sd = {k: v.cuda().contiguous() for k, v in sd.items()}
+        y_mom = ops.linear_attention(x, sd)
+        monkeypatch.setenv("CD_NO_ATTN_MOMENTS", "1")
+        y_sep = ops.linear_attention(x, sd)
+        monkeypatch.delenv("CD_NO_ATTN_MOMENTS")
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(y_mom).all())
+        assert not torch.equal(y_mom, y_sep)  # (the two forms really are different launches)
+        # both against the oracle in float64, on the attention branch alone (the residual x is common and larger than it)
+        from oracle import torch_oracle
+        sd64 = {"a." + k: v.double().cpu() for k, v in sd.items()}
+        x64 = x.double().cpu().permute(0, 4, 1, 2, 3)
+        want = (torch_oracle.attn_residual(sd64, "a", x64, True) - x64).permute(0, 2, 3, 4, 1).numpy()
+        e_mom = rel_l2((y_mom.double().cpu() - x.double().cpu()).numpy(), want)
+        e_sep = rel_l2((y_sep.double().cpu() - x.double().cpu()).numpy(), want)
+        print(f"{shape} q x{qscale} bias {bias}: rel L2 of the branch against float64 -- moment form {e_mom:.2e}, closing pass {e_sep:.2e}")
+        assert e_mom < 2e-6, (shape, qscale, bias, e_mom, e_sep)
