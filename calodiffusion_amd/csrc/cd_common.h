@@ -96,6 +96,11 @@ struct GnDefer {
   int add_ld = 0;
   int C = 0, groups = 0;
   int64_t vox = 0;
+  // training tape: the folded table ([B][C][4]) and {mean, rstd} per (sample, group) ([B][G][2]) are also written to memory, by
+  // every workgroup that folds them (the fold is deterministic, so they all store the same values): the backward pass reads what
+  // the forward used, and no gn_finalize launch is needed for it
+  float* coef_out = nullptr;
+  float* stat_out = nullptr;
 };
 
 struct ConvFusion {
@@ -271,11 +276,15 @@ size_t wgrad_partial_floats(int64_t out_vox, int batch, bool per_sample, int A, 
 // dW[a][b][tap] (or [b][a][tap] if transposed_out) = sum_{n,o} g[n][o][a] * x[n][in(o,tap)][xoff + b]; see kernels_bwd.hip
 void launch_wgrad(const float* g, int A, Dims3 dg, const float* x, int Bc, int xld, int xoff, Dims3 dx, int kd, int kh, int kw,
                   int sz, int sxy, int batch, bool per_sample, float* partial, float* dw, bool accumulate, bool transposed_out,
-                  hipStream_t s, int b_total = 0, int b_off = 0);
+                  hipStream_t s, int b_total = 0, int b_off = 0,
+                  // x is read through silu(coef[0] x + coef[1]) + coef[2] per (sample, channel) ([B][xld][4]): only where
+                  // wgrad_x_norm_supported() says so (the fp16-pipe 3x3x3 kernel)
+                  const float* xcoef = nullptr);
+bool wgrad_x_norm_supported(Dims3 dg, Dims3 dx, int kd, int kh, int kw, int sz, int sxy);
 // stride-1 3x3x3 weight gradient on the fp16 matrix pipe (kernels_wgrad16.hip); false = geometry not eligible
 bool wgrad_f16x2_eligible(Dims3 d);
 bool try_launch_wgrad_f16x2(const float* g, int A, const float* x, int Bc, int xld, int xoff, Dims3 d, int batch, float* partial,
-                            unsigned* gmax_word, int* nblk_out, hipStream_t s);
+                            unsigned* gmax_word, int* nblk_out, hipStream_t s, const float* xcoef = nullptr);
 // the strided (KD, 4, 4) convs between the levels (and the transposed conv with the tensors' roles swapped): kernels_wgrad16.hip
 bool try_launch_wgrad_strided_f16x2(const float* g, int A, Dims3 dg, const float* x, int Bc, int xld, int xoff, Dims3 dx, int kd, int sz,
                                     int batch, float* partial, int max_slots, int* nblk_out, hipStream_t s);
@@ -286,6 +295,7 @@ void launch_softmax32_bwd(const float* qs, const float* dqs, float* dqkv, int64_
 void launch_ksoftmax_bwd(const float* qkv, const float* dks, const float* kstat, const float* ctx, const float* dctx, float dscale,
                          float* dqkv, int batch, int64_t vox, hipStream_t s);
 void launch_pack_sample32(const float* m, float* wpk, int batch, bool transpose, float scale, hipStream_t s);
+void launch_pack_sample32_pair(const float* m, float* wpk_plain, float* wpk_tr, int batch, float scale, hipStream_t s);
 int head_bwd_blocks(int batch, int64_t vox);
 // loss_type (here and below): CD_LOSS_* of calodiff.h -- 0 l2 (hybrid weight), 1 l1, 2 mse, 3 huber (models/loss.py:97-116)
 // objective: CD_OBJ_* (objective_residual / objective_weight below); noise is only read for noise_pred

@@ -70,6 +70,10 @@ __device__ __forceinline__ void gn_defer_to_lds(const GnDefer& g, int b, float* 
     var = var < 0.0 ? 0.0 : var;
     sMR[tid * 2] = (float)mu;
     sMR[tid * 2 + 1] = (float)(1.0 / sqrt(var + 1e-5));
+    if (g.stat_out) {
+      g.stat_out[((size_t)b * G + tid) * 2] = sMR[tid * 2];
+      g.stat_out[((size_t)b * G + tid) * 2 + 1] = sMR[tid * 2 + 1];
+    }
   }
   __syncthreads();
   for (int c = tid; c < C; c += nthreads) {
@@ -82,6 +86,7 @@ __device__ __forceinline__ void gn_defer_to_lds(const GnDefer& g, int b, float* 
     o[2] = pre ? pa : (g.add ? g.add[(size_t)b * g.add_ld + c] : 0.f);
     o[3] = 0.f;
     *(f32x4*)(coef_lds + c * 4) = o;
+    if (g.coef_out) *(f32x4*)(g.coef_out + ((size_t)b * C + c) * 4) = o;
   }
   __syncthreads();
 }

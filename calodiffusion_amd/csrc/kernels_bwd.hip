@@ -368,10 +368,16 @@ size_t wgrad_partial_floats(int64_t out_vox, int batch, bool per_sample, int A, 
   return slots * A * Bc * T;
 }
 
+bool wgrad_x_norm_supported(Dims3 dg, Dims3 dx, int kd, int kh, int kw, int sz, int sxy) {
+  return kd * kh * kw == 27 && sz == 1 && sxy == 1 && dg.vox() == dx.vox() && wgrad_f16x2_eligible(dg);
+}
+
 void launch_wgrad(const float* g, int A, Dims3 dg, const float* x, int Bc, int xld, int xoff, Dims3 dx, int kd, int kh, int kw,
                   int sz, int sxy, int batch, bool per_sample, float* partial, float* dw, bool accumulate, bool transposed_out,
-                  hipStream_t s, int b_total, int b_off) {
+                  hipStream_t s, int b_total, int b_off, const float* xcoef) {
   CD_REQUIRE(A % 32 == 0 && Bc % 32 == 0, "wgrad: channel counts must be multiples of 32");
+  CD_REQUIRE(!xcoef || (!per_sample && wgrad_x_norm_supported(dg, dx, kd, kh, kw, sz, sxy)),
+             "wgrad: a normalised x operand is only read by the fp16-pipe 3x3x3 kernel");
   if (b_total <= 0) b_total = Bc;
   WgradArgs a;
   a.g = g; a.x = x; a.A = A; a.Bc = Bc; a.xld = xld; a.xoff = xoff;
@@ -387,7 +393,7 @@ void launch_wgrad(const float* g, int A, Dims3 dg, const float* x, int Bc, int x
       char cat16[96];
       std::snprintf(cat16, sizeof cat16, "wgrad T27 C%dx%d n%ld", A, Bc, (long)dg.vox());
       prof::Scope scope16(cat16, s, 2.0 * 27 * A * Bc * (double)dg.vox() * batch, 4.0 * batch * (double)dg.vox() * (A + Bc));
-      CD_REQUIRE(try_launch_wgrad_f16x2(g, A, x, Bc, xld, xoff, dg, batch, partial, gmax_word, &nblk16, s), "internal: wgrad f16x2");
+      CD_REQUIRE(try_launch_wgrad_f16x2(g, A, x, Bc, xld, xoff, dg, batch, partial, gmax_word, &nblk16, s, xcoef), "internal: wgrad f16x2");
       const size_t total = (size_t)A * Bc * 27;
       hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256), 1), dim3(256), 0, s, partial, dw, A, Bc, 27, nblk16,
                          accumulate ? 1 : 0, transposed_out ? 1 : 0, (size_t)nblk16 * total, total, b_total, b_off);
@@ -641,13 +647,73 @@ __global__ void param_grad_from_samples_kernel(const float* __restrict__ sums_bc
 }
 
 // dh = gc0*dz + gc1*h + gc2 (+ dh_accum), dz = dy*act'(scale*h+shift)
+// `fold` (round 4): the arithmetic of gn_bwd_finalize_kernel in the prologue of every workgroup of the sample, from the statistics
+// partials (a few KB per sample) -- same operations in the same order, so the result equals the three-launch form bit for bit;
+// the sample's first workgroup writes the per-sample sums for the parameter gradients.  One launch less per GroupNorm layer.
+struct GnBwdFold {
+  const float* part = nullptr;   // [B][nsplit][C][4] of gn_bwd_stats_kernel; null: gcoef is read from memory
+  const float* gamma = nullptr;
+  const float* stat = nullptr;
+  float* sums_bc = nullptr;
+  float* dadd = nullptr;
+  int nsplit = 0, dadd_ld = 0, groups = 0;
+};
 __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ h,
                                                            const float* __restrict__ coef, const float* __restrict__ gcoef,
                                                            float* __restrict__ dh, int channels, int64_t vox, int silu,
-                                                           int blocks_per_sample, unsigned* __restrict__ amax_out) {
+                                                           int blocks_per_sample, unsigned* __restrict__ amax_out, GnBwdFold fold) {
   __shared__ float sAmax[4];
+  __shared__ double fs0[256], fs1[256];
+  __shared__ float fm1[64], fm2[64];
+  __shared__ __attribute__((aligned(16))) float sGc[256][4];
   const int tid = threadIdx.x;
   const int b = blockIdx.x / blocks_per_sample, blk = blockIdx.x % blocks_per_sample;
+  if (fold.part) {
+    const int cc = tid, cpg = channels / fold.groups;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (cc < channels) {
+      const float* p = fold.part + ((size_t)b * fold.nsplit * channels + cc) * 4;
+      int u = 0;
+      for (; u + 8 <= fold.nsplit; u += 8) {  // eight partials in flight (same order of additions as the plain loop)
+        f32x4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = *(const f32x4*)(p + (size_t)(u + k) * channels * 4);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { a0 += (double)v[k][0]; a1 += (double)v[k][1]; a2 += (double)v[k][2]; a3 += (double)v[k][3]; }
+      }
+      for (; u < fold.nsplit; ++u) {
+        const f32x4 v = *(const f32x4*)(p + (size_t)u * channels * 4);
+        a0 += (double)v[0]; a1 += (double)v[1]; a2 += (double)v[2]; a3 += (double)v[3];
+      }
+      fs0[cc] = a0 * (double)fold.gamma[cc];
+      fs1[cc] = a1 * (double)fold.gamma[cc];
+    }
+    __syncthreads();
+    if (cc < fold.groups) {
+      double t0 = 0.0, t1 = 0.0;
+      for (int k = 0; k < cpg; ++k) { t0 += fs0[cc * cpg + k]; t1 += fs1[cc * cpg + k]; }
+      const double cnt = (double)vox * cpg;
+      fm1[cc] = (float)(t0 / cnt);
+      fm2[cc] = (float)(t1 / cnt);
+    }
+    __syncthreads();
+    if (cc < channels) {
+      const int g = cc / cpg;
+      const float mean = fold.stat[((size_t)b * fold.groups + g) * 2], rstd = fold.stat[((size_t)b * fold.groups + g) * 2 + 1];
+      f32x4 o;
+      o[0] = rstd * fold.gamma[cc];
+      o[1] = -rstd * rstd * fm2[g];
+      o[2] = rstd * (-fm1[g] + mean * rstd * fm2[g]);
+      o[3] = 0.f;
+      *(f32x4*)sGc[cc] = o;
+      if (blk == 0) {
+        const float sdh = (float)((double)o[0] * a0 - (double)rstd * ((double)fm1[g] * (double)vox + (double)rstd * (double)fm2[g] * a3));
+        *(f32x4*)(fold.sums_bc + ((size_t)b * channels + cc) * 4) = f32x4{(float)a0, (float)a1, sdh, (float)a2};
+        if (fold.dadd) fold.dadd[(size_t)b * fold.dadd_ld + cc] = (float)a2;
+      }
+    }
+    __syncthreads();
+  }
   const int cols = channels >> 2, rows = 256 / cols;
   const int64_t vper = (vox + blocks_per_sample - 1) / blocks_per_sample;
   const int64_t v0 = blk * vper, v1 = (v0 + vper < vox) ? v0 + vper : vox;
@@ -659,7 +725,7 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const float* __restri
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     cf[e] = *(const f32x4*)(coef + ((size_t)b * channels + c + e) * 4);
-    gc[e] = *(const f32x4*)(gcoef + ((size_t)b * channels + c + e) * 4);
+    gc[e] = fold.part ? *(const f32x4*)sGc[c + e] : *(const f32x4*)(gcoef + ((size_t)b * channels + c + e) * 4);
   }
   const size_t sb = (size_t)b * vox * channels + c;
   for (int64_t v = v0 + row; v < v1; v += rows) {
@@ -892,15 +958,24 @@ void launch_gn_backward(const float* dy, const float* h, const float* coef, cons
     return;
   }
   hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(ns, batch), dim3(256), 0, s, dy, h, coef, stat, part, channels, vox, groups, silu, ns);
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(batch), dim3(256), 0, s, part, ns, gamma, stat, gcoef, sums_bc, dadd, dadd_ld,
-                     channels, groups, vox);
+  // the finalize arithmetic runs in the apply kernel's prologue when the parameter-gradient reduction is queued behind it
+  // (stand-alone calls reduce over the batch right here, between the two, and keep the three-launch form)
+  static const bool no_fold = getenv("CD_NO_GN_BWD_FOLD") != nullptr;
+  GnBwdFold fold;
+  if (queue && !no_fold) {
+    fold.part = part; fold.gamma = gamma; fold.stat = stat; fold.sums_bc = sums_bc; fold.dadd = dadd; fold.nsplit = ns;
+    fold.dadd_ld = dadd_ld; fold.groups = groups;
+  } else {
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(batch), dim3(256), 0, s, part, ns, gamma, stat, gcoef, sums_bc, dadd, dadd_ld,
+                       channels, groups, vox);
+  }
   if (!queue)
     hipLaunchKernelGGL(param_grad_from_samples_kernel, dim3((channels + 63) / 64), dim3(64), 0, s, sums_bc, batch, channels, dgamma,
                        dbeta, accumulate_params ? 1 : 0, dbias, dsumdy);
   const int bps = gn_apply_blocks_per_sample(batch, channels, vox);
   unsigned* amax_word = absmax_word_fresh(dh, s);  // zeroed; the consumer's launch_absmax_bits(dh) finds it instead of re-reading dh
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)(batch * bps)), dim3(256), 0, s, dy, h, coef, gcoef, dh, channels, vox, silu, bps,
-                     amax_word);
+                     amax_word, fold);
   CD_HIP(hipGetLastError());
 }
 // out[v][c] = a[v][aoff + c] + (b ? b[v][boff + c] : 0)   (row strides lda / ldb / C): gradient fan-in, channel slices of
@@ -1081,6 +1156,21 @@ __global__ void pack_sample32_kernel(const float* __restrict__ m, float* __restr
 }
 void launch_pack_sample32(const float* m, float* wpk, int batch, bool transpose, float scale, hipStream_t s) {
   hipLaunchKernelGGL(pack_sample32_kernel, dim3(batch), dim3(256), 0, s, m, wpk, transpose ? 1 : 0, scale);
+  CD_HIP(hipGetLastError());
+}
+// both images of the same matrices in one launch: wpk_plain (transpose = false) and wpk_tr (transpose = true)
+__global__ void pack_sample32_pair_kernel(const float* __restrict__ m, float* __restrict__ wpk_plain, float* __restrict__ wpk_tr,
+                                          float scale) {
+  const int b = blockIdx.x, tr = blockIdx.y;
+  float* wpk = tr ? wpk_tr : wpk_plain;
+  for (int i = threadIdx.x; i < 1024; i += blockDim.x) {
+    const int e4 = i & 3, lane = (i >> 2) & 63, q = (i >> 8) & 3;
+    const int co = lane & 31, ci = (lane >> 5) * 16 + q * 4 + e4;
+    wpk[(size_t)b * 1024 + i] = scale * (tr ? m[((size_t)b * 32 + co) * 32 + ci] : m[((size_t)b * 32 + ci) * 32 + co]);
+  }
+}
+void launch_pack_sample32_pair(const float* m, float* wpk_plain, float* wpk_tr, int batch, float scale, hipStream_t s) {
+  hipLaunchKernelGGL(pack_sample32_pair_kernel, dim3(batch, 2), dim3(256), 0, s, m, wpk_plain, wpk_tr, scale);
   CD_HIP(hipGetLastError());
 }
 

@@ -1734,9 +1734,10 @@ void launch_conv_mfma(const float* in0, int c0, const float* in1, int c1, const 
   ConvFusion fu = fu_in;
   auto materialise = [&]() {
     if (!fu.defer.part) return;
+    if (fu.defer.coef_out) fu.coef_buf = fu.defer.coef_out;  // (training tape: the table is wanted in memory anyway)
     CD_REQUIRE(fu.coef_buf, "conv: deferred normalisation needs a coefficient buffer for kernels without the prologue");
     launch_gn_finalize(fu.defer.part, fu.defer.units, fu.defer.gamma, fu.defer.beta, fu.defer.add, fu.defer.add_ld, fu.coef_buf, batch,
-                       fu.defer.C, fu.defer.groups, fu.defer.vox, s);
+                       fu.defer.C, fu.defer.groups, fu.defer.vox, s, fu.defer.stat_out);
     fu.coef = fu.coef_buf;
     fu.defer = GnDefer();
   };

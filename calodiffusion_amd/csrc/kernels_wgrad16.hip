@@ -64,6 +64,10 @@ struct Wgrad16Args {
   float* partial;   // [gridDim.x][tilesA][tilesB][27][32][32]
   int tilesB;
   const unsigned* gmax_bits;  // max |dy| of the whole tensor (bit pattern)
+  // x is read through a GroupNorm + SiLU + embedding: x_eff = silu(coef[0] x + coef[1]) + coef[2] per (sample, channel) -- the
+  // second conv of a ResnetBlock saw its input that way in the forward pass (only ever formed in that conv's staging), and
+  // recomputing it here saves the backward a gn_apply pass and a tensor per block
+  const float* xcoef;         // [B][xld][4] or null
 };
 
 __device__ __forceinline__ fh8 cat8(fh4 a, fh4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
@@ -171,6 +175,11 @@ __global__ void __launch_bounds__(512, 1) wgrad_f16x2_kernel(Wgrad16Args a) {
       // ---- stage x planes z0-1 .. z0+NZ (zero outside the sample), interior rows + phi halo copies ------------------
       const float* xs = a.x + (size_t)n * vox * a.xld + a.xoff + tb * 32;
       const int nst = (WG_NZ + 2) * PV * 8;
+      f32x4 xc[4];  // (a thread stages the same channel quad of every voxel: i & 7 == tid & 7)
+      if (a.xcoef) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xc[e] = *(const f32x4*)(a.xcoef + ((size_t)n * a.xld + a.xoff + tb * 32 + (tid & 7) * 4 + e) * 4);
+      }
       for (int i0 = tid; i0 < nst; i0 += 4 * 512) {
         f32x4 val[4];
 #pragma unroll
@@ -179,7 +188,13 @@ __global__ void __launch_bounds__(512, 1) wgrad_f16x2_kernel(Wgrad16Args a) {
           const int v = i >> 3;
           const int zl = div_pv(v), z = z0 - 1 + zl;
           val[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (i < nst && z >= 0 && z < a.D) val[k] = *(const f32x4*)(xs + ((size_t)z * PV + (v - zl * PV)) * a.xld + (i & 7) * 4);
+          if (i < nst && z >= 0 && z < a.D) {
+            val[k] = *(const f32x4*)(xs + ((size_t)z * PV + (v - zl * PV)) * a.xld + (i & 7) * 4);
+            if (a.xcoef) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) val[k][e] = cd_fast_silu(xc[e][0] * val[k][e] + xc[e][1]) + xc[e][2];
+            }
+          }
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -524,10 +539,11 @@ bool wgrad_f16x2_eligible(Dims3 d) {
   return d.d >= 1 && d.h * d.w >= min_pv && wgrad16_lds(d) <= 160 * 1024;
 }
 bool try_launch_wgrad_f16x2(const float* g, int A, const float* x, int Bc, int xld, int xoff, Dims3 d, int batch, float* partial,
-                            unsigned* gmax_word, int* nblk_out, hipStream_t s) {
+                            unsigned* gmax_word, int* nblk_out, hipStream_t s, const float* xcoef) {
   if (!wgrad_f16x2_eligible(d)) return false;
   const size_t lds = wgrad16_lds(d);
   Wgrad16Args f;
+  f.xcoef = xcoef;
   f.g = g; f.x = x; f.A = A; f.xld = xld; f.xoff = xoff; f.D = d.d; f.H = d.h; f.W = d.w;
   f.units_per_sample = (d.d + WG_NZ - 1) / WG_NZ;
   f.total_units = f.units_per_sample * batch;

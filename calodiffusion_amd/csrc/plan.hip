@@ -35,6 +35,7 @@ struct WeightEntry {
   // input-gradient images of the training step (dgrad_images below), floats into CdPlan::dg_arena; dg_mode 0 = none
   int dg_mode = 0;
   size_t dg_pk_off = 0, dg_pk3_off = 0;
+  bool dg_1x1 = false;  // a 1x1 conv kept raw for the forward (attention to_out: folded per sample) whose backward wants the image
 };
 // packed images a convolution's input gradient reads (conv_backward / conv_transpose_backward); null members: pack on the fly
 struct DgImg {
@@ -250,6 +251,7 @@ AttnW add_attn(CdPlan* p, const std::string& pre, int c) {
   a.c = c;
   a.qkv = add_weight(p, pre + ".fn.fn.to_qkv.conv.weight", (int64_t)96 * c, PK_CONV, c, 96, 1);
   a.ow = add_weight(p, pre + ".fn.fn.to_out.0.conv.weight", (int64_t)c * 32);
+  p->weights[a.ow].cin = 32; p->weights[a.ow].cout = c; p->weights[a.ow].taps = 1; p->weights[a.ow].dg_1x1 = true;
   a.ob = add_weight(p, pre + ".fn.fn.to_out.0.conv.bias", c);
   a.gg = add_weight(p, pre + ".fn.fn.to_out.1.weight", c);
   a.gb = add_weight(p, pre + ".fn.fn.to_out.1.bias", c);
@@ -744,8 +746,9 @@ void bias_grad(Run& r, const float* dy, int C, int64_t vox, float* db) {
 //   dx (optional): (B, vox_in, c0+c1) gradient of the concatenated input
 //   dw: torch layout (cout, c0+c1, taps);  db: (cout) or null.   w_raw: torch-layout weights (device).
 // img (optional): the input gradient's weight images already packed for this step (CdPlan::dg); without them they are packed here.
+// xcoef (optional, single-source x0 only): the conv's input was silu(coef[0] x0 + coef[1]) + coef[2] (see launch_wgrad)
 void conv_backward(Run& r, const float* x0, int c0, const float* x1, int c1, const float* w_raw, const float* dy, float* dx,
-                   float* dw, float* db, int cout, const ConvGeom& g, const DgImg* img = nullptr) {
+                   float* dw, float* db, int cout, const ConvGeom& g, const DgImg* img = nullptr, const float* xcoef = nullptr) {
   Arena* ws = r.ws;
   const int cin = c0 + c1, T = g.kd * g.kh * g.kw;
   const bool pre = img && img->pk;
@@ -799,7 +802,8 @@ void conv_backward(Run& r, const float* x0, int c0, const float* x1, int c1, con
   }
   float* part = ws->get<float>(wgrad_partial_floats(g.out.vox(), r.B, false, cout, c0 > c1 ? c0 : c1, T));
   if (!r.dry()) {
-    launch_wgrad(dy, cout, g.out, x0, c0, c0, 0, g.in, g.kd, g.kh, g.kw, g.sz, g.sh, r.B, false, part, dw, false, false, r.s, cin, 0);
+    CD_REQUIRE(!xcoef || !c1, "conv backward: a normalised input has one source");
+    launch_wgrad(dy, cout, g.out, x0, c0, c0, 0, g.in, g.kd, g.kh, g.kw, g.sz, g.sh, r.B, false, part, dw, false, false, r.s, cin, 0, xcoef);
     if (c1) launch_wgrad(dy, cout, g.out, x1, c1, c1, 0, g.in, g.kd, g.kh, g.kw, g.sz, g.sh, r.B, false, part, dw, false, false, r.s, cin, c0);
     absmax_note_drop();  // max |dy| served this backward only
   }
@@ -1904,7 +1908,7 @@ static void dgrad_images(CdPlan* p) {
   auto bump = [&](size_t n) { size_t o = off; off += (n + 63) & ~(size_t)63; return o; };
   std::vector<PackJob> jobs;
   for (auto& w : p->weights) {
-    if (w.pack != PK_CONV && w.pack != PK_CONVT) continue;
+    if (w.pack != PK_CONV && w.pack != PK_CONVT && !w.dg_1x1) continue;
     PackJob j{};
     j.kind = 1;
     j.taps = w.taps;
