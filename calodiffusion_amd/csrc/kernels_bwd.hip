@@ -142,6 +142,185 @@ __global__ void __launch_bounds__(1024) wgrad_kernel(WgradArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Weight gradient of a 1x1x1 conv (ResnetBlock shortcuts, the attention's to_qkv / to_out and -- per sample -- its context
+// gradient): dW[a][b] = sum over rows of g[row][a] x[row][b], a tiny output over a very long K, i.e. a streaming pass over the two
+// tensors.  Round 4: wgrad_kernel<1> ran it as ~12 k single-wave workgroups of dword loads, a pre-reduction of their 4096 partials
+// and the final reduction -- three launches and ~60 us for the 107 MB of the level-0 to_qkv gradient, 27 times per training step.
+// Here a workgroup of four waves loops over units of R rows: both tensors' rows are staged in LDS with 16-byte loads (fp32, row
+// pitch = 32 mod 64 floats so that the two half-waves of an operand read hit disjoint banks), wave w runs rows 32 w .. 32 w + 31
+// of the unit as 16 K-steps of v_mfma_f32_32x32x2_f32 for each of the workgroup's (a, b) tiles (lanes are channels, the lane
+// half is the row of the pair: exact fp32, nothing to rescale), accumulators live across all units, and the four waves' sums are
+// added in a fixed order through LDS into ONE partial per workgroup.  Segments: the whole batch (rows contiguous across samples)
+// or, per_sample, one sample each.
+// ------------------------------------------------------------------------------------------------------------
+struct Wgrad1Args {
+  const float* g;   // (rows, A)
+  const float* x;   // (rows, xld) read at channel offset xoff, Bc channels
+  int A, Bc, xld, xoff;
+  int ldA, ldB;     // LDS row pitches (floats)
+  int R;            // rows per unit (multiple of 128)
+  long long rows_per_seg;
+  int units_per_seg, wgs_per_seg;
+  int tilesB, ntiles;
+  float* partial;   // [gridDim.x][tilesA][tilesB][32][32]
+  int dbg;          // ablation (CD_W1_DBG): 1 = no MFMAs, 2 = no global loads
+};
+
+// NQ: 16-byte quads of a unit per thread = ceil(R (A + Bc) / 4 / 256); W1_NT: (a, b) tiles per workgroup (blockIdx.y takes the next
+// W1_NT; the launcher picks a divisor of the tile count, so every tile index below is valid)
+template <int NQ, int W1_NT>
+__global__ void __launch_bounds__(256) wgrad1x1_kernel(Wgrad1Args a) {
+  extern __shared__ __attribute__((aligned(16))) float w1[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, col = lane & 31;
+  const int seg = blockIdx.x / a.wgs_per_seg, wq = blockIdx.x % a.wgs_per_seg;
+  const int tile0 = blockIdx.y * W1_NT;
+  float* const sG = w1;
+  float* const sX = w1 + (size_t)a.R * a.ldA;
+  int ga[W1_NT], xb[W1_NT];  // channel offsets of this lane's operand element per tile
+#pragma unroll
+  for (int t = 0; t < W1_NT; ++t) {
+    const int tile = tile0 + t;
+    ga[t] = (tile / a.tilesB) * 32 + col;
+    xb[t] = (tile % a.tilesB) * 32 + col;
+  }
+  f32x16 acc[W1_NT];
+#pragma unroll
+  for (int t = 0; t < W1_NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  const float* gseg = a.g + (size_t)seg * a.rows_per_seg * a.A;
+  const float* xseg = a.x + (size_t)seg * a.rows_per_seg * a.xld + a.xoff;
+  const int qa = a.A >> 2, qb = a.Bc >> 2, qrow = qa + qb;  // 16-byte quads per row: g's, then x's
+  const int nq = a.R * qrow;
+  // exact small-integer division by reciprocal: (i + 0.5) / qrow is never within float error of an integer for i < 2^20
+  const float inv_qrow = 1.f / (float)qrow;
+  auto row_of = [&](int i) { return (int)(((float)i + 0.5f) * inv_qrow); };
+  // a unit's rows travel global -> registers -> LDS; the loads of unit u + 1 are issued before the MFMAs of unit u and land under
+  // them (one memory round trip per unit was most of a workgroup's time: the first version took 45 us for the 107 MB of the level-0
+  // to_qkv gradient)
+  f32x4 v[NQ];
+  auto issue = [&](int u) {
+    const long long r0 = (long long)u * a.R;
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+      const int i = tid + k * 256;
+      const int row = row_of(i), q = i - row * qrow;
+      v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (i < nq && r0 + row < a.rows_per_seg && !(a.dbg & 2))
+        v[k] = q < qa ? *(const f32x4*)(gseg + (size_t)(r0 + row) * a.A + q * 4)
+                      : *(const f32x4*)(xseg + (size_t)(r0 + row) * a.xld + (q - qa) * 4);
+    }
+  };
+  int u = wq;
+  if (u < a.units_per_seg) issue(u);
+  for (; u < a.units_per_seg; u += a.wgs_per_seg) {
+    __syncthreads();  // the previous unit has been consumed
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+      const int i = tid + k * 256;
+      if (i < nq) {
+        const int row = row_of(i), q = i - row * qrow;
+        if (q < qa) *(f32x4*)(sG + (size_t)row * a.ldA + q * 4) = v[k];
+        else *(f32x4*)(sX + (size_t)row * a.ldB + (q - qa) * 4) = v[k];
+      }
+    }
+    __syncthreads();
+    if (u + a.wgs_per_seg < a.units_per_seg) issue(u + a.wgs_per_seg);
+    for (int rb = wave * 32; rb < ((a.dbg & 1) ? 0 : a.R); rb += 128) {
+      // eight K-steps' operands are requested before their MFMAs (as a plain loop every MFMA waited for its own LDS round trip
+      // behind a branch: 400 cycles per 64-cycle instruction)
+#pragma unroll
+      for (int s0 = 0; s0 < 16; s0 += 8) {
+        float gv[8][W1_NT], xv[8][W1_NT];
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) {
+          const int row = rb + 2 * (s0 + s2) + half;
+#pragma unroll
+          for (int t = 0; t < W1_NT; ++t) {
+            gv[s2][t] = sG[row * a.ldA + ga[t]];
+            xv[s2][t] = sX[row * a.ldB + xb[t]];
+          }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2)
+#pragma unroll
+          for (int t = 0; t < W1_NT; ++t) acc[t] = MFMA32(gv[s2][t], xv[s2][t], acc[t]);
+      }
+    }
+  }
+  // the four waves' sums, wave 0 first, through LDS: one partial per workgroup
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < W1_NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) w1[((wave * W1_NT + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 32 + col] = acc[t][r];
+  __syncthreads();
+  const int tilesA = a.A / 32;
+  for (int i = tid; i < W1_NT * 1024; i += 256) {
+    const int t = i >> 10, e = i & 1023;
+    const float v = ((w1[(0 * W1_NT + t) * 1024 + e] + w1[(1 * W1_NT + t) * 1024 + e]) + w1[(2 * W1_NT + t) * 1024 + e]) +
+                    w1[(3 * W1_NT + t) * 1024 + e];
+    const int tile = tile0 + t;
+    a.partial[(((size_t)blockIdx.x * tilesA + tile / a.tilesB) * a.tilesB + tile % a.tilesB) * 1024 + e] = v;
+  }
+}
+
+// returns false when the shape does not fit (the caller runs wgrad_kernel<1>)
+static bool try_launch_wgrad1x1(const float* g, int A, const float* x, int Bc, int xld, int xoff, int64_t vox, int batch, bool per_sample,
+                                float* partial, size_t partial_slots, int* nslots_out, hipStream_t s) {
+  static const bool off = getenv("CD_NO_WGRAD1X1") != nullptr;
+  if (off || A % 32 || Bc % 32 || xld % 4 || xoff % 4) return false;
+  Wgrad1Args a;
+  a.g = g; a.x = x; a.A = A; a.Bc = Bc; a.xld = xld; a.xoff = xoff;
+  a.ldA = A + (A % 64 == 32 ? 0 : 32);
+  a.ldB = Bc + (Bc % 64 == 32 ? 0 : 32);
+  a.tilesB = Bc / 32;
+  a.ntiles = (A / 32) * (Bc / 32);
+  a.R = 128;
+  const int NT = a.ntiles % 4 == 0 ? 4 : (a.ntiles % 3 == 0 ? 3 : (a.ntiles % 2 == 0 ? 2 : (a.ntiles == 1 ? 1 : 0)));
+  if (!NT) return false;
+  const size_t stage = (size_t)a.R * (a.ldA + a.ldB) * 4, red = (size_t)4 * NT * 4096;
+  const size_t lds = stage > red ? stage : red;
+  if (lds > 160 * 1024) return false;
+  a.rows_per_seg = per_sample ? vox : (int64_t)batch * vox;
+  const int64_t units = (a.rows_per_seg + a.R - 1) / a.R;
+  CD_REQUIRE(units < (1ll << 30), "wgrad 1x1: too many rows");
+  a.units_per_seg = (int)units;
+  const int groups = a.ntiles / NT;
+  // workgroups: two per CU where the staging fits twice (one streams while the other multiplies), at least 2 units each
+  const int nseg = per_sample ? batch : 1;
+  int64_t want = (lds <= 80 * 1024 ? 512 : 256) / groups / nseg;
+  if (want < 1) want = 1;
+  if (want > units) want = units;
+  if ((size_t)want * nseg > partial_slots) want = (int64_t)(partial_slots / nseg);
+  if (want < 1) return false;
+  a.wgs_per_seg = (int)want;
+  a.partial = partial;
+  static const int dbg = getenv("CD_W1_DBG") ? atoi(getenv("CD_W1_DBG")) : 0;
+  a.dbg = dbg;
+  const int nqt = (a.R * ((A + Bc) / 4) + 255) / 256;
+  const dim3 grid((unsigned)(a.wgs_per_seg * nseg), (unsigned)groups);
+#define W1_CASE(N, T)                                                                                                           \
+  if (nqt <= N && NT == T) {                                                                                                    \
+    static bool attr = false;                                                                                                   \
+    if (!attr) {                                                                                                                \
+      CD_HIP(hipFuncSetAttribute((const void*)wgrad1x1_kernel<N, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));   \
+      attr = true;                                                                                                              \
+    }                                                                                                                           \
+    hipLaunchKernelGGL((wgrad1x1_kernel<N, T>), grid, dim3(256), lds, s, a);                                                    \
+    CD_HIP(hipGetLastError());                                                                                                  \
+    *nslots_out = a.wgs_per_seg;                                                                                                \
+    return true;                                                                                                                \
+  }
+#define W1_CASES(N) W1_CASE(N, 1) W1_CASE(N, 2) W1_CASE(N, 3) W1_CASE(N, 4)
+  W1_CASES(8) W1_CASES(16) W1_CASES(24) W1_CASES(32)
+#undef W1_CASES
+#undef W1_CASE
+  return false;  // (wider than 128 + 128 channels: the general kernel)
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Weight gradient of the stride-1 3x3x3 conv, LDS-staged and persistent (the hot backward kernel).
 // A workgroup loops over (sample, 256-voxel flat range) units; per unit it stages the output-gradient rows [R][32] and
 // the input z-planes the range touches (+1 halo plane each side, zero outside) as [voxel][32] fp32, plus a per-voxel
@@ -319,6 +498,50 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __
   *d = accumulate ? *d + s : s;
 }
 
+// The same reduction for T = 1 with hundreds of slots (wgrad1x1_kernel: one per workgroup), two levels in one launch: a block of
+// 256 threads = 16 consecutive outputs x 16 slot lanes; lane j sums slots j, j + 16, ... (16 loads in flight), the 16 lanes are
+// combined in a fixed xor tree.  Deterministic; ~2 rounds of loads for 512 slots where the single-level loop needs 32.
+__global__ void __launch_bounds__(256) wgrad_reduce1_kernel(const float* __restrict__ partial, float* __restrict__ dw, int A, int Bc,
+                                                            int nslots, int accumulate, int transposed_out,
+                                                            size_t sample_stride_partial, size_t sample_stride_out, int b_total, int b_off) {
+  const size_t total = (size_t)A * Bc;
+  const int oi = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const size_t idx = (size_t)blockIdx.x * 16 + oi;
+  const int n = blockIdx.y;
+  float acc = 0.f;
+  if (idx < total) {
+    const float* p = partial + (size_t)n * sample_stride_partial + idx;
+    float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int k = sl;
+    for (; k + 16 * 15 < nslots; k += 16 * 16) {
+      float v[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = p[(size_t)(k + 16 * j) * total];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) a8[j & 7] += v[j];
+    }
+    for (int j = 0; k < nslots; k += 16, ++j) a8[j & 7] += p[(size_t)k * total];
+    acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+  }
+  // lanes of one output: threads oi, oi + 16, ... = lane bits 4, 5 of the wave and the four waves
+  acc += __shfl_xor(acc, 16, 64);
+  acc += __shfl_xor(acc, 32, 64);
+  __shared__ float sR[4][16];
+  if ((threadIdx.x & 63) < 16) sR[threadIdx.x >> 6][oi] = acc;
+  __syncthreads();
+  if (threadIdx.x < 16 && idx < total) {
+    const float sum = (sR[0][oi] + sR[1][oi]) + (sR[2][oi] + sR[3][oi]);
+    const int cb = idx & 31, ra = (idx >> 5) & 31;
+    const size_t rest = idx >> 10;
+    const int tilesB = Bc / 32;
+    const int tb = rest % tilesB, ta = rest / tilesB;
+    const int ga = ta * 32 + ra, gb2 = tb * 32 + cb;
+    const size_t o = transposed_out ? ((size_t)(gb2 + b_off) * A + ga) : ((size_t)ga * b_total + b_off + gb2);
+    float* d = dw + (size_t)n * sample_stride_out + o;
+    *d = accumulate ? *d + sum : sum;
+  }
+}
+
 // First level of the slot reduction when there are many slots (the 1x1 convs write 4096 four-KiB partials: a single-level
 // reduce is 1024 threads x 4096 serial loads = 75 us of a 100 us weight gradient).  Group g sums its `per` consecutive slots
 // in a fixed order into the group's first slot, in place; wgrad_reduce_kernel then sums the group heads (slot_step = per).
@@ -452,6 +675,21 @@ void launch_wgrad(const float* g, int A, Dims3 dg, const float* x, int Bc, int x
       const size_t total = (size_t)A * Bc * Ts;
       hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256), 1), dim3(256), 0, s, partial, dw, A, Bc, Ts, nblk,
                          accumulate ? 1 : 0, transposed_out ? 1 : 0, (size_t)nblk * total, total, b_total, b_off);
+      CD_HIP(hipGetLastError());
+      return;
+    }
+  }
+  if (Tt == 1 && sz == 1 && sxy == 1 && dg.vox() == dx.vox()) {
+    const size_t cap_slots = (size_t)wgrad_chunks(dg.vox(), batch, per_sample, A, Bc, 1) * batch;  // what the caller's buffer holds
+    int ns = 0;
+    char cat1[96];
+    std::snprintf(cat1, sizeof cat1, "wgrad T1 C%dx%d n%ld", A, Bc, (long)dg.vox());
+    prof::Scope scope1(cat1, s, 2.0 * A * Bc * (double)dg.vox() * batch, 4.0 * batch * (double)dg.vox() * (A + Bc));
+    if (try_launch_wgrad1x1(g, A, x, Bc, xld, xoff, dg.vox(), batch, per_sample, partial, cap_slots, &ns, s)) {
+      const size_t total = (size_t)A * Bc;
+      dim3 rg1((unsigned)((total + 15) / 16), per_sample ? batch : 1);
+      hipLaunchKernelGGL(wgrad_reduce1_kernel, rg1, dim3(256), 0, s, partial, dw, A, Bc, ns, accumulate ? 1 : 0,
+                         transposed_out ? 1 : 0, (size_t)ns * total, total, b_total, b_off);
       CD_HIP(hipGetLastError());
       return;
     }
