@@ -120,6 +120,11 @@ struct ConvFusion {
   // staged input by 2^s (bringing that maximum to ~2^10) and their output by 2^-s: the input gradients of a conv are
   // O(1e-6), deep in the fp16 subnormals, and the conv is linear.  Needs bias == null and no input normalisation.
   const unsigned* in_absmax = nullptr;
+  // out = conv + add_src (a tensor shaped like `out`, bias == null): the identity shortcut's share of a ResnetBlock's input gradient
+  // joins the input-gradient conv's epilogue instead of a separate elementwise pass.  The f16x2 kernels (z-slide, flat, small-grid)
+  // honour it and set *add_done = 1 on the host; any other kernel ignores it and the caller adds the tensor itself.
+  const float* add_src = nullptr;
+  int* add_done = nullptr;
   // Output side of a ResnetBlock's second conv on a grid small enough for one workgroup to see a whole (sample, 32-channel tile)
   // (kernels_conv_small.hip): the kernel applies the block's closing GroupNorm + SiLU and adds the shortcut itself,
   //   out = silu(gn(conv + bias)) + (res0 | res1),

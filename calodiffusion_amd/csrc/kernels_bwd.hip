@@ -498,48 +498,62 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __
   *d = accumulate ? *d + s : s;
 }
 
-// The same reduction for T = 1 with hundreds of slots (wgrad1x1_kernel: one per workgroup), two levels in one launch: a block of
-// 256 threads = 16 consecutive outputs x 16 slot lanes; lane j sums slots j, j + 16, ... (16 loads in flight), the 16 lanes are
-// combined in a fixed xor tree.  Deterministic; ~2 rounds of loads for 512 slots where the single-level loop needs 32.
+// The same reduction with hundreds of slots (one per workgroup of the persistent weight-gradient kernels), two levels in one
+// launch: a block of 256 threads = 64 consecutive outputs x 4 slot lanes (one wave each: a wave's load is 256 contiguous bytes of
+// one slot); wave w sums slots w, w + 4, ... with 16 loads in flight, the four waves are combined in a fixed order through LDS.
+// Deterministic; 4 rounds of loads for 256 slots where the single-level loop needs 16.
 __global__ void __launch_bounds__(256) wgrad_reduce1_kernel(const float* __restrict__ partial, float* __restrict__ dw, int A, int Bc,
                                                             int nslots, int accumulate, int transposed_out,
-                                                            size_t sample_stride_partial, size_t sample_stride_out, int b_total, int b_off) {
-  const size_t total = (size_t)A * Bc;
-  const int oi = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const size_t idx = (size_t)blockIdx.x * 16 + oi;
+                                                            size_t sample_stride_partial, size_t sample_stride_out, int b_total, int b_off,
+                                                            int T = 1) {
+  const size_t total = (size_t)A * Bc * T;
+  const int oi = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const size_t idx = (size_t)blockIdx.x * 64 + oi;
   const int n = blockIdx.y;
   float acc = 0.f;
   if (idx < total) {
     const float* p = partial + (size_t)n * sample_stride_partial + idx;
     float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int k = sl;
-    for (; k + 16 * 15 < nslots; k += 16 * 16) {
+    for (; k + 4 * 15 < nslots; k += 4 * 16) {
       float v[16];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) v[j] = p[(size_t)(k + 16 * j) * total];
+      for (int j = 0; j < 16; ++j) v[j] = p[(size_t)(k + 4 * j) * total];
 #pragma unroll
       for (int j = 0; j < 16; ++j) a8[j & 7] += v[j];
     }
-    for (int j = 0; k < nslots; k += 16, ++j) a8[j & 7] += p[(size_t)k * total];
+    for (int j = 0; k < nslots; k += 4, ++j) a8[j & 7] += p[(size_t)k * total];
     acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
   }
-  // lanes of one output: threads oi, oi + 16, ... = lane bits 4, 5 of the wave and the four waves
-  acc += __shfl_xor(acc, 16, 64);
-  acc += __shfl_xor(acc, 32, 64);
-  __shared__ float sR[4][16];
-  if ((threadIdx.x & 63) < 16) sR[threadIdx.x >> 6][oi] = acc;
+  __shared__ float sR[4][64];
+  sR[sl][oi] = acc;
   __syncthreads();
-  if (threadIdx.x < 16 && idx < total) {
+  if (threadIdx.x < 64 && idx < total) {
     const float sum = (sR[0][oi] + sR[1][oi]) + (sR[2][oi] + sR[3][oi]);
     const int cb = idx & 31, ra = (idx >> 5) & 31;
-    const size_t rest = idx >> 10;
+    size_t rest = idx >> 10;
+    const int tap = rest % T;
+    rest /= T;
     const int tilesB = Bc / 32;
     const int tb = rest % tilesB, ta = rest / tilesB;
     const int ga = ta * 32 + ra, gb2 = tb * 32 + cb;
-    const size_t o = transposed_out ? ((size_t)(gb2 + b_off) * A + ga) : ((size_t)ga * b_total + b_off + gb2);
+    const size_t o = (transposed_out ? ((size_t)(gb2 + b_off) * A + ga) : ((size_t)ga * b_total + b_off + gb2)) * T + tap;
     float* d = dw + (size_t)n * sample_stride_out + o;
     *d = accumulate ? *d + sum : sum;
   }
+}
+// the slot reduction of the 27- and 48-tap weight gradients (up to 256 partials, one per workgroup): two-level from 64 slots on
+static void launch_wgrad_reduce_slots(const float* partial, float* dw, int A, int Bc, int T, int nslots, bool accumulate,
+                                      bool transposed_out, int b_total, int b_off, hipStream_t s) {
+  const size_t total = (size_t)A * Bc * T;
+  static const bool one_level = getenv("CD_WGRAD_REDUCE_1LEVEL") != nullptr;
+  if (nslots >= 64 && !one_level)
+    hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3((unsigned)((total + 63) / 64), 1), dim3(256), 0, s, partial, dw, A, Bc, nslots,
+                       accumulate ? 1 : 0, transposed_out ? 1 : 0, (size_t)nslots * total, total, b_total, b_off, T);
+  else
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256), 1), dim3(256), 0, s, partial, dw, A, Bc, T, nslots,
+                       accumulate ? 1 : 0, transposed_out ? 1 : 0, (size_t)nslots * total, total, b_total, b_off);
+  CD_HIP(hipGetLastError());
 }
 
 // First level of the slot reduction when there are many slots (the 1x1 convs write 4096 four-KiB partials: a single-level
@@ -617,10 +631,7 @@ void launch_wgrad(const float* g, int A, Dims3 dg, const float* x, int Bc, int x
       std::snprintf(cat16, sizeof cat16, "wgrad T27 C%dx%d n%ld", A, Bc, (long)dg.vox());
       prof::Scope scope16(cat16, s, 2.0 * 27 * A * Bc * (double)dg.vox() * batch, 4.0 * batch * (double)dg.vox() * (A + Bc));
       CD_REQUIRE(try_launch_wgrad_f16x2(g, A, x, Bc, xld, xoff, dg, batch, partial, gmax_word, &nblk16, s, xcoef), "internal: wgrad f16x2");
-      const size_t total = (size_t)A * Bc * 27;
-      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256), 1), dim3(256), 0, s, partial, dw, A, Bc, 27, nblk16,
-                         accumulate ? 1 : 0, transposed_out ? 1 : 0, (size_t)nblk16 * total, total, b_total, b_off);
-      CD_HIP(hipGetLastError());
+      launch_wgrad_reduce_slots(partial, dw, A, Bc, 27, nblk16, accumulate, transposed_out, b_total, b_off, s);
       return;
     }
   }
@@ -656,10 +667,7 @@ void launch_wgrad(const float* g, int A, Dims3 dg, const float* x, int Bc, int x
       }
       hipLaunchKernelGGL(wgrad_flat_kernel<4>, dim3(nblk, tiles), dim3(64 * 7), lds, s, f);
       CD_HIP(hipGetLastError());
-      const size_t total = (size_t)A * Bc * 27;
-      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256), 1), dim3(256), 0, s, partial, dw, A, Bc, 27, nblk,
-                         accumulate ? 1 : 0, transposed_out ? 1 : 0, (size_t)nblk * total, total, b_total, b_off);
-      CD_HIP(hipGetLastError());
+      launch_wgrad_reduce_slots(partial, dw, A, Bc, 27, nblk, accumulate, transposed_out, b_total, b_off, s);
       return;
     }
   }
@@ -672,10 +680,7 @@ void launch_wgrad(const float* g, int A, Dims3 dg, const float* x, int Bc, int x
     std::snprintf(cats, sizeof cats, "wgrad T%d C%dx%d n%ld", Ts, A, Bc, (long)dg.vox());
     prof::Scope scope_s(cats, s, 2.0 * Ts * A * Bc * (double)dg.vox() * batch, 4.0 * batch * ((double)dg.vox() * A + (double)dx.vox() * Bc));
     if (try_launch_wgrad_strided_f16x2(g, A, dg, x, Bc, xld, xoff, dx, kd, sz, batch, partial, max_slots, &nblk, s)) {
-      const size_t total = (size_t)A * Bc * Ts;
-      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256), 1), dim3(256), 0, s, partial, dw, A, Bc, Ts, nblk,
-                         accumulate ? 1 : 0, transposed_out ? 1 : 0, (size_t)nblk * total, total, b_total, b_off);
-      CD_HIP(hipGetLastError());
+      launch_wgrad_reduce_slots(partial, dw, A, Bc, Ts, nblk, accumulate, transposed_out, b_total, b_off, s);
       return;
     }
   }
@@ -687,7 +692,7 @@ void launch_wgrad(const float* g, int A, Dims3 dg, const float* x, int Bc, int x
     prof::Scope scope1(cat1, s, 2.0 * A * Bc * (double)dg.vox() * batch, 4.0 * batch * (double)dg.vox() * (A + Bc));
     if (try_launch_wgrad1x1(g, A, x, Bc, xld, xoff, dg.vox(), batch, per_sample, partial, cap_slots, &ns, s)) {
       const size_t total = (size_t)A * Bc;
-      dim3 rg1((unsigned)((total + 15) / 16), per_sample ? batch : 1);
+      dim3 rg1((unsigned)((total + 63) / 64), per_sample ? batch : 1);
       hipLaunchKernelGGL(wgrad_reduce1_kernel, rg1, dim3(256), 0, s, partial, dw, A, Bc, ns, accumulate ? 1 : 0,
                          transposed_out ? 1 : 0, (size_t)ns * total, total, b_total, b_off);
       CD_HIP(hipGetLastError());
@@ -758,8 +763,10 @@ void launch_bias_grad(const float* part, int units, int batch, int channels, flo
 //       (dh = A dz + Bh h + C0 with A = rstd gamma, Bh = -rstd^2 m2, C0 = rstd (-m1 + mean rstd m2): gn_bwd_finalize_kernel)
 //   the bias of a convolution that adds into y (a ResnetBlock's 1x1 shortcut):  sum_v dy.
 // ------------------------------------------------------------------------------------------------------------
+// (on the transcendental unit, like the forward's cd_fast_silu: ~3 ulp; libm's expf and a division were ~40 vector instructions
+// per element in kernels that stream two tensors)
 __device__ __forceinline__ float silu_grad(float z) {
-  const float sg = 1.f / (1.f + expf(-z));
+  const float sg = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(z * -1.4426950408889634f));
   return sg * (1.f + z * (1.f - sg));
 }
 
@@ -782,7 +789,29 @@ __global__ void __launch_bounds__(256) gn_bwd_stats_kernel(const float* __restri
     for (int e = 0; e < 4; ++e) cf[e] = *(const f32x4*)(coef + ((size_t)b * channels + c + e) * 4);
     const float mean = stat[((size_t)b * groups + c / cpg) * 2], rstd = stat[((size_t)b * groups + c / cpg) * 2 + 1];
     const size_t sb = (size_t)b * vox * channels + c;
-    for (int64_t v = v0 + row; v < v1; v += rows) {
+    // four voxels per trip: eight loads in flight (one pair per trip ran at 3.2 TB/s at level 0); the order of the additions into
+    // a thread's sums is that of the plain loop
+    int64_t v = v0 + row;
+    for (; v + 3 * rows < v1; v += 4 * rows) {
+      f32x4 g4[4], h4[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        g4[k] = *(const f32x4*)(dy + sb + (size_t)(v + k * rows) * channels);
+        h4[k] = *(const f32x4*)(h + sb + (size_t)(v + k * rows) * channels);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float z = cf[e][0] * h4[k][e] + cf[e][1];
+          const float dz = silu ? g4[k][e] * silu_grad(z) : g4[k][e];
+          s0[e] += dz;
+          s1[e] += dz * (h4[k][e] - mean) * rstd;
+          s2[e] += g4[k][e];
+          s3[e] += h4[k][e] - mean;
+        }
+    }
+    for (; v < v1; v += rows) {
       const f32x4 g = *(const f32x4*)(dy + sb + (size_t)v * channels);
       const f32x4 hv = *(const f32x4*)(h + sb + (size_t)v * channels);
 #pragma unroll
@@ -966,7 +995,28 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const float* __restri
     gc[e] = fold.part ? *(const f32x4*)sGc[c + e] : *(const f32x4*)(gcoef + ((size_t)b * channels + c + e) * 4);
   }
   const size_t sb = (size_t)b * vox * channels + c;
-  for (int64_t v = v0 + row; v < v1; v += rows) {
+  int64_t v = v0 + row;
+  for (; v + 3 * rows < v1; v += 4 * rows) {  // four voxels per trip: eight loads in flight
+    f32x4 g4[4], h4[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      g4[k] = *(const f32x4*)(dy + sb + (size_t)(v + k * rows) * channels);
+      h4[k] = *(const f32x4*)(h + sb + (size_t)(v + k * rows) * channels);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float z = cf[e][0] * h4[k][e] + cf[e][1];
+        const float dz = silu ? g4[k][e] * silu_grad(z) : g4[k][e];
+        o[e] = gc[e][0] * dz + gc[e][1] * h4[k][e] + gc[e][2];
+      }
+      *(f32x4*)(dh + sb + (size_t)(v + k * rows) * channels) = o;
+      am = fmaxf(am, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
+    }
+  }
+  for (; v < v1; v += rows) {
     const f32x4 g = *(const f32x4*)(dy + sb + (size_t)v * channels);
     const f32x4 hv = *(const f32x4*)(h + sb + (size_t)v * channels);
     f32x4 o;

@@ -383,6 +383,7 @@ struct ConvFlatArgs {
   GnDefer defer;          // split-16 kernels: fold the input normalisation in the prologue (table at lds + coef_lds_off)
   int coef_lds_off = 0;
   const unsigned* in_absmax = nullptr;  // f16x2: power-of-two input rescaling (ConvFusion::in_absmax)
+  const float* add_src = nullptr;       // split-16 kernels: out = conv + add_src (ConvFusion::add_src)
 };
 
 template <int VT, int CT>
@@ -950,6 +951,23 @@ __global__ void __launch_bounds__(512, (VT * CT * (NTERM == 2 ? 2 : 1) <= 2 ? 3 
   float bv[CT];
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) bv[ct] = a.bias ? a.bias[(ct0 + ct) * 32 + col] : 0.f;
+  if (a.add_src) {  // (the loads of all rows first: one round trip, not one per row)
+    const float* addb = a.add_src + (size_t)b * voxo * a.cout;
+#pragma unroll
+    for (int vt = 0; vt < VT; ++vt) {
+      float ad[16][CT];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int off = __shfl(ooff[vt], (r & 3) + 8 * (r >> 2) + 4 * half, 64);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) ad[r][ct] = off >= 0 ? addb[off + (ct0 + ct) * 32 + col] : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[vt][ct][r] += ad[r][ct];
+    }
+  }
 #pragma unroll
   for (int vt = 0; vt < VT; ++vt) {
 #pragma unroll
@@ -1638,6 +1656,7 @@ static bool try_launch_conv3_flat(const float* in0, int c0, const float* in1, in
     a.R = 32 * NT; a.P = planes(NT); a.cout = cout; a.CTtot = CTtot;
     a.dbg = getenv("CD_FLAT_DBG") ? atoi(getenv("CD_FLAT_DBG")) : 0;
     a.coef = fu.coef; a.act = fu.act; a.ch_part = fu.ch_part; a.status = fu.status; a.in_absmax = fu.in_absmax;
+    a.add_src = prec >= 2 && !bias ? fu.add_src : nullptr;  // (the split-16 kernels only: the caller adds the tensor itself otherwise)
     size_t lds = ((size_t)a.P * HW + 1) * vox_bytes;
     const size_t red = (size_t)(NT / VT) * CT * 32 * 2 * 4;  // cross-wave reduction scratch of the stats epilogue
     if (lds < red) lds = red;
@@ -1658,6 +1677,7 @@ static bool try_launch_conv3_flat(const float* in0, int c0, const float* in1, in
       if constexpr (V * C <= 4) launch_flat3_inst<V, C, 2>(a, grid, threads, lds, s, geo); \
       else return false;                                                     \
     } else launch_flat_inst<V, C>(a, grid, threads, lds, s);                 \
+    if (a.add_src && fu.add_done) *fu.add_done = 1;                          \
     return true;                                                             \
   }
     CD_FLAT_CASE(1, 1) CD_FLAT_CASE(2, 1) CD_FLAT_CASE(3, 1) CD_FLAT_CASE(4, 1)

@@ -40,6 +40,7 @@ struct ConvSmallArgs {
   GnDefer defer;      // input normalisation folded in the prologue (table at cs_lds + coef_lds_off) instead of `coef`
   int coef_lds_off;
   const unsigned* in_absmax;  // power-of-two input rescaling (ConvFusion::in_absmax) or null
+  const float* add_src;       // plain output only: out = conv + add_src (ConvFusion::add_src) or null
   // closing GroupNorm + SiLU + shortcut of a ResnetBlock in the epilogue (ConvFusion::GnOut), gamma == null: plain conv output
   const float *gn_gamma, *gn_beta;
   int gn_cpg;                 // channels per group (divides 32: a group never straddles two channel tiles)
@@ -241,6 +242,14 @@ __global__ void __launch_bounds__(CS_NW * 64, 1) conv_small_f16x2_kernel(ConvSma
     s1 = s2 = 0.f;
     if (wave < NT) {
       float* o = store_to ? store_to + ((size_t)b * vox + wave * 32) * ld + ct * 32 + col : nullptr;
+      const float* ad = (a.add_src && store_to == a.out) ? a.add_src + ((size_t)b * vox + wave * 32) * ld + ct * 32 + col : nullptr;
+      if (ad) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (wave * 32 + row < vox) hold[r] += ad[(size_t)row * ld];
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -434,6 +443,7 @@ bool try_launch_conv_small(const float* in0, int c0, const float* in1, int c1, c
   a.wpk = (const u32x4*)wpk_f16x2; a.CTtot = cout / 32; a.bias = bias; a.out = out; a.cout = cout; a.ch_part = fu.ch_part;
   a.D = g.in.d; a.H = g.in.h; a.W = g.in.w; a.VB = VB; a.status = fu.status;
   a.defer = fu.defer; a.coef_lds_off = (int)coef_off; a.in_absmax = fu.in_absmax;
+  a.add_src = !bias ? fu.add_src : nullptr;
   a.gn_gamma = nullptr; a.gn_beta = nullptr; a.gn_cpg = 0; a.res0 = a.res1 = nullptr; a.res_c0 = 0; a.part_out = nullptr;
   a.wpk2 = nullptr; a.bias2 = nullptr; a.gn1_gamma = a.gn1_beta = a.emb = nullptr; a.emb_ld = 0; a.h1 = nullptr;
   const ConvFusion::GnOut& go = fu.gn_out;
@@ -450,6 +460,7 @@ bool try_launch_conv_small(const float* in0, int c0, const float* in1, int c1, c
     default: launch_small_inst<4>(a, grid, lds, s); break;
   }
   if (fu.units) *fu.units = (fu.ch_part && !a.gn_gamma) ? 1 : 0;
+  if (a.add_src && !a.gn_gamma && fu.add_done) *fu.add_done = 1;
   return true;
 }
 
@@ -478,7 +489,7 @@ bool try_launch_res_block_small(const float* x0, int c0, const float* x1, int c1
   a.in0 = x0; a.in1 = x1; a.c0 = c0; a.c1 = c1; a.coef = nullptr; a.act = 0;
   a.wpk = (const u32x4*)w1_f16x2; a.CTtot = 1; a.bias = b1; a.out = out; a.cout = 32; a.ch_part = nullptr;
   a.D = dims.d; a.H = dims.h; a.W = dims.w; a.VB = VB; a.status = status;
-  a.defer = GnDefer(); a.coef_lds_off = (int)coef_off; a.in_absmax = nullptr;
+  a.defer = GnDefer(); a.coef_lds_off = (int)coef_off; a.in_absmax = nullptr; a.add_src = nullptr;
   a.gn_gamma = gn2_gamma; a.gn_beta = gn2_beta; a.gn_cpg = 32 / groups; a.res0 = res0; a.res1 = res1; a.res_c0 = res_c0;
   a.part_out = part_out;
   a.wpk2 = (const u32x4*)w2_f16x2; a.bias2 = b2; a.gn1_gamma = gn1_gamma; a.gn1_beta = gn1_beta; a.emb = emb; a.emb_ld = emb_ld;

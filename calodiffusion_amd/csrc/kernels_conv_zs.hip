@@ -107,6 +107,7 @@ struct ConvZsArgs {
   const u32x4* wpk;  // f16x2 image, already offset to the first k-step of these 32 input channels
   int CTtot;
   const float* bias; // null for a continuation launch
+  long long acc_delta = 0;  // continuation instances read what they add to at out + acc_delta bytes (ConvFusion::add_src; 0: out itself)
   float* out;        // (B, vox, cout)
   int cout;
   float* ch_part;    // [B][nchunk*4][cout][2] or null
@@ -469,7 +470,7 @@ __device__ __forceinline__ void zs_helper_wave(const ConvZsArgs& a, char* lds, c
     if (ACC) {  // continuation launch of a wider-K conv: add to what the previous launch stored
       float prev[8];
 #pragma unroll
-      for (int r = 0; r < 8; ++r) prev[r] = *dst[r];
+      for (int r = 0; r < 8; ++r) prev[r] = ok[r] ? *(const float*)((const char*)dst[r] + a.acc_delta) : 0.f;
 #pragma unroll
       for (int r = 0; r < 8; ++r) sum[r] = sum[r] * ginv + prev[r];
     } else {
@@ -961,8 +962,9 @@ __device__ __forceinline__ void z3_wave(const ConvZsArgs& a, char* lds) {
     }
     f32x2 prev[4];
     if (ACC && full) {
+      const char* tbs = (const char*)tb + a.acc_delta;
 #pragma unroll
-      for (int r = 0; r < 8; ++r) prev[r >> 1][r & 1] = *(const float*)((const char*)tb + (unsigned)off[r]);
+      for (int r = 0; r < 8; ++r) prev[r >> 1][r & 1] = *(const float*)(tbs + (unsigned)off[r]);
     }
     f32x2 sum[4];  // k-step 0's slice + k-step 1's (fp32 addition commutes: the same sum whichever wave reduces)
     {
@@ -1001,7 +1003,7 @@ __device__ __forceinline__ void z3_wave(const ConvZsArgs& a, char* lds) {
         if (vt + rrow8[r] < G.cend) {  // (chunk tail)
           float* dst = (float*)((char*)tb + (unsigned)off[r]);
           float v = sum[r >> 1][r & 1];
-          if (ACC) v += *dst;  // continuation launch of a wider-K conv: add to what the previous launch stored
+          if (ACC) v += *(const float*)((const char*)dst + a.acc_delta);  // continuation launch: add to what the previous launch stored
           v += bv1;
           *dst = v;
           s1[r & 1] += v;
@@ -1202,6 +1204,8 @@ bool try_launch_conv_zslide(const float* in0, int c0, const float* in1, int c1, 
     a.wpk = (const u32x4*)wpk_f16x2 + (size_t)(kb * 2) * 27 * CTtot * 128;
     a.CTtot = CTtot;
     a.bias = kb == 0 ? bias : nullptr;
+    const bool add0 = kb == 0 && fu.add_src && !bias;  // out = conv + add_src: the first K-block runs as a continuation of add_src
+    a.acc_delta = add0 ? (long long)((const char*)fu.add_src - (const char*)out) : 0;
     a.out = out;
     a.cout = cout;
     a.ch_part = kb == nblk - 1 ? fu.ch_part : nullptr;
@@ -1253,13 +1257,14 @@ bool try_launch_conv_zslide(const float* in0, int c0, const float* in1, int c1, 
     }
 #endif
     if (v1) {
-      if (kb == 0) hipLaunchKernelGGL(conv_zslide_f16x2_kernel<false>, grid, dim3(512), lds, s, a);
+      if (kb == 0 && !add0) hipLaunchKernelGGL(conv_zslide_f16x2_kernel<false>, grid, dim3(512), lds, s, a);
       else hipLaunchKernelGGL(conv_zslide_f16x2_kernel<true>, grid, dim3(512), lds, s, a);
     } else {
-      z3_launch(a, kb != 0, grid, lds, s);
+      z3_launch(a, kb != 0 || add0, grid, lds, s);
     }
     CD_HIP(hipGetLastError());
   }
+  if (fu.add_src && !bias && fu.add_done) *fu.add_done = 1;
   if (fu.units) *fu.units = nstrip * nchunk * 4;
   return true;
 }

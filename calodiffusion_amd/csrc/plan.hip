@@ -748,7 +748,10 @@ void bias_grad(Run& r, const float* dy, int C, int64_t vox, float* db) {
 // img (optional): the input gradient's weight images already packed for this step (CdPlan::dg); without them they are packed here.
 // xcoef (optional, single-source x0 only): the conv's input was silu(coef[0] x0 + coef[1]) + coef[2] (see launch_wgrad)
 void conv_backward(Run& r, const float* x0, int c0, const float* x1, int c1, const float* w_raw, const float* dy, float* dx,
-                   float* dw, float* db, int cout, const ConvGeom& g, const DgImg* img = nullptr, const float* xcoef = nullptr) {
+                   float* dw, float* db, int cout, const ConvGeom& g, const DgImg* img = nullptr, const float* xcoef = nullptr,
+                   // dx = (input gradient) + dx_add, a tensor shaped like dx, where the kernel that runs can add it in its
+                   // epilogue (3x3x3 stride 1 on the fp16 pipe): *dx_added says whether it did
+                   const float* dx_add = nullptr, int* dx_added = nullptr) {
   Arena* ws = r.ws;
   const int cin = c0 + c1, T = g.kd * g.kh * g.kw;
   const bool pre = img && img->pk;
@@ -775,6 +778,7 @@ void conv_backward(Run& r, const float* x0, int c0, const float* x1, int c1, con
         ConvFusion fu;
         fu.wpk_bf16x3 = pre ? img->pk3 : wp3;
         fu.in_absmax = launch_absmax_bits(dy, (size_t)r.B * g.out.vox() * cout, r.s);  // also serves the weight gradient below
+        fu.add_src = dx_add; fu.add_done = dx_added;
         launch_conv_mfma(dy, cout, nullptr, 0, pre ? img->pk : wp, nullptr, dx, r.B, cin, gd, r.s, fu);
       }
       if (wp3) ws->release(wp3);
