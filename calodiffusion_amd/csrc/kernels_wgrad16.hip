@@ -147,61 +147,52 @@ __global__ void __launch_bounds__(512, 1) wgrad_f16x2_kernel(Wgrad16Args a) {
     const int n = u / a.units_per_sample, uz = u - n * a.units_per_sample;
     const int z0 = uz * WG_NZ;
     __syncthreads();  // previous unit fully consumed
-    // ---- stage dy rows (scaled) ---------------------------------------------------------------------------------
+    // ---- stage the unit: dy rows (scaled) and x planes z0-1 .. z0+NZ (zero outside the sample; interior rows + phi halo copies).
+    // One item = a 16-byte channel quad of a voxel: items [0, R*8) are dy's, the rest x's.  Six items per thread and trip (eight spill: the accumulators of four taps
+    // are live across the unit loop), their loads all issued before the first is converted (round 4: dy and x ran as separate loops of four -- five dependent memory round
+    // trips per unit, ~10 us of a 14 us unit at level 0, with the matrix cores idle: one workgroup owns the CU's LDS).
     {
       const float* gs = a.g + ((size_t)n * vox + (size_t)z0 * PV) * a.A + ta * 32;
       const int nvalid = min(R, vox - z0 * PV);
-      for (int i0 = tid; i0 < R * 8; i0 += 4 * 512) {
-        f32x4 val[4];
+      const float* xs = a.x + (size_t)n * vox * a.xld + a.xoff + tb * 32;
+      const int ndy = R * 8, nst = (WG_NZ + 2) * PV * 8, nall = ndy + nst;
+      f32x4 xc[4];  // (a thread stages the same channel quad of every voxel: item & 7 == tid & 7)
+      if (a.xcoef) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int i = i0 + k * 512;
+        for (int e = 0; e < 4; ++e) xc[e] = *(const f32x4*)(a.xcoef + ((size_t)n * a.xld + a.xoff + tb * 32 + (tid & 7) * 4 + e) * 4);
+      }
+      for (int i0 = tid; i0 < nall; i0 += 6 * 512) {
+        f32x4 val[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          const int it = i0 + k * 512;
           val[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (i < R * 8 && (i >> 3) < nvalid) val[k] = *(const f32x4*)(gs + (size_t)(i >> 3) * a.A + (i & 7) * 4);
+          if (it < ndy) {
+            if ((it >> 3) < nvalid) val[k] = *(const f32x4*)(gs + (size_t)(it >> 3) * a.A + (it & 7) * 4);
+          } else if (it < nall) {
+            const int i = it - ndy, v = i >> 3;
+            const int zl = div_pv(v), z = z0 - 1 + zl;
+            if (z >= 0 && z < a.D) val[k] = *(const f32x4*)(xs + ((size_t)z * PV + (v - zl * PV)) * a.xld + (i & 7) * 4);
+          }
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int i = i0 + k * 512;
-          if (i < R * 8) {
-            const int v = i >> 3, qd = i & 7;
+        for (int k = 0; k < 6; ++k) {
+          const int it = i0 + k * 512;
+          if (it < ndy) {
+            const int v = it >> 3, qd = it & 7;
             u32x2 t1, t2;
             split2(val[k] * gscale, t1, t2);
             char* d = gL + v * WG_VB + (qd >> 2) * 64 + (qd & 3) * 8;
             *(u32x2*)d = t1;
             *(u32x2*)(d + 32) = t2;
-          }
-        }
-      }
-      // ---- stage x planes z0-1 .. z0+NZ (zero outside the sample), interior rows + phi halo copies ------------------
-      const float* xs = a.x + (size_t)n * vox * a.xld + a.xoff + tb * 32;
-      const int nst = (WG_NZ + 2) * PV * 8;
-      f32x4 xc[4];  // (a thread stages the same channel quad of every voxel: i & 7 == tid & 7)
-      if (a.xcoef) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) xc[e] = *(const f32x4*)(a.xcoef + ((size_t)n * a.xld + a.xoff + tb * 32 + (tid & 7) * 4 + e) * 4);
-      }
-      for (int i0 = tid; i0 < nst; i0 += 4 * 512) {
-        f32x4 val[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int i = i0 + k * 512;
-          const int v = i >> 3;
-          const int zl = div_pv(v), z = z0 - 1 + zl;
-          val[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (i < nst && z >= 0 && z < a.D) {
-            val[k] = *(const f32x4*)(xs + ((size_t)z * PV + (v - zl * PV)) * a.xld + (i & 7) * 4);
-            if (a.xcoef) {
+          } else if (it < nall) {
+            const int i = it - ndy, v = i >> 3, qd = i & 7;
+            const int zl = div_pv(v), p = v - zl * PV, h = div_w(p), w = p - h * W;
+            const int z = z0 - 1 + zl;
+            if (a.xcoef && z >= 0 && z < a.D) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) val[k][e] = cd_fast_silu(xc[e][0] * val[k][e] + xc[e][1]) + xc[e][2];
             }
-          }
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int i = i0 + k * 512;
-          if (i < nst) {
-            const int v = i >> 3, qd = i & 7;
-            const int zl = div_pv(v), p = v - zl * PV, h = div_w(p), w = p - h * W;
             u32x2 t1, t2;
             split2(val[k], t1, t2);
             char* d = xL + ((zl * (H + 2) + (h + 1)) * pitch + w) * WG_VB + (qd >> 2) * 64 + (qd & 3) * 8;
