@@ -146,9 +146,30 @@ __device__ __forceinline__ void load_coef(const AttnArgs& a, int b, int half, f3
     }
 }
 
+// Whether the passes re-read the coefficients per tile from an LDS table instead of holding them in 32 NCH registers: the moment
+// form of pass 1 has none to spare, and from 64 channels on both passes spilled (33 / 116 / 194 registers at 64 / 96 / 128 channels)
+template <int NCH, bool MOM>
+struct AttnCfl {
+  static constexpr bool value = MOM || NCH >= 2;
+};
+// the table: [half][ch][8] quads; returns this lane's half.  Call from every thread (a barrier follows the fill).
+template <int NCH>
+__device__ __forceinline__ const f32x4* attn_cf_table(const f32x4 (&cf)[NCH][8], f32x4* table) {
+  const int lane = threadIdx.x & 63, half = lane >> 5;
+  if (threadIdx.x < 64 && (lane & 31) == 0) {
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) table[(half * NCH + ch) * 8 + i] = cf[ch][i];
+  }
+  __syncthreads();
+  return table + half * NCH * 8;
+}
+
 // pass 1 of sample b over tiles [t0, t1): partial `split` of the sample
 template <int NCH, bool MOM = false>
-__device__ __forceinline__ void attn_pass1(const AttnArgs& a, int b, int split, int64_t t0, int64_t t1, const f32x4 (&cf)[NCH][8]) {
+__device__ __forceinline__ void attn_pass1(const AttnArgs& a, int b, int split, int64_t t0, int64_t t1, const f32x4 (&cf)[NCH][8],
+                                           const f32x4* cf_lds = nullptr /* AttnCfl: the table of attn_cf_table */) {
   __shared__ float sMax[8][32];
   __shared__ float sSum[16][32];
   __shared__ float sCtx[8][1024];
@@ -169,17 +190,7 @@ __device__ __forceinline__ void attn_pass1(const AttnArgs& a, int b, int split, 
   __shared__ __attribute__((aligned(16))) float sQt[MOM ? 8 * 32 * 36 : 4];
   f32x16 mS, mSB;
   float msum = 0.f;
-  __shared__ __attribute__((aligned(16))) f32x4 sCf[MOM ? 2 * NCH * 8 : 1];
-  const f32x4* cf_lds = nullptr;
   if constexpr (MOM) {
-    if (wave == 0 && col == 0) {
-#pragma unroll
-      for (int ch = 0; ch < NCH; ++ch)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) sCf[(half * NCH + ch) * 8 + i] = cf[ch][i];
-    }
-    __syncthreads();
-    cf_lds = sCf + half * NCH * 8;
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
       wq1[ks] = a.wqkv[(size_t)(ks * 3 + 0) * 128 + lane];
@@ -246,7 +257,7 @@ __device__ __forceinline__ void attn_pass1(const AttnArgs& a, int b, int split, 
   for (int64_t tt = t0 + wave; tt < t1; tt += 8) {
     u32x4 x1[NKS], x2[NKS];
     load_raw<NCH>(a, b, tt, tlast, col, half, raw);
-    norm_split<NCH, MOM>(a, tt * 32, col, cf, raw, x1, x2, amax, cf_lds);
+    norm_split<NCH, AttnCfl<NCH, MOM>::value>(a, tt * 32, col, cf, raw, x1, x2, amax, cf_lds);
     const f32x16 k = project(x1, x2, wk1, wk2);
     const f32x16 v = project(x1, x2, wv1, wv2);
     const bool full = tt * 32 + 32 <= a.vox;  // (only a sample's last tile can be partial)
@@ -408,7 +419,10 @@ __global__ void __launch_bounds__(512) attn_kv_context_kernel(AttnArgs a) {
   const int64_t t1 = (t0 + a.tiles_per_wg < T) ? t0 + a.tiles_per_wg : T;
   f32x4 cf[NCH][8];
   load_coef<NCH>(a, b, half, cf);
-  attn_pass1<NCH, MOM>(a, b, split, t0, t1, cf);
+  __shared__ __attribute__((aligned(16))) f32x4 sCfT[2 * NCH * 8];
+  const f32x4* cfl = nullptr;
+  if constexpr (AttnCfl<NCH, MOM>::value) cfl = attn_cf_table<NCH>(cf, sCfT);
+  attn_pass1<NCH, MOM>(a, b, split, t0, t1, cf, cfl);
 }
 
 // Merge of the pass-1 partials and fold of the context into the output projection, by every workgroup of pass 2 for its own
@@ -531,7 +545,7 @@ __device__ __forceinline__ void attn_fold_weights(const AttnArgs& a, int b, floa
 // MOM: the output is the block's (closing GroupNorm from the fold's closed form, residual added), no channel sums
 template <int NCH, bool MOM = false>
 __device__ __forceinline__ void attn_pass2(const AttnArgs& a, int b, int unit, int nunits, int64_t t0, int64_t t1,
-                                           const f32x4 (&cf)[NCH][8], float* trbuf = nullptr) {
+                                           const f32x4 (&cf)[NCH][8], float* trbuf = nullptr, const f32x4* cf_lds = nullptr) {
   __shared__ float sRed[MOM ? 1 : 8][NCH * 32][2];
   __shared__ float sOut[MOM ? NCH * 32 : 1][2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -605,7 +619,7 @@ __device__ __forceinline__ void attn_pass2(const AttnArgs& a, int b, int unit, i
     if (t >= t1) break;
     u32x4 x1[NKS], x2[NKS];
     if (!PRE) load_raw<NCH>(a, b, t, tlast, col, half, raw[d]);
-    norm_split<NCH>(a, t * 32, col, cf, raw[d], x1, x2, amax);
+    norm_split<NCH, AttnCfl<NCH, MOM>::value>(a, t * 32, col, cf, raw[d], x1, x2, amax, cf_lds);
     if (PRE && t + 8 * DEPTH < t1) load_raw<NCH>(a, b, t + 8 * DEPTH, tlast, col, half, raw[d]);
     // q^T[d][n]: A = W_q (row d), B = xn^T (column n); the registers of a lane are 16 channels d of its voxel n = col
     f32x16 q = zero16, qb = zero16;
@@ -730,7 +744,10 @@ __global__ void __launch_bounds__(512) attn_out_kernel(AttnArgs a) {
   f32x4 cf[NCH][8];
   load_coef<NCH>(a, b, half, cf);
   __shared__ __attribute__((aligned(16))) float sTr[8 * 32 * 36];  // per-wave output tile on its way to row-major quads
-  attn_pass2<NCH, MOM>(a, b, unit, (int)gridDim.x, t0, t1, cf, sTr);
+  __shared__ __attribute__((aligned(16))) f32x4 sCfT[2 * NCH * 8];
+  const f32x4* cfl = nullptr;
+  if constexpr (AttnCfl<NCH, MOM>::value) cfl = attn_cf_table<NCH>(cf, sCfT);
+  attn_pass2<NCH, MOM>(a, b, unit, (int)gridDim.x, t0, t1, cf, sTr, cfl);
 }
 
 // The whole Residual(PreNorm(LinearAttention)) of one sample in ONE workgroup, for grids of a few hundred voxels (Dataset-2 below
@@ -747,10 +764,13 @@ __global__ void __launch_bounds__(512) attn_small_kernel(AttnArgs a) {
   const int64_t T = (a.vox + 31) / 32;
   f32x4 cf[NCH][8];
   load_coef<NCH>(a, b, half, cf);
-  attn_pass1<NCH>(a, b, 0, 0, T, cf);
+  __shared__ __attribute__((aligned(16))) f32x4 sCfT[2 * NCH * 8];
+  const f32x4* cfl = nullptr;
+  if constexpr (AttnCfl<NCH, false>::value) cfl = attn_cf_table<NCH>(cf, sCfT);
+  attn_pass1<NCH>(a, b, 0, 0, T, cf, cfl);
   __threadfence_block();
   __syncthreads();  // the partial of this sample is in memory (written and read by this workgroup only)
-  attn_pass2<NCH>(a, b, 0, 1, 0, T, cf);
+  attn_pass2<NCH>(a, b, 0, 1, 0, T, cf, nullptr, cfl);
   __threadfence_block();
   __syncthreads();  // y and its channel sums are in memory
   const int C = NCH * 32;
@@ -839,9 +859,12 @@ __global__ void __launch_bounds__(512) attn_coop_kernel(AttnArgs a) {
   unsigned* const sync = a.sync + (size_t)b * 2;
   f32x4 cf[NCH][8];
   load_coef<NCH>(a, b, half, cf);
-  attn_pass1<NCH>(a, b, part, t0, t1, cf);
+  __shared__ __attribute__((aligned(16))) f32x4 sCfT[2 * NCH * 8];
+  const f32x4* cfl = nullptr;
+  if constexpr (AttnCfl<NCH, false>::value) cfl = attn_cf_table<NCH>(cf, sCfT);
+  attn_pass1<NCH>(a, b, part, t0, t1, cf, cfl);
   attn_group_barrier(sync, P, a.status);
-  attn_pass2<NCH>(a, b, part, P, t0, t1, cf);
+  attn_pass2<NCH>(a, b, part, P, t0, t1, cf, nullptr, cfl);
   attn_group_barrier(sync, P, a.status);
   const int C = NCH * 32;
   if (tid == 0) {
