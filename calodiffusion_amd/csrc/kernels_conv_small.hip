@@ -57,7 +57,16 @@ struct ConvSmallArgs {
   float* h1;
 };
 
-constexpr int CS_PD = 6;  // weight fragments requested this many pairs ahead
+// weight fragments requested this many pairs ahead: 6 with four waves (512 registers each); 2 with eight (256 each: at 6 the kernel
+// spilled 78 registers -- HGCal 57.6 showers/s at 6, 59.3 at 3, 59.8 at 2, same box -- and the second wave of a SIMD covers what the
+// shallower ring exposes)
+#ifndef CS_PD8
+#define CS_PD8 2
+#endif
+template <int NW>
+struct CsPd {
+  static constexpr int value = NW == 8 ? CS_PD8 : 6;
+};
 // waves per workgroup: the (tap, k-step) pairs of a conv are dealt round-robin to them (K split).  4 where the step is power-bound
 // (Dataset-2's deepest level: 8 waves measured the same step time for twice the partial exchange); 8 on four-tile samples (HGCal's 7 x 3 x 5
 // grid at batch 16 lights 48 CUs, nothing is power-bound there: 1.466 -> 1.442 ms per denoise step, same-box A/B, round 4).  The choice
@@ -65,6 +74,7 @@ constexpr int CS_PD = 6;  // weight fragments requested this many pairs ahead
 template <int NT, int CS_NW>  // NT: row tiles (32 voxels each) of the sample: ceil(vox / 32) <= 4
 __global__ void __launch_bounds__(CS_NW * 64, 1) conv_small_f16x2_kernel(ConvSmallArgs a) {
   constexpr int CS_THREADS = CS_NW * 64;
+  constexpr int CS_PD = CsPd<CS_NW>::value;
   extern __shared__ __attribute__((aligned(16))) char cs_lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
   const int b = blockIdx.x, ct = blockIdx.y;
@@ -401,7 +411,10 @@ __global__ void __launch_bounds__(CS_NW * 64, 1) conv_small_f16x2_kernel(ConvSma
   }
 }
 
-constexpr int cs_waves_for(int NT) { return NT >= 4 ? 8 : 4; }
+#ifndef CS_NW8_FROM
+#define CS_NW8_FROM 4
+#endif
+constexpr int cs_waves_for(int NT) { return NT >= CS_NW8_FROM ? 8 : 4; }
 template <int NT>
 void launch_small_inst(const ConvSmallArgs& a, dim3 grid, size_t lds, hipStream_t s) {
   constexpr int NW = cs_waves_for(NT);

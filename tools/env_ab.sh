@@ -5,6 +5,6 @@ mkdir -p gpurun_out/envab
 for rep in 1 2; do
   for v in default "$kv"; do
     if [ "$v" = default ]; then pre=""; else pre="$v"; fi
-    env $pre timeout -k 10 300 python bench.py --no-extra --steps 2 "$@" 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v $*', round(d['value'],2), round(d['config']['denoise_ms'],4))" | tee -a gpurun_out/envab/ab.log
+    env $pre timeout -k 10 300 python bench.py --no-extra --steps 2 "$@" 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v $*', round(d['value'],2), round(d['config'].get('denoise_ms', d['ms_per_step']),4))" | tee -a gpurun_out/envab/ab.log
   done
 done
