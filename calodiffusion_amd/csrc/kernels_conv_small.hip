@@ -59,7 +59,9 @@ struct ConvSmallArgs {
 
 // weight fragments requested this many pairs ahead: 6 with four waves (512 registers each); 2 with eight (256 each: at 6 the kernel
 // spilled 78 registers -- HGCal 57.6 showers/s at 6, 59.3 at 3, 59.8 at 2, same box -- and the second wave of a SIMD covers what the
-// shallower ring exposes)
+// shallower ring exposes).  Tile groups -- waves 0-3 on tiles 0-1, waves 4-7 on tiles 2-3, 64 accumulator registers instead of 128, no
+// spills with the six-deep ring -- were built and measured too: 57.7 against 59.3 showers/s, the doubled weight-fragment traffic
+// from L2 costs more than the spills.
 #ifndef CS_PD8
 #define CS_PD8 2
 #endif
