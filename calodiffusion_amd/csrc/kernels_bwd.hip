@@ -826,6 +826,39 @@ __global__ void __launch_bounds__(256) gn_bwd_stats_kernel(const float* __restri
     }
   }
   float* dst = part + (((size_t)b * nsplit + split) * channels) * 4;
+  if (cols == 8 || cols == 16) {  // (32 and 64 channels; the scratch below is 8 KB = 4 waves x 16 quads x 16 doubles)
+    // the threads of one channel quad are `cols` lanes apart: fp64 xor tree inside the wave, then the four waves through LDS (fixed
+    // order).  The LDS-only form below serialised 4 x (barrier, `rows` fp64 loads by `cols` threads, barrier): ~6 us of a 15 us launch
+    // whose workgroups stream 250 voxels each.
+    double d[4][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      d[e][0] = (double)s0[e]; d[e][1] = (double)s1[e]; d[e][2] = (double)s2[e]; d[e][3] = (double)s3[e];
+    }
+    for (int m = cols; m < 64; m <<= 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) d[e][k] += __shfl_xor(d[e][k], m, 64);
+    }
+    const int lane = tid & 63, wave = tid >> 6;
+    double* sW = &sP[0][0];  // [4 waves][cols][16]
+    if (lane < cols) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sW[(wave * cols + lane) * 16 + e * 4 + k] = d[e][k];
+    }
+    __syncthreads();
+    for (int i = tid; i < cols * 4; i += 256) {  // (quad, element)
+      const int q = i >> 2, e = i & 3;
+      double a[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) a[k] = ((sW[(0 * cols + q) * 16 + e * 4 + k] + sW[(1 * cols + q) * 16 + e * 4 + k]) + sW[(2 * cols + q) * 16 + e * 4 + k]) + sW[(3 * cols + q) * 16 + e * 4 + k];
+      *(f32x4*)(dst + (q * 4 + e) * 4) = f32x4{(float)a[0], (float)a[1], (float)a[2], (float)a[3]};
+    }
+    return;
+  }
   for (int e = 0; e < 4; ++e) {
     sP[tid][0] = (double)s0[e]; sP[tid][1] = (double)s1[e]; sP[tid][2] = (double)s2[e]; sP[tid][3] = (double)s3[e];
     __syncthreads();

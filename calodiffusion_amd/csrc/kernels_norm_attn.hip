@@ -22,7 +22,8 @@ namespace cd {
 // ------------------------------------------------------------------------------------------------------------
 int gn_nsplit_for(int64_t vox, int batch) {
   // enough blocks to fill 256 CUs a few times over, but >= 256 voxels per block
-  int64_t want = (2048 + batch - 1) / batch;
+  static const int target = getenv("CD_GN_NSPLIT_TARGET") ? atoi(getenv("CD_GN_NSPLIT_TARGET")) : 2048;
+  int64_t want = (target + batch - 1) / batch;
   int64_t cap = (vox + 255) / 256;
   int64_t n = want < cap ? want : cap;
   if (n < 1) n = 1;
