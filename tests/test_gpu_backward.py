@@ -66,6 +66,21 @@ def test_conv_backward(ops):
     _conv_case(ops, 32, 32, (1, 2, 16, 9), (3, 3, 3), (1, 1, 1), gen, dy_scale=2e4)
 
 
+def test_pointwise_conv_weight_gradient_streaming_kernel(ops):
+    """1x1x1 convs: dW comes from wgrad1x1_kernel (round 4): one, three (96 x 32), four (64 x 64) and nine (96 x 96: three tile groups)
+    32 x 32 output tiles; row counts that are no multiple of a 128-row unit; more units than workgroups, so that a workgroup loops and
+    the next unit's prefetch is exercised; gradients far below and above the fp16 range (this kernel stays on the f32-input MFMA: nothing
+    is rescaled); a concatenated input (two launches into column slices of one dW)."""
+    gen = torch.Generator().manual_seed(29)
+    _conv_case(ops, 32, 96, (1, 5, 7, 3), (1, 1, 1), (1, 1, 1), gen)           # A = 96 (dy), Bc = 32: 105 rows
+    _conv_case(ops, 64, 64, (2, 3, 11, 5), (1, 1, 1), (1, 1, 1), gen)          # four tiles in one workgroup
+    _conv_case(ops, 96, 96, (1, 7, 3, 6), (1, 1, 1), (1, 1, 1), gen)           # nine tiles = three groups
+    _conv_case(ops, 32, 32, (6, 45, 16, 9), (1, 1, 1), (1, 1, 1), gen)         # 77 760 rows = 608 units on 512 workgroups
+    _conv_case(ops, 32, 32, (1, 9, 5, 3), (1, 1, 1), (1, 1, 1), gen, dy_scale=3e-7)
+    _conv_case(ops, 32, 32, (1, 9, 5, 3), (1, 1, 1), (1, 1, 1), gen, dy_scale=2e4)
+    _conv_case(ops, 96, 32, (2, 4, 6, 5), (1, 1, 1), (1, 1, 1), gen, split=64)  # skip concat: 64 + 32 input channels
+
+
 def test_conv_transpose_backward(ops):
     gen = torch.Generator().manual_seed(22)
     for c, shp, kz, zs, op in ((32, (1, 4, 4, 2), 3, 2, (0, 0, 0)), (32, (2, 5, 4, 4), 3, 2, (0, 0, 1)),
