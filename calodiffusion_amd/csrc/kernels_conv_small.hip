@@ -35,7 +35,8 @@ struct ConvSmallArgs {
   int cout;
   float* ch_part;     // [B][1][cout][2] or null
   int D, H, W;
-  int VB;             // bytes per voxel record = min(cin, 64) * 4 + 16
+  int VB;             // bytes per voxel record = min(cin, CB) * 4 + 16
+  int CB;             // input channels staged per block (64, or 96 / 128 where the image still fits LDS: fewer stage / barrier phases)
   int* status;        // bit 0: a staged value exceeded the fp16 range
   GnDefer defer;      // input normalisation folded in the prologue (table at cs_lds + coef_lds_off) instead of `coef`
   int coef_lds_off;
@@ -113,8 +114,8 @@ __global__ void __launch_bounds__(CS_NW * 64, 1) conv_small_f16x2_kernel(ConvSma
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) accA[t][r] = accB[t][r] = 0.f;
-  for (int cb = 0; cb < cin; cb += 64) {  // input channels in blocks of <= 64
-    const int cn = min(64, cin - cb);     // channels in this block (multiple of 16)
+  for (int cb = 0; cb < cin; cb += a.CB) {  // input channels in blocks of <= CB
+    const int cn = min(a.CB, cin - cb);     // channels in this block (multiple of 16)
     const int nq = cn >> 2;               // channel quads per voxel
     __syncthreads();                      // previous block's MFMAs have finished reading the image
     // ---- zero the image, then stage the sample (interior records; phi halo rows are copies) ----------------------
@@ -442,21 +443,31 @@ bool try_launch_conv_small(const float* in0, int c0, const float* in1, int c1, c
   const int cin = c0 + c1;
   if (cin % 16 || cout % 32 || c0 % 4 || c1 % 4) return false;
   // a 64-channel block must not straddle the two sources unless the split is at a multiple of 4 (quads never straddle)
-  const int VB = (cin < 64 ? cin : 64) * 4 + 16;
   const int NT = (int)((vox + 31) / 32);
-  const size_t image = (size_t)(g.in.d + 2) * (g.in.h + 2) * (g.in.w + 1) * VB;
   const size_t partial = (size_t)NT * cs_waves_for(NT) * 4096;
-  size_t lds = image > partial ? image : partial;
-  lds = (lds + 255) & ~(size_t)255;
-  const size_t coef_off = lds;
   // coefficient table: of the deferred input normalisation and / or of the GroupNorm the kernel computes itself ([32][4] floats)
-  if (fu.defer.part) lds += (size_t)fu.defer.C * 16 + gn_defer_scratch_bytes(fu.defer.C);
-  else if (fu.gn_out.gamma) lds += 512;
+  const size_t table = fu.defer.part ? (size_t)fu.defer.C * 16 + gn_defer_scratch_bytes(fu.defer.C) : (fu.gn_out.gamma ? 512 : 0);
+  // channels per staged block: all of them up to 128 if the image then still fits (HGCal's 96-channel level: one stage / barrier /
+  // MFMA phase instead of 64 + 32), else 64.  A property of the geometry, never of the batch.
+  static const int cb_max = getenv("CD_CONV_SMALL_CB") ? atoi(getenv("CD_CONV_SMALL_CB")) : 128;
+  int CB = cin < cb_max ? cin : cb_max;
+  if (CB < 64) CB = cin < 64 ? cin : 64;
+  size_t lds = 0, coef_off = 0;
+  int VB = 0;
+  for (;; CB = 64) {
+    VB = (cin < CB ? cin : CB) * 4 + 16;
+    const size_t image = (size_t)(g.in.d + 2) * (g.in.h + 2) * (g.in.w + 1) * VB;
+    lds = image > partial ? image : partial;
+    lds = (lds + 255) & ~(size_t)255;
+    coef_off = lds;
+    lds += table;
+    if (lds <= 160 * 1024 || CB <= 64) break;
+  }
   if (lds > 160 * 1024) return false;
   ConvSmallArgs a;
   a.in0 = in0; a.in1 = in1; a.c0 = c0; a.c1 = c1; a.coef = fu.coef; a.act = fu.act;
   a.wpk = (const u32x4*)wpk_f16x2; a.CTtot = cout / 32; a.bias = bias; a.out = out; a.cout = cout; a.ch_part = fu.ch_part;
-  a.D = g.in.d; a.H = g.in.h; a.W = g.in.w; a.VB = VB; a.status = fu.status;
+  a.D = g.in.d; a.H = g.in.h; a.W = g.in.w; a.VB = VB; a.CB = CB; a.status = fu.status;
   a.defer = fu.defer; a.coef_lds_off = (int)coef_off; a.in_absmax = fu.in_absmax;
   a.add_src = !bias ? fu.add_src : nullptr;
   a.gn_gamma = nullptr; a.gn_beta = nullptr; a.gn_cpg = 0; a.res0 = a.res1 = nullptr; a.res_c0 = 0; a.part_out = nullptr;
@@ -503,7 +514,7 @@ bool try_launch_res_block_small(const float* x0, int c0, const float* x1, int c1
   ConvSmallArgs a;
   a.in0 = x0; a.in1 = x1; a.c0 = c0; a.c1 = c1; a.coef = nullptr; a.act = 0;
   a.wpk = (const u32x4*)w1_f16x2; a.CTtot = 1; a.bias = b1; a.out = out; a.cout = 32; a.ch_part = nullptr;
-  a.D = dims.d; a.H = dims.h; a.W = dims.w; a.VB = VB; a.status = status;
+  a.D = dims.d; a.H = dims.h; a.W = dims.w; a.VB = VB; a.CB = 64; a.status = status;
   a.defer = GnDefer(); a.coef_lds_off = (int)coef_off; a.in_absmax = nullptr; a.add_src = nullptr;
   a.gn_gamma = gn2_gamma; a.gn_beta = gn2_beta; a.gn_cpg = 32 / groups; a.res0 = res0; a.res1 = res1; a.res_c0 = res_c0;
   a.part_out = part_out;
