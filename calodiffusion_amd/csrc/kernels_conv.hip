@@ -2646,8 +2646,9 @@ __global__ void __launch_bounds__(256) init_conv_f16x2_kernel(InitConvArgs a, co
   {
     const float* xb = a.x + (size_t)b * D * PV;
     float amax = 0.f;
+    const float inv_wp = 1.f / (float)WP, inv_hp = 1.f / (float)HP;
     for (int i = tid; i < (nz + 2) * HP * WP; i += 256) {
-      const int lw = i % WP, r = i / WP, lh = r % HP, lz = r / HP;
+      const int r = (int)(((float)i + 0.5f) * inv_wp), lw = i - r * WP, lz = (int)(((float)r + 0.5f) * inv_hp), lh = r - lz * HP;
       const int gz = z0 - 1 + lz, gw = lw - 1;
       int gh = lh - 1;
       gh = gh < 0 ? gh + H : (gh >= H ? gh - H : gh);
@@ -2672,6 +2673,7 @@ __global__ void __launch_bounds__(256) init_conv_f16x2_kernel(InitConvArgs a, co
   __syncthreads();
   const int nvox = nz * PV, ntiles = (nvox + 31) / 32;
   const int64_t vox = a.dims.vox();
+  const float inv_pv = 1.f / (float)PV, inv_w = 1.f / (float)W;
   for (int ct = 0; ct < a.cout / 32; ++ct) {
     u32x4 w1[2], w2[2];
 #pragma unroll
@@ -2688,19 +2690,26 @@ __global__ void __launch_bounds__(256) init_conv_f16x2_kernel(InitConvArgs a, co
       w1[ks] = u32x4{a1[0], a1[1], b1[0], b1[1]};
       w2[ks] = u32x4{a2[0], a2[1], b2[0], b2[1]};
     }
-    for (int tile = wave; tile < ntiles; tile += 4) {
-      const int v = min(tile * 32 + col, nvox - 1);
-      const int lz = v / PV, p = v - lz * PV, h = p / W, w = p - h * W;
-      const float* base = img + (lz * HP + h) * WP + w;
-      // the table rows of this tile are requested first, unconditionally (clamped), so that all loads are in flight under the
-      // gather and the MFMAs: as whole 16-byte quads, row 8 k + (lane >> 3), channels 4 (lane & 7) .. + 3 -- the layout the tile is
-      // stored in after a transpose through LDS (16 scalar row stores per lane in accumulator layout ran at a third of the HBM rate)
-      f32x4 tb[4];
+    // the table rows of a tile as whole 16-byte quads, row 8 k + (lane >> 3), channels 4 (lane & 7) .. + 3 -- the layout the tile is
+    // stored in after a transpose through LDS (16 scalar row stores per lane in accumulator layout ran at a third of the HBM rate) --
+    // requested ONE TILE AHEAD (round 4): with two waves per SIMD a tile's gather and six MFMAs are ~150 ns, an L2 round trip several
+    // times that, and the tile ended up waiting for its own table rows
+    auto load_table = [&](int tile, f32x4 (&t4)[4]) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int vr = min(tile * 32 + 8 * k + (lane >> 3), nvox - 1);
-        tb[k] = *(const f32x4*)(table + ((size_t)z0 * PV + vr) * a.cout + ct * 32 + (lane & 7) * 4);
+        t4[k] = *(const f32x4*)(table + ((size_t)z0 * PV + vr) * a.cout + ct * 32 + (lane & 7) * 4);
       }
+    };
+    f32x4 tb[4], tbn[4];
+    load_table(min(wave, ntiles - 1), tb);
+    for (int tile = wave; tile < ntiles; tile += 4) {
+      const int v = min(tile * 32 + col, nvox - 1);
+      // (exact small-integer division by reciprocal: (v + 0.5) / d is never within float error of an integer for v < 2^20; two run-time
+      // integer divisions were ~80 of a tile's ~300 instructions)
+      const int lz = (int)(((float)v + 0.5f) * inv_pv), p = v - lz * PV, h = (int)(((float)p + 0.5f) * inv_w), w = p - h * W;
+      const float* base = img + (lz * HP + h) * WP + w;
+      load_table(min(tile + 4, ntiles - 1), tbn);
       f32x16 accA, accB;
 #pragma unroll
       for (int r = 0; r < 16; ++r) accA[r] = accB[r] = 0.f;
@@ -2728,6 +2737,8 @@ __global__ void __launch_bounds__(256) init_conv_f16x2_kernel(InitConvArgs a, co
         const f32x4 o = *(const f32x4*)(tr + row * 36 + (lane & 7) * 4) + tb[k];
         if (vr < nvox) *(f32x4*)(a.out + ((size_t)b * vox + (size_t)z0 * PV + vr) * a.cout + ct * 32 + (lane & 7) * 4) = o;
       }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) tb[k] = tbn[k];
     }
   }
 }
@@ -2758,7 +2769,8 @@ void launch_init_conv(const InitConvArgs& a, hipStream_t s) {
     if (!a.table_ready) launch_init_coord_table(a, s);  // (~25 us of scalar-kernel latency: callers that can, keep the table)
     // 2. the x part on the matrix cores: TZ planes per workgroup, about two rounds of workgroups
     const int D = a.dims.d;
-    int slabs = (512 + a.batch - 1) / a.batch;
+    static const int init_wgs = getenv("CD_INIT_WGS") ? atoi(getenv("CD_INIT_WGS")) : 512;
+    int slabs = (init_wgs + a.batch - 1) / a.batch;
     slabs = slabs < 1 ? 1 : (slabs > D ? D : slabs);
     int TZ = (D + slabs - 1) / slabs;
     while (TZ > 1 && (size_t)(TZ + 2) * (a.dims.h + 2) * (a.dims.w + 2) * 4 > 60 * 1024) --TZ;
