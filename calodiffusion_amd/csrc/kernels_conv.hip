@@ -740,8 +740,12 @@ __global__ void __launch_bounds__(512, (VT * CT * (NTERM == 2 ? 2 : 1) <= 2 ? 3 
   const int voxo = a.Do * HWo;       // output voxels per sample
   const int v0 = blockIdx.x * a.R;
   const int vend = min(v0 + a.R, voxo);
-  const int zA = (v0 / HWo) * SZ - 1;                   // first staged input plane (may be -1: zero plane)
-  const int zB = ((vend - 1) / HWo) * SZ + KD - 2;      // last staged input plane
+  // (index arithmetic by reciprocal -- (v + 0.5) / d is never within float error of an integer for v < 2^20: a run-time integer
+  // division is ~40 vector instructions, and this prologue had four to ten of them in workgroups that live ~15 us)
+  const float inv_hwo = 1.f / (float)HWo, inv_wo = 1.f / (float)a.Wo;
+  auto fdiv = [](int x, float inv) { return (int)(((float)x + 0.5f) * inv); };
+  const int zA = fdiv(v0, inv_hwo) * SZ - 1;                   // first staged input plane (may be -1: zero plane)
+  const int zB = fdiv(vend - 1, inv_hwo) * SZ + KD - 2;        // last staged input plane
   const int nstage = (zB - zA + 1) * HW;
   const int NZ = a.P * HW;  // all-zero voxel
   const int half = lane >> 5, col = lane & 31;
@@ -759,9 +763,9 @@ __global__ void __launch_bounds__(512, (VT * CT * (NTERM == 2 ? 2 : 1) <= 2 ? 3 
     const int v = v0 + (wave * VT + vt) * 32 + col;
     const bool valid = v < vend;
     const int vv = valid ? v : v0;
-    const int oz = vv / HWo;
+    const int oz = fdiv(vv, inv_hwo);
     const int r = vv - oz * HWo;
-    const int oh = r / a.Wo, ow = r - oh * a.Wo;
+    const int oh = fdiv(r, inv_wo), ow = r - oh * a.Wo;
     const int ih0 = oh * SXY, iw0 = ow * SXY;
     nb[vt] = (oz * SZ - 1 - zA) * HW + ih0 * a.W + iw0;
     unsigned m = 0;

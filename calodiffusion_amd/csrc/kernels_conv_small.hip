@@ -138,13 +138,17 @@ __global__ void __launch_bounds__(CS_NW * 64, 1) conv_small_f16x2_kernel(ConvSma
         wr[i][0] = wp[0];
         wr[i][1] = wp[64];
       }
-    // staging: all of a thread's global loads are issued before the first conversion (4 items per batch)
+    // staging: all of a thread's global loads are issued before the first conversion (4 items per batch).  Index arithmetic by
+    // reciprocal ((i + 0.5) / d is never within float error of an integer for i < 2^20): run-time integer divisions were five per item,
+    // ~200 instructions where the conversion itself is ~30
+    const float inv_nq = 1.f / (float)nq, inv_pv = 1.f / (float)PV, inv_w = 1.f / (float)W;
+    auto fdiv = [](int x, float inv) { return (int)(((float)x + 0.5f) * inv); };
     for (int i0 = tid; i0 < vox * nq; i0 += 4 * CS_THREADS) {
       f32x4 xs[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int i = min(i0 + k * CS_THREADS, vox * nq - 1);
-        const int v = i / nq, q = i - v * nq;
+        const int v = fdiv(i, inv_nq), q = i - v * nq;
         const int c = cb + q * 4;
         const float* src = c < c0 ? in0 + ((size_t)b * vox + v) * c0 + c : in1 + ((size_t)b * vox + v) * c1 + (c - c0);
         xs[k] = *(const f32x4*)src;
@@ -153,7 +157,7 @@ __global__ void __launch_bounds__(CS_NW * 64, 1) conv_small_f16x2_kernel(ConvSma
       for (int k = 0; k < 4; ++k) {
         const int i = i0 + k * CS_THREADS;
         if (i >= vox * nq) break;
-        const int v = i / nq, q = i - v * nq;
+        const int v = fdiv(i, inv_nq), q = i - v * nq;
         const int c = cb + q * 4;
         f32x4 x = xs[k] * gscale;
         if (normed) {
@@ -169,7 +173,7 @@ __global__ void __launch_bounds__(CS_NW * 64, 1) conv_small_f16x2_kernel(ConvSma
         amax = fmaxf(amax, fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3]))));
         u32x2 t1, t2;
         split2(x, t1, t2);
-        const int z = v / PV, p = v - z * PV, h = p / W, w = p - h * W;
+        const int z = fdiv(v, inv_pv), p = v - z * PV, h = fdiv(p, inv_w), w = p - h * W;
         // record layout: [k-step][term][16 ch] => quad q sits at (q >> 2) * 64 + term * 32 + (q & 3) * 8
         const int off = (q >> 2) * 64 + (q & 3) * 8;
         char* d = cs_lds + (((z + 1) * (H + 2) + (h + 1)) * pitch + w) * VB + off;
