@@ -775,18 +775,28 @@ __global__ void __launch_bounds__(512) attn_small_kernel(AttnArgs a) {
   __syncthreads();  // y and its channel sums are in memory
   const int C = NCH * 32;
   const float* cp = a.ch_part + (size_t)b * C * 2;
-  if (tid == 0) {
+  if (tid < 64) {
+    // one wave: lane l takes channels l, l + 64, then a fixed fp64 xor tree (one thread summing C pairs was C dependent trips to L2:
+    // ~10 us of this 30-50 us kernel)
     double a1 = 0.0, a2 = 0.0;
-    for (int c = 0; c < C; ++c) {
-      a1 += (double)cp[c * 2];
-      a2 += (double)cp[c * 2 + 1];
+    for (int c = tid; c < C; c += 64) {
+      const float2 v = *(const float2*)(cp + c * 2);
+      a1 += (double)v.x;
+      a2 += (double)v.y;
     }
-    const double cnt = (double)a.vox * C;
-    const double mu = a1 / cnt;
-    double var = a2 / cnt - mu * mu;
-    var = var < 0.0 ? 0.0 : var;
-    sTot[0] = mu;
-    sTot[1] = 1.0 / sqrt(var + 1e-5);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+      a1 += __shfl_xor(a1, m, 64);
+      a2 += __shfl_xor(a2, m, 64);
+    }
+    if (tid == 0) {
+      const double cnt = (double)a.vox * C;
+      const double mu = a1 / cnt;
+      double var = a2 / cnt - mu * mu;
+      var = var < 0.0 ? 0.0 : var;
+      sTot[0] = mu;
+      sTot[1] = 1.0 / sqrt(var + 1e-5);
+    }
   }
   __syncthreads();
   if (tid < C) {
@@ -867,21 +877,28 @@ __global__ void __launch_bounds__(512) attn_coop_kernel(AttnArgs a) {
   attn_pass2<NCH>(a, b, part, P, t0, t1, cf, nullptr, cfl);
   attn_group_barrier(sync, P, a.status);
   const int C = NCH * 32;
-  if (tid == 0) {
+  if (tid < 64) {
     double a1 = 0.0, a2 = 0.0;
     for (int u = 0; u < P; ++u) {
       const float* cp = a.ch_part + ((size_t)b * P + u) * C * 2;
-      for (int c = 0; c < C; ++c) {
+      for (int c = tid; c < C; c += 64) {
         a1 += (double)attn_peer_load(cp + c * 2, 1);
         a2 += (double)attn_peer_load(cp + c * 2 + 1, 1);
       }
     }
-    const double cnt = (double)a.vox * C;
-    const double mu = a1 / cnt;
-    double var = a2 / cnt - mu * mu;
-    var = var < 0.0 ? 0.0 : var;
-    sTot[0] = mu;
-    sTot[1] = 1.0 / sqrt(var + 1e-5);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+      a1 += __shfl_xor(a1, m, 64);
+      a2 += __shfl_xor(a2, m, 64);
+    }
+    if (tid == 0) {
+      const double cnt = (double)a.vox * C;
+      const double mu = a1 / cnt;
+      double var = a2 / cnt - mu * mu;
+      var = var < 0.0 ? 0.0 : var;
+      sTot[0] = mu;
+      sTot[1] = 1.0 / sqrt(var + 1e-5);
+    }
   }
   __syncthreads();
   if (tid < C) {
