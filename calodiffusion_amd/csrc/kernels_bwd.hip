@@ -1293,7 +1293,12 @@ void launch_gn_backward(const float* dy, const float* h, const float* coef, cons
   if (!queue)
     hipLaunchKernelGGL(param_grad_from_samples_kernel, dim3((channels + 63) / 64), dim3(64), 0, s, sums_bc, batch, channels, dgamma,
                        dbeta, accumulate_params ? 1 : 0, dbias, dsumdy);
-  const int bps = gn_apply_blocks_per_sample(batch, channels, vox);
+  // one round of workgroups: each repeats the finalize arithmetic in its prologue, so fewer and longer-lived ones win (same-box A/B at
+  // batch 32: 7.31 -> 7.22 ms per training step from ~1024 to 256 workgroups; the forward gn_apply is neutral to the same change)
+  static const int bwd_wgs = getenv("CD_GN_BWD_APPLY_WGS") ? atoi(getenv("CD_GN_BWD_APPLY_WGS")) : 256;
+  int bps = gn_apply_blocks_per_sample(batch, channels, vox);
+  const int bps_cap = (bwd_wgs + batch - 1) / batch;
+  if (fold.part && bps > bps_cap) bps = bps_cap < 1 ? 1 : bps_cap;
   unsigned* amax_word = absmax_word_fresh(dh, s);  // zeroed; the consumer's launch_absmax_bits(dh) finds it instead of re-reading dh
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)(batch * bps)), dim3(256), 0, s, dy, h, coef, gcoef, dh, channels, vox, silu, bps,
                      amax_word, fold);
