@@ -173,7 +173,7 @@ __device__ __forceinline__ void attn_pass1(const AttnArgs& a, int b, int split, 
   __shared__ float sMax[8][32];
   __shared__ float sSum[16][32];
   __shared__ float sCtx[8][1024];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, col = lane & 31;
   constexpr int NKS = NCH * 2;
   u32x4 wk1[NKS], wk2[NKS], wv1[NKS], wv2[NKS];
@@ -548,7 +548,7 @@ __device__ __forceinline__ void attn_pass2(const AttnArgs& a, int b, int unit, i
                                            const f32x4 (&cf)[NCH][8], float* trbuf = nullptr, const f32x4* cf_lds = nullptr) {
   __shared__ float sRed[MOM ? 1 : 8][NCH * 32][2];
   __shared__ float sOut[MOM ? NCH * 32 : 1][2];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, col = lane & 31;
   constexpr int NKS = NCH * 2;
   u32x4 wq1[NKS], wq2[NKS];

@@ -79,7 +79,10 @@ __global__ void __launch_bounds__(CS_NW * 64, 1) conv_small_f16x2_kernel(ConvSma
   constexpr int CS_THREADS = CS_NW * 64;
   constexpr int CS_PD = CsPd<CS_NW>::value;
   extern __shared__ __attribute__((aligned(16))) char cs_lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, col = lane & 31;
+  // (wave-uniform by construction: telling the compiler so moves the pair -> (k-step, tap) decode, the tap displacement and the weight
+  // fragment addresses to the scalar unit and its registers)
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x, ct = blockIdx.y;
   const int D = a.D, H = a.H, W = a.W, PV = H * W, vox = D * PV;
   const int pitch = W + 1, prow = (H + 2) * pitch;  // records per row / per plane
