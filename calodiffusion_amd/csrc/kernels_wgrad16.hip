@@ -272,6 +272,289 @@ __global__ void __launch_bounds__(512, 1) wgrad_f16x2_kernel(Wgrad16Args a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// The same contraction, sliding along z (round 4, second session).  wgrad_f16x2_kernel above restages four x planes for every two
+// planes of dy (each x plane is fetched and split twice) and its staging and matrix phases alternate: a unit's loads are requested,
+// awaited, converted, and only then do the MFMAs start -- 58 us per level-0 launch for 17 us of MFMAs.  Here a workgroup owns a
+// CHUNK of consecutive units (NZ z-planes each) of one sample:
+//  * the x planes live in a RING of S = 2 NZ + 2 plane slots (plane p in slot (p + 1) mod S): the unit in flight reads NZ + 2 of
+//    them, the NZ new planes of the next unit go into the others -- every x plane is fetched and split once per chunk (+ two halo
+//    planes per chunk), and dy alternates between two images;
+//  * the next unit's global loads are issued BEFORE the K loop of the current one and converted after it: the memory round trip
+//    runs under the MFMAs, one barrier per unit;
+//  * taps -> waves so that a wave's first three taps are kz = 0, 1, 2 of ONE (kh, kw) (wave = 3 kh + kw < 8; the ninth (kh, kw)
+//    goes to waves 0..2 as a fourth tap, kz = wave): the ring wrap of a tap's plane is then a per-lane base chosen by a
+//    compile-time index (three bases per lane and K step), not a per-tap computation.
+struct WgradRingArgs {
+  const float* g;
+  const float* x;
+  int A, xld, xoff;
+  int D, H, W;
+  int NZ, S;                       // planes per unit, ring slots
+  int U, upc, cps, total_chunks;   // units per sample, units per chunk, chunks per sample
+  float* partial;                  // [gridDim.x][tilesA][tilesB][27][32][32]
+  int tilesB;
+  const unsigned* gmax_bits;
+  const float* xcoef;              // as Wgrad16Args
+};
+
+__global__ void __launch_bounds__(512, 1) wgrad_ring_f16x2_kernel(WgradRingArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char wl[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, col = lane & 31;
+  const int ta = blockIdx.y / a.tilesB, tb = blockIdx.y % a.tilesB;
+  const int H = a.H, W = a.W, PV = H * W, vox = a.D * PV, NZ = a.NZ, S = a.S;
+  const int pitch = W + 1, prow = (H + 2) * pitch;
+  const int R = NZ * PV, RP = (R + 15) & ~15;
+  char* const gL = wl;                                     // two dy images [2][RP][WG_VB]
+  char* const xB = wl + (size_t)(2 * RP + 1) * WG_VB;      // record (slot 0, row 0, column 0); the record before it stays zero
+  const int ringbytes = S * prow * WG_VB;
+  float* const ctab = (float*)(xB + ringbytes);            // [32][4] GroupNorm coefficients of the chunk's sample (xcoef)
+
+  float gscale, ginv;
+  pow2_scale_for(*a.gmax_bits, &gscale, &ginv);
+  for (int i = tid; i < ((2 * RP + 1) * WG_VB + ringbytes) / 16; i += 512) ((u32x4*)wl)[i] = u32x4{0u, 0u, 0u, 0u};
+
+  const int ntap = wave < 3 ? 4 : 3;
+  const int kz3 = wave < 3 ? wave : 0;
+  int toff[4];
+  {
+    const int kh = wave / 3, kw = wave - 3 * kh;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) toff[t] = (t * prow + kh * pitch + kw - 1) * WG_VB;
+    toff[3] = (kz3 * prow + 2 * pitch + 1) * WG_VB;
+  }
+  f32x16 accA[4], accB[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accA[t][r] = accB[t][r] = 0.f;
+
+  const int g4 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+  const int chan_off = (g4 & 1) * 64 + p4 * 8;
+  const int vrow0 = 8 * (g4 >> 1) + q4;
+  const int adv_h = 16 / W, adv_w = 16 - adv_h * W;
+  const float inv_pv = 1.f / (float)PV, inv_w = 1.f / (float)W;
+  auto div_pv = [&](int v) { return (int)(((float)v + 0.5f) * inv_pv); };
+  auto div_w = [&](int v) { return (int)(((float)v + 0.5f) * inv_w); };
+
+  // staging roles: a thread moves the channel quad qd of voxels vb, vb + 64, vb + 128 (R <= 192) of a unit
+  const int qd = tid & 7, vb_ = tid >> 3;
+  const int qoff = (qd >> 2) * 64 + (qd & 3) * 8;
+  const float* const gcol = a.g + ta * 32 + qd * 4;
+  const float* const xcol = a.x + a.xoff + tb * 32 + qd * 4;
+
+  // The loads are UNCONDITIONAL (clamped addresses; validity is applied when the value is converted): a load under a divergent
+  // branch makes the compiler wait for it at the join, which serialises the round trips the prefetch exists to overlap.
+  // (the voxel index is laundered through an empty asm in each stage: hoisted out of the unit loop, the stages' index arithmetic
+  // occupies ~30 registers across the K loop, and the reloads of what then spills sit between the prefetch and the MFMAs)
+  // An explicit vmcnt(0) stands before every convert: a value first used under a divergent branch (`v < R`) is waited for inside
+  // that branch only, the compiler's wait model then carries the load as still pending into the next K loop and drains the
+  // PREFETCH in front of its first LDS read.
+  constexpr int WAIT_VM0 = 0x0F70;  // vmcnt(0), expcnt / lgkmcnt untouched
+  auto fresh = [](int v) { asm volatile("" : "+v"(v)); return v; };
+  auto ld_g = [&](int n, int z0, f32x4 (&r)[3]) {
+    const int vb = fresh(vb_);
+    const float* gs = gcol + ((size_t)n * vox + (size_t)z0 * PV) * a.A;
+    const int last = min(R, vox - z0 * PV) - 1;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) r[k] = *(const f32x4*)(gs + (size_t)min(vb + 64 * k, last) * a.A);
+  };
+  auto st_g = [&](char* gbuf, int z0, const f32x4 (&r)[3]) {
+    const int vb = fresh(vb_);
+    const int nvalid = min(R, vox - z0 * PV);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int v = vb + 64 * k;
+      if (v < R) {
+        u32x2 t1, t2;
+        split2(v < nvalid ? r[k] * gscale : f32x4{0.f, 0.f, 0.f, 0.f}, t1, t2);
+        char* d = gbuf + v * WG_VB + qoff;
+        *(u32x2*)d = t1;
+        *(u32x2*)(d + 32) = t2;
+      }
+    }
+  };
+  // np <= NZ planes p0 .. p0 + np - 1 (zero outside the sample)
+  auto ld_x = [&](int n, int p0, int np, f32x4 (&r)[3]) {
+    const int vb = fresh(vb_);
+    const float* xs = xcol + (size_t)n * vox * a.xld;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int v = min(vb + 64 * k, np * PV - 1);
+      const int pl = div_pv(v), p = min(max(p0 + pl, 0), a.D - 1);
+      r[k] = *(const f32x4*)(xs + ((size_t)p * PV + (v - pl * PV)) * a.xld);
+    }
+  };
+  auto st_x = [&](int p0, int np, f32x4 (&r)[3]) {
+    const int vb = fresh(vb_);
+    const int slot0 = (p0 + 1) % S;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int v = vb + 64 * k;
+      if (v < np * PV) {
+        const int pl = div_pv(v), pv = v - pl * PV, h = div_w(pv), w = pv - h * W, p = p0 + pl;
+        const bool inside = p >= 0 && p < a.D;
+        f32x4 val = r[k];
+        if (a.xcoef) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const f32x4 c = *(const f32x4*)(ctab + ((qd * 4 + e) * 4));
+            val[e] = cd_fast_silu(c[0] * val[e] + c[1]) + c[2];
+          }
+        }
+        u32x2 t1, t2;
+        split2(inside ? val : f32x4{0.f, 0.f, 0.f, 0.f}, t1, t2);
+        int sl = slot0 + pl;
+        if (sl >= S) sl -= S;
+        char* d = xB + ((sl * (H + 2) + h + 1) * pitch + w) * WG_VB + qoff;
+        *(u32x2*)d = t1;
+        *(u32x2*)(d + 32) = t2;
+        if (h == 0) {
+          char* d2 = d + H * pitch * WG_VB;
+          *(u32x2*)d2 = t1;
+          *(u32x2*)(d2 + 32) = t2;
+        }
+        if (h == H - 1) {
+          char* d2 = d - H * pitch * WG_VB;
+          *(u32x2*)d2 = t1;
+          *(u32x2*)(d2 + 32) = t2;
+        }
+      }
+    }
+  };
+
+  for (int ch = blockIdx.x; ch < a.total_chunks; ch += gridDim.x) {
+    const int n = ch / a.cps, cc = ch - n * a.cps;
+    const int u0 = cc * a.upc, u1 = min(u0 + a.upc, a.U);
+    const int zc = u0 * NZ;  // first plane of the chunk
+    // (every wave left the previous chunk's last K loop at that unit's closing barrier: images and table are free)
+    if (a.xcoef && tid < 32) *(f32x4*)(ctab + tid * 4) = *(const f32x4*)(a.xcoef + ((size_t)n * a.xld + a.xoff + tb * 32 + tid) * 4);
+    __syncthreads();  // the coefficient table
+    {
+      // prologue: halo planes zc - 1, zc, then the first unit's own stage (planes zc + 1 .. zc + NZ, dy of unit u0) -- two rounds of
+      // loads (all four sets in flight at once spill, and the reloads serialise the round trips)
+      f32x4 ra[3], rb[3];
+      const int npa = min(NZ, 2);
+      ld_x(n, zc - 1, npa, ra);
+      if (NZ == 1) ld_x(n, zc, 1, rb);
+      __builtin_amdgcn_s_waitcnt(WAIT_VM0);
+      st_x(zc - 1, npa, ra);
+      if (NZ == 1) st_x(zc, 1, rb);
+    }
+    {
+      f32x4 rc[3], rg[3];
+      ld_x(n, zc + 1, NZ, rc);
+      ld_g(n, zc, rg);
+      __builtin_amdgcn_s_waitcnt(WAIT_VM0);
+      st_x(zc + 1, NZ, rc);
+      st_g(gL, zc, rg);
+    }
+    __syncthreads();
+
+    for (int u = u0; u < u1; ++u) {
+      const int zk = u * NZ;
+      const bool more = u + 1 < u1;
+      f32x4 rx[3], rg[3];
+      if (more) {
+        ld_x(n, zk + NZ + 1, NZ, rx);
+        ld_g(n, zk + NZ, rg);
+      }
+      // ---- K loop of unit u: dy image (u - u0) & 1, x planes zk - 1 .. zk + NZ ----
+      const char* gbuf = gL + ((u - u0) & 1) * RP * WG_VB;
+      const int sb = zk % S;  // slot of plane zk - 1
+      int vloc[2], vz[2], vh[2], vw[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int v = vrow0 + 4 * j;
+        vloc[j] = v;
+        const int vv = min(v, R - 1);
+        vz[j] = div_pv(vv);
+        const int p = vv - vz[j] * PV;
+        vh[j] = div_w(p);
+        vw[j] = p - vh[j] * W;
+      }
+      for (int c = 0; c < RP / 16; ++c) {
+        int lb[2][3];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const bool in = vloc[j] < R;  // past the unit: any valid record (dy is zero there)
+          int mz = sb + (in ? vz[j] : 0);
+          if (mz >= S) mz -= S;
+          const int base = ((mz * (H + 2) + (in ? vh[j] : 0)) * pitch + (in ? vw[j] : 0)) * WG_VB + chan_off;
+          lb[j][0] = base;
+          lb[j][1] = base - (mz + 1 >= S ? ringbytes : 0);
+          lb[j][2] = base - (mz + 2 >= S ? ringbytes : 0);
+        }
+        fh4 g0[2], g1[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const char* gp = gbuf + (size_t)min(vloc[j], RP - 1) * WG_VB + chan_off;
+          g0[j] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fh4*)(gp));
+          g1[j] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fh4*)(gp + 32));
+        }
+        const fh8 G0 = cat8(g0[0], g0[1]), G1 = cat8(g1[0], g1[1]);
+        // two taps' fragments at a time (all four at once, as wgrad_f16x2_kernel does, spill next to the prefetched unit)
+#pragma unroll
+        for (int tp = 0; tp < 4; tp += 2) {
+          fh8 X0[2], X1[2];
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt) {
+            const int t = tp + tt;
+            if (t < 3 || ntap == 4) {
+              fh4 x0[2], x1[2];
+#pragma unroll
+              for (int j = 0; j < 2; ++j) {
+                const int l = t < 3 ? lb[j][t] : (kz3 == 0 ? lb[j][0] : (kz3 == 1 ? lb[j][1] : lb[j][2]));
+                const char* xp = xB + l + toff[t];
+                x0[j] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fh4*)(xp));
+                x1[j] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fh4*)(xp + 32));
+              }
+              X0[tt] = cat8(x0[0], x0[1]);
+              X1[tt] = cat8(x1[0], x1[1]);
+            }
+          }
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt) {
+            const int t = tp + tt;
+            if (t < 3 || ntap == 4) {
+              accA[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(G0, X0[tt], accA[t], 0, 0, 0);
+              accB[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(G0, X1[tt], accB[t], 0, 0, 0);
+              accB[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(G1, X0[tt], accB[t], 0, 0, 0);
+            }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          vloc[j] += 16;
+          vw[j] += adv_w;
+          vh[j] += adv_h;
+          if (vw[j] >= W) { vw[j] -= W; vh[j] += 1; }
+          while (vh[j] >= H) { vh[j] -= H; vz[j] += 1; }
+        }
+      }
+      if (more) {
+        __builtin_amdgcn_s_waitcnt(WAIT_VM0);
+        st_x(zk + NZ + 1, NZ, rx);
+        st_g(gL + ((u + 1 - u0) & 1) * RP * WG_VB, zk + NZ, rg);
+      }
+      __syncthreads();
+    }
+  }
+
+  float* pbase = a.partial + (((size_t)blockIdx.x * (a.A / 32) + ta) * a.tilesB + tb) * (size_t)27 * 1024;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    if (t < ntap) {
+      const int tap = t < 3 ? 9 * t + wave : 9 * wave + 8;
+      float* pp = pbase + (size_t)tap * 1024;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        pp[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + col] = (accA[t][r] + accB[t][r] * (1.f / 2048.f)) * ginv;
+    }
+  }
+}
 
 // ------------------------------------------------------------------------------------------------------------
 // The same contraction for the STRIDED (KD, 4, 4) convs between the U-Net's levels (Downsample, models.py:360-365; and, with the two
@@ -522,6 +805,25 @@ static size_t wgrad16_lds(Dims3 d) {
   const int RP = (WG_NZ * PV + 15) & ~15;
   return (size_t)(RP + 1) * WG_VB + (size_t)(WG_NZ + 2) * (d.h + 2) * (d.w + 1) * WG_VB;
 }
+// geometry of the z-sliding form: NZ planes per unit (units of <= 144 voxels, <= 192 for one large plane), a ring of 2 NZ + 2 plane
+// slots, two dy images and the coefficient table within 160 KB
+static bool wgrad_ring_geometry(Dims3 d, int* NZ_out, size_t* lds_out) {
+  const int PV = d.h * d.w;
+  if (PV > 192 || PV < 1) return false;
+  int NZ = 144 / PV;
+  if (NZ < 1) NZ = 1;
+  if (NZ > d.d) NZ = d.d;
+  for (; NZ >= 1; --NZ) {
+    const int RP = (NZ * PV + 15) & ~15;
+    const size_t lds = ((size_t)2 * RP + 1 + (size_t)(2 * NZ + 2) * (d.h + 2) * (d.w + 1)) * WG_VB + 512;
+    if (lds <= 160 * 1024) {
+      *NZ_out = NZ;
+      *lds_out = lds;
+      return true;
+    }
+  }
+  return false;
+}
 bool wgrad_f16x2_eligible(Dims3 d) {
   if (getenv("CD_NO_WGRAD16")) return false;
   // (planes under 64 voxels were once left to the fp32 kernels: with the max-|dy| pass shared and at HBM speed the fp16 pipe
@@ -547,6 +849,38 @@ bool try_launch_wgrad_f16x2(const float* g, int A, const float* x, int Bc, int x
   const int tiles = (A / 32) * (Bc / 32);
   int nblk = 256 / tiles;
   if (nblk < 32) nblk = 32;
+  {
+    // z-sliding form (wgrad_ring_f16x2_kernel): every workgroup one chunk of consecutive units of one sample where the batch allows
+    int NZ = 0;
+    size_t rlds = 0;
+    static const bool no_ring = getenv("CD_NO_WGRAD_RING") != nullptr;
+    if (!no_ring && wgrad_ring_geometry(d, &NZ, &rlds)) {
+      WgradRingArgs r;
+      r.g = g; r.x = x; r.A = A; r.xld = xld; r.xoff = xoff; r.D = d.d; r.H = d.h; r.W = d.w;
+      r.NZ = NZ; r.S = 2 * NZ + 2;
+      r.U = (d.d + NZ - 1) / NZ;
+      int want = nblk;
+      if (const char* e = getenv("CD_WGRAD_RING_NBLK")) want = atoi(e) > 0 ? atoi(e) : nblk;  // tests: few workgroups => long chunks, several per workgroup
+      if (want > nblk) want = nblk;
+      int cps = want / batch;
+      if (cps < 1) cps = 1;
+      if (cps > r.U) cps = r.U;
+      r.upc = (r.U + cps - 1) / cps;
+      r.cps = (r.U + r.upc - 1) / r.upc;
+      r.total_chunks = r.cps * batch;
+      r.partial = partial; r.tilesB = Bc / 32; r.gmax_bits = f.gmax_bits; r.xcoef = xcoef;
+      int rblk = want < r.total_chunks ? want : r.total_chunks;
+      static bool ring_attr = false;
+      if (!ring_attr) {
+        CD_HIP(hipFuncSetAttribute((const void*)wgrad_ring_f16x2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ring_attr = true;
+      }
+      hipLaunchKernelGGL(wgrad_ring_f16x2_kernel, dim3(rblk, tiles), dim3(512), rlds, s, r);
+      CD_HIP(hipGetLastError());
+      *nblk_out = rblk;
+      return true;
+    }
+  }
   if (nblk > f.total_units) nblk = f.total_units;
   static bool attr_set = false;
   if (!attr_set) {

@@ -117,3 +117,21 @@ def test_group_norm_backward(ops):
         assert rel_l2(dg.cpu().numpy(), gm.grad.numpy()) < TOL, ("dgamma", C, G)
         assert rel_l2(db.cpu().numpy(), bt.grad.numpy()) < TOL, ("dbeta", C, G)
         assert rel_l2(dadd.cpu().numpy(), add.grad.numpy()) < TOL, ("dadd", C, G)
+
+
+@pytest.mark.parametrize("nblk", [None, "3", "8"])
+def test_conv_weight_gradient_z_sliding_kernel(ops, nblk, monkeypatch):
+    """3x3x3 stride-1 dW from wgrad_ring_f16x2_kernel (round 4): a workgroup owns a chunk of consecutive units of one sample, x
+    planes in a ring of 2 NZ + 2 slots, the next unit prefetched under the K loop.  Cases: one plane per unit (144-voxel planes:
+    the ring wraps every four units), several planes per unit with a ragged last unit (23 planes of 32 voxels, NZ = 4), units
+    whose 16-voxel K steps straddle planes (8-voxel planes), the normalised-x operand is covered by the training tests.
+    CD_WGRAD_RING_NBLK caps the workgroups: long chunks (12+ units), more chunks than workgroups (a workgroup starts a second
+    chunk with a used ring), and the default (one unit per chunk at these batch sizes: prologue only)."""
+    if nblk:
+        monkeypatch.setenv("CD_WGRAD_RING_NBLK", nblk)
+    gen = torch.Generator().manual_seed(31)
+    _conv_case(ops, 32, 32, (2, 45, 16, 9), (3, 3, 3), (1, 1, 1), gen)
+    _conv_case(ops, 64, 64, (4, 23, 8, 4), (3, 3, 3), (1, 1, 1), gen)
+    _conv_case(ops, 64, 32, (3, 12, 4, 2), (3, 3, 3), (1, 1, 1), gen)
+    _conv_case(ops, 64, 32, (1, 7, 16, 9), (3, 3, 3), (1, 1, 1), gen, split=32)
+    _conv_case(ops, 32, 32, (5, 9, 12, 7), (3, 3, 3), (1, 1, 1), gen, dy_scale=3e-7)
