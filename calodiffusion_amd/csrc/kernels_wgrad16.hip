@@ -296,8 +296,10 @@ struct WgradRingArgs {
   int tilesB;
   const unsigned* gmax_bits;
   const float* xcoef;              // as Wgrad16Args
+  int abl;                         // experiment builds (-DCD_WGRAD_ABL): phases switched off, tools/wgrad_bench.py
 };
 
+template <bool ONE>
 __global__ void __launch_bounds__(512, 1) wgrad_ring_f16x2_kernel(WgradRingArgs a) {
   extern __shared__ __attribute__((aligned(16))) char wl[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -331,9 +333,17 @@ __global__ void __launch_bounds__(512, 1) wgrad_ring_f16x2_kernel(WgradRingArgs 
 #pragma unroll
     for (int r = 0; r < 16; ++r) accA[t][r] = accB[t][r] = 0.f;
 
+  // Transposing-load roles, laid out for the LDS banks: a ds_read_b64_tr_b16 is served in two groups of 32 lanes (16-lane groups
+  // g4 = 0, 1 and 2, 3: both channel blocks of the same four voxel rows), each conflict-free when its 32 eight-byte pieces cover
+  // the 64 banks once.  Records of 36 dwords: four CONSECUTIVE voxels start at banks 0, 36, 8, 44 and the two channel blocks of
+  // wgrad_f16x2_kernel's record ([block][term]: 16 dwords apart) wrap onto each other -- every fragment read took twice its
+  // LDS cycles, 560 of them per K step and CU beside 672 cycles of MFMAs per SIMD.  Here the record is [term][block] (a voxel's
+  // two blocks are one 64-byte run) and the four rows of a load are voxels 4 q apart (K slot (half, j, q) <-> voxel
+  // 4 q + 2 half + j of the step): 4 x 36 dwords = 16 mod 64, so the rows start at banks 0, 16, 32, 48 (dy image: always; x
+  // image: unless an r row or plane ends between them).
   const int g4 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
-  const int chan_off = (g4 & 1) * 64 + p4 * 8;
-  const int vrow0 = 8 * (g4 >> 1) + q4;
+  const int chan_off = (g4 & 1) * 32 + p4 * 8;
+  const int vrow0 = 4 * q4 + 2 * (g4 >> 1);
   const int adv_h = 16 / W, adv_w = 16 - adv_h * W;
   const float inv_pv = 1.f / (float)PV, inv_w = 1.f / (float)W;
   auto div_pv = [&](int v) { return (int)(((float)v + 0.5f) * inv_pv); };
@@ -341,7 +351,7 @@ __global__ void __launch_bounds__(512, 1) wgrad_ring_f16x2_kernel(WgradRingArgs 
 
   // staging roles: a thread moves the channel quad qd of voxels vb, vb + 64, vb + 128 (R <= 192) of a unit
   const int qd = tid & 7, vb_ = tid >> 3;
-  const int qoff = (qd >> 2) * 64 + (qd & 3) * 8;
+  const int qoff = qd * 8;  // [term][block][16 fp16]: quad qd of term 0 at byte 8 qd, term 1 64 bytes on
   const float* const gcol = a.g + ta * 32 + qd * 4;
   const float* const xcol = a.x + a.xoff + tb * 32 + qd * 4;
 
@@ -372,7 +382,7 @@ __global__ void __launch_bounds__(512, 1) wgrad_ring_f16x2_kernel(WgradRingArgs 
         split2(v < nvalid ? r[k] * gscale : f32x4{0.f, 0.f, 0.f, 0.f}, t1, t2);
         char* d = gbuf + v * WG_VB + qoff;
         *(u32x2*)d = t1;
-        *(u32x2*)(d + 32) = t2;
+        *(u32x2*)(d + 64) = t2;
       }
     }
   };
@@ -410,16 +420,16 @@ __global__ void __launch_bounds__(512, 1) wgrad_ring_f16x2_kernel(WgradRingArgs 
         if (sl >= S) sl -= S;
         char* d = xB + ((sl * (H + 2) + h + 1) * pitch + w) * WG_VB + qoff;
         *(u32x2*)d = t1;
-        *(u32x2*)(d + 32) = t2;
+        *(u32x2*)(d + 64) = t2;
         if (h == 0) {
           char* d2 = d + H * pitch * WG_VB;
           *(u32x2*)d2 = t1;
-          *(u32x2*)(d2 + 32) = t2;
+          *(u32x2*)(d2 + 64) = t2;
         }
         if (h == H - 1) {
           char* d2 = d - H * pitch * WG_VB;
           *(u32x2*)d2 = t1;
-          *(u32x2*)(d2 + 32) = t2;
+          *(u32x2*)(d2 + 64) = t2;
         }
       }
     }
@@ -455,7 +465,11 @@ __global__ void __launch_bounds__(512, 1) wgrad_ring_f16x2_kernel(WgradRingArgs 
 
     for (int u = u0; u < u1; ++u) {
       const int zk = u * NZ;
+#ifdef CD_WGRAD_ABL
+      const bool more = u + 1 < u1 && !(a.abl & 4);
+#else
       const bool more = u + 1 < u1;
+#endif
       f32x4 rx[3], rg[3];
       if (more) {
         ld_x(n, zk + NZ + 1, NZ, rx);
@@ -464,10 +478,99 @@ __global__ void __launch_bounds__(512, 1) wgrad_ring_f16x2_kernel(WgradRingArgs 
       // ---- K loop of unit u: dy image (u - u0) & 1, x planes zk - 1 .. zk + NZ ----
       const char* gbuf = gL + ((u - u0) & 1) * RP * WG_VB;
       const int sb = zk % S;  // slot of plane zk - 1
+#ifdef CD_WGRAD_ABL
+      if (a.abl & 2) { __syncthreads(); continue; }
+#endif
+      // (Tried: the second wave of each SIMD entering the K loop 3-10 x 64 cycles late, so that one wave's fragment reads run under
+      // the other's MFMAs instead of both reading, then both multiplying: +0.6 ... +1.4 us per launch, the delay itself.  The sum
+      // of the two phases is not a matter of phase: LDS reads issue slowly beside another wave's MFMA stream.)
+      if constexpr (ONE) {
+        // One plane per unit (level 0): every lane's voxel is in plane zk, so a tap's ring slot is a per-unit SCALAR and a lane only
+        // advances a record offset.  ~20 vector instructions per K step instead of ~100: beside the other wave's MFMA stream a
+        // wave issues one vector instruction per 10-17 cycles, and the general form's index arithmetic, not its 21 MFMAs
+        // per SIMD (672 cycles), set the K step's ~1800 cycles.
+        int tu[4];
+        {
+          int sk[3];
+#pragma unroll
+          for (int kz = 0; kz < 3; ++kz) {
+            int sl = sb + kz;
+            if (sl >= S) sl -= S;
+            sk[kz] = sl * prow * WG_VB;
+          }
+#pragma unroll
+          for (int t = 0; t < 3; ++t) tu[t] = toff[t] - t * prow * WG_VB + sk[t];
+          tu[3] = toff[3] - kz3 * prow * WG_VB + (kz3 == 0 ? sk[0] : (kz3 == 1 ? sk[1] : sk[2]));
+        }
+        int vloc[2], vw[2], roff[2], goff[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int v = vrow0 + j;
+          vloc[j] = v;
+          const int vv = min(v, R - 1);
+          const int h = div_w(vv);
+          vw[j] = vv - h * W;
+          roff[j] = v < R ? (h * pitch + vw[j]) * WG_VB + chan_off : chan_off;
+          goff[j] = v * WG_VB + chan_off;
+        }
+        const int step_b = (adv_h * pitch + adv_w) * WG_VB;
+        for (int c = 0; c < RP / 16; ++c) {
+          fh4 g0[2], g1[2];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const char* gp = gbuf + goff[j];
+            g0[j] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fh4*)(gp));
+            g1[j] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fh4*)(gp + 64));
+          }
+          const fh8 G0 = cat8(g0[0], g0[1]), G1 = cat8(g1[0], g1[1]);
+          fh8 X0[4], X1[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            if (t < 3 || ntap == 4) {
+              fh4 x0[2], x1[2];
+#pragma unroll
+              for (int j = 0; j < 2; ++j) {
+                const char* xp = xB + roff[j] + tu[t];
+                x0[j] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fh4*)(xp));
+                x1[j] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fh4*)(xp + 64));
+              }
+              X0[t] = cat8(x0[0], x0[1]);
+              X1[t] = cat8(x1[0], x1[1]);
+            }
+          }
+#if defined(CD_WGRAD_ABL) && CD_WGRAD_ABL == 1  // no MFMAs (the fragment reads stay)
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            if (t < 3 || ntap == 4) {
+              accA[t][0] += (float)X0[t][0] + (float)G0[0];
+              accB[t][0] += (float)X1[t][0] + (float)G1[0];
+            }
+#else
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            if (t < 3 || ntap == 4) {
+              accA[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(G0, X0[t], accA[t], 0, 0, 0);
+              accB[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(G0, X1[t], accB[t], 0, 0, 0);
+              accB[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(G1, X0[t], accB[t], 0, 0, 0);
+            }
+          }
+#endif
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            vloc[j] += 16;
+            goff[j] += 16 * WG_VB;
+            vw[j] += adv_w;
+            const bool carry = vw[j] >= W;
+            vw[j] -= carry ? W : 0;
+            roff[j] += step_b + (carry ? WG_VB : 0);
+            if (vloc[j] >= R) roff[j] = chan_off;  // past the unit (dy is zero there): any valid record
+          }
+        }
+      } else {
       int vloc[2], vz[2], vh[2], vw[2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const int v = vrow0 + 4 * j;
+        const int v = vrow0 + j;
         vloc[j] = v;
         const int vv = min(v, R - 1);
         vz[j] = div_pv(vv);
@@ -492,7 +595,7 @@ __global__ void __launch_bounds__(512, 1) wgrad_ring_f16x2_kernel(WgradRingArgs 
         for (int j = 0; j < 2; ++j) {
           const char* gp = gbuf + (size_t)min(vloc[j], RP - 1) * WG_VB + chan_off;
           g0[j] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fh4*)(gp));
-          g1[j] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fh4*)(gp + 32));
+          g1[j] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fh4*)(gp + 64));
         }
         const fh8 G0 = cat8(g0[0], g0[1]), G1 = cat8(g1[0], g1[1]);
         // two taps' fragments at a time (all four at once, as wgrad_f16x2_kernel does, spill next to the prefetched unit)
@@ -509,7 +612,7 @@ __global__ void __launch_bounds__(512, 1) wgrad_ring_f16x2_kernel(WgradRingArgs 
                 const int l = t < 3 ? lb[j][t] : (kz3 == 0 ? lb[j][0] : (kz3 == 1 ? lb[j][1] : lb[j][2]));
                 const char* xp = xB + l + toff[t];
                 x0[j] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fh4*)(xp));
-                x1[j] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fh4*)(xp + 32));
+                x1[j] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fh4*)(xp + 64));
               }
               X0[tt] = cat8(x0[0], x0[1]);
               X1[tt] = cat8(x1[0], x1[1]);
@@ -534,6 +637,7 @@ __global__ void __launch_bounds__(512, 1) wgrad_ring_f16x2_kernel(WgradRingArgs 
           while (vh[j] >= H) { vh[j] -= H; vz[j] += 1; }
         }
       }
+      }
       if (more) {
         __builtin_amdgcn_s_waitcnt(WAIT_VM0);
         st_x(zk + NZ + 1, NZ, rx);
@@ -544,6 +648,9 @@ __global__ void __launch_bounds__(512, 1) wgrad_ring_f16x2_kernel(WgradRingArgs 
   }
 
   float* pbase = a.partial + (((size_t)blockIdx.x * (a.A / 32) + ta) * a.tilesB + tb) * (size_t)27 * 1024;
+#ifdef CD_WGRAD_ABL
+  if ((a.abl & 8) && accA[0][0] != 12345.f) return;
+#endif
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     if (t < ntap) {
@@ -869,13 +976,17 @@ bool try_launch_wgrad_f16x2(const float* g, int A, const float* x, int Bc, int x
       r.cps = (r.U + r.upc - 1) / r.upc;
       r.total_chunks = r.cps * batch;
       r.partial = partial; r.tilesB = Bc / 32; r.gmax_bits = f.gmax_bits; r.xcoef = xcoef;
+      r.abl = getenv("CD_WGRAD_ABL") ? atoi(getenv("CD_WGRAD_ABL")) : 0;
       int rblk = want < r.total_chunks ? want : r.total_chunks;
       static bool ring_attr = false;
       if (!ring_attr) {
-        CD_HIP(hipFuncSetAttribute((const void*)wgrad_ring_f16x2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        CD_HIP(hipFuncSetAttribute((const void*)wgrad_ring_f16x2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        CD_HIP(hipFuncSetAttribute((const void*)wgrad_ring_f16x2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ring_attr = true;
       }
-      hipLaunchKernelGGL(wgrad_ring_f16x2_kernel, dim3(rblk, tiles), dim3(512), rlds, s, r);
+      static const bool no_one = getenv("CD_WGRAD_RING_GENERAL") != nullptr;  // A/B: the general K loop for one-plane units too
+      if (NZ == 1 && !no_one) hipLaunchKernelGGL(wgrad_ring_f16x2_kernel<true>, dim3(rblk, tiles), dim3(512), rlds, s, r);
+      else hipLaunchKernelGGL(wgrad_ring_f16x2_kernel<false>, dim3(rblk, tiles), dim3(512), rlds, s, r);
       CD_HIP(hipGetLastError());
       *nblk_out = rblk;
       return true;

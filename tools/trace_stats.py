@@ -17,6 +17,7 @@ ap.add_argument("--marker", required=True)
 ap.add_argument("--last", type=int, required=True, help="the region starts at the N-th last launch of the marker kernel")
 ap.add_argument("--out", required=True)
 ap.add_argument("--steps", type=int, default=1, help="steps in the region (printed per-step figures)")
+ap.add_argument("--list", default=None, help="also print every launch of kernels whose name contains this (duration, grid, LDS) of the LAST step")
 a = ap.parse_args()
 rows = list(csv.DictReader(open(a.trace)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
@@ -40,3 +41,10 @@ print(f"timed region: {len(rows)} launches, kernel time {tot / 1e6:.3f} ms, wall
       f"{tot / 1e6 / a.steps:.3f} ms of kernels and {len(rows) / a.steps:.0f} launches per step")
 for k, e in sorted(agg.items(), key=lambda kv: -kv[1][1])[:30]:
     print(f"  {k[:100]:100s} calls/step {e[0] / a.steps:6.1f} avg {e[1] / e[0] / 1e3:8.1f} us  {100.0 * e[1] / tot:5.1f} %")
+if a.list:
+    per = len(rows) // a.steps
+    for r in rows[-per:]:
+        if a.list in r["Kernel_Name"]:
+            d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+            print(f"  {d / 1e3:8.1f} us  grid {r.get('Grid_Size_X', '?')}x{r.get('Grid_Size_Y', '?')}x{r.get('Grid_Size_Z', '?')} wg {r.get('Workgroup_Size_X', '?')} "
+                  f"lds {r.get('LDS_Block_Size', '?')}  {r['Kernel_Name'][:60]}")
