@@ -481,6 +481,9 @@ __global__ void __launch_bounds__(512, 1) wgrad_ring_f16x2_kernel(WgradRingArgs 
 #ifdef CD_WGRAD_ABL
       if (a.abl & 2) { __syncthreads(); continue; }
 #endif
+      // (Tried and measured, same box: ONE wave per SIMD -- four waves of seven tap slots, slot s + 1's fragments requested before slot
+      // s's MFMAs, the next K step's under the last slot's, 452 registers, no spills: 55-62 us per level-0 launch against 46-49 here,
+      // 35-37 against 29-30 at level 1: with one wave nothing covers the staging's and the prologue's memory round trips.)
       // (Tried: the second wave of each SIMD entering the K loop 3-10 x 64 cycles late, so that one wave's fragment reads run under
       // the other's MFMAs instead of both reading, then both multiplying: +0.6 ... +1.4 us per launch, the delay itself.  The sum
       // of the two phases is not a matter of phase: LDS reads issue slowly beside another wave's MFMA stream.)
