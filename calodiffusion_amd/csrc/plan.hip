@@ -180,6 +180,7 @@ struct CdPlan {
     return g;
   }
   hipGraphExec_t graph_exec = nullptr;
+  hipGraphExec_t graph_exec_chunk = nullptr;  // kEmbedChunk consecutive steps as ONE graph (same key): no gap between their launches
   struct GraphKey {
     int batch = 0; const void* ws = nullptr; const void* cond = nullptr; const void* x = nullptr; int noisy = 0; uint64_t seed = 0, offset = 0;
     int precision = 0;  // the captured kernels are those of the convolution precision in force at capture time
@@ -1144,6 +1145,10 @@ void destroy_graph(CdPlan* p) {
     hipGraphExecDestroy(p->graph_exec);
     p->graph_exec = nullptr;
   }
+  if (p->graph_exec_chunk) {
+    hipGraphExecDestroy(p->graph_exec_chunk);
+    p->graph_exec_chunk = nullptr;
+  }
 }
 void destroy_prog_graph(CdPlan* p) {
   if (p->prog_exec) {
@@ -1658,9 +1663,29 @@ int cd_ddim_sample(CdPlan* plan, int batch, const float* start, const float* con
         CdPlan::GraphKey key;
         key.batch = batch; key.ws = workspace; key.cond = cond; key.x = x_out; key.noisy = noisy ? 1 : 0;
         key.precision = conv_precision();
+        // `count` consecutive steps as one graph: every step reads its index from the device counter, so the same capture serves any
+        // position in the schedule
+        auto capture = [&](int count) -> hipGraphExec_t {
+          if (!plan->cap_stream) CD_HIP(hipStreamCreateWithFlags(&plan->cap_stream, hipStreamNonBlocking));
+          hipStream_t cs = plan->cap_stream;
+          hipGraph_t graph = nullptr;
+          CD_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed));
+          try {
+            for (int k = 0; k < count; ++k) one_step(cs, 0, nullptr, nullptr, nullptr);
+          } catch (...) {
+            hipStreamEndCapture(cs, &graph);
+            if (graph) hipGraphDestroy(graph);
+            throw;
+          }
+          CD_HIP(hipStreamEndCapture(cs, &graph));
+          hipGraphExec_t exec = nullptr;
+          hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+          hipGraphDestroy(graph);
+          if (e != hipSuccess) throw Fail{CD_EHIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)};
+          return exec;
+        };
         if (!(plan->graph_exec && plan->graph_key == key)) {
           destroy_graph(plan);
-          hipGraph_t graph = nullptr;
           // one eager pass first: per-geometry kernel tuning (and lazy function attributes) cannot happen during capture.
           // It only writes x0 / scratch, which the replayed steps overwrite.
           launch_load_step(plan->d_table, plan->d_counter, plan->d_stepvals, sigma_b, batch, s);
@@ -1668,28 +1693,22 @@ int cd_ddim_sample(CdPlan* plan, int batch, const float* start, const float* con
           forward_impl(plan, batch, x_out, cond, sigma_b, x0, false, s);
           CD_HIP(hipMemsetAsync(plan->d_counter, 0, sizeof(int), s));
           CD_HIP(hipStreamSynchronize(s));
-          if (!plan->cap_stream) CD_HIP(hipStreamCreateWithFlags(&plan->cap_stream, hipStreamNonBlocking));
-          hipStream_t cs = plan->cap_stream;
-          CD_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed));
-          try {
-            one_step(cs, 0, nullptr, nullptr, nullptr);
-          } catch (...) {
-            hipStreamEndCapture(cs, &graph);
-            if (graph) hipGraphDestroy(graph);
-            throw;
-          }
-          CD_HIP(hipStreamEndCapture(cs, &graph));
-          hipError_t e = hipGraphInstantiate(&plan->graph_exec, graph, nullptr, nullptr, 0);
-          hipGraphDestroy(graph);
-          if (e != hipSuccess) {
-            plan->graph_exec = nullptr;
-            throw Fail{CD_EHIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)};
-          }
+          plan->graph_exec = capture(1);
           plan->graph_key = key;
         }
-        for (int i = 0; i < n_steps; ++i) {
+        // Schedules of at least one embedding chunk replay the chunk's kEmbedChunk steps as ONE graph (8.5 us of idle time sat
+        // between two graph launches: profiles/r04_graph_gaps.txt); the tail, and short schedules, replay the one-step graph.
+        static const bool no_chunk = getenv("CD_NO_CHUNK_GRAPH") != nullptr;
+        if (!no_chunk && n_steps >= K && !plan->graph_exec_chunk) plan->graph_exec_chunk = capture(K);
+        for (int i = 0; i < n_steps;) {
           if (i % K == 0) embed_ahead(s, i);
-          CD_HIP(hipGraphLaunch(plan->graph_exec, s));
+          if (!no_chunk && plan->graph_exec_chunk && i % K == 0 && i + K <= n_steps) {
+            CD_HIP(hipGraphLaunch(plan->graph_exec_chunk, s));
+            i += K;
+          } else {
+            CD_HIP(hipGraphLaunch(plan->graph_exec, s));
+            i += 1;
+          }
         }
       } else {
         for (int i = 0; i < n_steps; ++i) {
