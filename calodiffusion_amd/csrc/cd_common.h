@@ -278,6 +278,29 @@ void launch_gn_finalize(const float* part, int units, const float* gamma, const 
 
 // ---- backward (kernels_bwd.hip) ---------------------------------------------------------------------------------
 size_t wgrad_partial_floats(int64_t out_vox, int batch, bool per_sample, int A, int Bc, int T);
+// Deferred slot reductions of the weight gradients (training step).  Every launch_wgrad ends in a reduction of its per-workgroup
+// partials: ~28 MB read for a few hundred KB of dw whatever the level, 65 launches of 4-7 us per step.  While a queue is current
+// (wgrad_queue_set), launch_wgrad takes its partial buffer from the queue's own region instead of the caller's (which the caller
+// reuses for its next weight gradient) and records the reduction as a job; wgrad_queue_flush runs all of them in ONE launch (same
+// two-level fixed-order sum per output: deterministic).  A queue without room (region too small, job table full) simply leaves
+// the reduction where it was.
+struct WgradReduceJob {
+  const float* partial;
+  float* dw;
+  int A, Bc, T, nslots, flags /* 1 accumulate, 2 transposed_out */, b_total, b_off;
+  unsigned first_block;
+};
+struct WgradReduceQueue {
+  static constexpr int kMax = 80;   // (the job table travels as a kernel argument: 48 B x 80 < 4 KB)
+  WgradReduceJob job[kMax];
+  int n = 0;
+  unsigned blocks = 0;
+  float* base = nullptr;            // region the owner keeps until the flush
+  size_t cap = 0, used = 0;         // floats
+  size_t need = 0;                  // floats all requests of this pass asked for (the owner sizes the next pass's region by it)
+};
+void wgrad_queue_set(WgradReduceQueue* q);  // nullptr: reductions are launched where they arise
+void wgrad_queue_flush(WgradReduceQueue* q, hipStream_t s);
 // dW[a][b][tap] (or [b][a][tap] if transposed_out) = sum_{n,o} g[n][o][a] * x[n][in(o,tap)][xoff + b]; see kernels_bwd.hip
 void launch_wgrad(const float* g, int A, Dims3 dg, const float* x, int Bc, int xld, int xoff, Dims3 dx, int kd, int kh, int kw,
                   int sz, int sxy, int batch, bool per_sample, float* partial, float* dw, bool accumulate, bool transposed_out,

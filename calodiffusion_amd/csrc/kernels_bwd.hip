@@ -542,10 +542,100 @@ __global__ void __launch_bounds__(256) wgrad_reduce1_kernel(const float* __restr
     *d = accumulate ? *d + sum : sum;
   }
 }
+// All queued slot reductions of a training step in one launch (WgradReduceQueue, cd_common.h): a block finds its job by binary
+// search over the jobs' first blocks, then runs wgrad_reduce1_kernel's body (64 consecutive outputs x 4 slot lanes).
+struct WgradReduceJobs {
+  WgradReduceJob job[WgradReduceQueue::kMax];
+  int n;
+};
+__global__ void __launch_bounds__(256) wgrad_reduce_jobs_kernel(WgradReduceJobs J) {
+  int lo = 0, hi = J.n - 1;
+  while (lo < hi) {  // last job whose first_block <= blockIdx.x
+    const int mid = (lo + hi + 1) >> 1;
+    if (J.job[mid].first_block <= blockIdx.x) lo = mid;
+    else hi = mid - 1;
+  }
+  const WgradReduceJob& j = J.job[lo];
+  const int A = j.A, Bc = j.Bc, T = j.T, nslots = j.nslots;
+  const size_t total = (size_t)A * Bc * T;
+  const int oi = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const size_t idx = (size_t)(blockIdx.x - j.first_block) * 64 + oi;
+  float acc = 0.f;
+  if (idx < total) {
+    const float* p = j.partial + idx;
+    float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int k = sl;
+    for (; k + 4 * 15 < nslots; k += 4 * 16) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = p[(size_t)(k + 4 * u) * total];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) a8[u & 7] += v[u];
+    }
+    for (int u = 0; k < nslots; k += 4, ++u) a8[u & 7] += p[(size_t)k * total];
+    acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+  }
+  __shared__ float sR[4][64];
+  sR[sl][oi] = acc;
+  __syncthreads();
+  if (threadIdx.x < 64 && idx < total) {
+    const float sum = (sR[0][oi] + sR[1][oi]) + (sR[2][oi] + sR[3][oi]);
+    const int cb = idx & 31, ra = (idx >> 5) & 31;
+    size_t rest = idx >> 10;
+    const int tap = rest % T;
+    rest /= T;
+    const int tilesB = Bc / 32;
+    const int tb = rest % tilesB, ta = rest / tilesB;
+    const int ga = ta * 32 + ra, gb2 = tb * 32 + cb;
+    const size_t o = ((j.flags & 2) ? ((size_t)(gb2 + j.b_off) * A + ga) : ((size_t)ga * j.b_total + j.b_off + gb2)) * T + tap;
+    float* d = j.dw + o;
+    *d = (j.flags & 1) ? *d + sum : sum;
+  }
+}
+namespace {
+thread_local WgradReduceQueue* g_wq = nullptr;
+}
+void wgrad_queue_set(WgradReduceQueue* q) { g_wq = q; }
+void wgrad_queue_flush(WgradReduceQueue* q, hipStream_t s) {
+  if (!q || q->n <= 0) return;
+  WgradReduceJobs J;
+  for (int i = 0; i < q->n; ++i) J.job[i] = q->job[i];
+  J.n = q->n;
+  hipLaunchKernelGGL(wgrad_reduce_jobs_kernel, dim3(q->blocks), dim3(256), 0, s, J);
+  CD_HIP(hipGetLastError());
+  q->n = 0;
+  q->blocks = 0;
+}
+// a partial buffer of the current queue (or nullptr: none current / no room); counts the request either way
+static float* wgrad_queue_alloc(size_t nfloats) {
+  WgradReduceQueue* q = g_wq;
+  if (!q) return nullptr;
+  nfloats = (nfloats + 63) & ~(size_t)63;
+  q->need += nfloats;
+  if (!q->base || q->used + nfloats > q->cap) return nullptr;
+  float* r = q->base + q->used;
+  q->used += nfloats;
+  return r;
+}
+// the reduction of `partial` (a buffer of the current queue) as a job; false if it has to be launched here
+static bool wgrad_queue_push(const float* partial, float* dw, int A, int Bc, int T, int nslots, bool accumulate, bool transposed_out,
+                             int b_total, int b_off, hipStream_t s) {
+  WgradReduceQueue* q = g_wq;
+  if (!q || !q->base || partial < q->base || partial >= q->base + q->cap) return false;
+  if (q->n == WgradReduceQueue::kMax) wgrad_queue_flush(q, s);  // (deeper networks than the shipped ones: flush and go on)
+  WgradReduceJob& j = q->job[q->n++];
+  j.partial = partial; j.dw = dw; j.A = A; j.Bc = Bc; j.T = T; j.nslots = nslots;
+  j.flags = (accumulate ? 1 : 0) | (transposed_out ? 2 : 0);
+  j.b_total = b_total; j.b_off = b_off; j.first_block = q->blocks;
+  q->blocks += (unsigned)(((size_t)A * Bc * T + 63) / 64);
+  return true;
+}
+
 // the slot reduction of the 27- and 48-tap weight gradients (up to 256 partials, one per workgroup): two-level from 64 slots on
 static void launch_wgrad_reduce_slots(const float* partial, float* dw, int A, int Bc, int T, int nslots, bool accumulate,
                                       bool transposed_out, int b_total, int b_off, hipStream_t s) {
   const size_t total = (size_t)A * Bc * T;
+  if (wgrad_queue_push(partial, dw, A, Bc, T, nslots, accumulate, transposed_out, b_total, b_off, s)) return;
   static const bool one_level = getenv("CD_WGRAD_REDUCE_1LEVEL") != nullptr;
   if (nslots >= 64 && !one_level)
     hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3((unsigned)((total + 63) / 64), 1), dim3(256), 0, s, partial, dw, A, Bc, nslots,
@@ -616,6 +706,9 @@ void launch_wgrad(const float* g, int A, Dims3 dg, const float* x, int Bc, int x
   CD_REQUIRE(!xcoef || (!per_sample && wgrad_x_norm_supported(dg, dx, kd, kh, kw, sz, sxy)),
              "wgrad: a normalised x operand is only read by the fp16-pipe 3x3x3 kernel");
   if (b_total <= 0) b_total = Bc;
+  if (!per_sample) {  // training step: a buffer that outlives the caller's, its reduction deferred (WgradReduceQueue)
+    if (float* qp = wgrad_queue_alloc(wgrad_partial_floats(dg.vox(), batch, false, A, Bc, kd * kh * kw))) partial = qp;
+  }
   WgradArgs a;
   a.g = g; a.x = x; a.A = A; a.Bc = Bc; a.xld = xld; a.xoff = xoff;
   a.Dg = dg.d; a.Hg = dg.h; a.Wg = dg.w; a.Dx = dx.d; a.Hx = dx.h; a.Wx = dx.w;
@@ -692,6 +785,7 @@ void launch_wgrad(const float* g, int A, Dims3 dg, const float* x, int Bc, int x
     prof::Scope scope1(cat1, s, 2.0 * A * Bc * (double)dg.vox() * batch, 4.0 * batch * (double)dg.vox() * (A + Bc));
     if (try_launch_wgrad1x1(g, A, x, Bc, xld, xoff, dg.vox(), batch, per_sample, partial, cap_slots, &ns, s)) {
       const size_t total = (size_t)A * Bc;
+      if (!per_sample && wgrad_queue_push(partial, dw, A, Bc, 1, ns, accumulate, transposed_out, b_total, b_off, s)) return;
       dim3 rg1((unsigned)((total + 63) / 64), per_sample ? batch : 1);
       hipLaunchKernelGGL(wgrad_reduce1_kernel, rg1, dim3(256), 0, s, partial, dw, A, Bc, ns, accumulate ? 1 : 0,
                          transposed_out ? 1 : 0, (size_t)ns * total, total, b_total, b_off);
@@ -1751,7 +1845,18 @@ void launch_init_wgrad_mfma(const InitConvArgs& a, const float* g, float* scratc
   float* part = dw32 + (((size_t)a.cout * 32 * 27 + 63) & ~(size_t)63);
   hipLaunchKernelGGL(init_pad_input_kernel, dim3((unsigned)((vox + 255) / 256), (unsigned)a.batch), dim3(256), 0, s, a, xin);
   CD_HIP(hipGetLastError());
-  launch_wgrad(g, a.cout, a.dims, xin, 32, 32, 0, a.dims, 3, 3, 3, 1, 1, a.batch, false, part, dw32, false, false, s);
+  {
+    // dw32 is read right below: this reduction cannot wait in a queue
+    WgradReduceQueue* const q = g_wq;
+    g_wq = nullptr;
+    try {
+      launch_wgrad(g, a.cout, a.dims, xin, 32, 32, 0, a.dims, 3, 3, 3, 1, 1, a.batch, false, part, dw32, false, false, s);
+    } catch (...) {
+      g_wq = q;
+      throw;
+    }
+    g_wq = q;
+  }
   const int total = a.cout * a.cin * 27;
   hipLaunchKernelGGL(init_extract_dw_kernel, dim3((total + 255) / 256), dim3(256), 0, s, dw32, dw, a.cout, a.cin);
   CD_HIP(hipGetLastError());

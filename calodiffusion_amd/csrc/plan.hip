@@ -168,6 +168,10 @@ struct CdPlan {
   // training: the re-packed (channel-transposed, tap-flipped) weight images of every convolution's input gradient, made by ONE
   // job list per step (two launches) instead of two or three pack launches inside each conv_backward (118 launches per step)
   float* dg_arena = nullptr;
+  // training: region for the weight gradients' per-workgroup partials while their reductions are queued (WgradReduceQueue); sized by
+  // the first step's requests (that step reduces where it always did), re-sized if a later step asks for more (a larger batch)
+  float* wq_region = nullptr;
+  size_t wq_cap = 0;
   PackJob* d_dg_jobs = nullptr;
   int n_dg_jobs = 0;
   DgImg dg(int i) const {
@@ -1256,6 +1260,7 @@ int cd_plan_destroy(CdPlan* plan) {
     if (plan->d_pack_jobs) hipFree(plan->d_pack_jobs);
     if (plan->d_dg_jobs) hipFree(plan->d_dg_jobs);
     if (plan->dg_arena) hipFree(plan->dg_arena);
+    if (plan->wq_region) hipFree(plan->wq_region);
     if (plan->arena) hipFree(plan->arena);
     if (plan->d_embed_layers) hipFree(plan->d_embed_layers);
     if (plan->d_coords) hipFree(plan->d_coords);

@@ -41,26 +41,33 @@ def test_parameter_gradients_match_autograd(name, B):
     sd_cpu = {k[6:]: v.detach().cpu() for k, v in m.state_dict().items()}
     want_loss, want = _oracle_grads(cfg, sd_cpu, data, E, noise, layers, rnd, tsteps)
 
-    m.zero_grad()
-    sigma = m.loss_function.draw_sigma(data.cuda(), time=tsteps.cuda(), rnd_normal=rnd.cuda())
-    loss = m.loss_function.loss_function(m, data.cuda(), E.cuda(), sigma=sigma, noise=noise.cuda(),
-                                         layers=None if layers is None else layers.cuda())
-    assert loss.requires_grad and loss.dim() == 0
-    assert abs(float(loss) - want_loss) <= 1e-5 * abs(want_loss)
-    loss.backward()
-    worst = []
-    for kname, p in m.model.named_parameters():
-        assert p.grad is not None, kname
-        err = rel_l2(p.grad.cpu().numpy(), want[kname].numpy())
-        worst.append((err, kname))
-    worst.sort(reverse=True)
-    print(f"[{name}] worst per-tensor gradient errors: {[(round(e, 8), k) for e, k in worst[:3]]}")
-    assert worst[0][0] < 1e-4, worst[:8]
-    # all gradients together
-    got_all = np.concatenate([p.grad.cpu().numpy().ravel() for _, p in m.model.named_parameters()])
-    want_all = np.concatenate([want[k].numpy().ravel() for k, _ in m.model.named_parameters()])
-    print(f"[{name}] all gradients together: {rel_l2(got_all, want_all):.3e}")
-    assert rel_l2(got_all, want_all) < 5e-6
+    # Two identical steps: the plan's first training step reduces every weight gradient's partials where they arise and sizes the
+    # region for them; from the second step on the reductions are queued and run as one launch (WgradReduceQueue): both against
+    # the reference's gradients, and against each other.
+    got_steps = []
+    for rep in range(2):
+        m.zero_grad()
+        sigma = m.loss_function.draw_sigma(data.cuda(), time=tsteps.cuda(), rnd_normal=rnd.cuda())
+        loss = m.loss_function.loss_function(m, data.cuda(), E.cuda(), sigma=sigma, noise=noise.cuda(),
+                                             layers=None if layers is None else layers.cuda())
+        assert loss.requires_grad and loss.dim() == 0
+        assert abs(float(loss) - want_loss) <= 1e-5 * abs(want_loss)
+        loss.backward()
+        worst = []
+        for kname, p in m.model.named_parameters():
+            assert p.grad is not None, kname
+            err = rel_l2(p.grad.cpu().numpy(), want[kname].numpy())
+            worst.append((err, kname))
+        worst.sort(reverse=True)
+        print(f"[{name}] step {rep}: worst per-tensor gradient errors: {[(round(e, 8), k) for e, k in worst[:3]]}")
+        assert worst[0][0] < 1e-4, worst[:8]
+        # all gradients together
+        got_all = np.concatenate([p.grad.cpu().numpy().ravel() for _, p in m.model.named_parameters()])
+        want_all = np.concatenate([want[k].numpy().ravel() for k, _ in m.model.named_parameters()])
+        print(f"[{name}] step {rep}: all gradients together: {rel_l2(got_all, want_all):.3e}")
+        assert rel_l2(got_all, want_all) < 5e-6
+        got_steps.append(got_all)
+    assert rel_l2(got_steps[1], got_steps[0]) < 1e-6  # (the queued reduction sums short slot lists in another order)
 
 
 def test_training_loop_protocol_one_adam_step():
