@@ -421,8 +421,11 @@ __global__ void __launch_bounds__(CS_NW * 64, 1) conv_small_f16x2_kernel(ConvSma
   }
 }
 
+// Eight waves from this many 32-voxel tiles per sample on (four below).  Four-tile samples (HGCal's deepest level): +1.7 % on its
+// sampling step; three-tile samples (Dataset-2's 12 x 4 x 2 level, which the TRAINING step runs through this kernel 24 times --
+// sampling takes deep_level_kernel there): 6.773 / 6.782 -> 6.626 / 6.680 ms per training step, same box (tools/lib_ab.sh cs3).
 #ifndef CS_NW8_FROM
-#define CS_NW8_FROM 4
+#define CS_NW8_FROM 3
 #endif
 constexpr int cs_waves_for(int NT) { return NT >= CS_NW8_FROM ? 8 : 4; }
 template <int NT>
