@@ -13,8 +13,9 @@ host<->device ``extract`` round trips) in between.  Here every sampler is ONE C-
   graph; the others (Restart's nested loops, DPM-Solver-fast's changing orders) run their steps eagerly.
 
 ``DPMAdaptive`` decides every step on the host from a norm of the state: it is a host loop around ``denoise`` (one
-``cd_denoise_safe`` call per model evaluation), not a step program.  Not provided: ``DPMPPSDE`` / ``DPMPP2MSDE`` / ``DPMPP3MSDE``
-(``torchsde`` Brownian trees) and ``BespokeNonStationary`` (needs a trained theta file); asking for them raises.
+``cd_denoise_safe`` call per model evaluation), not a step program.  ``DPMPPSDE`` / ``DPMPP2MSDE`` / ``DPMPP3MSDE`` are step
+programs whose Brownian-tree noise (``torchsde`` in the reference) is drawn with the same law from the device Philox stream
+(``_BrownianSDE``).  Not provided: ``BespokeNonStationary`` (needs a trained theta file); asking for it raises.
 """
 from __future__ import annotations
 
@@ -675,7 +676,160 @@ class DPMAdaptive(DPM):
         return x, None, None
 
 
-DPMPPSDE = _unavailable("DPMPPSDE", "needs torchsde's Brownian tree")
-DPMPP2MSDE = _unavailable("DPMPP2MSDE", "needs torchsde's Brownian tree")
-DPMPP3MSDE = _unavailable("DPMPP3MSDE", "needs torchsde's Brownian tree")
+def _ancestral_step(sigma_from, sigma_to, eta):
+    """get_ancestral_step (utils/sampling.py:31-41): (sigma_down, sigma_up)."""
+    if not eta:
+        return sigma_to, 0.0
+    sigma_up = min(sigma_to, eta * (sigma_to ** 2 * (sigma_from ** 2 - sigma_to ** 2) / sigma_from ** 2) ** 0.5)
+    return (sigma_to ** 2 - sigma_up ** 2) ** 0.5, sigma_up
+
+
+class _BrownianSDE(DPM):
+    """The stochastic DPM-Solver++ samplers (models/sample.py:347-574).  The reference draws their noise from
+    `sampling.BrownianTreeNoiseSampler` (utils/sampling.py:356-382, a torchsde Brownian tree over sigma): a call
+    noise(sigma, sigma') returns (W(sigma') - W(sigma)) / sqrt|sigma' - sigma| -- a unit normal tensor, and draws over disjoint sigma
+    intervals are independent.  torchsde is not installed here and nothing in the tree fixes the VALUES of a path, only its law,
+    so the step programs build the same law from the device Philox stream: one fresh unit normal per disjoint interval, in the
+    order the sampler walks down the schedule, and -- where a sampler asks for two overlapping intervals in one step (DPMPPSDE:
+    [sigma_s, sigma_i] and [sigma_next, sigma_i]) -- the second draw as the variance-weighted sum the Brownian path implies,
+        n(sigma_i -> sigma_next) = (sqrt(d1) n(sigma_i -> sigma_s) + sqrt(d2) n(sigma_s -> sigma_next)) / sqrt(d1 + d2).
+    With ETA = 0 (the DPM family's default) every noise coefficient is exactly zero: the reference still calls its sampler and
+    multiplies by 0.0, the programs draw nothing (and then replay one captured step graph).  There is no reference trajectory to pin
+    these classes to (the reference cannot construct them here): they are pinned by the same loops restated on the CPU oracle with
+    the same unit normals (oracle/samplers_oracle.py: dpmpp_sde / dpmpp_2m_sde / dpmpp_3m_sde)."""
+
+
+class DPMPPSDE(_BrownianSDE):
+    """DPM-Solver++ (stochastic), models/sample.py:347-416: two denoise calls per step, ancestral split of each half step.
+    SAMPLER_OPTIONS: R (0.5), ETA (0), S_NOISE (1)."""
+
+    def __init__(self, config):
+        super().__init__(config)
+        self.r = self.sample_config.get("R", 0.5)
+
+    def build(self, model, num_steps, sample_offset) -> Program:
+        sig = self.setup_sigmas(model, num_steps)
+        prog = Program(6, _f(sig[0]))
+        sg, tf = self.sigma_fn, self.time_fn
+        for i in range(len(sig) - 1):
+            t, t_next = tf(sig[i]), tf(sig[i + 1])
+            h = t_next - t
+            s = t + h * self.r
+            fac = 1 / (2 * self.r)
+            st = prog.step()
+            st.denoise(DN, X, _f(sig[i]))
+            # step 1: to sigma(s)
+            sd, su = _ancestral_step(sg(t), sg(s), self.eta)
+            s_ = tf(torch.as_tensor(sd))
+            terms = [(X, _f(sg(s_) / sg(t))), (DN, -_f((t - s_).expm1()))]
+            if _f(su) != 0.0:
+                st.randn(NZ)  # A = (W(sigma_i) - W(sigma_s)) / sqrt(d1); the reference's draw is (W(sigma_s) - W(sigma_i)) / sqrt(d1) = -A
+                terms.append((NZ, -_f(self.s_noise * su)))
+            st.lin(X2, terms)
+            st.denoise(DN2, X2, _f(sg(s)))
+            # step 2: to sigma(t_next), on the mixed estimate
+            sd, su2 = _ancestral_step(sg(t), sg(t_next), self.eta)
+            t_next_ = tf(torch.as_tensor(sd))
+            e = _f((t - t_next_).expm1())
+            terms = [(X, _f(sg(t_next_) / sg(t))), (DN, -e * (1 - fac)), (DN2, -e * fac)]
+            if _f(su2) != 0.0:
+                d1, d2 = _f(sg(t) - sg(s)), _f(sg(s) - sg(t_next))
+                amp = _f(self.s_noise * su2)
+                if _f(su) == 0.0:
+                    st.randn(NZ)
+                st.randn(XH)  # B = (W(sigma_s) - W(sigma_next)) / sqrt(d2)
+                terms += [(NZ, -amp * math.sqrt(d1 / (d1 + d2))), (XH, -amp * math.sqrt(d2 / (d1 + d2)))]
+            st.lin(X, terms)
+        return prog
+
+
+class DPMPP2MSDE(_BrownianSDE):
+    """DPM-Solver++(2M) SDE, models/sample.py:451-518.  SAMPLER_OPTIONS: SOLVER ('heun' | 'midpoint'), ETA (0), S_NOISE (1)."""
+
+    def __init__(self, config):
+        super().__init__(config)
+        self.solver_type = self.sample_config.get("SOLVER", "heun")
+        if self.solver_type not in {"heun", "midpoint"}:
+            raise ValueError("'SOLVER' must be 'heun' or 'midpoint'")
+
+    def build(self, model, num_steps, sample_offset) -> Program:
+        sig = self.setup_sigmas(model, num_steps)
+        prog = Program(6, _f(sig[0]))
+        OLD = X2
+        h_last = None
+        for i in range(len(sig) - 1):
+            st = prog.step()
+            st.denoise(DN, X, _f(sig[i]))
+            if sig[i + 1] == 0:
+                st.lin(X, [(DN, 1.0)])
+            else:
+                t, s = -sig[i].log(), -sig[i + 1].log()
+                h = s - t
+                eta_h = self.eta * h
+                a, b = _f(sig[i + 1] / sig[i] * (-eta_h).exp()), _f((-h - eta_h).expm1().neg())
+                c = 0.0
+                if h_last is not None:
+                    r = h_last / h
+                    if self.solver_type == "heun":
+                        c = _f(((-h - eta_h).expm1().neg() / (-h - eta_h) + 1) * (1 / r))
+                    else:
+                        c = _f(0.5 * (-h - eta_h).expm1().neg() * (1 / r))
+                terms = [(X, a), (DN, b + c), (OLD, -c)]
+                if self.eta:
+                    st.randn(NZ)  # A over [sigma_next, sigma_i]; the reference's draw is -A
+                    terms.append((NZ, -_f(sig[i + 1] * (-2 * eta_h).expm1().neg().sqrt() * self.s_noise)))
+                st.lin(X, terms)
+                h_last = h
+            st.lin(OLD, [(DN, 1.0)])
+        return prog
+
+
+class DPMPP3MSDE(_BrownianSDE):
+    """DPM-Solver++(3M) SDE, models/sample.py:521-574.  SAMPLER_OPTIONS: ETA (0), S_NOISE (1)."""
+
+    def build(self, model, num_steps, sample_offset) -> Program:
+        sig = self.setup_sigmas(model, num_steps)
+        prog = Program(8, _f(sig[0]))
+        D1, D2 = X2, DN2  # denoised_1, denoised_2
+        h_1 = h_2 = None
+        for i in range(len(sig) - 1):
+            st = prog.step()
+            st.denoise(DN, X, _f(sig[i]))
+            if sig[i + 1] == 0:
+                st.lin(X, [(DN, 1.0)])
+                h = None
+            else:
+                t, s = -sig[i].log(), -sig[i + 1].log()
+                h = s - t
+                h_eta = h * (self.eta + 1)
+                cx, cd, c1, c2 = _f(torch.exp(-h_eta)), _f((-h_eta).expm1().neg()), 0.0, 0.0
+                if h_2 is not None:
+                    r0, r1 = h_1 / h, h_2 / h
+                    phi_2 = h_eta.neg().expm1() / h_eta + 1
+                    phi_3 = phi_2 / h_eta - 0.5
+                    k = r0 / (r0 + r1)
+                    # x += phi_2 d1 - phi_3 d2 with d1_0 = (D - D1) / r0, d1_1 = (D1 - D2) / r1,
+                    # d1 = d1_0 + (d1_0 - d1_1) k, d2 = (d1_0 - d1_1) / (r0 + r1)
+                    P = phi_2 * (1 + k) - phi_3 / (r0 + r1)   # coefficient of d1_0
+                    Q = -phi_2 * k + phi_3 / (r0 + r1)        # coefficient of d1_1
+                    cd += _f(P / r0)
+                    c1 = _f(-P / r0 + Q / r1)
+                    c2 = _f(-Q / r1)
+                elif h_1 is not None:
+                    r = h_1 / h
+                    phi_2 = h_eta.neg().expm1() / h_eta + 1
+                    cd += _f(phi_2 / r)
+                    c1 = -_f(phi_2 / r)
+                terms = [(X, cx), (DN, cd), (D1, c1), (D2, c2)]
+                nz = _f(sig[i + 1] * (-2 * h * self.eta).expm1().neg().sqrt() * self.s_noise)
+                if nz != 0.0:
+                    st.randn(NZ)  # A over [sigma_next, sigma_i]; the reference's draw is -A
+                    terms.append((NZ, -nz))
+                st.lin(X, terms)
+            st.lin(D2, [(D1, 1.0)])
+            st.lin(D1, [(DN, 1.0)])
+            h_1, h_2 = h, h_1
+        return prog
+
+
 BespokeNonStationary = _unavailable("BespokeNonStationary", "needs a trained theta file (SAMPLER_PATH)")

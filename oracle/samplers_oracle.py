@@ -168,6 +168,136 @@ def dpmpp2s(denoise: Denoise, start: Tensor, sig: Tensor, noise: Iterator[Tensor
     return x
 
 
+class BrownianPath:
+    """Stand-in for sampling.BrownianTreeNoiseSampler (utils/sampling.py:327-382; torchsde is not installed here, so the reference's
+    SDE samplers cannot run and these three restatements are PARITY UNPINNED: no reference trajectory exists for them in this
+    tree).  The reference's sampler returns noise(sigma, sigma') = (W(sigma') - W(sigma)) / sqrt|sigma' - sigma| for a Brownian path
+    W over sigma (BatchedBrownianTree.__call__ sorts the pair and multiplies by the sort sign, which gives exactly this difference).
+    Here W is built on the points the sampler asks for, walking DOWN the schedule: a new point p below the lowest known point L
+    gets W(p) = W(L) - sqrt(L - p) xi with xi the next unit normal of `noise` -- xi is the normalised increment over [p, L]."""
+
+    def __init__(self, noise: Iterator[Tensor], sigma_top):
+        self.noise = noise
+        self.pts = [(float(sigma_top), 0.0)]  # (sigma, W), sigma descending
+
+    def w(self, sigma):
+        sigma = float(sigma)
+        for p, wv in self.pts:
+            if p == sigma:
+                return wv
+        low, wl = self.pts[-1]
+        assert sigma < low, "BrownianPath: points must be requested walking down the schedule"
+        wv = wl - math.sqrt(low - sigma) * next(self.noise)
+        self.pts.append((sigma, wv))
+        return wv
+
+    def __call__(self, sigma, sigma_next):
+        w0 = self.w(sigma)
+        return (self.w(sigma_next) - w0) / math.sqrt(abs(float(sigma_next) - float(sigma)))
+
+
+def _ancestral_step(sigma_from, sigma_to, eta):
+    """get_ancestral_step (utils/sampling.py:31-41)."""
+    if not eta:
+        return sigma_to, 0.0
+    up = min(sigma_to, eta * (sigma_to ** 2 * (sigma_from ** 2 - sigma_to ** 2) / sigma_from ** 2) ** 0.5)
+    return (sigma_to ** 2 - up ** 2) ** 0.5, up
+
+
+def dpmpp_sde(denoise: Denoise, start: Tensor, sig: Tensor, noise: Iterator[Tensor], eta=0.0, s_noise=1.0, r=0.5):
+    """DPMPPSDE.sample (sample.py:363-416).  A noise term whose amplitude is exactly zero is skipped (the reference multiplies its
+    draw by 0.0): with eta = 0 nothing is drawn."""
+    ns = BrownianPath(noise, sig[0])
+    x = start * sig[0]
+    for i in range(len(sig) - 1):
+        den = denoise(x, sig[i])
+        t, t_next = -sig[i].log(), -sig[i + 1].log()
+        h = t_next - t
+        s = t + h * r
+        fac = 1 / (2 * r)
+        sd, su = _ancestral_step((-t).exp(), (-s).exp(), eta)
+        s_ = -torch.as_tensor(sd).log()
+        x_2 = ((-s_).exp() / (-t).exp()) * x - (t - s_).expm1() * den
+        # (path points: the schedule's own sigma_i / sigma_next and sigma(s); the reference passes sigma_fn(time_fn(sigma_i)), the same
+        # number to rounding -- a point one ulp off would be a new, spurious increment of the path here)
+        sig_s = (-s).exp()
+        if float(su) != 0.0:
+            x_2 = x_2 + ns(sig[i], sig_s) * s_noise * su
+        den_2 = denoise(x_2, sig_s)
+        sd, su = _ancestral_step((-t).exp(), (-t_next).exp(), eta)
+        t_next_ = -torch.as_tensor(sd).log()
+        den_d = (1 - fac) * den + fac * den_2
+        x = ((-t_next_).exp() / (-t).exp()) * x - (t - t_next_).expm1() * den_d
+        if float(su) != 0.0:
+            ns.w(sig[i]), ns.w(sig_s)  # (the path passes through sigma(s) whether or not step 1 drew there)
+            x = x + ns(sig[i], sig[i + 1]) * s_noise * su
+    return x
+
+
+def dpmpp_2m_sde(denoise: Denoise, start: Tensor, sig: Tensor, noise: Iterator[Tensor], eta=0.0, s_noise=1.0, solver="heun"):
+    """DPMPP2MSDE.sample (sample.py:468-518)."""
+    ns = BrownianPath(noise, sig[0])
+    x = start * sig[0]
+    old, h_last = None, None
+    for i in range(len(sig) - 1):
+        den = denoise(x, sig[i])
+        if sig[i + 1] == 0:
+            x = den
+        else:
+            t, s = -sig[i].log(), -sig[i + 1].log()
+            h = s - t
+            eta_h = eta * h
+            x = sig[i + 1] / sig[i] * (-eta_h).exp() * x + (-h - eta_h).expm1().neg() * den
+            if old is not None:
+                rr = h_last / h
+                if solver == "heun":
+                    x = x + ((-h - eta_h).expm1().neg() / (-h - eta_h) + 1) * (1 / rr) * (den - old)
+                else:
+                    x = x + 0.5 * (-h - eta_h).expm1().neg() * (1 / rr) * (den - old)
+            if eta:
+                x = x + ns(sig[i], sig[i + 1]) * sig[i + 1] * (-2 * eta_h).expm1().neg().sqrt() * s_noise
+        old = den
+        h_last = h
+    return x
+
+
+def dpmpp_3m_sde(denoise: Denoise, start: Tensor, sig: Tensor, noise: Iterator[Tensor], eta=0.0, s_noise=1.0):
+    """DPMPP3MSDE.sample (sample.py:530-574); the noise term is skipped where its amplitude is exactly zero (eta = 0)."""
+    ns = BrownianPath(noise, sig[0])
+    x = start * sig[0]
+    den_1 = den_2 = None
+    h_1 = h_2 = None
+    for i in range(len(sig) - 1):
+        den = denoise(x, sig[i])
+        if sig[i + 1] == 0:
+            x = den
+            h = None
+        else:
+            t, s = -sig[i].log(), -sig[i + 1].log()
+            h = s - t
+            h_eta = h * (eta + 1)
+            x = torch.exp(-h_eta) * x + (-h_eta).expm1().neg() * den
+            if h_2 is not None:
+                r0, r1 = h_1 / h, h_2 / h
+                d1_0, d1_1 = (den - den_1) / r0, (den_1 - den_2) / r1
+                d1 = d1_0 + (d1_0 - d1_1) * r0 / (r0 + r1)
+                d2 = (d1_0 - d1_1) / (r0 + r1)
+                phi_2 = h_eta.neg().expm1() / h_eta + 1
+                phi_3 = phi_2 / h_eta - 0.5
+                x = x + phi_2 * d1 - phi_3 * d2
+            elif h_1 is not None:
+                rr = h_1 / h
+                d = (den - den_1) / rr
+                phi_2 = h_eta.neg().expm1() / h_eta + 1
+                x = x + phi_2 * d
+            amp = sig[i + 1] * (-2 * h * eta).expm1().neg().sqrt() * s_noise
+            if float(amp) != 0.0:
+                x = x + ns(sig[i], sig[i + 1]) * amp
+        den_1, den_2 = den, den_1
+        h_1, h_2 = h, h_1
+    return x
+
+
 def dpm_fast(denoise: Denoise, start: Tensor, sig: Tensor, nfe: int):
     """DPM.sample -> DPMSolver.dpm_solver_fast with eta = 0 (sample.py:164-177, utils/sampling.py:412-506)."""
     x = start * sig[0]

@@ -115,9 +115,10 @@ def test_samplers_on_dataset2_and_by_name():
     assert rel_l2(xs[3].cpu().numpy(), g["heun_xs3"]) < TOL_TRAJ and rel_l2(x0s[3].cpu().numpy(), g["heun_x0s3"]) < TOL_TRAJ
     m = _model("dataset2", {"SAMPLER": "LMS"})
     assert rel_l2(m.sample(E, layers, num_steps=6, start=start), g["lms_6"]) < TOL_TRAJ
-    for name in ("DDim", "DDPM", "Euler", "Heun", "DPM2", "LMS", "Restart", "DPM", "DPMPP2S", "DPMPP2M", "Consistency", "DPMAdaptive"):
+    for name in ("DDim", "DDPM", "Euler", "Heun", "DPM2", "LMS", "Restart", "DPM", "DPMPP2S", "DPMPP2M", "Consistency", "DPMAdaptive",
+                 "DPMPPSDE", "DPMPP2MSDE", "DPMPP3MSDE"):
         assert load_attr("sampler", name) is getattr(sample, name)
-    for name in ("DPMPPSDE", "DPMPP2MSDE", "DPMPP3MSDE", "BespokeNonStationary"):
+    for name in ("BespokeNonStationary",):
         with pytest.raises(NotImplementedError):
             load_attr("sampler", name)({})
     with pytest.raises(ValueError):

@@ -220,3 +220,50 @@ def test_attention_moment_form_equals_the_separate_closing_pass(shape, batch, mo
         e_sep = rel_l2((y_sep.double().cpu() - x.double().cpu()).numpy(), want)
         print(f"{shape} q x{qscale} bias {bias}: rel L2 of the branch against float64 -- moment form {e_mom:.2e}, closing pass {e_sep:.2e}")
         assert e_mom < 2e-6, (shape, qscale, bias, e_mom, e_sep)
+
+
+def _sde_cases():
+    from test_host import SDE_CASES
+    return SDE_CASES
+
+
+@pytest.mark.parametrize("name,opts", _sde_cases())
+def test_sde_samplers_on_the_device_equal_the_restated_loops(name, opts):
+    """DPMPPSDE / DPMPP2MSDE / DPMPP3MSDE (models/sample.py:347-574) through cd_sampler_run with the unit normals injected, against
+    the reference's loops restated on the CPU oracle with the same normals (torchsde is absent: parity unpinned, there is no
+    reference trajectory for these classes); and, drawing from the device Philox stream, two runs differ while ETA = 0 is
+    deterministic."""
+    from oracle import samplers_oracle as SO
+    from oracle import torch_oracle as O
+    from test_gpu_round2 import _model
+    from test_host import sde_oracle_run
+    m = _model("tiny", {"SAMPLER": name, "SAMPLER_OPTIONS": dict(opts)})
+    smp = m.sampler_algorithm
+    assert type(smp).__name__ == name
+    n, rows = 7, 2
+    gen = torch.Generator().manual_seed(43)
+    start = torch.randn((rows, 1, 8, 8, 8), generator=gen)
+    E, layers = torch.rand((rows, 3), generator=gen), torch.randn((rows, 9), generator=gen)
+    prog = smp.build(m, n, 0).finalize()
+    sig = SO.model_sigmas(m.loss_function, n)
+    m.loss_function.update_step(m.nsteps)
+    noise = [torch.randn(start.shape, generator=gen) for _ in range(prog.n_randn)]
+    om = O.OracleModel(m.config, {k[6:]: v.detach().cpu() for k, v in m.state_dict().items()})
+    den = lambda x, s: om.denoise(x, E, torch.as_tensor(s).float().expand(rows), layers)  # noqa: E731
+    with torch.no_grad():
+        want = sde_oracle_run(name, opts, den, start, sig, noise)
+    if prog.n_randn:
+        smp.step_noise = torch.stack(noise).cuda()
+    got = m.sample(E.cuda(), layers.cuda(), num_steps=n, start=start.cuda())
+    err = rel_l2(np.asarray(got), want.numpy())
+    assert err < 1e-4, (name, opts, err)
+    # the device's own stream
+    smp.step_noise = None
+    a = m.sample(E.cuda(), layers.cuda(), num_steps=n, start=start.cuda())
+    b = m.sample(E.cuda(), layers.cuda(), num_steps=n, start=start.cuda())
+    a, b = np.asarray(a), np.asarray(b)
+    assert np.isfinite(a).all() and np.isfinite(b).all()
+    if opts.get("ETA"):
+        assert rel_l2(a, b) > 1e-3  # fresh noise per call
+    else:
+        assert np.array_equal(a, b) and rel_l2(a, want.numpy()) < 1e-4

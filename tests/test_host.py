@@ -324,3 +324,60 @@ def test_dpm_adaptive_host_loop():
         dpm_adaptive_on_oracle({"ORDER": 2, "H_INIT": 3.0, "R_TOL": 1e-6, "A_TOL": 1e-8}, 8)
     with pytest.raises(ValueError):
         dpm_adaptive_on_oracle({"ORDER": 4}, 8)
+
+
+SDE_CASES = [("DPMPPSDE", {}), ("DPMPPSDE", {"ETA": 1.0, "S_NOISE": 1.1}), ("DPMPPSDE", {"ETA": 0.6, "R": 0.4}),
+             ("DPMPP2MSDE", {}), ("DPMPP2MSDE", {"ETA": 1.0}), ("DPMPP2MSDE", {"ETA": 0.7, "SOLVER": "midpoint", "S_NOISE": 0.9}),
+             ("DPMPP3MSDE", {}), ("DPMPP3MSDE", {"ETA": 1.0}), ("DPMPP3MSDE", {"ETA": 0.5, "S_NOISE": 1.2})]
+
+
+def sde_oracle_run(name, opts, den, start, sig, noise):
+    """One SDE case on the CPU restatement (oracle/samplers_oracle.py) with the given unit normals."""
+    from oracle import samplers_oracle as SO
+    eta, s_noise = opts.get("ETA", 0.0), opts.get("S_NOISE", 1.0)
+    if name == "DPMPPSDE":
+        return SO.dpmpp_sde(den, start, sig, iter(noise), eta, s_noise, opts.get("R", 0.5))
+    if name == "DPMPP2MSDE":
+        return SO.dpmpp_2m_sde(den, start, sig, iter(noise), eta, s_noise, opts.get("SOLVER", "heun"))
+    return SO.dpmpp_3m_sde(den, start, sig, iter(noise), eta, s_noise)
+
+
+@pytest.mark.parametrize("name,opts", SDE_CASES)
+def test_sde_sampler_programs_equal_the_restated_loops(name, opts):
+    """DPMPPSDE / DPMPP2MSDE / DPMPP3MSDE (models/sample.py:347-574) as step programs, interpreted on the CPU with the oracle as
+    denoiser, against the reference's loops restated on the oracle with the SAME unit normals (the reference's torchsde Brownian
+    tree is not installed: there is no reference trajectory; parity unpinned, see sample._BrownianSDE).  ETA = 0 draws nothing
+    and is a uniform program; DPMPPSDE draws two normals per step and mixes them as the Brownian path implies."""
+    import copy
+    from oracle import samplers_oracle as SO
+    base = load_config("tiny")
+    om = O.OracleModel(base, seeded_unet("tiny").state_dict())
+    cfg = copy.deepcopy(base)
+    cfg["SAMPLER"] = name
+    cfg["SAMPLER_OPTIONS"] = dict(opts)
+    m = CaloDiffusion(cfg, n_steps=cfg["NSTEPS"], loss_type=cfg["LOSS_TYPE"])
+    smp = m.sampler_algorithm
+    assert type(smp).__name__ == name
+    n, rows = 7, 2
+    prog = smp.build(m, n, 0).finalize()
+    sig = SO.model_sigmas(m.loss_function, n)
+    m.loss_function.update_step(m.nsteps)
+    gen = torch.Generator().manual_seed(41)
+    start = torch.randn((rows, 1, 8, 8, 8), generator=gen)
+    E, layers = torch.rand((rows, 3), generator=gen), torch.randn((rows, 9), generator=gen)
+    per_step = {"DPMPPSDE": 2, "DPMPP2MSDE": 1, "DPMPP3MSDE": 1}[name] if opts.get("ETA") else 0
+    assert prog.n_randn == per_step * (n - 1)
+    if not opts.get("ETA") and name == "DPMPPSDE":
+        assert prog.op_begin is None  # nothing drawn, same ops every step: one captured step graph
+    noise = [torch.randn(start.shape, generator=gen) for _ in range(prog.n_randn)]
+    den = lambda x, s: om.denoise(x, E, torch.as_tensor(s).float().expand(rows), layers)  # noqa: E731
+    with torch.no_grad():
+        got, _, _ = _interpret_program(prog, den, start, noise)
+        want = sde_oracle_run(name, opts, den, start, sig, noise)
+    err = rel_l2(got.numpy(), want.numpy())
+    assert err < 2e-5, (name, opts, err)
+    if opts.get("ETA"):
+        # the noise matters: another set of normals moves the end point by far more than the bound above
+        with torch.no_grad():
+            other, _, _ = _interpret_program(prog, den, start, [torch.randn(start.shape, generator=gen) for _ in range(prog.n_randn)])
+        assert rel_l2(other.numpy(), want.numpy()) > 1e-2
