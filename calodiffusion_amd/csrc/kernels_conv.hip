@@ -2587,7 +2587,11 @@ __global__ void __launch_bounds__(256) init_conv_kernel(InitConvArgs a) {
 #pragma unroll
   for (int j = 0; j < 32; ++j) acc[j] = bias ? bias[ct * 32 + j] : 0.f;
 
-  const float* __restrict__ wpk = a.wpk;
+  // this channel tile's weights in LDS (27 CIN rows of 32): read from global as wave-uniform scalar loads they were 81 dependent
+  // round trips per thread -- 52 us for the batch-1 coordinate table the training step refreshes every step (26 workgroups)
+  __shared__ __attribute__((aligned(16))) float wsm[27 * CIN * 32];
+  for (int i = threadIdx.x; i < 27 * CIN * 32; i += 256) wsm[i] = a.wpk[(size_t)(i >> 5) * a.cout + ct * 32 + (i & 31)];
+  __syncthreads();
   for (int kd = 0; kd < 3; ++kd) {
     const int zz = z + kd - 1;
     for (int kh = 0; kh < 3; ++kh) {
@@ -2614,7 +2618,7 @@ __global__ void __launch_bounds__(256) init_conv_kernel(InitConvArgs a) {
               else v = a.phi_h[hh];
             }
           }
-          const float* __restrict__ wr = wpk + ((size_t)(tap * CIN + ci) * a.cout + ct * 32);
+          const float* wr = wsm + (tap * CIN + ci) * 32;
 #pragma unroll
           for (int j = 0; j < 32; ++j) acc[j] = fmaf(v, wr[j], acc[j]);
         }
