@@ -1176,26 +1176,58 @@ __global__ void __launch_bounds__(512) gn_bwd_small_kernel(const float* __restri
                                                            float* __restrict__ sums_bc, float* __restrict__ dadd, int dadd_ld,
                                                            int channels, int64_t vox, int groups, int silu,
                                                            unsigned* __restrict__ amax_out) {
-  __shared__ double sP[512][4];
+  // The launch is a chain of dependent latencies around microseconds of streaming (14-20 us for 24-100 KB per tensor); round 4's
+  // second session removed four of them: gamma / mean / rstd are fetched into LDS beside the first pass's loads (they were read
+  // from global in the middle of the fold, twice), the column sums of all four channels of a quad are formed at once -- rows of a
+  // wave by shuffles, waves through ONE LDS hop (eight barrier-separated serial sums before) -- and a sample of at most four row
+  // trips per thread (the deepest level) keeps dy / h in registers for the second pass.
+  __shared__ double sW[8][32][4][4];   // [wave][column][e][sum]: per-wave column sums (channels <= 128: launcher)
   __shared__ double sCol[256][4];
   __shared__ float m1[64], m2[64];
   __shared__ __attribute__((aligned(16))) float sG[256][4];
+  __shared__ float sGam[256], sMean[64], sRstd[64];
   __shared__ float sAmax[8];
-  const int tid = threadIdx.x, b = blockIdx.x;
-  const int cols = channels >> 2, rows = 512 / cols;
+  const int tid = threadIdx.x, b = blockIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cols = channels >> 2, rows = 512 / cols;   // cols in {8, 16, 32} (launcher)
   const int colid = tid % cols, row = tid / cols;
   const int c = colid * 4, cpg = channels / groups;
   const size_t sb = (size_t)b * vox * channels + c;
+  if (tid < channels) sGam[tid] = gamma[tid];
+  if (tid < groups) {
+    sMean[tid] = stat[((size_t)b * groups + tid) * 2];
+    sRstd[tid] = stat[((size_t)b * groups + tid) * 2 + 1];
+  }
   f32x4 cf[4];
-  float mean = 0.f, rstd = 0.f;
-  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
-  if (row < rows) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) cf[e] = *(const f32x4*)(coef + ((size_t)b * channels + c + e) * 4);
-    mean = stat[((size_t)b * groups + c / cpg) * 2];
-    rstd = stat[((size_t)b * groups + c / cpg) * 2 + 1];
-    // four voxel rows per trip: eight 16-byte loads in flight per thread (one workgroup streams the whole sample: a load per
-    // trip left it waiting on a memory latency per 32 bytes)
+  for (int e = 0; e < 4; ++e) cf[e] = *(const f32x4*)(coef + ((size_t)b * channels + c + e) * 4);
+  const float mean = stat[((size_t)b * groups + c / cpg) * 2], rstd = stat[((size_t)b * groups + c / cpg) * 2 + 1];
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+  auto acc1 = [&](const f32x4 g, const f32x4 hv) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float z = cf[e][0] * hv[e] + cf[e][1];
+      const float dz = silu ? g[e] * silu_grad(z) : g[e];
+      s0[e] += dz;
+      s1[e] += dz * (hv[e] - mean) * rstd;
+      s2[e] += g[e];
+      s3[e] += hv[e] - mean;
+    }
+  };
+  const bool keep = vox <= (int64_t)4 * rows;  // block-uniform: the whole sample is one trip of four rows per thread
+  f32x4 kg[4], kh[4];
+  if (keep) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t v = row + (int64_t)u * rows;
+      const int64_t vc = v < vox ? v : vox - 1;
+      kg[u] = *(const f32x4*)(dy + sb + (size_t)vc * channels);
+      kh[u] = *(const f32x4*)(h + sb + (size_t)vc * channels);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (row + (int64_t)u * rows < vox) acc1(kg[u], kh[u]);
+  } else {
+    // four voxel rows per trip: eight 16-byte loads in flight per thread
     int64_t v = row;
     for (; v + 3 * rows < vox; v += 4 * rows) {
       f32x4 g[4], hv[4];
@@ -1205,50 +1237,49 @@ __global__ void __launch_bounds__(512) gn_bwd_small_kernel(const float* __restri
         hv[u] = *(const f32x4*)(h + sb + (size_t)(v + u * rows) * channels);
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float z = cf[e][0] * hv[u][e] + cf[e][1];
-          const float dz = silu ? g[u][e] * silu_grad(z) : g[u][e];
-          s0[e] += dz;
-          s1[e] += dz * (hv[u][e] - mean) * rstd;
-          s2[e] += g[u][e];
-          s3[e] += hv[u][e] - mean;
-        }
+      for (int u = 0; u < 4; ++u) acc1(g[u], hv[u]);
     }
-    for (; v < vox; v += rows) {
-      const f32x4 g = *(const f32x4*)(dy + sb + (size_t)v * channels);
-      const f32x4 hv = *(const f32x4*)(h + sb + (size_t)v * channels);
+    for (; v < vox; v += rows) acc1(*(const f32x4*)(dy + sb + (size_t)v * channels), *(const f32x4*)(h + sb + (size_t)v * channels));
+  }
+  // column sums in fp64: the rows a wave holds of one column sit cols lanes apart (cols < 64) -> xor shuffles; then the eight waves
+  // through LDS, summed in wave order by one thread per (column, e)
+  {
+    double p[4][4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float z = cf[e][0] * hv[e] + cf[e][1];
-        const float dz = silu ? g[e] * silu_grad(z) : g[e];
-        s0[e] += dz;
-        s1[e] += dz * (hv[e] - mean) * rstd;
-        s2[e] += g[e];
-        s3[e] += hv[e] - mean;
-      }
+    for (int e = 0; e < 4; ++e) {
+      p[e][0] = (double)s0[e]; p[e][1] = (double)s1[e]; p[e][2] = (double)s2[e]; p[e][3] = (double)s3[e];
+    }
+    for (int o = 32; o >= cols; o >>= 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) p[e][q] += __shfl_xor(p[e][q], o, 64);
+    }
+    if (lane < cols) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sW[wave][lane][e][q] = p[e][q];
     }
   }
-  for (int e = 0; e < 4; ++e) {
-    sP[tid][0] = (double)s0[e]; sP[tid][1] = (double)s1[e]; sP[tid][2] = (double)s2[e]; sP[tid][3] = (double)s3[e];
-    __syncthreads();
-    if (tid < cols) {
-      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-      for (int r = 0; r < rows; ++r) {
-        a0 += sP[r * cols + tid][0]; a1 += sP[r * cols + tid][1]; a2 += sP[r * cols + tid][2]; a3 += sP[r * cols + tid][3];
-      }
-      // (rounded to float like the split form's partials, so that both forms give the same coefficients)
-      sCol[tid * 4 + e][0] = (double)(float)a0; sCol[tid * 4 + e][1] = (double)(float)a1;
-      sCol[tid * 4 + e][2] = (double)(float)a2; sCol[tid * 4 + e][3] = (double)(float)a3;
+  __syncthreads();
+  if (tid < channels) {
+    // thread = channel cc = 4 column + e (every wave holds rows of every column: cols <= 32)
+    const int col = tid >> 2, e = tid & 3;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (int w = 0; w < 8; ++w) {
+      a0 += sW[w][col][e][0]; a1 += sW[w][col][e][1]; a2 += sW[w][col][e][2]; a3 += sW[w][col][e][3];
     }
-    __syncthreads();
+    // (rounded to float like the split form's partials)
+    sCol[tid][0] = (double)(float)a0; sCol[tid][1] = (double)(float)a1;
+    sCol[tid][2] = (double)(float)a2; sCol[tid][3] = (double)(float)a3;
   }
+  __syncthreads();
   if (tid < groups) {
     double t0 = 0.0, t1 = 0.0;
     for (int k = 0; k < cpg; ++k) {
-      t0 += sCol[tid * cpg + k][0] * (double)gamma[tid * cpg + k];
-      t1 += sCol[tid * cpg + k][1] * (double)gamma[tid * cpg + k];
+      t0 += sCol[tid * cpg + k][0] * (double)sGam[tid * cpg + k];
+      t1 += sCol[tid * cpg + k][1] * (double)sGam[tid * cpg + k];
     }
     const double cnt = (double)vox * cpg;
     m1[tid] = (float)(t0 / cnt);
@@ -1257,8 +1288,8 @@ __global__ void __launch_bounds__(512) gn_bwd_small_kernel(const float* __restri
   __syncthreads();
   if (tid < channels) {
     const int cc = tid, g = cc / cpg;
-    const float mn = stat[((size_t)b * groups + g) * 2], rs = stat[((size_t)b * groups + g) * 2 + 1];
-    const float A = rs * gamma[cc];
+    const float mn = sMean[g], rs = sRstd[g];
+    const float A = rs * sGam[cc];
     sG[cc][0] = A;
     sG[cc][1] = -rs * rs * m2[g];
     sG[cc][2] = rs * (-m1[g] + mn * rs * m2[g]);
@@ -1272,7 +1303,7 @@ __global__ void __launch_bounds__(512) gn_bwd_small_kernel(const float* __restri
   }
   __syncthreads();
   float am = 0.f;
-  if (row < rows) {
+  {
     f32x4 gc[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) gc[e] = *(const f32x4*)sG[c + e];
@@ -1287,18 +1318,24 @@ __global__ void __launch_bounds__(512) gn_bwd_small_kernel(const float* __restri
       *(f32x4*)(dh + sb + (size_t)v * channels) = o;
       am = fmaxf(am, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
     };
-    int64_t v = row;
-    for (; v + 3 * rows < vox; v += 4 * rows) {
-      f32x4 g[4], hv[4];
+    if (keep) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        g[u] = *(const f32x4*)(dy + sb + (size_t)(v + u * rows) * channels);
-        hv[u] = *(const f32x4*)(h + sb + (size_t)(v + u * rows) * channels);
+      for (int u = 0; u < 4; ++u)
+        if (row + (int64_t)u * rows < vox) one(kg[u], kh[u], row + (int64_t)u * rows);
+    } else {
+      int64_t v = row;
+      for (; v + 3 * rows < vox; v += 4 * rows) {
+        f32x4 g[4], hv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          g[u] = *(const f32x4*)(dy + sb + (size_t)(v + u * rows) * channels);
+          hv[u] = *(const f32x4*)(h + sb + (size_t)(v + u * rows) * channels);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) one(g[u], hv[u], v + u * rows);
       }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) one(g[u], hv[u], v + u * rows);
+      for (; v < vox; v += rows) one(*(const f32x4*)(dy + sb + (size_t)v * channels), *(const f32x4*)(h + sb + (size_t)v * channels), v);
     }
-    for (; v < vox; v += rows) one(*(const f32x4*)(dy + sb + (size_t)v * channels), *(const f32x4*)(h + sb + (size_t)v * channels), v);
   }
   if (amax_out) {
 #pragma unroll
@@ -1362,7 +1399,7 @@ void launch_gn_backward(const float* dy, const float* h, const float* coef, cons
   // (one workgroup streams its sample twice: 24 KB at the deepest level in ~6 us against four launches' ~20; at 188 KB -- level 1
   // with 64 channels -- it took 35 us against the split form's 27, so the bound sits between the two)
   static const size_t small_max = getenv("CD_GN_BWD_SMALL_KB") ? (size_t)atoi(getenv("CD_GN_BWD_SMALL_KB")) * 1024 : 100 * 1024;
-  if (!no_small && (size_t)vox * channels * 4 <= small_max && channels <= 256 && 512 % (channels >> 2) == 0) {
+  if (!no_small && (size_t)vox * channels * 4 <= small_max && channels <= 128 && 512 % (channels >> 2) == 0) {
     unsigned* amax_word = absmax_word_fresh(dh, s);
     hipLaunchKernelGGL(gn_bwd_small_kernel, dim3((unsigned)batch), dim3(512), 0, s, dy, h, coef, stat, gamma, dh, sums_bc, dadd, dadd_ld,
                        channels, vox, groups, silu, amax_word);

@@ -102,7 +102,9 @@ def test_conv_transpose_backward(ops):
 def test_group_norm_backward(ops):
     gen = torch.Generator().manual_seed(23)
     for C, G, shp, silu in ((32, 8, (2, 5, 6, 4), True), (64, 8, (1, 23, 8, 4), True), (96, 8, (1, 3, 3, 5), True),
-                            (64, 1, (2, 7, 3, 5), False), (32, 1, (1, 12, 4, 2), False)):
+                            (64, 1, (2, 7, 3, 5), False), (32, 1, (1, 12, 4, 2), False),
+                            # one-launch form beyond four row trips per thread (the second pass re-reads), 128 channels, 16 channels
+                            (32, 8, (2, 10, 6, 5), True), (128, 8, (1, 5, 6, 4), True), (16, 4, (3, 4, 3, 5), True)):
         x = (torch.randn((shp[0], C) + shp[1:], generator=gen) * 2 + 0.7).requires_grad_()
         gm = torch.randn(C, generator=gen, requires_grad=True)
         bt = torch.randn(C, generator=gen, requires_grad=True)
