@@ -121,3 +121,30 @@ def test_fused_adam_matches_torch_adam():
         o_t = torch.optim.Adam(dev, lr=1e-3, weight_decay=wd)
         o_t.load_state_dict(o_dev.state_dict())
         assert int(o_t.state[dev[0]]["step"]) == 6
+
+
+def test_queued_weight_gradient_reductions_follow_the_batch_size():
+    """The region that holds the weight gradients' partials until their single reduction launch is sized by the first training step
+    of a plan and re-sized when a later step asks for more: batch 2, 2, 5, 5, 2 on one model -- the first step at each new, larger
+    batch reduces (partly) where the partials arise, the following ones from the queue -- every step against autograd through
+    the oracle."""
+    m, cfg = _model("tiny")
+    sd_cpu = {k[6:]: v.detach().cpu() for k, v in m.state_dict().items()}
+    for step, B in enumerate((2, 2, 5, 5, 2)):
+        gen = torch.Generator().manual_seed(100 + step)
+        shape = [B] + list(cfg["SHAPE_PAD"][1:])
+        data, noise = torch.randn(shape, generator=gen), torch.randn(shape, generator=gen)
+        E = torch.rand((B, 3 if cfg.get("HGCAL") else 1), generator=gen)
+        layers = torch.randn((B, 1 + cfg["SHAPE_FINAL"][2]), generator=gen) if "layer" in cfg["SHOWERMAP"] else None
+        rnd = torch.randn((B,), generator=gen)
+        tsteps = torch.randint(0, cfg["NSTEPS"], (B,), generator=gen)
+        want_loss, want = _oracle_grads(cfg, sd_cpu, data, E, noise, layers, rnd, tsteps)
+        m.zero_grad()
+        sigma = m.loss_function.draw_sigma(data.cuda(), time=tsteps.cuda(), rnd_normal=rnd.cuda())
+        loss = m.loss_function.loss_function(m, data.cuda(), E.cuda(), sigma=sigma, noise=noise.cuda(),
+                                             layers=None if layers is None else layers.cuda())
+        assert abs(float(loss) - want_loss) <= 1e-5 * abs(want_loss), (step, B)
+        loss.backward()
+        got_all = np.concatenate([p.grad.cpu().numpy().ravel() for _, p in m.model.named_parameters()])
+        want_all = np.concatenate([want[k].numpy().ravel() for k, _ in m.model.named_parameters()])
+        assert rel_l2(got_all, want_all) < 5e-6, (step, B, rel_l2(got_all, want_all))
