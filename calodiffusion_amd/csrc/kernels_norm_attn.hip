@@ -301,9 +301,20 @@ __global__ void __launch_bounds__(256) attn_context_kernel(const float* __restri
   const int64_t v1 = (v0 + per < vox) ? v0 + per : vox;
   const float* base = qkv + (size_t)b * vox * 96;
 
-  // local max of k over this block's voxels, per channel
+  // local max of k over this block's voxels, per channel.  Both sweeps below fetch eight voxels per trip (round 4: one voxel per
+  // trip was a memory round trip per 256 bytes and wave -- 40 us at Dataset-2's level 0 for 53 MB, with the training step's seven
+  // attention blocks 0.17 ms of pure latency); indices past the block are clamped and their values masked.
   float m = -3.0e38f;
-  for (int64_t n = v0 + 2 * wave + half; n < v1; n += 8) m = fmaxf(m, base[(size_t)n * 96 + 32 + col]);
+  for (int64_t n = v0 + 2 * wave + half; n < v1; n += 64) {
+    float kv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t nu = n + 8 * u;
+      kv[u] = base[(size_t)(nu < v1 ? nu : v1 - 1) * 96 + 32 + col];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) m = fmaxf(m, kv[u]);  // (a clamped index repeats a voxel of the block: harmless under max)
+  }
   m = fmaxf(m, __shfl_xor(m, 32, 64));
   if (half == 0) sMax[wave][col] = m;
   __syncthreads();
@@ -314,14 +325,28 @@ __global__ void __launch_bounds__(256) attn_context_kernel(const float* __restri
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   float ssum = 0.f;
   // A[i = d][k = voxel half] = exp(k[n][d] - m[d]),  B[k][j = e] = v[n][e]
-  for (int64_t n = v0 + 2 * wave + half; n < v0 + per; n += 8) {
-    float av = 0.f, bv = 0.f;
-    if (n < v1) {
-      av = expf(base[(size_t)n * 96 + 32 + col] - m);
-      bv = base[(size_t)n * 96 + 64 + col];
+  // (the loop bound is wave-uniform: per is even and a wave's two halves take voxels n, n + 1 of a pair, both below v0 + per or
+  // both not -- every lane of a wave runs the same MFMAs, in the same order as the one-voxel-per-trip form: bit-identical sums)
+  for (int64_t n = v0 + 2 * wave + half; n < v0 + per; n += 64) {
+    float kk[8], vv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t nu = n + 8 * u;
+      const size_t o = (size_t)(nu < v1 ? nu : v1 - 1) * 96;
+      kk[u] = base[o + 32 + col];
+      vv[u] = base[o + 64 + col];
     }
-    ssum += av;
-    acc = MFMA32(av, bv, acc);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t nu = n + 8 * u;
+      if (nu - half < v0 + per) {  // (wave-uniform: the pair's first voxel)
+        const bool in = nu < v1;
+        const float av = in ? expf(kk[u] - m) : 0.f;
+        const float bv = in ? vv[u] : 0.f;
+        ssum += av;
+        acc = MFMA32(av, bv, acc);
+      }
+    }
   }
   sSum[wave * 2 + half][col] = ssum;
 #pragma unroll
@@ -368,10 +393,23 @@ __global__ void __launch_bounds__(256) attn_combine_kernel(const float* __restri
     }
   }
   __syncthreads();
+  // rescaling factors of the partials, once per (partial, channel) instead of once per context entry (32 x fewer exponentials and
+  // loads of the maxima in the loop below; same expression, same summation order: bit-identical)
+  __shared__ float sF[128 * 32];  // nsplit <= 128 (attn_nsplit_for)
+  for (int i = tid; i < nsplit * 32; i += 256) sF[i] = expf(p[(size_t)(i >> 5) * 1088 + (i & 31)] - sM[i & 31]);
+  __syncthreads();
   for (int i = tid; i < 1024; i += 256) {
     const int d = i >> 5;
     float c = 0.f;
-    for (int k = 0; k < nsplit; ++k) c += p[(size_t)k * 1088 + 64 + i] * expf(p[(size_t)k * 1088 + d] - sM[d]);
+    int k = 0;
+    for (; k + 4 <= nsplit; k += 4) {  // four partials' loads in flight
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = p[(size_t)(k + u) * 1088 + 64 + i];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) c += v[u] * sF[(k + u) * 32 + d];
+    }
+    for (; k < nsplit; ++k) c += p[(size_t)k * 1088 + 64 + i] * sF[k * 32 + d];
     sCtx[i] = c * sInv[d];
     if (ctx_out) ctx_out[(size_t)b * 1024 + i] = sCtx[i] / scale;
   }
