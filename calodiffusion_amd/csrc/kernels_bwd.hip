@@ -1534,58 +1534,74 @@ void launch_strided_dgrad_naive(const float* dy, const float* w, float* dx, int 
 // Linear attention backward helpers (forward: kernels_norm_attn.hip; reference LinearAttention.forward models.py:301-318)
 // ------------------------------------------------------------------------------------------------------------
 // qs[n][d] = softmax over the 32 channels of q (q = channels [0,32) of the (B, n, 96) qkv tensor); one thread per voxel
-__global__ void softmax32_kernel(const float* __restrict__ qkv, float* __restrict__ qs, int64_t rows) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= rows) return;
-  const f32x4* src = (const f32x4*)(qkv + (size_t)i * 96);
-  f32x4 v[8];
-  float m = -3.0e38f;
+// Eight lanes per row (a quad of the 32 channels each: a wave's load is 8 rows x 128 contiguous bytes), the row's max / sum by
+// three xor shuffles, four rows per lane in flight.  (Round 4: one THREAD per row read its 128 bytes as eight 16-byte loads
+// 384 bytes apart from its neighbours' -- every instruction touched 64 cache lines: 2.7 TB/s at level 0.)
+__global__ void __launch_bounds__(256) softmax32_kernel(const float* __restrict__ qkv, float* __restrict__ qs, int64_t rows) {
+  const int q = threadIdx.x & 7;
+  const int64_t r0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3;       // 32 rows per block and trip
+  const int64_t stride = (int64_t)gridDim.x * 32;
+  for (int64_t r = r0; r < rows; r += 4 * stride) {
+    f32x4 v[4];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    v[k] = src[k];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) m = fmaxf(m, v[k][e]);
-  }
-  float ssum = 0.f;
-#pragma unroll
-  for (int k = 0; k < 8; ++k)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      v[k][e] = expf(v[k][e] - m);
-      ssum += v[k][e];
+    for (int u = 0; u < 4; ++u) {
+      const int64_t ru = r + u * stride;
+      v[u] = *(const f32x4*)(qkv + (size_t)(ru < rows ? ru : rows - 1) * 96 + q * 4);
     }
-  const float inv = 1.f / ssum;
-  f32x4* dst = (f32x4*)(qs + (size_t)i * 32);
 #pragma unroll
-  for (int k = 0; k < 8; ++k) dst[k] = v[k] * inv;
+    for (int u = 0; u < 4; ++u) {
+      float m = fmaxf(fmaxf(v[u][0], v[u][1]), fmaxf(v[u][2], v[u][3]));
+#pragma unroll
+      for (int o = 1; o < 8; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+      float ssum = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[u][e] = expf(v[u][e] - m);
+        ssum += v[u][e];
+      }
+#pragma unroll
+      for (int o = 1; o < 8; o <<= 1) ssum += __shfl_xor(ssum, o, 64);
+      const int64_t ru = r + u * stride;
+      if (ru < rows) *(f32x4*)(qs + (size_t)ru * 32 + q * 4) = v[u] * (1.f / ssum);
+    }
+  }
 }
 void launch_softmax32(const float* qkv, float* qs, int64_t rows, hipStream_t s) {
-  hipLaunchKernelGGL(softmax32_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, qkv, qs, rows);
+  int64_t blocks = (rows + 127) / 128;  // four rows per lane
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(softmax32_kernel, dim3((unsigned)blocks), dim3(256), 0, s, qkv, qs, rows);
   CD_HIP(hipGetLastError());
 }
 
-// dq[n][d] = qs*(dqs - sum_d' qs*dqs)  written into channels [0,32) of dqkv (row stride 96)
-__global__ void softmax32_bwd_kernel(const float* __restrict__ qs, const float* __restrict__ dqs, float* __restrict__ dqkv,
-                                     int64_t rows) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= rows) return;
-  const f32x4* a = (const f32x4*)(qs + (size_t)i * 32);
-  const f32x4* g = (const f32x4*)(dqs + (size_t)i * 32);
-  f32x4 av[8], gv[8];
-  float dot = 0.f;
+// dq[n][d] = qs*(dqs - sum_d' qs*dqs)  written into channels [0,32) of dqkv (row stride 96); same lane layout
+__global__ void __launch_bounds__(256) softmax32_bwd_kernel(const float* __restrict__ qs, const float* __restrict__ dqs,
+                                                            float* __restrict__ dqkv, int64_t rows) {
+  const int q = threadIdx.x & 7;
+  const int64_t r0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3;
+  const int64_t stride = (int64_t)gridDim.x * 32;
+  for (int64_t r = r0; r < rows; r += 4 * stride) {
+    f32x4 av[4], gv[4];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    av[k] = a[k];
-    gv[k] = g[k];
+    for (int u = 0; u < 4; ++u) {
+      const int64_t ru = r + u * stride;
+      const size_t o = (size_t)(ru < rows ? ru : rows - 1) * 32 + q * 4;
+      av[u] = *(const f32x4*)(qs + o);
+      gv[u] = *(const f32x4*)(dqs + o);
+    }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) dot += av[k][e] * gv[k][e];
+    for (int u = 0; u < 4; ++u) {
+      float dot = (av[u][0] * gv[u][0] + av[u][1] * gv[u][1]) + (av[u][2] * gv[u][2] + av[u][3] * gv[u][3]);
+#pragma unroll
+      for (int o = 1; o < 8; o <<= 1) dot += __shfl_xor(dot, o, 64);
+      const int64_t ru = r + u * stride;
+      if (ru < rows) *(f32x4*)(dqkv + (size_t)ru * 96 + q * 4) = av[u] * (gv[u] - dot);
+    }
   }
-  f32x4* dst = (f32x4*)(dqkv + (size_t)i * 96);
-#pragma unroll
-  for (int k = 0; k < 8; ++k) dst[k] = av[k] * (gv[k] - dot);
 }
 void launch_softmax32_bwd(const float* qs, const float* dqs, float* dqkv, int64_t rows, hipStream_t s) {
-  hipLaunchKernelGGL(softmax32_bwd_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, qs, dqs, dqkv, rows);
+  int64_t blocks = (rows + 127) / 128;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(softmax32_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, qs, dqs, dqkv, rows);
   CD_HIP(hipGetLastError());
 }
 
