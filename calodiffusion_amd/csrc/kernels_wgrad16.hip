@@ -339,8 +339,10 @@ __global__ void __launch_bounds__(512, 1) wgrad_ring_f16x2_kernel(WgradRingArgs 
   // wgrad_f16x2_kernel's record ([block][term]: 16 dwords apart) wrap onto each other -- every fragment read took twice its
   // LDS cycles, 560 of them per K step and CU beside 672 cycles of MFMAs per SIMD.  Here the record is [term][block] (a voxel's
   // two blocks are one 64-byte run) and the four rows of a load are voxels 4 q apart (K slot (half, j, q) <-> voxel
-  // 4 q + 2 half + j of the step): 4 x 36 dwords = 16 mod 64, so the rows start at banks 0, 16, 32, 48 (dy image: always; x
-  // image: unless an r row or plane ends between them).
+  // 4 q + 2 half + j of the step): 4 x 36 dwords = 16 mod 64, so the rows start at banks 0, 16, 32, 48 -- in the dy image.  In the
+  // x image an r row ends every W voxels (its closing zero record shifts the next row by 36 dwords), most loads still overlap banks,
+  // and SQ_LDS_BANK_CONFLICT is what it was (133 k against 136 k cycles per launch, profiles/r04_wgrad_pmc_summary.txt): the
+  // layout is kept for the dy reads, it did not move the launch time.
   const int g4 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
   const int chan_off = (g4 & 1) * 32 + p4 * 8;
   const int vrow0 = 4 * q4 + 2 * (g4 >> 1);
