@@ -307,7 +307,12 @@ __global__ void __launch_bounds__(512, 1) wgrad_ring_f16x2_kernel(WgradRingArgs 
   const int half = lane >> 5, col = lane & 31;
   const int ta = blockIdx.y / a.tilesB, tb = blockIdx.y % a.tilesB;
   const int H = a.H, W = a.W, PV = H * W, vox = a.D * PV, NZ = a.NZ, S = a.S;
-  const int pitch = W + 1, prow = (H + 2) * pitch;
+  // One-plane units (ONE): r rows WITHOUT the closing zero record -- a voxel's record is its index in the plane, so the four rows of
+  // a transposing load are always 4 records apart (banks 0 / 16 / 32 / 48: conflict-free; SQ_LDS_BANK_CONFLICT 133 k -> 41 k cycles
+  // per launch) -- and ONE zero record closing every plane slot: the r - 1 / r + 1 taps of the edge columns are redirected to it by
+  // giving an edge lane a base whose tap offset lands on that record in whichever slot the tap's plane sits (one compare and one
+  // select per lane and K step; selecting per tap cost more scalar and vector instructions than the conflicts it removed).
+  const int pitch = ONE ? W : W + 1, prow = (H + 2) * pitch + (ONE ? 1 : 0);
   const int R = NZ * PV, RP = (R + 15) & ~15;
   char* const gL = wl;                                     // two dy images [2][RP][WG_VB]
   char* const xB = wl + (size_t)(2 * RP + 1) * WG_VB;      // record (slot 0, row 0, column 0); the record before it stays zero
@@ -339,10 +344,10 @@ __global__ void __launch_bounds__(512, 1) wgrad_ring_f16x2_kernel(WgradRingArgs 
   // wgrad_f16x2_kernel's record ([block][term]: 16 dwords apart) wrap onto each other -- every fragment read took twice its
   // LDS cycles, 560 of them per K step and CU beside 672 cycles of MFMAs per SIMD.  Here the record is [term][block] (a voxel's
   // two blocks are one 64-byte run) and the four rows of a load are voxels 4 q apart (K slot (half, j, q) <-> voxel
-  // 4 q + 2 half + j of the step): 4 x 36 dwords = 16 mod 64, so the rows start at banks 0, 16, 32, 48 -- in the dy image.  In the
-  // x image an r row ends every W voxels (its closing zero record shifts the next row by 36 dwords), most loads still overlap banks,
-  // and SQ_LDS_BANK_CONFLICT is what it was (133 k against 136 k cycles per launch, profiles/r04_wgrad_pmc_summary.txt): the
-  // layout is kept for the dy reads, it did not move the launch time.
+  // 4 q + 2 half + j of the step): 4 x 36 dwords = 16 mod 64, so the rows start at banks 0, 16, 32, 48 -- wherever a voxel's
+  // record is its index: the dy image always, the x image in the one-plane form (see `pitch` above; with a closing record per r
+  // row the next row is shifted by 36 dwords and most loads overlap banks again).  Measured: conflicts 133 k -> 41 k cycles per
+  // launch, the launch time unchanged (profiles/r04_wgrad_pmc_summary.txt) -- the LDS array does not bound this K loop.
   const int g4 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
   const int chan_off = (g4 & 1) * 32 + p4 * 8;
   const int vrow0 = 4 * q4 + 2 * (g4 >> 1);
@@ -420,7 +425,7 @@ __global__ void __launch_bounds__(512, 1) wgrad_ring_f16x2_kernel(WgradRingArgs 
         split2(inside ? val : f32x4{0.f, 0.f, 0.f, 0.f}, t1, t2);
         int sl = slot0 + pl;
         if (sl >= S) sl -= S;
-        char* d = xB + ((sl * (H + 2) + h + 1) * pitch + w) * WG_VB + qoff;
+        char* d = xB + (sl * prow + (h + 1) * pitch + w) * WG_VB + qoff;
         *(u32x2*)d = t1;
         *(u32x2*)(d + 64) = t2;
         if (h == 0) {
@@ -519,6 +524,11 @@ __global__ void __launch_bounds__(512, 1) wgrad_ring_f16x2_kernel(WgradRingArgs 
           goff[j] = v * WG_VB + chan_off;
         }
         const int step_b = (adv_h * pitch + adv_w) * WG_VB;
+        // edge lanes: base + (the tap's offset) = the zero record closing the tap's plane slot
+        const int khA = wave / 3, kwA = wave - 3 * khA;     // (kh, kw) of this wave's taps 0..2 (tap 3, waves 0..2: (2, 2))
+        const int ecA = kwA == 0 ? 0 : (kwA == 2 ? W - 1 : -1);
+        const int zbA = ((H + 2) * pitch - (khA * pitch + kwA - 1)) * WG_VB + chan_off;
+        const int zb3 = ((H + 2) * pitch - (2 * pitch + 1)) * WG_VB + chan_off;
         for (int c = 0; c < RP / 16; ++c) {
           fh4 g0[2], g1[2];
 #pragma unroll
@@ -528,6 +538,12 @@ __global__ void __launch_bounds__(512, 1) wgrad_ring_f16x2_kernel(WgradRingArgs 
             g1[j] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fh4*)(gp + 64));
           }
           const fh8 G0 = cat8(g0[0], g0[1]), G1 = cat8(g1[0], g1[1]);
+          int rA[2], r3[2];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            rA[j] = vw[j] == ecA ? zbA : roff[j];
+            r3[j] = vw[j] == W - 1 ? zb3 : roff[j];
+          }
           fh8 X0[4], X1[4];
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
@@ -535,7 +551,7 @@ __global__ void __launch_bounds__(512, 1) wgrad_ring_f16x2_kernel(WgradRingArgs 
               fh4 x0[2], x1[2];
 #pragma unroll
               for (int j = 0; j < 2; ++j) {
-                const char* xp = xB + roff[j] + tu[t];
+                const char* xp = xB + (t < 3 ? rA[j] : r3[j]) + tu[t];
                 x0[j] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fh4*)(xp));
                 x1[j] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fh4*)(xp + 64));
               }
@@ -567,7 +583,7 @@ __global__ void __launch_bounds__(512, 1) wgrad_ring_f16x2_kernel(WgradRingArgs 
             vw[j] += adv_w;
             const bool carry = vw[j] >= W;
             vw[j] -= carry ? W : 0;
-            roff[j] += step_b + (carry ? WG_VB : 0);
+            roff[j] += step_b + (carry ? (pitch - W) * WG_VB : 0);
             if (vloc[j] >= R) roff[j] = chan_off;  // past the unit (dy is zero there): any valid record
           }
         }
@@ -590,7 +606,7 @@ __global__ void __launch_bounds__(512, 1) wgrad_ring_f16x2_kernel(WgradRingArgs 
           const bool in = vloc[j] < R;  // past the unit: any valid record (dy is zero there)
           int mz = sb + (in ? vz[j] : 0);
           if (mz >= S) mz -= S;
-          const int base = ((mz * (H + 2) + (in ? vh[j] : 0)) * pitch + (in ? vw[j] : 0)) * WG_VB + chan_off;
+          const int base = (mz * prow + (in ? vh[j] : 0) * pitch + (in ? vw[j] : 0)) * WG_VB + chan_off;
           lb[j][0] = base;
           lb[j][1] = base - (mz + 1 >= S ? ringbytes : 0);
           lb[j][2] = base - (mz + 2 >= S ? ringbytes : 0);
