@@ -465,6 +465,10 @@ struct EmbedArgs {
   // Several steps of one trajectory in one launch (the sampler loop's embeddings, a chunk of steps ahead): workgroup b embeds
   // sample b % cond_rows at the time value time_or_sigma[(b / cond_rows) * time_stride].  cond_rows = 0: one step, as before.
   int cond_rows = 0, time_stride = 0;
+  // The ResnetBlock projections are linear in SiLU(cat(t, c)) (models.py:176-180, 707): W SiLU(cat(t, c)) + b = [W_t SiLU(t) + b] +
+  // [W_c SiLU(c)].  part = 1: row b is a TIME row (time value time_or_sigma[b * time_stride], no condition): the first bracket and
+  // the scalings; part = 2: row b is a CONDITION row: the second bracket, no bias, no scalings.  0: the whole expression.
+  int part = 0;
 };
 void launch_embed(const EmbedArgs& a, hipStream_t s);
 void launch_silu_linear(const float* cond, const float* w, const float* bias, float* out, int batch, int nin, int nout,
@@ -508,6 +512,9 @@ struct StepChunk {
   float* scal_dst = nullptr;
   int scal_floats = 0;
   int chunk_steps = 0;
+  // separable form: emb_src / scal_src hold ONE row per step (EmbedArgs::part = 1), emb_cond one row per sample (part = 2):
+  // emb_dst[b] = emb_src[slot] + emb_cond[b], scal_dst[b] = scal_src[slot]; emb_floats / scal_floats are then the ROW lengths
+  const float* emb_cond = nullptr;
 };
 void launch_load_step(const float* table, int* counter, float* stepvals, float* sigma_b, int batch, hipStream_t s,
                       const StepChunk* chunk = nullptr);

@@ -65,11 +65,13 @@ __global__ void __launch_bounds__(512) embed_kernel(EmbedArgs a) {
   const int b = blockIdx.x, tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   const int bc = a.cond_rows ? b % a.cond_rows : b;  // row of `cond`
-  const float tv = a.cond_rows ? a.time_or_sigma[(size_t)(b / a.cond_rows) * a.time_stride] : a.time_or_sigma[b];
+  const float tv = a.part == 2 ? 1.f
+                   : a.part == 1 ? a.time_or_sigma[(size_t)b * a.time_stride]
+                   : a.cond_rows ? a.time_or_sigma[(size_t)(b / a.cond_rows) * a.time_stride] : a.time_or_sigma[b];
   float t_in = tv;
   if (a.time_kind == 0) t_in = 0.5f * logf(tv);
   else if (a.time_kind == 1) t_in = tv / sqrtf(1.f + tv * tv);
-  if (a.scal && tid == 0 && blockIdx.y == 0) {
+  if (a.scal && a.part != 2 && tid == 0 && blockIdx.y == 0) {
     const float sd = a.sigma_data;
     const float s2 = tv * tv + sd * sd;
     a.scal[b * 4 + 0] = 1.f / sqrtf(s2);           // c_in
@@ -91,26 +93,36 @@ __global__ void __launch_bounds__(512) embed_kernel(EmbedArgs a) {
     __syncthreads();
   };
   // time branch: Linear(1, half/2) GELU | sinusoidal(half/2);  Linear(half/2, half) GELU Linear(half, half)
-  if (a.time_sin) {
-    sinusoidal(t_in, bufB);
-  } else {
-    if (tid == 0) bufA[0] = t_in;
+  if (a.part == 2) {  // condition row: the time half of `conditions` contributes nothing (SiLU(0) = 0)
+    for (int i = tid; i < half; i += blockDim.x) cat[i] = 0.f;
     __syncthreads();
-    dense(a.tw1, a.tb1, bufA, bufB, 1, q, true);
+  } else {
+    if (a.time_sin) {
+      sinusoidal(t_in, bufB);
+    } else {
+      if (tid == 0) bufA[0] = t_in;
+      __syncthreads();
+      dense(a.tw1, a.tb1, bufA, bufB, 1, q, true);
+    }
+    dense(a.tw2, a.tb2, bufB, bufA, q, half, true);
+    dense(a.tw3, a.tb3, bufA, cat, half, half, false);
   }
-  dense(a.tw2, a.tb2, bufB, bufA, q, half, true);
-  dense(a.tw3, a.tb3, bufA, cat, half, half, false);
   // cond branch: Linear(cond_size, hidden) GELU | sinusoidal(half/2) of the scalar condition;  Linear(hidden, half) GELU
   // Linear(half, half)
-  if (a.cond_sin) {
-    sinusoidal(a.cond[bc], bufB);
-  } else {
-    for (int i = tid; i < a.cond_size; i += blockDim.x) bufA[i] = a.cond[(size_t)bc * a.cond_size + i];
+  if (a.part == 1) {  // time row: no condition half
+    for (int i = tid; i < half; i += blockDim.x) cat[half + i] = 0.f;
     __syncthreads();
-    dense(a.cw1, a.cb1, bufA, bufB, a.cond_size, a.cond_hidden, true);
+  } else {
+    if (a.cond_sin) {
+      sinusoidal(a.cond[bc], bufB);
+    } else {
+      for (int i = tid; i < a.cond_size; i += blockDim.x) bufA[i] = a.cond[(size_t)bc * a.cond_size + i];
+      __syncthreads();
+      dense(a.cw1, a.cb1, bufA, bufB, a.cond_size, a.cond_hidden, true);
+    }
+    dense(a.cw2, a.cb2, bufB, bufA, a.cond_hidden, half, true);
+    dense(a.cw3, a.cb3, bufA, cat + half, half, half, false);
   }
-  dense(a.cw2, a.cb2, bufB, bufA, a.cond_hidden, half, true);
-  dense(a.cw3, a.cb3, bufA, cat + half, half, half, false);
   // SiLU of conditions = cat(t, c)  (models.py:707; ResnetBlock.mlp[0])
   for (int i = tid; i < 2 * half; i += blockDim.x) {
     const float v = cat[i];
@@ -135,7 +147,7 @@ __global__ void __launch_bounds__(512) embed_kernel(EmbedArgs a) {
       for (int r = 0; r < 4; ++r) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) acc[r] += __shfl_xor(acc[r], o, 64);
-        if (lane == 0 && j0 + r < L.cout) a.emb[(size_t)b * a.emb_ld + L.offset + j0 + r] = acc[r] + L.b[j0 + r];
+        if (lane == 0 && j0 + r < L.cout) a.emb[(size_t)b * a.emb_ld + L.offset + j0 + r] = a.part == 2 ? acc[r] : acc[r] + L.b[j0 + r];
       }
     }
   }
@@ -308,10 +320,17 @@ __global__ void __launch_bounds__(1024) load_step_kernel(const float* __restrict
     const int slot = step % ch.chunk_steps;
     const f32x4* es = (const f32x4*)(ch.emb_src + (size_t)slot * ch.emb_floats);
     f32x4* ed = (f32x4*)ch.emb_dst;
-    for (int i = tid; i < ch.emb_floats / 4; i += blockDim.x) ed[i] = es[i];
     const f32x4* ss = (const f32x4*)(ch.scal_src + (size_t)slot * ch.scal_floats);
     f32x4* sd = (f32x4*)ch.scal_dst;
-    for (int i = tid; i < ch.scal_floats / 4; i += blockDim.x) sd[i] = ss[i];
+    if (ch.emb_cond) {  // separable form: the step's time row + every sample's condition row
+      const int rq = ch.emb_floats / 4;
+      const f32x4* ec = (const f32x4*)ch.emb_cond;
+      for (int i = tid; i < batch * rq; i += blockDim.x) ed[i] = es[i % rq] + ec[i];
+      for (int i = tid; i < batch; i += blockDim.x) sd[i] = ss[0];
+    } else {
+      for (int i = tid; i < ch.emb_floats / 4; i += blockDim.x) ed[i] = es[i];
+      for (int i = tid; i < ch.scal_floats / 4; i += blockDim.x) sd[i] = ss[i];
+    }
   }
   __syncthreads();
   if (tid == 0) *counter = step + 1;

@@ -1619,11 +1619,30 @@ int cd_ddim_sample(CdPlan* plan, int batch, const float* start, const float* con
     float* scal_cur = plan->ws.get<float>((size_t)batch * 4);
     float* emb_chunk = plan->ws.get<float>((size_t)K * batch * plan->emb_ld);
     float* scal_chunk = plan->ws.get<float>((size_t)K * batch * 4);
+    // Every sample of the batch runs at the step's sigma, and the ResnetBlock projections are linear in SiLU(cat(t, c))
+    // (EmbedArgs::part): a chunk needs its K TIME rows only (16 rows instead of 16 x batch: the chunk's launch was 165 us at batch 64,
+    // serial with the step graphs), the batch's CONDITION rows are computed once per call; load_step adds the two.  The regions
+    // above are sized for the unsplit form (CD_NO_EMBED_SPLIT), the split form uses the front of them.
+    static const bool no_split = getenv("CD_NO_EMBED_SPLIT") != nullptr;
+    const bool split = !no_split && plan->emb_ld % 4 == 0 && batch >= 2;  // (batch 1: K + 1 rows do not fit the K-row region, nothing to gain)
+    float* emb_cond = split ? emb_chunk + (size_t)K * plan->emb_ld : nullptr;  // [batch][emb_ld] behind the K time rows
     StepChunk chunk;
-    chunk.emb_src = emb_chunk; chunk.emb_dst = emb_cur; chunk.emb_floats = batch * plan->emb_ld;
-    chunk.scal_src = scal_chunk; chunk.scal_dst = scal_cur; chunk.scal_floats = batch * 4; chunk.chunk_steps = K;
+    chunk.emb_src = emb_chunk; chunk.emb_dst = emb_cur; chunk.emb_floats = split ? plan->emb_ld : batch * plan->emb_ld;
+    chunk.scal_src = scal_chunk; chunk.scal_dst = scal_cur; chunk.scal_floats = split ? 4 : batch * 4; chunk.chunk_steps = K;
+    chunk.emb_cond = emb_cond;
     auto embed_ahead = [&](hipStream_t st, int i0) {  // steps i0 .. i0 + K - 1 (slot = step % K; i0 is a multiple of K)
       const int nst = n_steps - i0 < K ? n_steps - i0 : K;
+      if (split) {
+        if (i0 == 0) {  // the condition rows, once
+          EmbedArgs c = embed_args(plan, batch, cond, plan->d_table, plan->desc.time_embed_kind, emb_cond, nullptr);
+          c.part = 2;
+          launch_embed(c, st);
+        }
+        EmbedArgs e = embed_args(plan, nst, cond, plan->d_table + (size_t)i0 * 4, plan->desc.time_embed_kind, emb_chunk, scal_chunk);
+        e.part = 1; e.time_stride = 4;
+        launch_embed(e, st);
+        return;
+      }
       EmbedArgs e = embed_args(plan, nst * batch, cond, plan->d_table + (size_t)i0 * 4, plan->desc.time_embed_kind, emb_chunk, scal_chunk);
       e.cond_rows = batch; e.time_stride = 4;
       launch_embed(e, st);
